@@ -1,0 +1,332 @@
+"""ctypes binding of libfsgpu.so (include/fsgpu.h + include/fshost.h) used by bench.py and the tests.
+
+This is plumbing, not the product: every call goes through the C ABI of the shared library (HIP kernels + C++ host
+code).  There is NO CPU fallback -- if the library or a GPU is missing the calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsgpu.so")
+
+HIT_DT = np.dtype([("id", np.uint32), ("score", np.int32)])
+SWRES_DT = np.dtype([("score", np.int32), ("qEnd", np.int32), ("dbEnd", np.int32), ("word", np.int32)])
+RESULT_DT = np.dtype([("dbKey", np.uint32), ("score", np.int32), ("qcov", np.float32), ("dbcov", np.float32),
+                      ("seqId", np.float32), ("_pad0", np.uint32), ("eval", np.float64), ("alnLength", np.uint32),
+                      ("qStartPos", np.int32), ("qEndPos", np.int32), ("qLen", np.uint32), ("dbStartPos", np.int32),
+                      ("dbEndPos", np.int32), ("dbLen", np.uint32), ("backtraceOff", np.uint32),
+                      ("backtraceLen", np.uint32), ("_pad1", np.uint32)])
+
+
+class Params(C.Structure):
+    _fields_ = [("maxResListLen", C.c_int), ("minDiagScoreThr", C.c_int), ("compBiasCorrection", C.c_int),
+                ("prefCompBiasScale", C.c_float), ("alignmentType", C.c_int), ("alnCompBiasScale", C.c_float),
+                ("gapOpen", C.c_int), ("gapExtend", C.c_int), ("evalThr", C.c_double), ("covThr", C.c_float),
+                ("covMode", C.c_int), ("addBacktrace", C.c_int), ("maxAccept", C.c_int), ("maxRejected", C.c_int),
+                ("seqIdThr", C.c_float), ("alnLenThr", C.c_int)]
+
+
+class FsgpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libfsgpu.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FsgpuError(f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
+    sig = {
+        "fsgpu_create": (i32, [i32, C.POINTER(vp)]),
+        "fsgpu_destroy": (None, [vp]),
+        "fsgpu_last_error": (C.c_char_p, [vp]),
+        "fsgpu_device": (i32, [vp]),
+        "fsgpu_stream": (vp, [vp]),
+        "fsgpu_db_load": (i32, [vp, vp, vp, vp, vp, u64, u64]),
+        "fsgpu_db_adopt_device": (i32, [vp, vp, vp, vp, vp, u64, u64]),
+        "fsgpu_db_size": (u64, [vp]),
+        "fsgpu_db_residues": (u64, [vp]),
+        "fsgpu_gapless_scan": (i32, [vp, vp, i32, i32, i32, i64, i32, vp, C.POINTER(i32)]),
+        "fsgpu_gapless_scores": (i32, [vp, vp]),
+        "fsgpu_gapless_launch": (i32, [vp, vp, i32, i32, i32, i64, i32]),
+        "fsgpu_gapless_finish": (i32, [vp, vp, C.POINTER(i32)]),
+        "fsgpu_sw_batch": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]),
+        "fsgpu_sw_launch": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32]),
+        "fsgpu_sw_finish": (i32, [vp, vp, vp]),
+        "fsgpu_last_kernel_ms": (f64, [vp, i32]),
+        "fshost_matrix_create": (vp, [i32, f32, f32]),
+        "fshost_matrix_from_text": (vp, [C.c_char_p, f32, f32]),
+        "fshost_matrix_free": (None, [vp]),
+        "fshost_matrix_size": (i32, [vp]),
+        "fshost_matrix_scores": (C.POINTER(C.c_int16), [vp]),
+        "fshost_matrix_background": (C.POINTER(C.c_double), [vp]),
+        "fshost_matrix_encode": (None, [vp, C.c_char_p, i32, vp]),
+        "fshost_matrix_letter": (C.c_char, [vp, i32]),
+        "fshost_comp_bias": (None, [vp, vp, i32, f32, vp]),
+        "fshost_round_bias": (None, [vp, i32, vp]),
+        "fshost_prefilter_profile": (i32, [vp, vp, i32, i32, f32, vp, C.POINTER(i32)]),
+        "fshost_align_profiles": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
+        "fshost_evaluer_create": (vp, [C.c_char_p, u64]),
+        "fshost_evaluer_free": (None, [vp]),
+        "fshost_predict_mu_lambda": (None, [vp, vp, C.c_uint, i32, C.POINTER(f64), C.POINTER(f64)]),
+        "fshost_evalue_corr": (f64, [vp, f64, f64, f64]),
+        "fshost_params_default": (None, [C.POINTER(Params)]),
+        "fshost_search_create": (vp, [vp, C.POINTER(Params), vp, C.c_char_p, vp, vp, vp, vp]),
+        "fshost_search_free": (None, [vp]),
+        "fshost_search_error": (C.c_char_p, [vp]),
+        "fshost_search_prefilter": (i32, [vp, vp, i32, i64, vp]),
+        "fshost_search_align": (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
+        "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
+        "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "fshost_format_prefilter_hit": (C.c_size_t, [C.c_char_p, C.c_uint32, i32, i32]),
+        "fshost_format_result": (C.c_size_t, [C.c_char_p, vp, C.c_char_p, i32]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
+            "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
+            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_launch", "fsgpu_sw_finish",
+            "fsgpu_last_kernel_ms"]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Matrix:
+    """fshost_matrix: bit-scaled substitution matrix (built-in 3Di / BLOSUM62 or user .out text)."""
+
+    def __init__(self, which=None, bit_factor=2.0, score_bias=0.0, text=None):
+        L = lib()
+        self.h = L.fshost_matrix_from_text(text.encode(), bit_factor, score_bias) if text is not None else \
+            L.fshost_matrix_create(which, bit_factor, score_bias)
+        if not self.h:
+            raise FsgpuError("matrix construction failed")
+        self.n = L.fshost_matrix_size(self.h)
+
+    def scores(self):
+        return np.ctypeslib.as_array(lib().fshost_matrix_scores(self.h), (self.n * self.n,)).copy().reshape(self.n, self.n)
+
+    def background(self):
+        return np.ctypeslib.as_array(lib().fshost_matrix_background(self.h), (self.n,)).copy()
+
+    def encode(self, s):
+        out = np.zeros(len(s), np.uint8)
+        lib().fshost_matrix_encode(self.h, s.encode(), len(s), _ptr(out))
+        return out
+
+    def comp_bias(self, seq, scale):
+        seq = np.ascontiguousarray(seq, np.uint8)
+        out = np.zeros(len(seq), np.float32)
+        lib().fshost_comp_bias(self.h, _ptr(seq), len(seq), scale, _ptr(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().fshost_matrix_free(self.h)
+            self.h = None
+
+
+def prefilter_profile(m3di, q3di, comp_bias=True, scale=0.15):
+    q = np.ascontiguousarray(q3di, np.uint8)
+    pssm = np.zeros((m3di.n, len(q)), np.int8)
+    cap = C.c_int(0)
+    rc = lib().fshost_prefilter_profile(m3di.h, _ptr(q), len(q), int(comp_bias), scale, _ptr(pssm), C.byref(cap))
+    if rc != 0:
+        raise FsgpuError(f"fshost_prefilter_profile rc={rc}")
+    return pssm, cap.value
+
+
+def align_profiles(mAA, m3Di, qAA, q3Di, comp_bias=True, scale=0.5):
+    qa = np.ascontiguousarray(qAA, np.uint8)
+    q3 = np.ascontiguousarray(q3Di, np.uint8)
+    n, L_ = m3Di.n, len(q3)
+    pAA = np.zeros((n, L_), np.int16)
+    p3 = np.zeros((n, L_), np.int16)
+    cbA = np.zeros(L_, np.int8)
+    cbS = np.zeros(L_, np.int8)
+    rc = lib().fshost_align_profiles(mAA.h, m3Di.h, _ptr(qa), _ptr(q3), L_, int(comp_bias), scale, _ptr(pAA), _ptr(p3),
+                                     _ptr(cbA), _ptr(cbS))
+    if rc != 0:
+        raise FsgpuError(f"fshost_align_profiles rc={rc}")
+    return pAA, p3, cbA, cbS
+
+
+class Evaluer:
+    def __init__(self, db_residues, nn_path=None):
+        self.h = lib().fshost_evaluer_create(nn_path.encode() if nn_path else None, db_residues)
+        if not self.h:
+            raise FsgpuError("cannot load e-value network")
+
+    def mu_lambda(self, q3di, alphabet=21):
+        q = np.ascontiguousarray(q3di, np.uint8)
+        lam, mu = C.c_double(), C.c_double()
+        lib().fshost_predict_mu_lambda(self.h, _ptr(q), len(q), alphabet, C.byref(lam), C.byref(mu))
+        return lam.value, mu.value
+
+    def evalue_corr(self, score, lam, mu):
+        return lib().fshost_evalue_corr(self.h, float(score), lam, mu)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().fshost_evaluer_free(self.h)
+            self.h = None
+
+
+class Context:
+    """fsgpu_ctx: one MI355X, one HIP stream, one resident target DB."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = lib().fsgpu_create(device, C.byref(h))
+        if rc != 0:
+            raise FsgpuError(f"fsgpu_create({device}) rc={rc}: {lib().fsgpu_last_error(None).decode()}")
+        self.h = h
+        self._keep = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise FsgpuError(f"{what} rc={rc}: {lib().fsgpu_last_error(self.h).decode()}")
+
+    def load_db(self, db):
+        """db: foldseek_amd.synth.PaddedDB-like (data3di, dataaa|None, offsets[n+1], lengths[n])."""
+        d3 = np.ascontiguousarray(db.data3di, np.uint8)
+        da = None if db.dataaa is None else np.ascontiguousarray(db.dataaa, np.uint8)
+        off = np.ascontiguousarray(db.offsets, np.uint64)
+        ln = np.ascontiguousarray(db.lengths, np.int32)
+        self._keep = (d3, da, off, ln)
+        self._chk(lib().fsgpu_db_load(self.h, _ptr(d3), _ptr(da), _ptr(off), _ptr(ln), len(ln), d3.size), "fsgpu_db_load")
+
+    def adopt_device_db(self, d3_ptr, da_ptr, off_ptr, len_ptr, n, nbytes):
+        self._chk(lib().fsgpu_db_adopt_device(self.h, d3_ptr, da_ptr, off_ptr, len_ptr, n, nbytes), "fsgpu_db_adopt_device")
+
+    @property
+    def n(self):
+        return lib().fsgpu_db_size(self.h)
+
+    @property
+    def residues(self):
+        return lib().fsgpu_db_residues(self.h)
+
+    @property
+    def stream(self):
+        return lib().fsgpu_stream(self.h)
+
+    def gapless_scan(self, pssm, cap, min_score=30, identity=-1, max_res=1000):
+        pssm = np.ascontiguousarray(pssm, np.int8)
+        out = np.zeros(max_res, HIT_DT)
+        nout = C.c_int(0)
+        self._chk(lib().fsgpu_gapless_scan(self.h, _ptr(pssm), pssm.shape[1], cap, min_score, identity, max_res, _ptr(out),
+                                           C.byref(nout)), "fsgpu_gapless_scan")
+        return out[:nout.value]
+
+    def gapless_scores(self):
+        s = np.zeros(self.n, np.uint8)
+        self._chk(lib().fsgpu_gapless_scores(self.h, _ptr(s)), "fsgpu_gapless_scores")
+        return s
+
+    def sw_batch(self, pAAf, p3f, pAAr, p3r, target_ids, gap_open=10, gap_extend=1):
+        p3f = np.ascontiguousarray(p3f, np.int16)
+        p3r = np.ascontiguousarray(p3r, np.int16)
+        pAAf = None if pAAf is None else np.ascontiguousarray(pAAf, np.int16)
+        pAAr = None if pAAr is None else np.ascontiguousarray(pAAr, np.int16)
+        t = np.ascontiguousarray(target_ids, np.uint32)
+        fwd = np.zeros(len(t), SWRES_DT)
+        rev = np.zeros(len(t), SWRES_DT)
+        self._chk(lib().fsgpu_sw_batch(self.h, _ptr(pAAf), _ptr(p3f), _ptr(pAAr), _ptr(p3r), p3f.shape[1], _ptr(t), len(t),
+                                       gap_open, gap_extend, _ptr(fwd), _ptr(rev)), "fsgpu_sw_batch")
+        return fwd, rev
+
+    def kernel_ms(self, which):
+        return lib().fsgpu_last_kernel_ms(self.h, which)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fsgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Search:
+    """fshost_search: one query at a time through prefilter + structurealign on a Context."""
+
+    def __init__(self, ctx, params=None, keys=None, nn_path=None):
+        self.ctx = ctx
+        self.par = params if params is not None else default_params()
+        d3, da, off, ln = ctx._keep
+        self._keys = None if keys is None else np.ascontiguousarray(keys, np.uint32)
+        self.h = lib().fshost_search_create(ctx.h, C.byref(self.par), _ptr(self._keys), nn_path.encode() if nn_path else None,
+                                            _ptr(d3), _ptr(da), _ptr(off), _ptr(ln))
+        err = lib().fshost_search_error(self.h).decode() if self.h else "null"
+        if not self.h or err:
+            raise FsgpuError(f"fshost_search_create: {err}")
+
+    def prefilter(self, q3di, identity=-1):
+        q = np.ascontiguousarray(q3di, np.uint8)
+        hits = np.zeros(self.par.maxResListLen, HIT_DT)
+        n = lib().fshost_search_prefilter(self.h, _ptr(q), len(q), identity, _ptr(hits))
+        if n < 0:
+            raise FsgpuError(f"prefilter rc={n}: {lib().fshost_search_error(self.h).decode()}")
+        return hits[:n]
+
+    def align(self, qAA, q3di, target_ids, identity=-1, with_backtrace=False):
+        qa = np.ascontiguousarray(qAA, np.uint8)
+        q3 = np.ascontiguousarray(q3di, np.uint8)
+        t = np.ascontiguousarray(target_ids, np.uint32)
+        res = np.zeros(max(1, len(t)), RESULT_DT)
+        n = lib().fshost_search_align(self.h, _ptr(qa), _ptr(q3), len(q3), identity, _ptr(t), len(t), _ptr(res))
+        if n < 0:
+            raise FsgpuError(f"align rc={n}: {lib().fshost_search_error(self.h).decode()}")
+        res = res[:n]
+        if with_backtrace:
+            bts = [lib().fshost_search_backtrace(self.h, C.c_void_p(res[i:i + 1].ctypes.data)).decode() for i in range(n)]
+            return res, bts
+        return res
+
+    def last_sw(self, n):
+        f, r = C.c_void_p(), C.c_void_p()
+        lib().fshost_search_last_sw(self.h, C.byref(f), C.byref(r))
+        fa = np.ctypeslib.as_array(C.cast(f, C.POINTER(C.c_int32)), (n * 4,)).copy().view(SWRES_DT)
+        ra = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_int32)), (n * 4,)).copy().view(SWRES_DT)
+        return fa, ra
+
+    def format_result(self, r, backtrace=None, add_backtrace=False):
+        buf = C.create_string_buffer(1024 + 65536 * 2)
+        n = lib().fshost_format_result(buf, C.c_void_p(r.ctypes.data), backtrace.encode() if backtrace else None, int(add_backtrace))
+        return buf.raw[:n].decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fshost_search_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def default_params():
+    p = Params()
+    lib().fshost_params_default(C.byref(p))
+    return p
+
+
+def format_prefilter_hit(key, score, diagonal=0):
+    buf = C.create_string_buffer(64)
+    n = lib().fshost_format_prefilter_hit(buf, key, score, diagonal)
+    return buf.raw[:n].decode()

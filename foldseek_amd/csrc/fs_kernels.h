@@ -1,0 +1,50 @@
+// fs_kernels.h -- shared constants / layout functions used by the HIP kernels and by the host code that
+// builds the LDS images.  gfx950 (MI355X) only: wave64, 64 LDS banks, ds_read_b128 serviced in 16-lane groups.
+#pragma once
+#include <stdint.h>
+
+namespace fs {
+
+constexpr int kAlphabet = 21;          // 20 states + X
+constexpr int kDeadCode = 21;          // extra profile row: "past the end of this target", never scores
+constexpr int kGaplessLanes = 8;       // lanes per target in the gapless scan (8 targets per wave64)
+constexpr int kStripeTargets = 8;      // targets interleaved per 128-byte line of the scan layout
+constexpr int kGaplessMaxR = 32;       // register rows per strip per lane -> single tile covers 16*R <= 512 query rows
+constexpr int kSwMaxR = 8;             // register rows per lane in the SW wavefront -> 64*R <= 512 rows per tile
+constexpr uint32_t kFloor2 = 0x80008000u; // packed (INT16_MIN, INT16_MIN): the gapless recurrence's "zero"
+
+// ------------------------------------------------------------------------------------------------------------
+// Gapless scan LDS image.  Lane g (0..7) of a target group owns query rows [g*2R, g*2R+2R); register r packs
+// (row g*2R + r) in the low half and (row g*2R + R + r) in the high half, so the diagonal hand-off is a whole-
+// register move.  One 256-byte LDS bank row holds, for one 4-register chunk k, two copies (A: groups 0,1,4,5;
+// B: groups 2,3,6,7) x 8 lanes x 16 B.  Row stride is a multiple of 256 B, hence the bank of an access depends
+// only on (copy, g): every ds_read_b128 is conflict free by construction.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int gaplessRowBytes(int R) { return (R / 4) * 256; }
+__host__ __device__ constexpr int gaplessLdsBytes(int R) { return (kAlphabet + 1) * gaplessRowBytes(R); }
+
+// ------------------------------------------------------------------------------------------------------------
+// SW wavefront LDS image: lane l owns query rows [l*R, l*R+R) of the current tile.  Registers are fetched in
+// chunks of 4/2/1 dwords; chunk c occupies a contiguous region of 64 lanes x width dwords, so lane stride equals
+// the access width and a wave's read of one chunk is a linear 64*width*4-byte sweep: conflict free although
+// every lane reads a different profile row (lanes sit on different target columns of the anti-diagonal).
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int swChunkWidth(int R, int r) {
+    return (r < (R / 4) * 4) ? 4 : ((R % 4) >= 2 && r < (R / 4) * 4 + 2) ? 2 : 1;
+}
+// dword index inside one profile row (of 64*R dwords) for (lane, register r)
+__host__ __device__ constexpr int swDwordIndex(int R, int lane, int r) {
+    int full = (R / 4) * 4;
+    if (r < full) return (r / 4) * 256 + lane * 4 + (r % 4);
+    int off = (R / 4) * 256;
+    int rem = R % 4;
+    if (rem >= 2) {
+        if (r < full + 2) return off + lane * 2 + (r - full);
+        off += 128;
+        return off + lane;          // rem == 3: last single
+    }
+    return off + lane;              // rem == 1
+}
+__host__ __device__ constexpr int swRowDwords(int R) { return 64 * R; }
+
+} // namespace fs

@@ -1,0 +1,614 @@
+// fsgpu.hip -- C ABI (include/fsgpu.h) over the gfx950 kernels.  Host side: HIP runtime only, no torch.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/fsgpu.h"
+#include "fs_kernels.h"
+#include "k_gapless.hpp"
+#include "k_select.hpp"
+#include "k_sw.hpp"
+
+using namespace fs;
+
+static thread_local std::string g_createError;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct fsgpu_ctx {
+    int device = 0;
+    int numCU = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gapless start/stop, sw start/stop
+    bool evValid[2] = {false, false};
+    std::string err;
+
+    // database
+    uint64_t n = 0, residues = 0, bytes = 0;
+    bool hasAA = false;
+    int maxLen = 0;
+    uint4 *scan = nullptr;
+    uint64_t *stripeOff = nullptr;
+    uint32_t *stripeLen = nullptr, *order = nullptr;
+    uint32_t nStripes = 0;
+    uint8_t *aln3di = nullptr, *alnAA = nullptr;
+    uint64_t *dOffsets = nullptr;
+    int32_t *dLengths = nullptr;
+    std::vector<int32_t> hLengths;
+
+    // gapless scratch
+    DevBuf pssm, scores, chunkHist, baseGt, baseTie, outId, outScore;
+    SelMeta *dMeta = nullptr;
+    uint32_t *queue = nullptr;
+    SelMeta *hMeta = nullptr;            // pinned
+    uint32_t *hOutId = nullptr;          // pinned
+    int32_t *hOutScore = nullptr;
+    size_t hOutCap = 0;
+    int pendingMaxRes = 0;
+    bool gaplessPending = false;
+
+    // sw scratch
+    DevBuf img, tids, res0, res1, border0, border1, keys;
+    int32_t *hRes0 = nullptr, *hRes1 = nullptr;   // pinned
+    size_t hResCap = 0;
+    struct {
+        bool pending = false;
+        int n = 0, L = 0, go = 0, ge = 0;
+        bool hasAA = false;
+        std::vector<uint32_t> tids;
+        const int16_t *pAAf = nullptr, *p3f = nullptr, *pAAr = nullptr, *p3r = nullptr;
+    } sw;
+};
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return FSGPU_E_HIP;                                                                        \
+        }                                                                                              \
+    } while (0)
+
+static int ensure(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return FSGPU_OK;
+    if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max(bytes, (size_t) 256);
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return FSGPU_OK;
+}
+
+extern "C" {
+
+int fsgpu_create(int device, fsgpu_ctx **out) {
+    if (!out) return FSGPU_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_createError = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return FSGPU_E_HIP;
+    }
+    if (device < 0 || device >= count) { g_createError = "device index out of range"; return FSGPU_E_ARG; }
+    fsgpu_ctx *ctx = new fsgpu_ctx();
+    ctx->device = device;
+    auto fail = [&](const char *what, hipError_t err) {
+        g_createError = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return FSGPU_E_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+    ctx->numCU = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    for (int i = 0; i < 4; i++)
+        if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipMalloc((void **) &ctx->dMeta, sizeof(SelMeta))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc((void **) &ctx->queue, 256)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc((void **) &ctx->hMeta, sizeof(SelMeta))) != hipSuccess) return fail("hipHostMalloc", e);
+    *out = ctx;
+    return FSGPU_OK;
+}
+
+static void freeDb(fsgpu_ctx *ctx) {
+    hipFree(ctx->scan); hipFree(ctx->stripeOff); hipFree(ctx->stripeLen); hipFree(ctx->order);
+    hipFree(ctx->aln3di); hipFree(ctx->alnAA); hipFree(ctx->dOffsets); hipFree(ctx->dLengths);
+    ctx->scan = nullptr; ctx->stripeOff = nullptr; ctx->stripeLen = nullptr; ctx->order = nullptr;
+    ctx->aln3di = nullptr; ctx->alnAA = nullptr; ctx->dOffsets = nullptr; ctx->dLengths = nullptr;
+    ctx->n = 0;
+}
+
+void fsgpu_destroy(fsgpu_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    freeDb(ctx);
+    DevBuf *bufs[] = {&ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
+                      &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys};
+    for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+    hipFree(ctx->dMeta); hipFree(ctx->queue);
+    hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId); hipHostFree(ctx->hOutScore);
+    hipHostFree(ctx->hRes0); hipHostFree(ctx->hRes1);
+    for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *fsgpu_last_error(const fsgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+int fsgpu_device(const fsgpu_ctx *ctx) { return ctx ? ctx->device : -1; }
+void *fsgpu_stream(const fsgpu_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+uint64_t fsgpu_db_size(const fsgpu_ctx *ctx) { return ctx ? ctx->n : 0; }
+uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx) { return ctx ? ctx->residues : 0; }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// database re-tiling kernels
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_db_scan_layout(const uint8_t *raw, const uint64_t *offsets, const int32_t *lengths,
+                                                        uint32_t n, const uint64_t *stripeOff, const uint32_t *stripeLen,
+                                                        uint4 *out) {
+    const uint32_t stripe = blockIdx.x;
+    const uint32_t len16 = stripeLen[stripe];
+    const int j = threadIdx.x & 7;
+    const uint32_t t = stripe * kStripeTargets + j;
+    const bool live = t < n;
+    const uint64_t off = live ? offsets[t] : 0;
+    const int L = live ? lengths[t] : 0;
+    uint4 *dst = out + stripeOff[stripe];
+    for (uint32_t c = threadIdx.x >> 3; c < len16; c += 32) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            int col = (int) c * 16 + b;
+            uint32_t code = kDeadCode;
+            if (col < L) {
+                code = raw[off + col];
+                code = code > 20 ? 20 : code;     // soft-masked (>= 32) and anything unknown -> X
+            }
+            w[b >> 2] |= code << ((b & 3) * 8);
+        }
+        dst[(size_t) c * 8 + j] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+__global__ void k_db_unmask(const uint8_t *raw, uint8_t *out, uint64_t bytes) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (; i < bytes; i += stride) {
+        uint8_t c = raw[i];
+        c = c >= 32 ? c - 32 : c;
+        out[i] = c > 20 ? 20 : c;
+    }
+}
+
+static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA, const uint64_t *dOff, const int32_t *dLen,
+                   uint64_t n, uint64_t bytes) {
+    // host copy of the lengths drives the stripe table
+    ctx->hLengths.resize(n);
+    HIPCHK(hipMemcpy(ctx->hLengths.data(), dLen, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const uint32_t nStripes = (uint32_t) ((n + kStripeTargets - 1) / kStripeTargets);
+    std::vector<uint64_t> sOff(nStripes);
+    std::vector<uint32_t> sLen(nStripes), ord(nStripes);
+    uint64_t total = 0, residues = 0;
+    int maxLen = 0;
+    for (uint32_t s = 0; s < nStripes; s++) {
+        int mx = 0;
+        for (uint64_t t = (uint64_t) s * 8; t < std::min<uint64_t>(n, (uint64_t) s * 8 + 8); t++) {
+            int L = ctx->hLengths[t];
+            if (L < 0 || L > FSGPU_MAX_SEQ_LEN) { ctx->err = "target length out of range"; return FSGPU_E_ARG; }
+            mx = std::max(mx, L);
+            residues += (uint64_t) L;
+        }
+        maxLen = std::max(maxLen, mx);
+        sLen[s] = (uint32_t) ((mx + 15) / 16);
+        sOff[s] = total;
+        total += (uint64_t) sLen[s] * 8;
+    }
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return sLen[a] > sLen[b]; });
+
+    HIPCHK(hipMalloc((void **) &ctx->scan, std::max<uint64_t>(total, 1) * sizeof(uint4)));
+    HIPCHK(hipMalloc((void **) &ctx->stripeOff, std::max<size_t>(nStripes, 1) * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **) &ctx->stripeLen, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &ctx->order, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &ctx->aln3di, std::max<uint64_t>(bytes, 1)));
+    HIPCHK(hipMalloc((void **) &ctx->dOffsets, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **) &ctx->dLengths, std::max<uint64_t>(n, 1) * sizeof(int32_t)));
+    if (nStripes) {
+        HIPCHK(hipMemcpy(ctx->stripeOff, sOff.data(), nStripes * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->stripeLen, sLen.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->order, ord.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(ctx->dOffsets, dOff, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(ctx->dLengths, dLen, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    if (nStripes) {
+        hipLaunchKernelGGL(k_db_scan_layout, dim3(nStripes), dim3(256), 0, ctx->stream, dRaw3di, ctx->dOffsets, ctx->dLengths,
+                           (uint32_t) n, ctx->stripeOff, ctx->stripeLen, ctx->scan);
+        HIPCHK(hipGetLastError());
+    }
+    if (bytes) {
+        hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRaw3di, ctx->aln3di, bytes);
+        HIPCHK(hipGetLastError());
+        if (dRawAA) {
+            HIPCHK(hipMalloc((void **) &ctx->alnAA, bytes));
+            hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRawAA, ctx->alnAA, bytes);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n = n; ctx->bytes = bytes; ctx->residues = residues; ctx->nStripes = nStripes; ctx->maxLen = maxLen;
+    ctx->hasAA = dRawAA != nullptr;
+    return FSGPU_OK;
+}
+
+extern "C" {
+
+int fsgpu_db_adopt_device(fsgpu_ctx *ctx, const void *d3, const void *dA, const void *dOff, const void *dLen,
+                          uint64_t n, uint64_t bytes) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (!d3 || !dOff || !dLen || n == 0 || n > 0xfffffff0ull) { ctx->err = "fsgpu_db_adopt_device: bad argument"; return FSGPU_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    freeDb(ctx);
+    int rc = buildDb(ctx, (const uint8_t *) d3, (const uint8_t *) dA, (const uint64_t *) dOff, (const int32_t *) dLen, n, bytes);
+    if (rc != FSGPU_OK) freeDb(ctx);
+    return rc;
+}
+
+int fsgpu_db_load(fsgpu_ctx *ctx, const uint8_t *data3di, const uint8_t *dataAA, const uint64_t *offsets,
+                  const int32_t *lengths, uint64_t n, uint64_t bytes) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (!data3di || !offsets || !lengths || n == 0) { ctx->err = "fsgpu_db_load: bad argument"; return FSGPU_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    uint8_t *r3 = nullptr, *rA = nullptr;
+    uint64_t *dO = nullptr;
+    int32_t *dL = nullptr;
+    HIPCHK(hipMalloc((void **) &r3, std::max<uint64_t>(bytes, 1)));
+    HIPCHK(hipMemcpy(r3, data3di, bytes, hipMemcpyHostToDevice));
+    if (dataAA) {
+        HIPCHK(hipMalloc((void **) &rA, std::max<uint64_t>(bytes, 1)));
+        HIPCHK(hipMemcpy(rA, dataAA, bytes, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void **) &dO, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMemcpy(dO, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **) &dL, n * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(dL, lengths, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    int rc = fsgpu_db_adopt_device(ctx, r3, rA, dO, dL, n, bytes);
+    hipFree(r3); hipFree(rA); hipFree(dO); hipFree(dL);
+    return rc;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// gapless scan
+// ------------------------------------------------------------------------------------------------------------
+template <int R>
+static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
+    const int lds = gaplessLdsBytes(R);
+    static thread_local bool attrSet[kGaplessMaxR + 1] = {false};
+    if (!attrSet[R]) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attrSet[R] = true;
+    }
+    int perCU = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_gapless<R>, 512, lds));
+    perCU = std::max(1, std::min(perCU, 4));
+    // one wave needs one stripe at a time: do not launch more waves than stripes
+    uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nStripes + 7) / 8);
+    blocks = std::max(blocks, 1u);
+    hipLaunchKernelGGL(k_gapless<R>, dim3(blocks), dim3(512), lds, ctx->stream, ga);
+    HIPCHK(hipGetLastError());
+    return FSGPU_OK;
+}
+
+extern "C" {
+
+int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore, int64_t identityId, int maxRes) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (!pssm || L <= 0 || L > FSGPU_MAX_SEQ_LEN || maxRes <= 0) { ctx->err = "fsgpu_gapless_launch: bad argument"; return FSGPU_E_ARG; }
+    if (ctx->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
+    const int rows = (L + 15) / 16;                       // rows per strip per lane
+    const int R = std::max(4, ((rows + 3) / 4) * 4);
+    if (R > kGaplessMaxR) { ctx->err = "query longer than 512 residues: multi-tile gapless scan not implemented yet"; return FSGPU_E_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t) ctx->n;
+    const uint32_t nChunks = (n + kSelChunk - 1) / kSelChunk;
+    const uint32_t K = (uint32_t) std::min<uint64_t>((uint64_t) maxRes, ctx->n);
+    int rc;
+    if ((rc = ensure(ctx, ctx->pssm, (size_t) kAlphabet * L)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->scores, n)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->chunkHist, (size_t) nChunks * 256 * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->baseGt, (size_t) nChunks * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->baseTie, (size_t) nChunks * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->outId, (size_t) K * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->outScore, (size_t) K * 4)) != FSGPU_OK) return rc;
+    if (ctx->hOutCap < K) {
+        hipHostFree(ctx->hOutId); hipHostFree(ctx->hOutScore);
+        ctx->hOutId = nullptr; ctx->hOutScore = nullptr;
+        HIPCHK(hipHostMalloc((void **) &ctx->hOutId, (size_t) K * 4));
+        HIPCHK(hipHostMalloc((void **) &ctx->hOutScore, (size_t) K * 4));
+        ctx->hOutCap = K;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->pssm.p, pssm, (size_t) kAlphabet * L, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
+    GaplessArgs ga;
+    ga.scan = ctx->scan; ga.stripeOff = ctx->stripeOff; ga.stripeLen = ctx->stripeLen; ga.order = ctx->order;
+    ga.nStripes = ctx->nStripes; ga.nTargets = n; ga.pssm = (const int8_t *) ctx->pssm.p; ga.L = L;
+    ga.cap = std::max(0, std::min(scoreCap, 255));
+    ga.scores = (uint8_t *) ctx->scores.p; ga.queue = ctx->queue;
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    switch (R) {
+        case 4: rc = launchGapless<4>(ctx, ga); break;
+        case 8: rc = launchGapless<8>(ctx, ga); break;
+        case 12: rc = launchGapless<12>(ctx, ga); break;
+        case 16: rc = launchGapless<16>(ctx, ga); break;
+        case 20: rc = launchGapless<20>(ctx, ga); break;
+        case 24: rc = launchGapless<24>(ctx, ga); break;
+        case 28: rc = launchGapless<28>(ctx, ga); break;
+        case 32: rc = launchGapless<32>(ctx, ga); break;
+        default: ctx->err = "internal: bad R"; return FSGPU_E_ARG;
+    }
+    if (rc != FSGPU_OK) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(k_sel_hist, dim3(nChunks), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->scores.p, n, minScore,
+                       identityId, (uint32_t *) ctx->chunkHist.p);
+    hipLaunchKernelGGL(k_sel_threshold, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *) ctx->chunkHist.p, nChunks, K, ctx->dMeta,
+                       (uint32_t *) ctx->baseGt.p, (uint32_t *) ctx->baseTie.p);
+    hipLaunchKernelGGL(k_sel_emit, dim3(nChunks), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->scores.p, n, minScore,
+                       identityId, (const SelMeta *) ctx->dMeta, (const uint32_t *) ctx->baseGt.p, (const uint32_t *) ctx->baseTie.p,
+                       (uint32_t *) ctx->outId.p, (int32_t *) ctx->outScore.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ctx->hMeta, ctx->dMeta, sizeof(SelMeta), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hOutId, ctx->outId.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hOutScore, ctx->outScore.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pendingMaxRes = (int) K;
+    ctx->gaplessPending = true;
+    ctx->evValid[0] = true;
+    return FSGPU_OK;
+}
+
+int fsgpu_gapless_finish(fsgpu_ctx *ctx, fsgpu_hit *out, int *nout) {
+    if (!ctx || !out || !nout) return FSGPU_E_ARG;
+    if (!ctx->gaplessPending) { ctx->err = "no gapless scan in flight"; return FSGPU_E_ARG; }
+    ctx->gaplessPending = false;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t m = std::min<uint32_t>(ctx->hMeta->nOut, (uint32_t) ctx->pendingMaxRes);
+    for (uint32_t i = 0; i < m; i++) { out[i].id = ctx->hOutId[i]; out[i].score = ctx->hOutScore[i]; }
+    // hit_t::compareHitsByScoreAndId (scores are non-negative here)
+    std::sort(out, out + m, [](const fsgpu_hit &a, const fsgpu_hit &b) {
+        if (a.score != b.score) return a.score > b.score;
+        return a.id < b.id;
+    });
+    *nout = (int) m;
+    return FSGPU_OK;
+}
+
+int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore, int64_t identityId, int maxRes,
+                       fsgpu_hit *out, int *nout) {
+    int rc = fsgpu_gapless_launch(ctx, pssm, L, scoreCap, minScore, identityId, maxRes);
+    if (rc != FSGPU_OK) return rc;
+    return fsgpu_gapless_finish(ctx, out, nout);
+}
+
+int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out) {
+    if (!ctx || !scores_out) return FSGPU_E_ARG;
+    if (ctx->n == 0 || !ctx->scores.p) { ctx->err = "no scan results"; return FSGPU_E_NODB; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(scores_out, ctx->scores.p, ctx->n, hipMemcpyDeviceToHost));
+    return FSGPU_OK;
+}
+
+double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which) {
+    if (!ctx || which < 0 || which > 1 || !ctx->evValid[which]) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]) != hipSuccess) return -1.0;
+    return (double) ms;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// Smith-Waterman batch
+// ------------------------------------------------------------------------------------------------------------
+static int swPickR(int rows) {
+    const int opts[] = {1, 2, 3, 4, 6, 8};
+    for (int r : opts) if (64 * r >= rows) return r;
+    return 8;
+}
+
+template <int R, bool HAS_AA, typename A>
+static int launchSwT(fsgpu_ctx *ctx, const SwArgs &sa, int nPairs) {
+    const int lds = (HAS_AA ? 2 : 1) * kAlphabet * swRowDwords(R) * 4;
+    static thread_local bool attrSet = false;
+    if (!attrSet) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_sw<R, HAS_AA, A>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attrSet = true;
+    }
+    // small batches (one query) -> 4 waves per workgroup so that all CUs get work; big batches -> 8
+    const int waves = nPairs <= 4096 ? 4 : 8;
+    const int blocks = (nPairs + waves - 1) / waves;
+    hipLaunchKernelGGL((k_sw<R, HAS_AA, A>), dim3(blocks), dim3(waves * 64), lds, ctx->stream, sa);
+    HIPCHK(hipGetLastError());
+    return FSGPU_OK;
+}
+
+template <typename A>
+static int launchSw(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nPairs) {
+#define FS_SW_CASE(RR)                                                                   \
+    case RR: return hasAA ? launchSwT<RR, true, A>(ctx, sa, nPairs) : launchSwT<RR, false, A>(ctx, sa, nPairs);
+    switch (R) {
+        FS_SW_CASE(1) FS_SW_CASE(2) FS_SW_CASE(3) FS_SW_CASE(4) FS_SW_CASE(6) FS_SW_CASE(8)
+        default: ctx->err = "internal: bad SW R"; return FSGPU_E_ARG;
+    }
+#undef FS_SW_CASE
+}
+
+// Builds the per-tile LDS images (host) and runs all row tiles of one pass.
+//   packed:  value = (fwd int16) | (rev int16) << 16;   int32: value = the selected direction's score
+static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int16_t *p3_0, const int16_t *pAA1, const int16_t *p3_1,
+                     int L, const uint32_t *dTids, int nPairs, int maxLt, int go, int ge, int32_t *dRes0, int32_t *dRes1) {
+    const bool hasAA = pAA0 != nullptr;
+    const int nTiles = L <= 64 * kSwMaxR ? 1 : (L + 64 * kSwMaxR - 1) / (64 * kSwMaxR);
+    const int R = nTiles == 1 ? swPickR(L) : kSwMaxR;
+    const int rowDw = swRowDwords(R);
+    const size_t tblDw = (size_t) kAlphabet * rowDw;
+    const size_t imgDw = tblDw * (hasAA ? 2 : 1);
+    std::vector<uint32_t> img(imgDw * nTiles, 0u);
+    for (int t = 0; t < nTiles; t++) {
+        const int base = t * 64 * R;
+        for (int tbl = 0; tbl < (hasAA ? 2 : 1); tbl++) {
+            const int16_t *f = tbl == 0 ? p3_0 : pAA0;
+            const int16_t *r = tbl == 0 ? p3_1 : pAA1;
+            uint32_t *dst = img.data() + imgDw * t + tblDw * tbl;
+            for (int a = 0; a < kAlphabet; a++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int rr = 0; rr < R; rr++) {
+                        const int q = base + lane * R + rr;
+                        uint32_t v = 0;
+                        if (q < L) {
+                            if (packed) v = (uint32_t) (uint16_t) f[(size_t) a * L + q] | ((uint32_t) (uint16_t) r[(size_t) a * L + q] << 16);
+                            else v = (uint32_t) (int32_t) f[(size_t) a * L + q];
+                        }
+                        dst[(size_t) a * rowDw + swDwordIndex(R, lane, rr)] = v;
+                    }
+        }
+    }
+    int rc;
+    if ((rc = ensure(ctx, ctx->img, img.size() * 4)) != FSGPU_OK) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->img.p, img.data(), img.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the staging vector must outlive the async copy: pageable memcpyAsync returns after staging, but be safe
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t stride = (uint32_t) ((maxLt + 63) / 64 * 64);
+    if (nTiles > 1) {
+        const size_t bbytes = (size_t) nPairs * stride * 3 * 4;
+        if ((rc = ensure(ctx, ctx->border0, bbytes)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->border1, bbytes)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->keys, (size_t) nPairs * 2 * 8)) != FSGPU_OK) return rc;
+    }
+    for (int t = 0; t < nTiles; t++) {
+        SwArgs sa;
+        sa.aa = ctx->alnAA; sa.ss = ctx->aln3di; sa.offsets = ctx->dOffsets; sa.lengths = ctx->dLengths;
+        sa.targetIds = dTids; sa.nPairs = nPairs;
+        sa.profSS = (const uint32_t *) ctx->img.p + imgDw * t;
+        sa.profAA = hasAA ? sa.profSS + tblDw : nullptr;
+        sa.tileBase = t * 64 * R;
+        sa.rowsInTile = std::min(64 * R, L - sa.tileBase);
+        sa.segLen = packed ? (L + 15) / 16 : (L + 7) / 8;
+        sa.go = packed ? ((uint32_t) go | ((uint32_t) go << 16)) : (uint32_t) go;
+        sa.ge = packed ? ((uint32_t) ge | ((uint32_t) ge << 16)) : (uint32_t) ge;
+        sa.tileIn = t > 0; sa.tileOut = t + 1 < nTiles;
+        sa.borderIn = (const uint32_t *) ((t & 1) ? ctx->border1.p : ctx->border0.p);
+        sa.borderOut = (uint32_t *) ((t & 1) ? ctx->border0.p : ctx->border1.p);
+        sa.borderStride = stride;
+        sa.keys = (uint64_t *) ctx->keys.p;
+        sa.res0 = dRes0; sa.res1 = dRes1;
+        rc = packed ? launchSw<Pk16>(ctx, R, hasAA, sa, nPairs) : launchSw<I32>(ctx, R, hasAA, sa, nPairs);
+        if (rc != FSGPU_OK) return rc;
+    }
+    return FSGPU_OK;
+}
+
+extern "C" {
+
+int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev,
+                    const int16_t *p3Di_rev, int L, const uint32_t *targetIds, int n, int gapOpen, int gapExtend) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (!p3Di_fwd || !p3Di_rev || L <= 0 || L > FSGPU_MAX_SEQ_LEN || n < 0 || (n > 0 && !targetIds) || ((pAA_fwd == nullptr) != (pAA_rev == nullptr))) {
+        ctx->err = "fsgpu_sw_launch: bad argument"; return FSGPU_E_ARG;
+    }
+    if (ctx->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (pAA_fwd && !ctx->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
+    if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
+        ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
+        return FSGPU_E_UNSUPPORTED;
+    }
+    if (ctx->sw.pending) { ctx->err = "previous SW batch not finished"; return FSGPU_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->sw.n = n; ctx->sw.L = L; ctx->sw.go = gapOpen; ctx->sw.ge = gapExtend; ctx->sw.hasAA = pAA_fwd != nullptr;
+    ctx->sw.pAAf = pAA_fwd; ctx->sw.p3f = p3Di_fwd; ctx->sw.pAAr = pAA_rev; ctx->sw.p3r = p3Di_rev;
+    ctx->sw.tids.assign(targetIds, targetIds + n);
+    ctx->sw.pending = true;
+    if (n == 0) return FSGPU_OK;
+    int maxLt = 1;
+    for (int i = 0; i < n; i++) {
+        if (targetIds[i] >= ctx->n) { ctx->sw.pending = false; ctx->err = "target id out of range"; return FSGPU_E_ARG; }
+        maxLt = std::max(maxLt, ctx->hLengths[targetIds[i]]);
+    }
+    int rc;
+    if ((rc = ensure(ctx, ctx->tids, (size_t) n * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->res0, (size_t) n * 16)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->res1, (size_t) n * 16)) != FSGPU_OK) return rc;
+    if (ctx->hResCap < (size_t) n) {
+        hipHostFree(ctx->hRes0); hipHostFree(ctx->hRes1);
+        ctx->hRes0 = ctx->hRes1 = nullptr;
+        HIPCHK(hipHostMalloc((void **) &ctx->hRes0, (size_t) n * 16));
+        HIPCHK(hipHostMalloc((void **) &ctx->hRes1, (size_t) n * 16));
+        ctx->hResCap = n;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->sw.tids.data(), (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = runSwPass(ctx, true, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, (const uint32_t *) ctx->tids.p, n, maxLt, gapOpen, gapExtend,
+                   (int32_t *) ctx->res0.p, (int32_t *) ctx->res1.p);
+    if (rc != FSGPU_OK) { ctx->sw.pending = false; return rc; }
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->evValid[1] = true;
+    HIPCHK(hipMemcpyAsync(ctx->hRes0, ctx->res0.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hRes1, ctx->res1.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    return FSGPU_OK;
+}
+
+int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev) {
+    if (!ctx || !fwd || !rev) return FSGPU_E_ARG;
+    if (!ctx->sw.pending) { ctx->err = "no SW batch in flight"; return FSGPU_E_ARG; }
+    ctx->sw.pending = false;
+    const int n = ctx->sw.n;
+    if (n == 0) return FSGPU_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(fwd, ctx->hRes0, (size_t) n * 16);
+    memcpy(rev, ctx->hRes1, (size_t) n * 16);
+    // int16 saturation -> int32 re-run with the int32 kernel's segment length (alignScoreEndPos, :313-336)
+    for (int dir = 0; dir < 2; dir++) {
+        fsgpu_swres *res = dir == 0 ? fwd : rev;
+        std::vector<uint32_t> ids;
+        std::vector<int> where;
+        int maxLt = 1;
+        for (int i = 0; i < n; i++)
+            if (res[i].score == 32767) {
+                ids.push_back(ctx->sw.tids[i]); where.push_back(i);
+                maxLt = std::max(maxLt, ctx->hLengths[ctx->sw.tids[i]]);
+            }
+        if (ids.empty()) continue;
+        const int m = (int) ids.size();
+        HIPCHK(hipMemcpyAsync(ctx->tids.p, ids.data(), (size_t) m * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const int16_t *pA = dir == 0 ? ctx->sw.pAAf : ctx->sw.pAAr;
+        const int16_t *p3 = dir == 0 ? ctx->sw.p3f : ctx->sw.p3r;
+        int rc = runSwPass(ctx, false, pA, p3, nullptr, nullptr, ctx->sw.L, (const uint32_t *) ctx->tids.p, m, maxLt, ctx->sw.go, ctx->sw.ge,
+                           (int32_t *) ctx->res0.p, nullptr);
+        if (rc != FSGPU_OK) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->hRes0, ctx->res0.p, (size_t) m * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < m; k++) memcpy(&res[where[k]], ctx->hRes0 + (size_t) k * 4, 16);
+    }
+    return FSGPU_OK;
+}
+
+int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev, const int16_t *p3Di_rev,
+                   int L, const uint32_t *targetIds, int n, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev) {
+    int rc = fsgpu_sw_launch(ctx, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, targetIds, n, gapOpen, gapExtend);
+    if (rc != FSGPU_OK) return rc;
+    return fsgpu_sw_finish(ctx, fwd, rev);
+}
+
+} // extern "C"

@@ -1,0 +1,299 @@
+// search.cpp -- per-query host logic of the two modules on the hot path:
+//   prefilter:  runFilterOnGpu's per-query body            (reference M/src/prefiltering/ungappedprefilter.cpp:170-326)
+//   align:      structurealign's per-query body + alignStructure
+//                                                          (reference F/src/strucclustutils/structurealign.cpp:37-112,318-452)
+// The DP itself runs on the device through fsgpu_gapless_scan / fsgpu_sw_batch; this file only prepares profiles,
+// applies the reference's gates in the reference's order, and formats results.
+#include "hostlib.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+using namespace fsh;
+
+struct fshost_search {
+    fsgpu_ctx *ctx = nullptr;
+    fshost_params par;
+    Matrix matPref;      // 3Di, 2.0 bits, bias 0.0   (ungappedprefilter.cpp:541)
+    Matrix mat3Di;       // 3Di, 2.1 bits             (structurealign.cpp:252)
+    Matrix matAA;        // blosum62, 1.4 bits or 0.0 (structurealign.cpp:264-265)
+    Evaluer evaluer;
+    std::vector<uint32_t> keys;
+    const uint8_t *data3di = nullptr, *dataAA = nullptr;   // caller-owned padded DB (host)
+    const uint64_t *offsets = nullptr;
+    const int32_t *lengths = nullptr;
+    std::string err;
+    // scratch
+    std::vector<int8_t> pssm;
+    std::vector<int16_t> pAAf, p3f, pAAr, p3r;
+    std::vector<int8_t> cbAA, cbSS;
+    std::vector<uint8_t> rAA, r3Di, tAA, t3Di;
+    std::vector<fsgpu_swres> fwd, rev;
+    std::string cigars;
+};
+
+extern "C" {
+
+void fshost_params_default(fshost_params *p) {
+    p->maxResListLen = 1000;
+    p->minDiagScoreThr = 30;
+    p->compBiasCorrection = 1;
+    p->prefCompBiasScale = 0.15f;
+    p->alignmentType = 2;
+    p->alnCompBiasScale = 0.5f;
+    p->gapOpen = 10;
+    p->gapExtend = 1;
+    p->evalThr = 10.0;
+    p->covThr = 0.0f;
+    p->covMode = 0;
+    p->addBacktrace = 0;
+    p->maxAccept = INT_MAX;
+    p->maxRejected = INT_MAX;
+    p->seqIdThr = 0.0f;
+    p->alnLenThr = 0;
+}
+
+fshost_search *fshost_search_create(fsgpu_ctx *ctx, const fshost_params *p, const uint32_t *keys, const char *nnPath,
+                                    const uint8_t *data3di, const uint8_t *dataAA, const uint64_t *offsets, const int32_t *lengths) {
+    if (!ctx || !p || !data3di || !offsets || !lengths) return nullptr;
+    fshost_search *s = new fshost_search();
+    s->ctx = ctx;
+    s->data3di = data3di; s->dataAA = dataAA; s->offsets = offsets; s->lengths = lengths;
+    s->par = *p;
+    const uint64_t n = fsgpu_db_size(ctx);
+    bool ok = s->matPref.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f) && s->mat3Di.builtin(FSHOST_MAT_3DI, 2.1f, 0.0f) &&
+              s->matAA.builtin(FSHOST_MAT_BLOSUM62, p->alignmentType == 2 ? 1.4f : 0.0f, 0.0f);
+    if (!ok) s->err = "matrix construction failed";
+    if (ok && !s->evaluer.load(nnPath, fsgpu_db_residues(ctx), s->err)) ok = false;
+    if (!ok) {
+        // keep the handle so the caller can read the error
+        s->ctx = nullptr;
+        return s;
+    }
+    s->keys.resize(n);
+    for (uint64_t i = 0; i < n; i++) s->keys[i] = keys ? keys[i] : (uint32_t) i;
+    return s;
+}
+
+void fshost_search_free(fshost_search *s) { delete s; }
+const char *fshost_search_error(const fshost_search *s) { return s ? s->err.c_str() : "null handle"; }
+
+int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_t identityId, fsgpu_hit *hits) {
+    if (!s || !s->ctx) return FSGPU_E_ARG;
+    s->pssm.resize((size_t) s->matPref.n * L);
+    int cap = 0;
+    int rc = prefilterProfile(s->matPref, q3di, L, s->par.compBiasCorrection != 0, s->par.prefCompBiasScale, s->pssm.data(), &cap);
+    if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
+    int nout = 0;
+    rc = fsgpu_gapless_scan(s->ctx, s->pssm.data(), L, cap, s->par.minDiagScoreThr, identityId, s->par.maxResListLen, hits, &nout);
+    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    return nout;
+}
+
+} // extern "C"
+
+// ---- helpers restating small reference functions -------------------------------------------------------------
+static float computeCov(unsigned int startPos, unsigned int endPos, unsigned int len) {   // StructureSmithWaterman.cpp:2028
+    return (std::min(len, std::max(startPos, endPos)) - std::min(startPos, endPos) + 1) / (float) len;
+}
+static bool canBeCovered(const float covThr, const int covMode, float queryLength, float targetLength) {   // Util.cpp:542
+    switch (covMode) {
+        case 0: return ((queryLength / targetLength >= covThr) && (targetLength / queryLength >= covThr));
+        case 2: return ((targetLength / queryLength) >= covThr);
+        case 1: return ((queryLength / targetLength) >= covThr);
+        case 3: return ((targetLength / queryLength) >= covThr) && (targetLength / queryLength) <= 1.0;
+        case 4: return ((queryLength / targetLength) >= covThr) && (queryLength / targetLength) <= 1.0;
+        case 5: return (std::min(targetLength, queryLength) / std::max(targetLength, queryLength)) >= covThr;
+        default: return true;
+    }
+}
+static bool hasCoverage(float covThr, int covMode, float queryCov, float targetCov) {   // Util.cpp:561
+    switch (covMode) {
+        case 0: return ((queryCov >= covThr) && (targetCov >= covThr));
+        case 2: return (queryCov >= covThr);
+        case 1: return (targetCov >= covThr);
+        default: return true;
+    }
+}
+static bool compareHits(const fshost_result &first, const fshost_result &second) {   // Matcher.h:161
+    if (first.eval != second.eval) return first.eval < second.eval;
+    if (first.score != second.score) return first.score > second.score;
+    if (first.dbLen != second.dbLen) return first.dbLen < second.dbLen;
+    return first.dbKey < second.dbKey;
+}
+
+extern "C" {
+
+int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
+                        const uint32_t *targetIds, int n, fshost_result *results) {
+    if (!s || !s->ctx || !qAA || !q3di || L <= 0 || n < 0) return FSGPU_E_ARG;
+    const fshost_params &par = s->par;
+    const int A = s->mat3Di.n;
+    const bool useAA = par.alignmentType == 2;
+    double lambda, mu;
+    s->evaluer.predictMuLambda(q3di, L, A, &lambda, &mu);
+    // forward and reversed-query profiles (structurealign.cpp:344-347)
+    s->pAAf.resize((size_t) A * L); s->p3f.resize((size_t) A * L); s->pAAr.resize((size_t) A * L); s->p3r.resize((size_t) A * L);
+    s->cbAA.resize(L); s->cbSS.resize(L);
+    s->rAA.assign(qAA, qAA + L); s->r3Di.assign(q3di, q3di + L);
+    std::reverse(s->rAA.begin(), s->rAA.end());
+    std::reverse(s->r3Di.begin(), s->r3Di.end());
+    int rc = alignProfiles(s->matAA, s->mat3Di, qAA, q3di, L, par.compBiasCorrection != 0, par.alnCompBiasScale, s->pAAf.data(), s->p3f.data(),
+                           s->cbAA.data(), s->cbSS.data());
+    if (rc == FSGPU_OK)
+        rc = alignProfiles(s->matAA, s->mat3Di, s->rAA.data(), s->r3Di.data(), L, par.compBiasCorrection != 0, par.alnCompBiasScale,
+                           s->pAAr.data(), s->p3r.data(), nullptr, nullptr);
+    if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
+    s->fwd.resize(n); s->rev.resize(n);
+    rc = fsgpu_sw_batch(s->ctx, useAA ? s->pAAf.data() : nullptr, s->p3f.data(), useAA ? s->pAAr.data() : nullptr, s->p3r.data(), L,
+                        targetIds, n, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
+    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+
+    s->cigars.clear();
+    int passedNum = 0, rejected = 0, nres = 0;
+    for (int k = 0; k < n && passedNum < par.maxAccept && rejected < par.maxRejected; k++) {
+        const uint32_t tid = targetIds[k];
+        const bool isIdentity = ((int64_t) tid == identityId);
+        if (tid >= s->keys.size()) { s->err = "target id out of range"; return FSGPU_E_ARG; }
+        const int Lt = s->lengths[tid];
+        if (!canBeCovered(par.covThr, par.covMode, (float) L, (float) Lt)) { rejected++; continue; }
+        // ---- alignStructure ----
+        const fsgpu_swres &f = s->fwd[k];
+        float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
+        if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) { rejected++; continue; }
+        double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, lambda, mu);
+        if (evalue > par.evalThr) { rejected++; continue; }
+        const int32_t score = f.score - s->rev[k].score;
+        evalue = s->evaluer.computeEvalueCorr(score, lambda, mu);
+        if (evalue > par.evalThr) { rejected++; continue; }
+        // start position + backtrace on the host (block aligner), only for hits that survived both gates
+        s->tAA.resize(Lt); s->t3Di.resize(Lt);
+        for (int i = 0; i < Lt; i++) {          // padded-DB codes: +32 = soft-masked, same letter for the aligner
+            uint8_t c = s->data3di[s->offsets[tid] + i];
+            c = c >= 32 ? c - 32 : c;
+            s->t3Di[i] = c > 20 ? 20 : c;
+            uint8_t a = s->dataAA ? s->dataAA[s->offsets[tid] + i] : 20;
+            a = a >= 32 ? a - 32 : a;
+            s->tAA[i] = a > 20 ? 20 : a;
+        }
+        BlockAlnOut bo;
+        blockBacktrace(s->matAA, s->mat3Di, qAA, q3di, s->cbAA.data(), s->cbSS.data(), L, s->tAA.data(), s->t3Di.data(), Lt, f.qEnd, f.dbEnd,
+                       f.score, par.gapOpen, par.gapExtend, bo);
+        fshost_result r;
+        memset(&r, 0, sizeof(r));
+        int qStart = -1, dbStart = -1;
+        float seqId = 0.0f;
+        if (bo.ok) {
+            qStart = bo.qStart; dbStart = bo.dbStart;
+            qCov = computeCov(qStart, f.qEnd, L);
+            tCov = computeCov(dbStart, f.dbEnd, Lt);
+        }
+        unsigned int alnLength = std::max(abs(f.qEnd - qStart), abs(f.dbEnd - dbStart)) + 1;   // Matcher::computeAlnLength
+        if (bo.backtrace.size() > 0) {
+            alnLength = bo.backtrace.size();
+            seqId = static_cast<float>(bo.identicalAA) / static_cast<float>(alnLength);          // SEQ_ID_ALN_LEN
+        }
+        r.dbKey = s->keys[tid]; r.score = score; r.qcov = qCov; r.dbcov = tCov; r.seqId = seqId; r.eval = evalue;
+        r.alnLength = alnLength; r.qStartPos = qStart; r.qEndPos = f.qEnd; r.qLen = L; r.dbStartPos = dbStart; r.dbEndPos = f.dbEnd;
+        r.dbLen = Lt; r.backtraceOff = (uint32_t) s->cigars.size(); r.backtraceLen = (uint32_t) bo.backtrace.size();
+        // Alignment::checkCriteria (Alignment.cpp:548)
+        const bool evalOk = (r.eval <= par.evalThr);
+        const bool seqIdOK = (r.seqId >= par.seqIdThr);
+        const bool covOK = hasCoverage(par.covThr, par.covMode, r.qcov, r.dbcov);
+        const bool alnLenOK = (int) r.alnLength >= par.alnLenThr;
+        if (isIdentity || (evalOk && seqIdOK && covOK && alnLenOK)) {
+            s->cigars.append(bo.backtrace);
+            s->cigars.push_back('\0');
+            results[nres++] = r;
+            passedNum++;
+            rejected = 0;
+        } else {
+            rejected++;
+        }
+    }
+    if (nres > 1) std::sort(results, results + nres, compareHits);
+    return nres;
+}
+
+const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r) { return s->cigars.c_str() + r->backtraceOff; }
+
+void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev) {
+    *fwd = s->fwd.data();
+    *rev = s->rev.data();
+}
+
+// ---- text formats --------------------------------------------------------------------------------------------
+static char *putU64(char *p, uint64_t v) {
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char) ('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+static char *putI32(char *p, int32_t v) {
+    if (v < 0) { *p++ = '-'; return putU64(p, (uint64_t) (-(int64_t) v)); }
+    return putU64(p, (uint64_t) v);
+}
+
+size_t fshost_format_prefilter_hit(char *buf, uint32_t key, int score, int diagonal) {
+    char *p = putU64(buf, key);
+    *p++ = '\t';
+    p = putI32(p, score);
+    *p++ = '\t';
+    p = putI32(p, (int32_t) (short) diagonal);
+    *p++ = '\n';
+    *p = '\0';
+    return (size_t) (p - buf);
+}
+
+size_t fshost_format_result(char *buf, const fshost_result *r, const char *backtrace, int addBacktrace) {
+    char *p = putU64(buf, r->dbKey);
+    *p++ = '\t';
+    p = putI32(p, r->score);
+    *p++ = '\t';
+    // Util::fastSeqIdToBuffer (Util.cpp:251-279)
+    if (r->seqId == 1.0) {
+        memcpy(p, "1.000", 5); p += 5;
+    } else {
+        *p++ = '0'; *p++ = '.';
+        if (r->seqId < 0.10) *p++ = '0';
+        if (r->seqId < 0.01) *p++ = '0';
+        p = putI32(p, (int) (r->seqId * 1000));
+    }
+    *p++ = '\t';
+    p += snprintf(p, 32, "%.3E", r->eval);
+    *p++ = '\t';
+    p = putI32(p, r->qStartPos); *p++ = '\t';
+    p = putI32(p, r->qEndPos); *p++ = '\t';
+    p = putI32(p, (int32_t) r->qLen); *p++ = '\t';
+    p = putI32(p, r->dbStartPos); *p++ = '\t';
+    p = putI32(p, r->dbEndPos); *p++ = '\t';
+    p = putI32(p, (int32_t) r->dbLen);
+    if (addBacktrace) {
+        *p++ = '\t';
+        // Matcher::compressAlignment (Matcher.cpp:168-186): run-length encode, first state 'M'
+        const char *bt = backtrace ? backtrace : "";
+        char state = 'M';
+        size_t counter = 0;
+        for (size_t i = 0; bt[i]; ++i) {
+            if (bt[i] != state) {
+                p = putU64(p, counter);
+                *p++ = state;
+                state = bt[i];
+                counter = 1;
+            } else {
+                counter++;
+            }
+        }
+        p = putU64(p, counter);
+        *p++ = state;
+    }
+    *p++ = '\n';
+    *p = '\0';
+    return (size_t) (p - buf);
+}
+
+} // extern "C"

@@ -1,0 +1,139 @@
+// k_gapless.hpp -- exhaustive gapless (ungapped-diagonal) scan of every target, gfx950.
+//
+// Semantics: SmithWaterman::ungapped_alignment (reference M/src/alignment/StripedSmithWaterman.cpp:1817-1876):
+//   S(q,i) = sat_u8(S(q-1,i-1) + prof) -sat bias ;  score = max S.   Because the profile carries +bias and
+//   the only clamp that can bind before the maximum is taken is the upper one, this equals
+//   min(255 - bias, best local run sum along any diagonal)   (proof sketch in DESIGN.md; pinned by tests).
+//
+// Mapping (not the CPU's striping, not a CUDA warp tiling):
+//   * 8 lanes x 2 strips x R registers hold one target's DP column; 8 targets per wave64.
+//   * scores live in packed int16 pairs biased by INT16_MIN: v_pk_add_i16 clamp performs "add, floor at zero"
+//     in ONE instruction, v_pk_max_i16 the running maximum -> 2 VALU ops per 2 cells.
+//   * the 22 x (16R) int16 profile sits in LDS in a 2-copy, bank-row aligned image: all ds_read_b128 are
+//     conflict free (fs_kernels.h).  LDS bytes/cell = 2, VALU ops/cell = 1: the two CU resources are balanced.
+//   * the target DB is pre-tiled in HBM as 8-target stripes interleaved at 16-byte granularity: one wave-level
+//     global load = one 128-byte line, every byte of the DB is read exactly once per query.
+//   * diagonal hand-off between lanes: v_mov_b32_dpp row_shr:1 + v_perm_b32 (no LDS round trip).
+//   * waves pull stripes from an atomic queue ordered by descending length (LPT), so the tail is short.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fs_kernels.h"
+
+namespace fs {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_adds_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+
+struct GaplessArgs {
+    const uint4 *scan;          // stripe-interleaved target residues (codes 0..20, 21 = past end)
+    const uint64_t *stripeOff;  // [nStripes] offset in uint4 units
+    const uint32_t *stripeLen;  // [nStripes] length in 16-column chunks
+    const uint32_t *order;      // [nStripes] stripe ids, longest first
+    uint32_t nStripes;
+    uint32_t nTargets;
+    const int8_t *pssm;         // [21][L] query profile (device copy)
+    int L;
+    int cap;                    // min(cap, score)
+    uint8_t *scores;            // [nTargets]
+    uint32_t *queue;            // work counter, zeroed before launch
+};
+
+template <int R>
+__global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
+    static_assert(R % 4 == 0 && R >= 4 && R <= kGaplessMaxR, "R must be a multiple of 4");
+    constexpr int ROWB = gaplessRowBytes(R);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- build the LDS image from the int8 pssm (once per workgroup) ----
+    {
+        const int L = a.L;
+        constexpr int nDw = (kAlphabet + 1) * (R / 4) * 2 * 8 * 4;  // dwords incl. both copies
+        for (int idx = threadIdx.x; idx < nDw; idx += blockDim.x) {
+            int w = idx & 3, g = (idx >> 2) & 7, copy = (idx >> 5) & 1;
+            int k = (idx >> 6) % (R / 4), row = (idx >> 6) / (R / 4);
+            int r = 4 * k + w;
+            int qlo = g * 2 * R + r, qhi = qlo + R;
+            uint32_t v;
+            if (row == kDeadCode) {
+                v = kFloor2;
+            } else {
+                int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
+                int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
+                v = ((uint32_t) (uint16_t) (int16_t) lo) | (((uint32_t) (uint16_t) (int16_t) hi) << 16);
+            }
+            *(uint32_t *) (smem + row * ROWB + k * 256 + copy * 128 + g * 16 + w * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int j = lane >> 3;          // target slot inside the stripe
+    const int g = lane & 7;           // lane inside the target group
+    const uint32_t laneOff = (uint32_t) (((j >> 1) & 1) * 128 + g * 16);
+    // v_perm selector for the hand-off: lo half <- hi half of the previous lane's last register,
+    // hi half <- lo half of my own last register.  {S0 = prev (bytes 4..7), S1 = own (bytes 0..3)}
+    const uint32_t sel = 0x01000706u;
+
+    for (;;) {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(a.queue, 1u);
+        w = __builtin_amdgcn_readfirstlane(w);
+        if (w >= a.nStripes) break;
+        const uint32_t stripe = a.order[w];
+        const uint32_t len16 = a.stripeLen[stripe];
+        const uint4 *src = a.scan + a.stripeOff[stripe] + j;
+
+        uint32_t S[R];
+        uint32_t M = kFloor2;
+#pragma unroll
+        for (int r = 0; r < R; r++) S[r] = kFloor2;
+
+        uint4 nxt = src[0];
+        for (uint32_t c = 0; c < len16; c++) {
+            const uint4 cur = nxt;
+            if (c + 1 < len16) nxt = src[(size_t) (c + 1) * 8];
+            const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t code = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                const unsigned char *rowp = smem + code * ROWB + laneOff;
+                uint32_t P[R];
+#pragma unroll
+                for (int k = 0; k < R / 4; k++) {
+                    const uint4 v = *(const uint4 *) (rowp + k * 256);
+                    P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
+                }
+                // diagonal hand-off
+                uint32_t prev = __builtin_amdgcn_update_dpp(kFloor2, S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+                prev = (g == 0) ? kFloor2 : prev;
+                const uint32_t in = __builtin_amdgcn_perm(prev, S[R - 1], sel);
+#pragma unroll
+                for (int r = R - 1; r >= 1; r--) {
+                    S[r] = pk_adds_i16(S[r - 1], P[r]);
+                    M = pk_max_i16(M, S[r]);
+                }
+                S[0] = pk_adds_i16(in, P[0]);
+                M = pk_max_i16(M, S[0]);
+            }
+        }
+        // max over both strips and the 8 lanes of the group
+        int m = max((int) (int16_t) (M & 0xffff), (int) (int16_t) (M >> 16));
+        m = max(m, __shfl_xor(m, 1));
+        m = max(m, __shfl_xor(m, 2));
+        m = max(m, __shfl_xor(m, 4));
+        const uint32_t tid = stripe * kStripeTargets + j;
+        if (g == 0 && tid < a.nTargets) {
+            int sc = m + 32768;
+            sc = sc < a.cap ? sc : a.cap;
+            a.scores[tid] = (uint8_t) sc;
+        }
+    }
+}
+
+} // namespace fs

@@ -1,0 +1,291 @@
+// k_sw.hpp -- dual-profile (3Di + AA) affine-gap local alignment, score + end position, gfx950.
+//
+// Semantics: StructureSmithWaterman::sw_sse2_word / sw_sse2_int (reference F/src/commons/StructureSmithWaterman.cpp:
+// 1093-1322, 1325-1554) INCLUDING the striped kernel's quirk that the horizontal gap state E only sees vertical
+// gaps opened inside the same stripe segment (lazy-F never updates E, :1230).  In row order that is
+//     Hm = max(sat(Hdiag + s), E, Fseg)     t  = max(Hm - go, 0)
+//     E' = max(E - ge, 0, t)                Fseg' = max(Fseg - ge, 0, t), reset to 0 at rows q % segLen == 0
+//     Ffull' = max(Ffull - ge, 0, t)        H  = max(Hm, Ffull)
+// (oracle/fs_oracle.c: fso_sw_rowmajor is the CPU statement of the same recurrence, tested against the literal
+// lane-by-lane emulation and against the reference's compiled code).  Tie-breaks: first target column that reaches
+// the maximum, then the smallest query row in that column (:1271-1292).
+//
+// Mapping: one wave64 per (query, target) pair; lane l owns R consecutive query rows; lanes run the anti-diagonal
+// wavefront (lane l works on target column s - l at step s).  Everything that crosses a lane boundary -- H of the
+// row above, both F chains, and the target residue itself -- rides a one-lane-per-step conveyor built from
+// v_mov_b32_dpp wave_shr:1.  The forward-query and reversed-query passes of structurealign (structurealign.cpp:46,65)
+// share the target and the control flow, so they are packed into the two int16 halves of every register:
+// v_pk_add_i16 clamp reproduces _mm256_adds_epi16, v_pk_sub_u16 clamp reproduces _mm256_subs_epu16.
+// Pairs whose int16 score saturates (32767) are re-run by the int32 instantiation with segLen = ceil(L/8), as
+// alignScoreEndPos does (:313-336).  Queries longer than 64*R rows are processed in row tiles; the three
+// boundary values per target column travel between tile launches through HBM (border arrays).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fs_kernels.h"
+#include "k_gapless.hpp"   // packed helpers
+
+namespace fs {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+struct Pk16 {                        // two independent int16 problems per register (lo: forward, hi: reversed query)
+    static constexpr bool packed = true;
+    static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, (s16x2) (__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b)));
+    }
+    static __device__ __forceinline__ uint32_t adds(uint32_t a, uint32_t b) { return pk_adds_i16(a, b); }
+    static __device__ __forceinline__ uint32_t max(uint32_t a, uint32_t b) { return pk_max_i16(a, b); }
+    static __device__ __forceinline__ uint32_t subus(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+    }
+    // per-half all-ones where a > b (values are non-negative)
+    static __device__ __forceinline__ uint32_t gtMask(uint32_t a, uint32_t b) {
+        uint32_t d = subus(a, b);
+        u16x2 one = {1, 1};
+        u16x2 x = __builtin_elementwise_min(__builtin_bit_cast(u16x2, d), one);
+        u16x2 z = {0, 0};
+        return __builtin_bit_cast(uint32_t, (u16x2) (z - x));
+    }
+    static __device__ __forceinline__ uint32_t splat(uint32_t v) { return (v & 0xffffu) | (v << 16); }
+};
+
+struct I32 {                         // one int32 problem per register (re-run of saturated pairs)
+    static constexpr bool packed = false;
+    static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return a + b; }
+    static __device__ __forceinline__ uint32_t adds(uint32_t a, uint32_t b) { return a + b; }
+    static __device__ __forceinline__ uint32_t max(uint32_t a, uint32_t b) { return (uint32_t) ::max((int) a, (int) b); }
+    static __device__ __forceinline__ uint32_t subus(uint32_t a, uint32_t b) { return (uint32_t) ::max((int) a - (int) b, 0); }
+    static __device__ __forceinline__ uint32_t gtMask(uint32_t a, uint32_t b) { return ((int) a > (int) b) ? 0xffffffffu : 0u; }
+    static __device__ __forceinline__ uint32_t splat(uint32_t v) { return v; }
+};
+
+struct SwArgs {
+    const uint8_t *aa;            // plain target AA codes (unmasked), may be NULL when !HAS_AA
+    const uint8_t *ss;            // plain target 3Di codes (unmasked)
+    const uint64_t *offsets;
+    const int32_t *lengths;
+    const uint32_t *targetIds;    // [nPairs]
+    int nPairs;
+    const uint32_t *profSS;       // LDS image of this tile, [21][64R] dwords
+    const uint32_t *profAA;
+    int tileBase;                 // first query row of this tile
+    int rowsInTile;               // valid rows (<= 64R)
+    int segLen;                   // ceil(L/16) for the int16 pass, ceil(L/8) for the int32 pass
+    uint32_t go, ge;              // gap open / extend, splat for the arithmetic in use
+    int tileIn, tileOut;          // this launch continues / is continued by another row tile
+    const uint32_t *borderIn;     // [nPairs][borderStride][3]
+    uint32_t *borderOut;
+    uint32_t borderStride;
+    uint64_t *keys;               // [nPairs][2] running best across tiles (packed: fwd, rev; int32: slot 0)
+    int32_t *res0;                // fsgpu_swres[nPairs] as int32 x4 (packed: forward; int32: the direction re-run)
+    int32_t *res1;                // packed only: reversed query
+};
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
+    return __builtin_amdgcn_update_dpp(0u, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
+
+template <int R>
+__device__ __forceinline__ void swLoadRow(const unsigned char *rowBase, int lane, uint32_t (&P)[R]) {
+    constexpr int full = (R / 4) * 4;
+#pragma unroll
+    for (int k = 0; k < R / 4; k++) {
+        const uint4 v = *(const uint4 *) (rowBase + (k * 256 + lane * 4) * 4);
+        P[4 * k] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
+    }
+    constexpr int rem = R % 4;
+    if constexpr (rem >= 2) {
+        const uint2 v = *(const uint2 *) (rowBase + ((R / 4) * 256 + lane * 2) * 4);
+        P[full] = v.x; P[full + 1] = v.y;
+        if constexpr (rem == 3) P[full + 2] = *(const uint32_t *) (rowBase + ((R / 4) * 256 + 128 + lane) * 4);
+    } else if constexpr (rem == 1) {
+        P[full] = *(const uint32_t *) (rowBase + ((R / 4) * 256 + lane) * 4);
+    }
+}
+
+__device__ __forceinline__ uint64_t waveMaxU64(uint64_t k) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t lo = __shfl_xor((uint32_t) k, d), hi = __shfl_xor((uint32_t) (k >> 32), d);
+        uint64_t o = ((uint64_t) hi << 32) | lo;
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+template <int R, bool HAS_AA, typename A>
+__global__ __launch_bounds__(512) void k_sw(SwArgs a) {
+    constexpr int ROWB = swRowDwords(R) * 4;
+    constexpr int TBL = kAlphabet * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const uint4 *s3 = (const uint4 *) a.profSS;
+        uint4 *d3 = (uint4 *) smem;
+        for (int i = threadIdx.x; i < TBL / 16; i += blockDim.x) d3[i] = s3[i];
+        if constexpr (HAS_AA) {
+            const uint4 *sa = (const uint4 *) a.profAA;
+            uint4 *da = (uint4 *) (smem + TBL);
+            for (int i = threadIdx.x; i < TBL / 16; i += blockDim.x) da[i] = sa[i];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wavesPerBlock = blockDim.x >> 6;
+    const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6));
+    if (pair >= a.nPairs) return;
+
+    // wave-uniform pair parameters -> SGPRs, scalar loop control
+    const uint32_t tid = __builtin_amdgcn_readfirstlane(a.targetIds[pair]);
+    const int Lt = __builtin_amdgcn_readfirstlane(a.lengths[tid]);
+    const uint64_t off64 = a.offsets[tid];
+    const uint64_t off = ((uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) (off64 >> 32)) << 32) |
+                         (uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) off64);
+    const int nLanes = a.tileOut ? 64 : (a.rowsInTile + R - 1) / R;
+    const int steps = Lt > 0 ? Lt + nLanes - 1 : 0;
+    const bool laneActive = lane < nLanes;
+
+    // segment-start masks for my rows
+    uint32_t segmask[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) segmask[r] = ((a.tileBase + lane * R + r) % a.segLen == 0) ? 0u : 0xffffffffu;
+
+    uint32_t E[R], Hp[R], snap[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { E[r] = 0; Hp[r] = 0; snap[r] = 0; }
+    uint32_t best = 0, bestcol = 0;
+    uint32_t hOut = 0, fsegOut = 0, ffullOut = 0, hUpPrev = 0, tval = 0;
+    uint32_t chunkCur = 0, chunkNxt = 0;
+    uint32_t bh = 0, bfs = 0, bff = 0, bhN = 0, bfsN = 0, bffN = 0;   // border-in chunks
+    uint32_t oh = 0, ofs = 0, off_ = 0;                                // border-out accumulators
+    const size_t bBase = (size_t) pair * a.borderStride;
+
+    auto loadChunk = [&](int s0) -> uint32_t {
+        int col = s0 + lane;
+        uint32_t v = 0;
+        if (col < Lt) {
+            uint32_t c3 = a.ss[off + col];
+            v = c3 * (uint32_t) ROWB;
+            if constexpr (HAS_AA) v |= ((uint32_t) a.aa[off + col] * (uint32_t) ROWB) << 16;
+        }
+        return v;
+    };
+    chunkNxt = loadChunk(0);
+    if (a.tileIn && lane < Lt) {
+        const uint32_t *p = a.borderIn + (bBase + lane) * 3;
+        bhN = p[0]; bfsN = p[1]; bffN = p[2];
+    }
+
+    for (int s = 0; s < steps; s++) {
+        if ((s & 63) == 0) {
+            chunkCur = chunkNxt;
+            chunkNxt = loadChunk(s + 64);
+            if (a.tileIn) {
+                bh = bhN; bfs = bfsN; bff = bffN;
+                int col = s + 64 + lane;
+                if (col < Lt) {
+                    const uint32_t *p = a.borderIn + (bBase + col) * 3;
+                    bhN = p[0]; bfsN = p[1]; bffN = p[2];
+                }
+            }
+        }
+        // ---- conveyor: everything moves one lane down per step ----
+        uint32_t hUpNew = wave_shr1(hOut);
+        uint32_t fsegIn = wave_shr1(fsegOut);
+        uint32_t ffullIn = wave_shr1(ffullOut);
+        tval = wave_shr1(tval);
+        {
+            const uint32_t tv = __builtin_amdgcn_readlane(chunkCur, s & 63);
+            if (lane == 0) tval = tv;
+            if (a.tileIn) {
+                const uint32_t x0 = __builtin_amdgcn_readlane(bh, s & 63);
+                const uint32_t x1 = __builtin_amdgcn_readlane(bfs, s & 63);
+                const uint32_t x2 = __builtin_amdgcn_readlane(bff, s & 63);
+                if (lane == 0) { hUpNew = x0; fsegIn = x1; ffullIn = x2; }
+            }
+        }
+        const int col = s - lane;
+        if (laneActive && col >= 0 && col < Lt) {
+            uint32_t P3[R], PA[R];
+            swLoadRow<R>(smem + (tval & 0xffffu), lane, P3);
+            if constexpr (HAS_AA) swLoadRow<R>(smem + TBL + (tval >> 16), lane, PA);
+            uint32_t diag = hUpPrev, fseg = fsegIn, ffull = ffullIn, cm = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t sc = P3[r];
+                if constexpr (HAS_AA) sc = A::add(PA[r], sc);
+                uint32_t h = A::adds(diag, sc);
+                h = A::max(h, E[r]);
+                fseg &= segmask[r];
+                h = A::max(h, fseg);
+                const uint32_t t = A::subus(h, a.go);
+                E[r] = A::max(A::subus(E[r], a.ge), t);
+                const uint32_t hf = A::max(h, ffull);
+                fseg = A::max(A::subus(fseg, a.ge), t);
+                ffull = A::max(A::subus(ffull, a.ge), t);
+                diag = Hp[r];
+                Hp[r] = hf;
+                cm = A::max(cm, hf);
+            }
+            hOut = Hp[R - 1]; fsegOut = fseg; ffullOut = ffull;
+            const uint32_t nb = A::max(best, cm);
+            if (nb != best) {
+                const uint32_t m = A::gtMask(cm, best);
+                const uint32_t cp = A::splat((uint32_t) col);
+                bestcol = (m & cp) | (~m & bestcol);
+#pragma unroll
+                for (int r = 0; r < R; r++) snap[r] = (m & Hp[r]) | (~m & snap[r]);
+                best = nb;
+            }
+        }
+        hUpPrev = hUpNew;
+        if (a.tileOut) {
+            const int c63 = s - 63;
+            if (c63 >= 0 && c63 < Lt) {
+                const uint32_t x0 = __builtin_amdgcn_readlane(hOut, 63);
+                const uint32_t x1 = __builtin_amdgcn_readlane(fsegOut, 63);
+                const uint32_t x2 = __builtin_amdgcn_readlane(ffullOut, 63);
+                const int slot = c63 & 63;
+                if (lane == slot) { oh = x0; ofs = x1; off_ = x2; }
+                if (slot == 63 || c63 == Lt - 1) {
+                    if (lane <= slot) {
+                        uint32_t *p = a.borderOut + (bBase + (size_t) (c63 - slot + lane)) * 3;
+                        p[0] = oh; p[1] = ofs; p[2] = off_;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- per-lane candidate -> wave reduction with the reference's tie-breaks ----
+    constexpr int NDIR = A::packed ? 2 : 1;
+#pragma unroll
+    for (int d = 0; d < NDIR; d++) {
+        uint32_t b, c;
+        if constexpr (A::packed) { b = (best >> (16 * d)) & 0xffffu; c = (bestcol >> (16 * d)) & 0xffffu; }
+        else { b = best; c = bestcol; }
+        int row = 0;
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) {
+            uint32_t v;
+            if constexpr (A::packed) v = (snap[r] >> (16 * d)) & 0xffffu; else v = snap[r];
+            if (v == b) row = r;
+        }
+        const uint32_t q = (uint32_t) (a.tileBase + lane * R + row);
+        uint64_t key = ((uint64_t) b << 32) | ((uint64_t) (0xffffu - (c & 0xffffu)) << 16) | (uint64_t) (0xffffu - (q & 0xffffu));
+        key = waveMaxU64(key);
+        if (a.tileIn) { const uint64_t pk = a.keys[(size_t) pair * 2 + d]; key = pk > key ? pk : key; }
+        if (lane == 0) {
+            if (a.tileOut) {
+                a.keys[(size_t) pair * 2 + d] = key;
+            } else {
+                int32_t *res = (d == 0 ? a.res0 : a.res1) + (size_t) pair * 4;
+                res[0] = (int32_t) (key >> 32);
+                res[1] = (int32_t) (0xffffu - (uint32_t) (key & 0xffffu));
+                res[2] = (int32_t) (0xffffu - (uint32_t) ((key >> 16) & 0xffffu));
+                res[3] = A::packed ? 1 : 2;
+            }
+        }
+    }
+}
+
+} // namespace fs

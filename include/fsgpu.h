@@ -1,0 +1,130 @@
+/*
+ * fsgpu.h -- C ABI of the MI355X-native Foldseek hot path (prefilter + structure alignment).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, never throws, never exits.
+ * Every entry point returns 0 on success or a negative FSGPU_E_* code; fsgpu_last_error() gives the text.
+ * One context per GPU and per host thread (the reference's single-caller Marv contract,
+ * M/src/prefiltering/ungappedprefilter.cpp:124-158,207).
+ *
+ * Reference interfaces these replace (M/ = lib/mmseqs of the reference tree, F/ = its root):
+ *   fsgpu_create / fsgpu_destroy      Marv::Marv / ~Marv                      M/lib/libmarv/src/marv.h:6-27
+ *   fsgpu_db_load                     Marv::loadDb + Marv::setDb              M/lib/libmarv/src/marv.h:37-43,
+ *                                                                             call site ungappedprefilter.cpp:150-155
+ *   fsgpu_db_adopt_device             (none: the reference has no collective; lets the caller hand over a
+ *                                      buffer that an RCCL broadcast already placed in HBM)
+ *   fsgpu_gapless_scan                Marv::scan                              M/lib/libmarv/src/marv.h:45-51,
+ *                                     + the filter/sort tail of runFilterOnCpu ungappedprefilter.cpp:450-470
+ *                                     (score semantics = SmithWaterman::ungapped_alignment,
+ *                                      M/src/alignment/StripedSmithWaterman.cpp:1817-1876, i.e. capped at 255-bias)
+ *   fsgpu_sw_batch                    StructureSmithWaterman::alignScoreEndPos x2 (forward query, reversed query)
+ *                                     F/src/commons/StructureSmithWaterman.cpp:263-362, call sites
+ *                                     F/src/strucclustutils/structurealign.cpp:46-47,65-67
+ *   fshost_*                          host-side pieces of the same path that stay on the CPU, exported so the
+ *                                     reference-side adapter and the tests can reach them.
+ */
+#ifndef FSGPU_H
+#define FSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSGPU_ALPHABET 21          /* 20 states + X, order ACDEFGHIKLMNPQRSTVWYX (M/src/commons/DBReader.cpp:353-361) */
+#define FSGPU_MAX_SEQ_LEN 65535    /* Parameters::maxSeqLen default, M/src/commons/Parameters.cpp:2496 */
+
+enum {
+    FSGPU_OK = 0,
+    FSGPU_E_ARG = -1,        /* bad argument */
+    FSGPU_E_HIP = -2,        /* a HIP runtime call failed (text in fsgpu_last_error) */
+    FSGPU_E_NODB = -3,       /* no database loaded / AA part missing */
+    FSGPU_E_UNSUPPORTED = -4,/* parameter combination not implemented on the device path */
+    FSGPU_E_NOMEM = -5
+};
+
+typedef struct fsgpu_ctx fsgpu_ctx;
+
+/* == Marv::Result without the unused end positions (M/lib/libmarv/src/marv.h:16-28): id = target index in the
+ * loaded DB (the caller maps it to a key with DBReader::getDbKey), score = gapless diagonal score. */
+typedef struct {
+    uint32_t id;
+    int32_t score;
+} fsgpu_hit;
+
+/* == the fields of StructureSmithWaterman::s_align that alignScoreEndPos fills (StructureSmithWaterman.h:84-109):
+ * score1, qEndPos1, dbEndPos1 and `word` (1: int16 pass final, 2: int32 re-run because score1 hit INT16_MAX). */
+typedef struct {
+    int32_t score;
+    int32_t qEnd;
+    int32_t dbEnd;
+    int32_t word;
+} fsgpu_swres;
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+int fsgpu_create(int device, fsgpu_ctx **out);
+void fsgpu_destroy(fsgpu_ctx *ctx);
+const char *fsgpu_last_error(const fsgpu_ctx *ctx); /* ctx may be NULL: returns the last creation error */
+int fsgpu_device(const fsgpu_ctx *ctx);
+/* HIP stream all kernels of this context are launched on (a hipStream_t), for callers that time with events */
+void *fsgpu_stream(const fsgpu_ctx *ctx);
+
+/* ---- target database -------------------------------------------------------------------------------------- */
+/* data3di/dataAA: the *padded GPU database* byte buffers exactly as makepaddedseqdb writes them
+ * (M/src/util/makepaddedseqdb.cpp:59-109): numeric codes 0..20, +32 when soft-masked, entries padded with 20.
+ * offsets[n+1] in bytes (offsets[n] = end), lengths[n] = residues per entry (index length - 2).
+ * dataAA may be NULL (prefilter only).  Pointers are borrowed for the duration of the call; the DB is copied to HBM
+ * and re-tiled there (coalesced 8-target stripes for the scan, plain unmasked copies for the aligner). */
+int fsgpu_db_load(fsgpu_ctx *ctx, const uint8_t *data3di, const uint8_t *dataAA,
+                  const uint64_t *offsets, const int32_t *lengths, uint64_t n, uint64_t bytes);
+/* Same, but the four buffers already live in this device's HBM (e.g. filled by an RCCL broadcast over xGMI).
+ * The context does not take ownership of them and does not need them after the call returns. */
+int fsgpu_db_adopt_device(fsgpu_ctx *ctx, const void *d_data3di, const void *d_dataAA,
+                          const void *d_offsets, const void *d_lengths, uint64_t n, uint64_t bytes);
+uint64_t fsgpu_db_size(const fsgpu_ctx *ctx);      /* entries */
+uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx);  /* sum of lengths */
+
+/* ---- prefilter: exhaustive gapless diagonal scan ----------------------------------------------------------- */
+/* pssm: int8 [21][L] row-major, pssm[a*L+i] = subMat[a][q_i] + round(compBias_i) -- what runFilterOnGpu hands to
+ *       Marv::scan (ungappedprefilter.cpp:195-203).
+ * scoreCap: 255 - bias of the CPU path (StripedSmithWaterman.cpp:1397-1406); scores are min(cap, best diagonal run),
+ *       which is exactly what the uint8 striped kernel returns.  Pass 0x7fff for uncapped (Marv-like) scores.
+ * Keeps targets with score > minScore (plus identityId if >= 0), orders them by (score desc, id asc)
+ * (hit_t::compareHitsByScoreAndId, QueryMatcher.h:38-48) and returns the first maxRes in out[0..*nout). */
+int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore,
+                       int64_t identityId, int maxRes, fsgpu_hit *out, int *nout);
+/* Raw per-target scores of the last scan (n bytes, already capped); for tests and statistics. */
+int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out);
+/* Asynchronous halves of fsgpu_gapless_scan for callers that pipeline several queries / time the device part:
+ * _launch enqueues profile upload + kernels on the context stream, _finish waits and post-processes. */
+int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore,
+                         int64_t identityId, int maxRes);
+int fsgpu_gapless_finish(fsgpu_ctx *ctx, fsgpu_hit *out, int *nout);
+
+/* ---- alignment: dual-profile striped-semantics affine Smith-Waterman, score + end position ----------------- */
+/* Profiles are the linear int16 word profiles of StructureSmithWaterman::ssw_init (StructureSmithWaterman.cpp:
+ * 1566-1640): pAA[a*L+i] = matAA[a][qAA_i] + cbAA_i, p3Di[a*L+i] = mat3Di[a][q3Di_i] + cbSS_i, a in 0..20,
+ * once for the forward query (_fwd) and once built from the reversed query (_rev, structurealign.cpp:345-347).
+ * pAA_* may be NULL when the AA matrix is all zero (--alignment-type 0).
+ * For every targetIds[k] the call returns alignScoreEndPos(...) of the forward profile in fwd[k] and of the
+ * reversed-query profile in rev[k], bit-identical to the AVX2 striped kernels including the int16->int32 re-run.
+ * Requires gapOpen > gapExtend >= 0 (Foldseek: 10/1); otherwise FSGPU_E_UNSUPPORTED. */
+int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
+                   const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,
+                   const uint32_t *targetIds, int n, int gapOpen, int gapExtend,
+                   fsgpu_swres *fwd, fsgpu_swres *rev);
+int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
+                    const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,
+                    const uint32_t *targetIds, int n, int gapOpen, int gapExtend);
+int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev);
+
+/* ---- instrumentation -------------------------------------------------------------------------------------- */
+/* Device time (ms, HIP events on the context stream) of the dominant kernel of the last _finish()ed call:
+ * which = 0 gapless scan kernel, 1 SW kernel.  Returns < 0 if nothing was recorded. */
+double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSGPU_H */

@@ -1,0 +1,133 @@
+/*
+ * fshost.h -- host-side (CPU) half of the hot path, C ABI.
+ *
+ * Everything here is cheap per-query or per-hit work that the reference also does on the CPU and that must be
+ * bit-identical for the device kernels' inputs/outputs to mean the same thing: substitution matrices, composition
+ * bias, query profiles, the e-value network, hit gating and the result text format.  It lives in libfsgpu.so next
+ * to the device entry points of fsgpu.h; none of it runs a DP on the CPU.
+ *
+ * Reference code each function mirrors (M/ = lib/mmseqs, F/ = repository root of the reference):
+ *   fshost_matrix_*            SubstitutionMatrix ctor / readProbMatrix      M/src/commons/SubstitutionMatrix.cpp:12-58,317-421
+ *                              BaseMatrix::generateSubMatrix                 M/src/commons/BaseMatrix.cpp:96-159
+ *   fshost_comp_bias           SubstitutionMatrix::calcLocalAaBiasCorrection M/src/commons/SubstitutionMatrix.cpp:79-109
+ *   fshost_prefilter_profile   runFilterOnGpu profile + ssw_init bias        M/src/prefiltering/ungappedprefilter.cpp:195-203,
+ *                                                                            M/src/alignment/StripedSmithWaterman.cpp:1375-1406
+ *   fshost_align_profiles      StructureSmithWaterman::ssw_init              F/src/commons/StructureSmithWaterman.cpp:1556-1640
+ *   fshost_evaluer_*           EvalueNeuralNet                               F/src/strucclustutils/EvalueNeuralNet.{h,cpp}
+ *   fshost_search_*            runFilterOnGpu + structurealign per-query body M/src/prefiltering/ungappedprefilter.cpp:41-326,
+ *                                                                            F/src/strucclustutils/structurealign.cpp:318-452
+ */
+#ifndef FSHOST_H
+#define FSHOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "fsgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fshost_matrix fshost_matrix;
+typedef struct fshost_evaluer fshost_evaluer;
+
+enum { FSHOST_MAT_3DI = 0, FSHOST_MAT_BLOSUM62 = 1 };
+
+/* built-in matrices (the parameter data compiled in from foldseek_amd/data/fs_params.h) */
+fshost_matrix *fshost_matrix_create(int which, float bitFactor, float scoreBias);
+/* user matrix in the .out text format (--sub-mat); NULL on parse error */
+fshost_matrix *fshost_matrix_from_text(const char *text, float bitFactor, float scoreBias);
+void fshost_matrix_free(fshost_matrix *m);
+int fshost_matrix_size(const fshost_matrix *m);                 /* alphabet size incl. X (21) */
+const int16_t *fshost_matrix_scores(const fshost_matrix *m);    /* [n*n] bit-scaled substitution scores */
+const double *fshost_matrix_background(const fshost_matrix *m); /* [n] BaseMatrix::pBack */
+/* ASCII -> numeric codes with the reference's letter mapping (lower case = same letter; J->L, U/O->X, Z->E, B->D) */
+void fshost_matrix_encode(const fshost_matrix *m, const char *ascii, int len, uint8_t *codes);
+char fshost_matrix_letter(const fshost_matrix *m, int code);
+
+void fshost_comp_bias(const fshost_matrix *m, const uint8_t *seq, int L, float scale, float *out);
+void fshost_round_bias(const float *cb, int L, int8_t *out);
+
+/* pssm: int8 [n][L]; scoreCap = 255 - bias of the CPU uint8 kernel.  compBias != 0 enables the correction. */
+int fshost_prefilter_profile(const fshost_matrix *m3di, const uint8_t *q3di, int L, int compBias, float scale,
+                             int8_t *pssm, int *scoreCap);
+
+/* pAA/p3Di: int16 [n][L] linear word profiles; cbAA/cbSS (int8 [L], may be NULL) receive the rounded biases.
+ * Both biases are computed against mAA (reference quirk, StructureSmithWaterman.cpp:1565,1570). */
+int fshost_align_profiles(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di,
+                          int L, int compBias, float scale3Di, int16_t *pAA, int16_t *p3Di, int8_t *cbAA, int8_t *cbSS);
+
+/* nnPath NULL: evalue_nn.bin next to libfsgpu.so (foldseek_amd/data/) */
+fshost_evaluer *fshost_evaluer_create(const char *nnPath, uint64_t dbResidues);
+void fshost_evaluer_free(fshost_evaluer *e);
+void fshost_predict_mu_lambda(const fshost_evaluer *e, const uint8_t *q3di, unsigned int L, int alphabetSize,
+                              double *lambda, double *mu);
+double fshost_evalue_corr(const fshost_evaluer *e, double score, double lambda, double mu);
+
+/* ---- one query through prefilter + structurealign (what bench.py times and the module executables call) ---- */
+typedef struct {
+    /* prefilter (ungappedprefilter defaults as set by Foldseek: F/src/workflow/StructureSearch.cpp:101-107) */
+    int maxResListLen;        /* --max-seqs, 1000 */
+    int minDiagScoreThr;      /* --min-ungapped-score, 30 */
+    int compBiasCorrection;   /* --comp-bias-corr, 1 */
+    float prefCompBiasScale;  /* 0.15 */
+    /* structurealign (F/src/commons/LocalParameters.cpp:382-421) */
+    int alignmentType;        /* 0: 3Di only, 2: 3Di+AA */
+    float alnCompBiasScale;   /* 0.5 */
+    int gapOpen, gapExtend;   /* 10, 1 */
+    double evalThr;           /* -e, 10 */
+    float covThr;             /* -c, 0.0 */
+    int covMode;              /* 0 */
+    int addBacktrace;         /* -a */
+    int maxAccept, maxRejected; /* INT_MAX */
+    float seqIdThr;           /* --min-seq-id 0 */
+    int alnLenThr;            /* --min-aln-len 0 */
+} fshost_params;
+
+void fshost_params_default(fshost_params *p);
+
+/* == Matcher::result_t minus the strings (M/src/alignment/Matcher.h:32-49) */
+typedef struct {
+    uint32_t dbKey;
+    int32_t score;
+    float qcov, dbcov, seqId;
+    double eval;
+    uint32_t alnLength;
+    int32_t qStartPos, qEndPos;
+    uint32_t qLen;
+    int32_t dbStartPos, dbEndPos;
+    uint32_t dbLen;
+    uint32_t backtraceOff, backtraceLen;  /* into the cigar buffer of the search handle */
+} fshost_result;
+
+typedef struct fshost_search fshost_search;
+
+/* Binds a device context (with a loaded DB) to matrices/e-value network; keys[n] maps target index -> DB key
+ * (NULL: identity).  data3di/dataAA/offsets/lengths are the host buffers that were given to fsgpu_db_load (the
+ * caller's mmap'd padded DB): like the reference's Marv handle (ungappedprefilter.cpp:124-158) they stay owned by
+ * the caller and must outlive the handle; the backtrace of accepted hits reads target residues from them.
+ * The handle owns its matrices; ctx is borrowed. */
+fshost_search *fshost_search_create(fsgpu_ctx *ctx, const fshost_params *p, const uint32_t *keys, const char *nnPath,
+                                    const uint8_t *data3di, const uint8_t *dataAA, const uint64_t *offsets,
+                                    const int32_t *lengths);
+void fshost_search_free(fshost_search *s);
+const char *fshost_search_error(const fshost_search *s);
+
+/* Prefilter one query: fills hits (capacity maxResListLen) sorted like the reference; returns count or < 0. */
+int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_t identityId, fsgpu_hit *hits);
+/* Align one query against a hit list (target indices); results (capacity n) sorted like structurealign writes them.
+ * Returns number of accepted alignments or < 0. */
+int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
+                        const uint32_t *targetIds, int n, fshost_result *results);
+const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r);
+/* Raw per-pair device results of the last fshost_search_align (n entries each), for tests. */
+void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev);
+
+/* text formats: QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:120-132), Matcher::resultToBuffer (Matcher.cpp:282) */
+size_t fshost_format_prefilter_hit(char *buf, uint32_t key, int score, int diagonal);
+size_t fshost_format_result(char *buf, const fshost_result *r, const char *backtrace, int addBacktrace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

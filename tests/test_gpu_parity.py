@@ -1,0 +1,195 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle on the same seeded inputs.
+Integer work: every comparison is exact (bit-identical scores, positions, hit lists)."""
+import numpy as np
+import pytest
+
+from foldseek_amd import api, synth
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_db():
+    q3, qa = synth.make_queries(6, seed=5, mean_len=250, lo=20, hi=500)
+    # force a spread of query lengths over the kernel's register-tile variants
+    rng = np.random.default_rng(77)
+    for i, L in enumerate((20, 64, 130, 260, 390, 512)):
+        q3[i] = rng.choice(20, size=L).astype(np.uint8)
+        qa[i] = rng.choice(20, size=L).astype(np.uint8)
+    db = synth.make_db(2500, (q3, qa), seed=7, homologs_per_query=40, mask_frac=0.02)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    yield ctx, db, q3, qa
+    ctx.close()
+
+
+def test_db_bookkeeping(small_db):
+    ctx, db, _, _ = small_db
+    assert ctx.n == db.n
+    assert ctx.residues == db.residues
+
+
+@pytest.mark.parametrize("qi", range(6))
+@pytest.mark.parametrize("comp_bias", [True, False])
+def test_gapless_scores_and_hits(small_db, qi, comp_bias):
+    ctx, db, q3, _ = small_db
+    m = api.Matrix(0, 2.0)
+    pssm, cap = api.prefilter_profile(m, q3[qi], comp_bias, 0.15)
+    hits = ctx.gapless_scan(pssm, cap, min_score=30, identity=-1, max_res=300)
+    got = ctx.gapless_scores().astype(np.int32)
+    want = helpers.o_ungapped_scores(q3[qi], db, comp_bias)
+    assert (got == want).all(), np.flatnonzero(got != want)[:10]
+    sel = helpers.o_prefilter_select(want, 30, -1, 300)
+    assert len(hits) == len(sel)
+    assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
+
+
+def test_gapless_identity_and_truncation(small_db):
+    ctx, db, q3, _ = small_db
+    m = api.Matrix(0, 2.0)
+    pssm, cap = api.prefilter_profile(m, q3[3], True, 0.15)
+    want = helpers.o_ungapped_scores(q3[3], db, True)
+    low = int(np.argmin(want))                       # an identity hit that would not pass the score filter
+    for max_res in (1, 7, 50, 100000):
+        hits = ctx.gapless_scan(pssm, cap, min_score=30, identity=low, max_res=max_res)
+        sel = helpers.o_prefilter_select(want, 30, low, max_res)
+        assert len(hits) == len(sel)
+        assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
+    # a high threshold leaves few or no hits
+    hits = ctx.gapless_scan(pssm, cap, min_score=254, identity=-1, max_res=10)
+    assert len(hits) == len(helpers.o_prefilter_select(want, 254, -1, 10))
+
+
+@pytest.mark.parametrize("atype", [2, 0])
+@pytest.mark.parametrize("qi", range(6))
+def test_sw_score_endpos(small_db, qi, atype):
+    ctx, db, q3, qa = small_db
+    mAA = api.Matrix(1, 1.4 if atype == 2 else 0.0)
+    m3 = api.Matrix(0, 2.1)
+    pAf, p3f, _, _ = api.align_profiles(mAA, m3, qa[qi], q3[qi], True, 0.5)
+    pAr, p3r, _, _ = api.align_profiles(mAA, m3, qa[qi][::-1].copy(), q3[qi][::-1].copy(), True, 0.5)
+    rng = np.random.default_rng(qi)
+    ids = np.unique(np.concatenate([rng.integers(0, db.n, size=150), np.arange(db.n - 20, db.n), np.arange(0, 20)])).astype(np.uint32)
+    fwd, rev = ctx.sw_batch(pAf if atype == 2 else None, p3f, pAr if atype == 2 else None, p3r, ids)
+    L = len(q3[qi])
+    for k, t in enumerate(ids):
+        ta, t3 = helpers.target_seqs(db, int(t))
+        for (pA, p3, got) in ((pAf, p3f, fwd[k]), (pAr, p3r, rev[k])):
+            want = helpers.o_sw(pA, p3, L, ta, t3)
+            assert (got["score"], got["qEnd"], got["dbEnd"], got["word"]) == (want["score"], want["qEnd"], want["dbEnd"], want["word"]), \
+                (qi, int(t), got, want)
+
+
+def test_sw_long_query_row_tiles():
+    """query longer than one 512-row tile: borders travel through HBM between tile launches"""
+    rng = np.random.default_rng(123)
+    q3 = [rng.choice(20, size=L).astype(np.uint8) for L in (700, 1300)]
+    qa = [rng.choice(20, size=L).astype(np.uint8) for L in (700, 1300)]
+    db = synth.make_db(300, (q3, qa), seed=11, homologs_per_query=30, hi=1500)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    mAA, m3 = api.Matrix(1, 1.4), api.Matrix(0, 2.1)
+    for qi in range(2):
+        pAf, p3f, _, _ = api.align_profiles(mAA, m3, qa[qi], q3[qi], True, 0.5)
+        pAr, p3r, _, _ = api.align_profiles(mAA, m3, qa[qi][::-1].copy(), q3[qi][::-1].copy(), True, 0.5)
+        ids = np.arange(0, db.n, 3, dtype=np.uint32)
+        fwd, rev = ctx.sw_batch(pAf, p3f, pAr, p3r, ids)
+        for k, t in enumerate(ids):
+            ta, t3 = helpers.target_seqs(db, int(t))
+            for (pA, p3, got) in ((pAf, p3f, fwd[k]), (pAr, p3r, rev[k])):
+                want = helpers.o_sw(pA, p3, len(q3[qi]), ta, t3)
+                assert (got["score"], got["qEnd"], got["dbEnd"], got["word"]) == (want["score"], want["qEnd"], want["dbEnd"], want["word"]), \
+                    (qi, int(t), got, want)
+    ctx.close()
+
+
+def _manual_db(seqs3, seqsa):
+    lens = np.array([len(x) for x in seqs3], dtype=np.int32)
+    order = np.argsort(lens, kind="stable")
+    lens = lens[order]
+    padded = (lens + 3) // 4 * 4
+    offsets = np.zeros(len(lens) + 1, np.int64)
+    offsets[1:] = np.cumsum(padded)
+    d3 = np.full(offsets[-1], 20, np.uint8)
+    da = np.full(offsets[-1], 20, np.uint8)
+    for new, old in enumerate(order):
+        d3[offsets[new]:offsets[new] + lens[new]] = seqs3[old]
+        da[offsets[new]:offsets[new] + lens[new]] = seqsa[old]
+    return synth.PaddedDB(d3, da, offsets, lens)
+
+
+def test_sw_int16_saturation_rerun():
+    """self-alignment of a long sequence exceeds INT16_MAX -> int32 re-run with segLen = ceil(L/8)"""
+    rng = np.random.default_rng(9)
+    L = 3000
+    q3 = rng.choice(20, size=L).astype(np.uint8)
+    qa = rng.choice(20, size=L).astype(np.uint8)
+    seqs3 = [rng.choice(20, size=int(l)).astype(np.uint8) for l in rng.integers(50, 2500, size=14)] + [q3.copy(), q3[100:2900].copy()]
+    seqsa = [rng.choice(20, size=len(x)).astype(np.uint8) for x in seqs3[:14]] + [qa.copy(), qa[100:2900].copy()]
+    db = _manual_db(seqs3, seqsa)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    mAA, m3 = api.Matrix(1, 1.4), api.Matrix(0, 2.1)
+    pAf, p3f, _, _ = api.align_profiles(mAA, m3, qa, q3, True, 0.5)
+    pAr, p3r, _, _ = api.align_profiles(mAA, m3, qa[::-1].copy(), q3[::-1].copy(), True, 0.5)
+    ids = np.arange(db.n, dtype=np.uint32)
+    fwd, rev = ctx.sw_batch(pAf, p3f, pAr, p3r, ids)
+    nsat = 0
+    for k, t in enumerate(ids):
+        ta, t3 = helpers.target_seqs(db, int(t))
+        for (pA, p3, got) in ((pAf, p3f, fwd[k]), (pAr, p3r, rev[k])):
+            want = helpers.o_sw(pA, p3, L, ta, t3)
+            nsat += int(want["word"] == 2)
+            assert (got["score"], got["qEnd"], got["dbEnd"], got["word"]) == (want["score"], want["qEnd"], want["dbEnd"], want["word"]), \
+                (int(t), got, want)
+    assert nsat >= 1
+    ctx.close()
+
+
+def test_unsupported_gap_costs_are_reported(small_db):
+    ctx, db, q3, qa = small_db
+    mAA, m3 = api.Matrix(1, 1.4), api.Matrix(0, 2.1)
+    pAf, p3f, _, _ = api.align_profiles(mAA, m3, qa[1], q3[1], True, 0.5)
+    with pytest.raises(api.FsgpuError):
+        ctx.sw_batch(pAf, p3f, pAf, p3f, np.arange(4, dtype=np.uint32), gap_open=1, gap_extend=1)
+
+
+def test_ragged_and_tiny_database():
+    """n not a multiple of 8, length-1 targets, a target that is all X / all masked"""
+    rng = np.random.default_rng(4)
+    lens = np.array([1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89], dtype=np.int32)
+    padded = (lens + 3) // 4 * 4
+    offsets = np.zeros(len(lens) + 1, np.int64)
+    offsets[1:] = np.cumsum(padded)
+    d3 = np.full(offsets[-1], 20, np.uint8)
+    da = np.full(offsets[-1], 20, np.uint8)
+    for i, l in enumerate(lens):
+        d3[offsets[i]:offsets[i] + l] = rng.integers(0, 20, size=l)
+        da[offsets[i]:offsets[i] + l] = rng.integers(0, 20, size=l)
+    d3[offsets[5]:offsets[5] + 8] = 20                      # all X
+    d3[offsets[6]:offsets[6] + 13] += 32                    # all soft-masked
+    db = synth.PaddedDB(d3, da, offsets, lens)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    q3 = rng.integers(0, 20, size=45).astype(np.uint8)
+    qa = rng.integers(0, 20, size=45).astype(np.uint8)
+    m = api.Matrix(0, 2.0)
+    pssm, cap = api.prefilter_profile(m, q3, True, 0.15)
+    ctx.gapless_scan(pssm, cap, min_score=0, max_res=100)
+    assert (ctx.gapless_scores().astype(np.int32) == helpers.o_ungapped_scores(q3, db, True)).all()
+    mAA, m3 = api.Matrix(1, 1.4), api.Matrix(0, 2.1)
+    pAf, p3f, _, _ = api.align_profiles(mAA, m3, qa, q3, True, 0.5)
+    pAr, p3r, _, _ = api.align_profiles(mAA, m3, qa[::-1].copy(), q3[::-1].copy(), True, 0.5)
+    ids = np.arange(db.n, dtype=np.uint32)
+    fwd, rev = ctx.sw_batch(pAf, p3f, pAr, p3r, ids)
+    for k in range(db.n):
+        ta, t3 = helpers.target_seqs(db, k)
+        want = helpers.o_sw(pAf, p3f, 45, ta, t3)
+        assert (fwd[k]["score"], fwd[k]["qEnd"], fwd[k]["dbEnd"]) == (want["score"], want["qEnd"], want["dbEnd"])
+        want = helpers.o_sw(pAr, p3r, 45, ta, t3)
+        assert (rev[k]["score"], rev[k]["qEnd"], rev[k]["dbEnd"]) == (want["score"], want["qEnd"], want["dbEnd"])
+    # empty hit list
+    fwd, rev = ctx.sw_batch(pAf, p3f, pAr, p3r, np.zeros(0, np.uint32))
+    assert len(fwd) == 0
+    ctx.close()

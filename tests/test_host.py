@@ -1,0 +1,137 @@
+"""CPU tests (no GPU): host-side C++ of libfsgpu.so against the oracle, C-ABI symbol export, formats."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from foldseek_amd import api, synth
+import helpers
+from oracle_lib import load_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(api.LIB_PATH)
+    for hdr in ("fsgpu.h", "fshost.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        names = set(re.findall(r"\b(fs(?:gpu|host)_[a-z0-9_]+)\s*\(", txt))
+        assert names, hdr
+        for n in names:
+            assert hasattr(L, n), f"{n} declared in include/{hdr} but not exported by libfsgpu.so"
+
+
+@pytest.mark.parametrize("which,name,bf", [(0, "MAT3DI", 2.0), (0, "MAT3DI", 2.1), (0, "MAT3DI", 8.0), (1, "BLOSUM62", 1.4),
+                                           (1, "BLOSUM62", 0.0)])
+def test_matrix_matches_oracle(which, name, bf):
+    m = api.Matrix(which, bf, 0.0)
+    sub, pb = helpers.o_submat(name, bf)
+    assert (m.scores().ravel() == sub).all()
+    assert (m.background() == pb).all()
+
+
+def test_matrix_from_text_roundtrip():
+    # rebuild the .out text from the parameter table and parse it back through the user-matrix path
+    import fsparams
+    p = fsparams.load()["MAT3DI"]
+    letters = "ACDEFGHIKLMNPQRSTVWYX"
+    txt = "# 3Di\n# Background (precomputed optional): " + " ".join(repr(float(x)) for x in p["back"]) + "\n"
+    txt += "# Lambda     (precomputed optional): " + repr(float(p["lam"])) + "\n"
+    txt += "    " + "   ".join(letters) + "\n"
+    for i, a in enumerate(letters):
+        txt += a + " " + " ".join(repr(float(x)) for x in p["score"][i]) + "\n"
+    m = api.Matrix(text=txt, bit_factor=2.0)
+    assert (m.scores() == api.Matrix(0, 2.0).scores()).all()
+
+
+def test_letter_mapping():
+    m = api.Matrix(1, 1.4)
+    codes = m.encode("ACDEFGHIKLMNPQRSTVWYXacdjzbuo*")
+    assert list(codes[:21]) == list(range(21))
+    assert list(codes[21:24]) == [0, 1, 2]
+    assert codes[24] == 9 and codes[25] == 3 and codes[26] == 2      # J->L, Z->E, B->D
+    assert (codes[27:] == 20).all()                                  # U, O, * -> X
+
+
+@pytest.mark.parametrize("L", [1, 7, 39, 40, 41, 350, 1500])
+def test_comp_bias_matches_oracle(L):
+    rng = np.random.default_rng(L)
+    for which, name, bf, scale in ((0, "MAT3DI", 2.0, 0.15), (1, "BLOSUM62", 1.4, 1.0), (1, "BLOSUM62", 1.4, 0.5)):
+        seq = rng.integers(0, 21, size=L).astype(np.uint8)
+        m = api.Matrix(which, bf)
+        sub, pb = helpers.o_submat(name, bf)
+        cbf, _ = helpers.o_round_bias(sub, pb, seq, scale)
+        assert (m.comp_bias(seq, scale) == cbf).all()
+
+
+def test_prefilter_profile_matches_oracle():
+    O = load_oracle()
+    rng = np.random.default_rng(3)
+    m = api.Matrix(0, 2.0)
+    sub, pb = helpers.o_submat("MAT3DI", 2.0)
+    for L in (5, 64, 350, 777):
+        q = rng.integers(0, 21, size=L).astype(np.uint8)
+        for cbon in (True, False):
+            pssm, cap = api.prefilter_profile(m, q, cbon, 0.15)
+            cb = helpers.o_round_bias(sub, pb, q, 0.15)[1] if cbon else np.zeros(L, np.int8)
+            bias = O.fso_ungapped_bias(sub.astype(np.int8), 21, cb, L)
+            assert cap == 255 - bias
+            ref = sub.reshape(21, 21)[:, q].astype(np.int32) + cb.astype(np.int32)[None, :]
+            assert (pssm.astype(np.int32) == ref).all()
+
+
+@pytest.mark.parametrize("atype", [0, 2])
+def test_align_profiles_match_oracle(atype):
+    rng = np.random.default_rng(11 + atype)
+    mAA = api.Matrix(1, 1.4 if atype == 2 else 0.0)
+    m3 = api.Matrix(0, 2.1)
+    for L in (3, 100, 350, 1200):
+        qa = rng.integers(0, 21, size=L).astype(np.uint8)
+        q3 = rng.integers(0, 21, size=L).astype(np.uint8)
+        pA, p3, cbA, cbS = api.align_profiles(mAA, m3, qa, q3, True, 0.5)
+        oA, o3, ocA, ocS = helpers.o_align_profiles(qa, q3, atype)
+        assert (pA.ravel() == oA).all() and (p3.ravel() == o3).all()
+        assert (cbA == ocA).all() and (cbS == ocS).all()
+        if atype == 0:
+            assert not pA.any()
+
+
+def test_evalue_network_matches_oracle():
+    O = load_oracle()
+    nn = np.fromfile(os.path.join(ROOT, "foldseek_amd", "data", "evalue_nn.bin"), dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    ev = api.Evaluer(35_000_000)
+    for L in (30, 350, 2000):
+        q = rng.integers(0, 21, size=L).astype(np.uint8)
+        lam, mu = ev.mu_lambda(q)
+        a, b = C.c_double(), C.c_double()
+        O.fso_predict_mu_lambda(nn, q, L, 21, C.byref(a), C.byref(b))
+        assert (lam, mu) == (a.value, b.value)
+        for score in (-20, 0, 31, 80, 250, 3000):
+            assert ev.evalue_corr(score, lam, mu) == O.fso_evalue_corr(score, lam, mu, np.log(35_000_000.0))
+
+
+def test_formats():
+    assert api.format_prefilter_hit(4711, 238, 0) == "4711\t238\t0\n"
+    assert api.format_prefilter_hit(0, 31, 65535) == "0\t31\t-1\n"
+    r = np.zeros(1, api.RESULT_DT)
+    r["dbKey"], r["score"], r["seqId"], r["eval"] = 12, 345, 0.0561, 1.234e-7
+    r["qStartPos"], r["qEndPos"], r["qLen"], r["dbStartPos"], r["dbEndPos"], r["dbLen"] = 0, 99, 100, 3, 104, 120
+    buf = C.create_string_buffer(4096)
+    n = api.lib().fshost_format_result(buf, C.c_void_p(r.ctypes.data), b"MMMIIMDDM", 1)
+    assert buf.raw[:n].decode() == "12\t345\t0.056\t1.234E-07\t0\t99\t100\t3\t104\t120\t3M2I1M2D1M\n"
+    r["seqId"] = 1.0
+    n = api.lib().fshost_format_result(buf, C.c_void_p(r.ctypes.data), None, 0)
+    assert buf.raw[:n].decode().split("\t")[2] == "1.000"
+    r["seqId"] = 0.5
+    n = api.lib().fshost_format_result(buf, C.c_void_p(r.ctypes.data), None, 0)
+    assert buf.raw[:n].decode().split("\t")[2] == "0.500"
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.FsgpuError):
+        api.Context(0)
