@@ -85,6 +85,8 @@ def lib():
         "fshost_search_align": (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
         "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
         "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "fshost_block_backtrace": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32),
+                                         C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
         "fshost_format_prefilter_hit": (C.c_size_t, [C.c_char_p, C.c_uint32, i32, i32]),
         "fshost_format_result": (C.c_size_t, [C.c_char_p, vp, C.c_char_p, i32]),
     }
@@ -318,6 +320,19 @@ class Search:
 
     def __del__(self):
         self.close()
+
+
+def block_backtrace(mAA, m3Di, qAA, q3Di, cbAA, cbSS, tAA, t3Di, q_end, db_end, score, gap_open=10, gap_extend=1):
+    """host start position + backtrace of one hit; returns (ok, qStart, dbStart, identicalAA, backtrace)"""
+    qa, q3 = np.ascontiguousarray(qAA, np.uint8), np.ascontiguousarray(q3Di, np.uint8)
+    ta, t3 = np.ascontiguousarray(tAA, np.uint8), np.ascontiguousarray(t3Di, np.uint8)
+    ca, cs = np.ascontiguousarray(cbAA, np.int8), np.ascontiguousarray(cbSS, np.int8)
+    qs, ds, ident = C.c_int(), C.c_int(), C.c_uint()
+    buf = C.create_string_buffer(len(qa) + len(ta) + 8)
+    ok = lib().fshost_block_backtrace(mAA.h, m3Di.h, _ptr(qa), _ptr(q3), _ptr(ca), _ptr(cs), len(qa), _ptr(ta), _ptr(t3), len(ta),
+                                      int(q_end), int(db_end), int(score), gap_open, gap_extend, C.byref(qs), C.byref(ds), C.byref(ident),
+                                      buf, len(buf))
+    return bool(ok), qs.value, ds.value, ident.value, buf.value.decode()
 
 
 def default_params():

@@ -257,4 +257,20 @@ int fshost_align_profiles(const fshost_matrix *mAA, const fshost_matrix *m3Di, c
     return fsh::alignProfiles(mAA->m, m3Di->m, qAA, q3Di, L, compBias != 0, scale3Di, pAA, p3Di, cbAA, cbSS);
 }
 
+int fshost_block_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di, const int8_t *cbAA,
+                           const int8_t *cbSS, int Lq, const uint8_t *tAA, const uint8_t *t3Di, int Lt, int qEnd, int dbEnd, int score,
+                           int gapOpen, int gapExtend, int *qStart, int *dbStart, unsigned int *identicalAA, char *backtrace, size_t btCap) {
+    fsh::BlockAlnOut o;
+    fsh::blockBacktrace(mAA->m, m3Di->m, qAA, q3Di, cbAA, cbSS, Lq, tAA, t3Di, Lt, qEnd, dbEnd, score, gapOpen, gapExtend, o);
+    if (qStart) *qStart = o.qStart;
+    if (dbStart) *dbStart = o.dbStart;
+    if (identicalAA) *identicalAA = o.identicalAA;
+    if (backtrace && btCap) {
+        size_t n = std::min(btCap - 1, o.backtrace.size());
+        memcpy(backtrace, o.backtrace.data(), n);
+        backtrace[n] = 0;
+    }
+    return o.ok ? 1 : 0;
+}
+
 } // extern "C"

@@ -123,6 +123,16 @@ const char *fshost_search_backtrace(const fshost_search *s, const fshost_result 
 /* Raw per-pair device results of the last fshost_search_align (n entries each), for tests. */
 void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev);
 
+/* Start position + backtrace of one accepted hit on the host (alignStartPosBacktraceBlock,
+ * F/src/commons/StructureSmithWaterman.cpp:369-537): qAA/q3Di/cbAA/cbSS describe the forward query (codes + rounded
+ * composition biases from fshost_align_profiles), tAA/t3Di the unmasked target, (qEnd, dbEnd, score) the forward
+ * alignScoreEndPos result.  Returns 1 and fills qStart/dbStart/identicalAA/backtrace (capacity btCap, NUL terminated)
+ * when the block aligner reproduces `score`, 0 when it does not (the reference then reports start -1 and no backtrace). */
+int fshost_block_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di,
+                           const int8_t *cbAA, const int8_t *cbSS, int Lq, const uint8_t *tAA, const uint8_t *t3Di, int Lt,
+                           int qEnd, int dbEnd, int score, int gapOpen, int gapExtend, int *qStart, int *dbStart,
+                           unsigned int *identicalAA, char *backtrace, size_t btCap);
+
 /* text formats: QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:120-132), Matcher::resultToBuffer (Matcher.cpp:282) */
 size_t fshost_format_prefilter_hit(char *buf, uint32_t key, int score, int diagonal);
 size_t fshost_format_result(char *buf, const fshost_result *r, const char *backtrace, int addBacktrace);

@@ -1,0 +1,162 @@
+"""Known-answer tests for the C++ restatement of the block aligner, ported from the Rust crate's own unit tests
+(reference lib/mmseqs/lib/block-aligner/src/scan_block.rs:2337-2413: test_x_drop, test_trace).  The crate's BLOSUM62 /
+NW1 constants are replaced by matrices that agree with them on the letters the tests use (A, R / A, T, G, C)."""
+import ctypes as C
+import numpy as np
+import pytest
+from foldseek_amd import api
+
+
+class OpLen(C.Structure):
+    _fields_ = [("op", C.c_uint8), ("len", C.c_size_t)]
+
+
+class Gaps(C.Structure):
+    _fields_ = [("open", C.c_int8), ("extend", C.c_int8)]
+
+
+class SizeRange(C.Structure):
+    _fields_ = [("min", C.c_size_t), ("max", C.c_size_t)]
+
+
+class AlignResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("query_idx", C.c_size_t), ("reference_idx", C.c_size_t)]
+
+
+@pytest.fixture(scope="module")
+def ba():
+    L = C.CDLL(api.LIB_PATH)
+    vp = C.c_void_p
+    L.block_new_simple_aamatrix.restype = vp
+    L.block_new_simple_aamatrix.argtypes = [C.c_int8, C.c_int8]
+    L.block_set_aamatrix.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_int8]
+    L.block_new_cigar.restype = vp
+    L.block_new_cigar.argtypes = [C.c_size_t, C.c_size_t]
+    L.block_get_cigar.restype = OpLen
+    L.block_get_cigar.argtypes = [vp, C.c_size_t]
+    L.block_len_cigar.restype = C.c_size_t
+    L.block_len_cigar.argtypes = [vp]
+    L.block_new_padded_aa.restype = vp
+    L.block_new_padded_aa.argtypes = [C.c_size_t, C.c_size_t]
+    L.block_set_bytes_padded_aa.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t]
+    for pre in ("block_new_aa_trace_xdrop", "block_new_aa_trace"):
+        getattr(L, pre).restype = vp
+        getattr(L, pre).argtypes = [C.c_size_t] * 3
+    for pre in ("block_align_aa_trace_xdrop", "block_align_aa_trace"):
+        getattr(L, pre).argtypes = [vp, vp, vp, vp, Gaps, SizeRange, C.c_int32]
+    for pre in ("block_res_aa_trace_xdrop", "block_res_aa_trace"):
+        getattr(L, pre).restype = AlignResult
+        getattr(L, pre).argtypes = [vp]
+    for pre in ("block_cigar_aa_trace_xdrop", "block_cigar_aa_trace"):
+        getattr(L, pre).argtypes = [vp, C.c_size_t, C.c_size_t, vp]
+    for pre in ("block_cigar_eq_aa_trace_xdrop", "block_cigar_eq_aa_trace"):
+        getattr(L, pre).argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
+    return L
+
+
+def padded(L, s, size):
+    p = L.block_new_padded_aa(len(s), size)
+    L.block_set_bytes_padded_aa(p, s, len(s), size)
+    return p
+
+
+def cigar_str(L, cg):
+    names = {1: "M", 2: "=", 3: "X", 4: "I", 5: "D"}
+    out = ""
+    for i in range(L.block_len_cigar(cg)):
+        o = L.block_get_cigar(cg, i)
+        out += f"{o.len}{names[o.op]}"
+    return out
+
+
+def blosum_ar(L):
+    m = L.block_new_simple_aamatrix(1, -1)
+    L.block_set_aamatrix(m, ord("A"), ord("A"), 4)
+    L.block_set_aamatrix(m, ord("A"), ord("R"), -1)
+    L.block_set_aamatrix(m, ord("R"), ord("R"), 5)
+    return m
+
+
+def test_x_drop(ba):
+    L = ba
+    m = blosum_ar(L)
+    g = Gaps(-11, -1)
+    a = L.block_new_aa_trace_xdrop(100, 100, 16)
+    L.block_align_aa_trace_xdrop(a, padded(L, b"AAAAAA", 16), padded(L, b"AAARRA", 16), m, g, SizeRange(16, 16), 1)
+    r = L.block_res_aa_trace_xdrop(a)
+    assert (r.score, r.query_idx, r.reference_idx) == (14, 6, 6)
+    L.block_align_aa_trace_xdrop(a, padded(L, b"A" * 44, 16), padded(L, b"A" * 15 + b"R" * 16 + b"A" * 13, 16), m, g, SizeRange(16, 16), 1)
+    r = L.block_res_aa_trace_xdrop(a)
+    assert (r.score, r.query_idx, r.reference_idx) == (60, 15, 15)
+    a = L.block_new_aa_trace_xdrop(2048, 2048, 2048)
+    s = b"A" * 2048
+    L.block_align_aa_trace_xdrop(a, padded(L, s, 2048), padded(L, s, 2048), m, g, SizeRange(2048, 2048), 100)
+    r = L.block_res_aa_trace_xdrop(a)
+    assert (r.score, r.query_idx, r.reference_idx) == (8192, 2048, 2048)
+
+
+def test_trace(ba):
+    L = ba
+    m = blosum_ar(L)
+    g = Gaps(-11, -1)
+    cg = L.block_new_cigar(100, 100)
+    a = L.block_new_aa_trace(100, 100, 16)
+    q, r = padded(L, b"AAAAAA", 16), padded(L, b"AAARRA", 16)
+    L.block_align_aa_trace(a, q, r, m, g, SizeRange(16, 16), 0)
+    res = L.block_res_aa_trace(a)
+    assert (res.score, res.query_idx, res.reference_idx) == (14, 6, 6)
+    L.block_cigar_eq_aa_trace(a, q, r, res.query_idx, res.reference_idx, cg)
+    assert cigar_str(L, cg) == "3=2X1="
+    q, r = padded(L, b"AAA", 16), padded(L, b"AAAA", 16)
+    L.block_align_aa_trace(a, q, r, m, g, SizeRange(16, 16), 0)
+    res = L.block_res_aa_trace(a)
+    assert (res.score, res.query_idx, res.reference_idx) == (1, 3, 4)
+    L.block_cigar_aa_trace(a, res.query_idx, res.reference_idx, cg)
+    assert cigar_str(L, cg) == "3M1D"
+    nw = L.block_new_simple_aamatrix(1, -1)
+    g2 = Gaps(-2, -1)
+    q, r = padded(L, b"TTTTTTTTAAAAAAATTTTTTTTT", 16), padded(L, b"TTAAAAAAATTTTTTTTTTTT", 16)
+    L.block_align_aa_trace(a, q, r, nw, g2, SizeRange(16, 16), 0)
+    res = L.block_res_aa_trace(a)
+    assert (res.score, res.query_idx, res.reference_idx) == (7, 24, 21)
+    L.block_cigar_aa_trace(a, res.query_idx, res.reference_idx, cg)
+    assert cigar_str(L, cg) == "2M6I16M3D"
+    a = L.block_new_aa_trace(100, 100, 32)
+    q, r = padded(L, b"AAAAAAAAATTGCGCT", 32), padded(L, b"AAAAAAAAAGCGC", 32)
+    L.block_align_aa_trace(a, q, r, nw, g2, SizeRange(32, 32), 0)
+    res = L.block_res_aa_trace(a)
+    assert (res.score, res.query_idx, res.reference_idx) == (8, 16, 13)
+    L.block_cigar_eq_aa_trace(a, q, r, res.query_idx, res.reference_idx, cg)
+    assert cigar_str(L, cg) == "9=2I4=1I"
+    m2 = L.block_new_simple_aamatrix(2, -1)
+    L.block_align_aa_trace(a, q, r, m2, Gaps(-5, -2), SizeRange(32, 32), 0)
+    res = L.block_res_aa_trace(a)
+    assert (res.score, res.query_idx, res.reference_idx) == (14, 16, 13)
+    L.block_cigar_eq_aa_trace(a, q, r, res.query_idx, res.reference_idx, cg)
+    assert cigar_str(L, cg) == "9=2I4=1I"
+
+
+def test_no_x_drop_scores(ba):
+    """scan_block.rs:2267-2334 (test_no_x_drop), the AA and the N-free nucleotide cases"""
+    L = ba
+    m = blosum_ar(L)
+    g = Gaps(-11, -1)
+    a = L.block_new_aa_trace(100, 100, 16)
+
+    def score(q, r, mat=m, gaps=g):
+        L.block_align_aa_trace(a, padded(L, q, 16), padded(L, r, 16), mat, gaps, SizeRange(16, 16), 0)
+        return L.block_res_aa_trace(a).score
+
+    assert score(b"AARA", b"AAAA") == 11
+    assert score(b"AARAAAA", b"AAAAAAAA") == 12
+    assert score(b"AAAA", b"AAAA") == 16
+    assert score(b"RRRR", b"AAAA") == -4
+    assert score(b"AAA", b"AAAA") == 1
+    nw = L.block_new_simple_aamatrix(1, -1)
+    g2 = Gaps(-2, -1)
+    assert score(b"A" * 32, b"A" * 32, nw, g2) == 32
+    assert score(b"T" * 32, b"A" * 32, nw, g2) == -32
+    assert score(b"TA" * 16, b"A" * 32, nw, g2) == 0
+    assert score(b"TTTTTTTTAAAAAAATTTTTTTTT", b"TTAAAAAAATTTTTTTTTTTT", nw, g2) == 7
+    assert score(b"C", b"AAAA", nw, g2) == -5
+    assert score(b"AAAA", b"C", nw, g2) == -5
