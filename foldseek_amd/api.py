@@ -47,6 +47,7 @@ def lib():
         "fsgpu_create": (i32, [i32, C.POINTER(vp)]),
         "fsgpu_destroy": (None, [vp]),
         "fsgpu_last_error": (C.c_char_p, [vp]),
+        "fsgpu_clone": (i32, [vp, C.POINTER(vp)]),
         "fsgpu_device": (i32, [vp]),
         "fsgpu_stream": (vp, [vp]),
         "fsgpu_db_load": (i32, [vp, vp, vp, vp, vp, u64, u64]),
@@ -84,6 +85,7 @@ def lib():
         "fshost_search_prefilter": (i32, [vp, vp, i32, i64, vp]),
         "fshost_search_align": (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
         "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
+        "fshost_search_stats": (None, [vp, vp]),
         "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "fshost_block_backtrace": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32),
                                          C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
@@ -192,13 +194,20 @@ class Evaluer:
 class Context:
     """fsgpu_ctx: one MI355X, one HIP stream, one resident target DB."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _clone_of=None):
         h = C.c_void_p()
-        rc = lib().fsgpu_create(device, C.byref(h))
+        if _clone_of is not None:
+            rc = lib().fsgpu_clone(_clone_of.h, C.byref(h))
+        else:
+            rc = lib().fsgpu_create(device, C.byref(h))
         if rc != 0:
             raise FsgpuError(f"fsgpu_create({device}) rc={rc}: {lib().fsgpu_last_error(None).decode()}")
         self.h = h
-        self._keep = None
+        self._keep = None if _clone_of is None else _clone_of._keep
+
+    def clone(self):
+        """second context (own stream + scratch) sharing this context's resident DB"""
+        return Context(_clone_of=self)
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -300,6 +309,11 @@ class Search:
             bts = [lib().fshost_search_backtrace(self.h, C.c_void_p(res[i:i + 1].ctypes.data)).decode() for i in range(n)]
             return res, bts
         return res
+
+    def stats(self):
+        out = np.zeros(8)
+        lib().fshost_search_stats(self.h, _ptr(out))
+        return out
 
     def last_sw(self, n):
         f, r = C.c_void_p(), C.c_void_p()

@@ -3,8 +3,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fsgpu.h"
@@ -21,6 +23,30 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
+struct PinBuf {          // pinned host staging
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// Device-resident target database; shared (ref-counted) between a context and its clones.
+struct DbStore {
+    uint64_t n = 0, residues = 0, bytes = 0;
+    bool hasAA = false;
+    int maxLen = 0;
+    uint4 *scan = nullptr;
+    uint64_t *stripeOff = nullptr;
+    uint32_t *stripeLen = nullptr, *order = nullptr;
+    uint32_t nStripes = 0;
+    uint64_t scanU4 = 0;          // size of `scan` in uint4 units
+    uint8_t *aln3di = nullptr, *alnAA = nullptr;
+    uint64_t *dOffsets = nullptr;
+    int32_t *dLengths = nullptr;
+    std::vector<int32_t> hLengths;
+    ~DbStore() {
+        (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(order);
+        (void) hipFree(aln3di); (void) hipFree(alnAA); (void) hipFree(dOffsets); (void) hipFree(dLengths);
+    }
+};
 
 struct fsgpu_ctx {
     int device = 0;
@@ -30,34 +56,22 @@ struct fsgpu_ctx {
     bool evValid[2] = {false, false};
     std::string err;
 
-    // database
-    uint64_t n = 0, residues = 0, bytes = 0;
-    bool hasAA = false;
-    int maxLen = 0;
-    uint4 *scan = nullptr;
-    uint64_t *stripeOff = nullptr;
-    uint32_t *stripeLen = nullptr, *order = nullptr;
-    uint32_t nStripes = 0;
-    uint8_t *aln3di = nullptr, *alnAA = nullptr;
-    uint64_t *dOffsets = nullptr;
-    int32_t *dLengths = nullptr;
-    std::vector<int32_t> hLengths;
+    // database (shared with clones)
+    std::shared_ptr<DbStore> db;
 
     // gapless scratch
-    DevBuf pssm, scores, chunkHist, baseGt, baseTie, outId, outScore;
+    DevBuf pssm, scores, chunkHist, baseGt, baseTie, outId, outScore, gBorder0, gBorder1, scoreAcc;
     SelMeta *dMeta = nullptr;
     uint32_t *queue = nullptr;
+    PinBuf hPssm, hImg, hTids;           // pinned staging for per-query uploads (no sync needed to reuse host vectors)
     SelMeta *hMeta = nullptr;            // pinned
-    uint32_t *hOutId = nullptr;          // pinned
-    int32_t *hOutScore = nullptr;
-    size_t hOutCap = 0;
+    PinBuf hOutId, hOutScore;            // pinned
     int pendingMaxRes = 0;
     bool gaplessPending = false;
 
     // sw scratch
     DevBuf img, tids, res0, res1, border0, border1, keys;
-    int32_t *hRes0 = nullptr, *hRes1 = nullptr;   // pinned
-    size_t hResCap = 0;
+    PinBuf hRes0, hRes1;                           // pinned result staging
     struct {
         bool pending = false;
         int n = 0, L = 0, go = 0, ge = 0;
@@ -75,6 +89,28 @@ struct fsgpu_ctx {
             return FSGPU_E_HIP;                                                                        \
         }                                                                                              \
     } while (0)
+
+// Wait for the context stream by polling: hipStreamSynchronize from a non-main host thread falls back to a blocking
+// wait that costs ~0.2 ms per call on this stack, more than the kernels it waits for.
+static int syncStream(fsgpu_ctx *ctx) {
+    for (unsigned spins = 0;; spins++) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return FSGPU_OK;
+        if (e != hipErrorNotReady) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
+        if (spins > 200000) { std::this_thread::yield(); }
+    }
+}
+
+static int ensurePinned(fsgpu_ctx *ctx, PinBuf &b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return FSGPU_OK;
+    if (b.p) { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; (void) hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    // grow geometrically in whole 64 KiB granules so steady-state queries never reallocate
+    size_t want = ((std::max(bytes * 2, (size_t) 65536) + 65535) / 65536) * 65536;
+    hipError_t e = hipHostMalloc(&b.p, want);
+    if (e != hipSuccess) { ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
+    b.cap = want;
+    return FSGPU_OK;
+}
 
 static int ensure(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.cap >= bytes && b.p) return FSGPU_OK;
@@ -118,12 +154,14 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     return FSGPU_OK;
 }
 
-static void freeDb(fsgpu_ctx *ctx) {
-    hipFree(ctx->scan); hipFree(ctx->stripeOff); hipFree(ctx->stripeLen); hipFree(ctx->order);
-    hipFree(ctx->aln3di); hipFree(ctx->alnAA); hipFree(ctx->dOffsets); hipFree(ctx->dLengths);
-    ctx->scan = nullptr; ctx->stripeOff = nullptr; ctx->stripeLen = nullptr; ctx->order = nullptr;
-    ctx->aln3di = nullptr; ctx->alnAA = nullptr; ctx->dOffsets = nullptr; ctx->dLengths = nullptr;
-    ctx->n = 0;
+static void freeDb(fsgpu_ctx *ctx) { ctx->db.reset(); }
+
+int fsgpu_clone(const fsgpu_ctx *src, fsgpu_ctx **out) {
+    if (!src || !out) return FSGPU_E_ARG;
+    int rc = fsgpu_create(src->device, out);
+    if (rc != FSGPU_OK) return rc;
+    (*out)->db = src->db;
+    return FSGPU_OK;
 }
 
 void fsgpu_destroy(fsgpu_ctx *ctx) {
@@ -131,12 +169,13 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     freeDb(ctx);
-    DevBuf *bufs[] = {&ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
+    DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
                       &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     hipFree(ctx->dMeta); hipFree(ctx->queue);
-    hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId); hipHostFree(ctx->hOutScore);
-    hipHostFree(ctx->hRes0); hipHostFree(ctx->hRes1);
+    hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId.p); hipHostFree(ctx->hOutScore.p);
+    hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p);
+    hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -145,8 +184,8 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
 const char *fsgpu_last_error(const fsgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
 int fsgpu_device(const fsgpu_ctx *ctx) { return ctx ? ctx->device : -1; }
 void *fsgpu_stream(const fsgpu_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
-uint64_t fsgpu_db_size(const fsgpu_ctx *ctx) { return ctx ? ctx->n : 0; }
-uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx) { return ctx ? ctx->residues : 0; }
+uint64_t fsgpu_db_size(const fsgpu_ctx *ctx) { return ctx && ctx->db ? ctx->db->n : 0; }
+uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx) { return ctx && ctx->db ? ctx->db->residues : 0; }
 
 } // extern "C"
 
@@ -192,9 +231,10 @@ __global__ void k_db_unmask(const uint8_t *raw, uint8_t *out, uint64_t bytes) {
 
 static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA, const uint64_t *dOff, const int32_t *dLen,
                    uint64_t n, uint64_t bytes) {
+    ctx->db = std::make_shared<DbStore>();
     // host copy of the lengths drives the stripe table
-    ctx->hLengths.resize(n);
-    HIPCHK(hipMemcpy(ctx->hLengths.data(), dLen, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    ctx->db->hLengths.resize(n);
+    HIPCHK(hipMemcpy(ctx->db->hLengths.data(), dLen, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     const uint32_t nStripes = (uint32_t) ((n + kStripeTargets - 1) / kStripeTargets);
     std::vector<uint64_t> sOff(nStripes);
     std::vector<uint32_t> sLen(nStripes), ord(nStripes);
@@ -203,7 +243,7 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
     for (uint32_t s = 0; s < nStripes; s++) {
         int mx = 0;
         for (uint64_t t = (uint64_t) s * 8; t < std::min<uint64_t>(n, (uint64_t) s * 8 + 8); t++) {
-            int L = ctx->hLengths[t];
+            int L = ctx->db->hLengths[t];
             if (L < 0 || L > FSGPU_MAX_SEQ_LEN) { ctx->err = "target length out of range"; return FSGPU_E_ARG; }
             mx = std::max(mx, L);
             residues += (uint64_t) L;
@@ -216,37 +256,38 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
     std::iota(ord.begin(), ord.end(), 0u);
     std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return sLen[a] > sLen[b]; });
 
-    HIPCHK(hipMalloc((void **) &ctx->scan, std::max<uint64_t>(total, 1) * sizeof(uint4)));
-    HIPCHK(hipMalloc((void **) &ctx->stripeOff, std::max<size_t>(nStripes, 1) * sizeof(uint64_t)));
-    HIPCHK(hipMalloc((void **) &ctx->stripeLen, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &ctx->order, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &ctx->aln3di, std::max<uint64_t>(bytes, 1)));
-    HIPCHK(hipMalloc((void **) &ctx->dOffsets, (n + 1) * sizeof(uint64_t)));
-    HIPCHK(hipMalloc((void **) &ctx->dLengths, std::max<uint64_t>(n, 1) * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **) &ctx->db->scan, std::max<uint64_t>(total, 1) * sizeof(uint4)));
+    HIPCHK(hipMalloc((void **) &ctx->db->stripeOff, std::max<size_t>(nStripes, 1) * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **) &ctx->db->stripeLen, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &ctx->db->order, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &ctx->db->aln3di, std::max<uint64_t>(bytes, 1)));
+    HIPCHK(hipMalloc((void **) &ctx->db->dOffsets, (n + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **) &ctx->db->dLengths, std::max<uint64_t>(n, 1) * sizeof(int32_t)));
     if (nStripes) {
-        HIPCHK(hipMemcpy(ctx->stripeOff, sOff.data(), nStripes * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->stripeLen, sLen.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->order, ord.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->db->stripeOff, sOff.data(), nStripes * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->db->stripeLen, sLen.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->db->order, ord.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMemcpy(ctx->dOffsets, dOff, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy(ctx->dLengths, dLen, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(ctx->db->dOffsets, dOff, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(ctx->db->dLengths, dLen, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
     if (nStripes) {
-        hipLaunchKernelGGL(k_db_scan_layout, dim3(nStripes), dim3(256), 0, ctx->stream, dRaw3di, ctx->dOffsets, ctx->dLengths,
-                           (uint32_t) n, ctx->stripeOff, ctx->stripeLen, ctx->scan);
+        hipLaunchKernelGGL(k_db_scan_layout, dim3(nStripes), dim3(256), 0, ctx->stream, dRaw3di, ctx->db->dOffsets, ctx->db->dLengths,
+                           (uint32_t) n, ctx->db->stripeOff, ctx->db->stripeLen, ctx->db->scan);
         HIPCHK(hipGetLastError());
     }
     if (bytes) {
-        hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRaw3di, ctx->aln3di, bytes);
+        hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRaw3di, ctx->db->aln3di, bytes);
         HIPCHK(hipGetLastError());
         if (dRawAA) {
-            HIPCHK(hipMalloc((void **) &ctx->alnAA, bytes));
-            hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRawAA, ctx->alnAA, bytes);
+            HIPCHK(hipMalloc((void **) &ctx->db->alnAA, bytes));
+            hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRawAA, ctx->db->alnAA, bytes);
             HIPCHK(hipGetLastError());
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->n = n; ctx->bytes = bytes; ctx->residues = residues; ctx->nStripes = nStripes; ctx->maxLen = maxLen;
-    ctx->hasAA = dRawAA != nullptr;
+    ctx->db->scanU4 = total;
+    ctx->db->n = n; ctx->db->bytes = bytes; ctx->db->residues = residues; ctx->db->nStripes = nStripes; ctx->db->maxLen = maxLen;
+    ctx->db->hasAA = dRawAA != nullptr;
     return FSGPU_OK;
 }
 
@@ -292,21 +333,22 @@ int fsgpu_db_load(fsgpu_ctx *ctx, const uint8_t *data3di, const uint8_t *dataAA,
 // ------------------------------------------------------------------------------------------------------------
 // gapless scan
 // ------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, bool TILED>
 static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
     const int lds = gaplessLdsBytes(R);
-    static thread_local bool attrSet[kGaplessMaxR + 1] = {false};
-    if (!attrSet[R]) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attrSet[R] = true;
+    static thread_local bool attrSet = false;
+    static thread_local int perCUcached = 0;
+    if (!attrSet) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, 512, lds));
+        attrSet = true;
     }
-    int perCU = 1;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_gapless<R>, 512, lds));
+    int perCU = perCUcached;
     perCU = std::max(1, std::min(perCU, 4));
     // one wave needs one stripe at a time: do not launch more waves than stripes
     uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nStripes + 7) / 8);
     blocks = std::max(blocks, 1u);
-    hipLaunchKernelGGL(k_gapless<R>, dim3(blocks), dim3(512), lds, ctx->stream, ga);
+    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks), dim3(512), lds, ctx->stream, ga);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
@@ -316,15 +358,15 @@ extern "C" {
 int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore, int64_t identityId, int maxRes) {
     if (!ctx) return FSGPU_E_ARG;
     if (!pssm || L <= 0 || L > FSGPU_MAX_SEQ_LEN || maxRes <= 0) { ctx->err = "fsgpu_gapless_launch: bad argument"; return FSGPU_E_ARG; }
-    if (ctx->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
     const int rows = (L + 15) / 16;                       // rows per strip per lane
-    const int R = std::max(4, ((rows + 3) / 4) * 4);
-    if (R > kGaplessMaxR) { ctx->err = "query longer than 512 residues: multi-tile gapless scan not implemented yet"; return FSGPU_E_UNSUPPORTED; }
+    const int nTiles = (L + 16 * kGaplessMaxR - 1) / (16 * kGaplessMaxR);
+    const int R = nTiles > 1 ? kGaplessMaxR : std::max(4, ((rows + 3) / 4) * 4);
     HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t n = (uint32_t) ctx->n;
+    const uint32_t n = (uint32_t) ctx->db->n;
     const uint32_t nChunks = (n + kSelChunk - 1) / kSelChunk;
-    const uint32_t K = (uint32_t) std::min<uint64_t>((uint64_t) maxRes, ctx->n);
+    const uint32_t K = (uint32_t) std::min<uint64_t>((uint64_t) maxRes, ctx->db->n);
     int rc;
     if ((rc = ensure(ctx, ctx->pssm, (size_t) kAlphabet * L)) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->scores, n)) != FSGPU_OK) return rc;
@@ -333,33 +375,50 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     if ((rc = ensure(ctx, ctx->baseTie, (size_t) nChunks * 4)) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->outId, (size_t) K * 4)) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->outScore, (size_t) K * 4)) != FSGPU_OK) return rc;
-    if (ctx->hOutCap < K) {
-        hipHostFree(ctx->hOutId); hipHostFree(ctx->hOutScore);
-        ctx->hOutId = nullptr; ctx->hOutScore = nullptr;
-        HIPCHK(hipHostMalloc((void **) &ctx->hOutId, (size_t) K * 4));
-        HIPCHK(hipHostMalloc((void **) &ctx->hOutScore, (size_t) K * 4));
-        ctx->hOutCap = K;
+    if (nTiles > 1) {
+        // border rows between query row tiles: 2 bytes per padded target column, ping-pong
+        const size_t bbytes = (size_t) ctx->db->scanU4 * 32;
+        if ((rc = ensure(ctx, ctx->gBorder0, bbytes)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->gBorder1, bbytes)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->scoreAcc, (size_t) n * 2)) != FSGPU_OK) return rc;
     }
-    HIPCHK(hipMemcpyAsync(ctx->pssm.p, pssm, (size_t) kAlphabet * L, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
+    if ((rc = ensurePinned(ctx, ctx->hOutId, (size_t) K * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hOutScore, (size_t) K * 4)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hPssm, (size_t) kAlphabet * L)) != FSGPU_OK) return rc;
+    memcpy(ctx->hPssm.p, pssm, (size_t) kAlphabet * L);
+    HIPCHK(hipMemcpyAsync(ctx->pssm.p, ctx->hPssm.p, (size_t) kAlphabet * L, hipMemcpyHostToDevice, ctx->stream));
     GaplessArgs ga;
-    ga.scan = ctx->scan; ga.stripeOff = ctx->stripeOff; ga.stripeLen = ctx->stripeLen; ga.order = ctx->order;
-    ga.nStripes = ctx->nStripes; ga.nTargets = n; ga.pssm = (const int8_t *) ctx->pssm.p; ga.L = L;
+    ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen; ga.order = ctx->db->order;
+    ga.nStripes = ctx->db->nStripes; ga.nTargets = n; ga.pssm = (const int8_t *) ctx->pssm.p; ga.L = L;
     ga.cap = std::max(0, std::min(scoreCap, 255));
     ga.scores = (uint8_t *) ctx->scores.p; ga.queue = ctx->queue;
+    ga.tileBase = 0; ga.firstTile = 1; ga.lastTile = 1; ga.borderIn = nullptr; ga.borderOut = nullptr; ga.scoreAcc = (int16_t *) ctx->scoreAcc.p;
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    switch (R) {
-        case 4: rc = launchGapless<4>(ctx, ga); break;
-        case 8: rc = launchGapless<8>(ctx, ga); break;
-        case 12: rc = launchGapless<12>(ctx, ga); break;
-        case 16: rc = launchGapless<16>(ctx, ga); break;
-        case 20: rc = launchGapless<20>(ctx, ga); break;
-        case 24: rc = launchGapless<24>(ctx, ga); break;
-        case 28: rc = launchGapless<28>(ctx, ga); break;
-        case 32: rc = launchGapless<32>(ctx, ga); break;
-        default: ctx->err = "internal: bad R"; return FSGPU_E_ARG;
+    if (nTiles == 1) {
+        HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
+        switch (R) {
+            case 4: rc = launchGapless<4, false>(ctx, ga); break;
+            case 8: rc = launchGapless<8, false>(ctx, ga); break;
+            case 12: rc = launchGapless<12, false>(ctx, ga); break;
+            case 16: rc = launchGapless<16, false>(ctx, ga); break;
+            case 20: rc = launchGapless<20, false>(ctx, ga); break;
+            case 24: rc = launchGapless<24, false>(ctx, ga); break;
+            case 28: rc = launchGapless<28, false>(ctx, ga); break;
+            case 32: rc = launchGapless<32, false>(ctx, ga); break;
+            default: ctx->err = "internal: bad R"; return FSGPU_E_ARG;
+        }
+        if (rc != FSGPU_OK) return rc;
+    } else {
+        // query row tiles of 512 rows: tile t+1 continues every diagonal of tile t through the border arrays in HBM
+        for (int t = 0; t < nTiles; t++) {
+            HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
+            ga.tileBase = t * 16 * kGaplessMaxR;
+            ga.firstTile = t == 0; ga.lastTile = t == nTiles - 1;
+            ga.borderIn = (const uint16_t *) ((t & 1) ? ctx->gBorder1.p : ctx->gBorder0.p);
+            ga.borderOut = (uint16_t *) ((t & 1) ? ctx->gBorder0.p : ctx->gBorder1.p);
+            if ((rc = launchGapless<kGaplessMaxR, true>(ctx, ga)) != FSGPU_OK) return rc;
+        }
     }
-    if (rc != FSGPU_OK) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(k_sel_hist, dim3(nChunks), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->scores.p, n, minScore,
                        identityId, (uint32_t *) ctx->chunkHist.p);
@@ -370,8 +429,8 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
                        (uint32_t *) ctx->outId.p, (int32_t *) ctx->outScore.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->hMeta, ctx->dMeta, sizeof(SelMeta), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->hOutId, ctx->outId.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->hOutScore, ctx->outScore.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hOutId.p, ctx->outId.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hOutScore.p, ctx->outScore.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pendingMaxRes = (int) K;
     ctx->gaplessPending = true;
     ctx->evValid[0] = true;
@@ -382,9 +441,9 @@ int fsgpu_gapless_finish(fsgpu_ctx *ctx, fsgpu_hit *out, int *nout) {
     if (!ctx || !out || !nout) return FSGPU_E_ARG;
     if (!ctx->gaplessPending) { ctx->err = "no gapless scan in flight"; return FSGPU_E_ARG; }
     ctx->gaplessPending = false;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; }
     const uint32_t m = std::min<uint32_t>(ctx->hMeta->nOut, (uint32_t) ctx->pendingMaxRes);
-    for (uint32_t i = 0; i < m; i++) { out[i].id = ctx->hOutId[i]; out[i].score = ctx->hOutScore[i]; }
+    for (uint32_t i = 0; i < m; i++) { out[i].id = ((const uint32_t *) ctx->hOutId.p)[i]; out[i].score = ((const int32_t *) ctx->hOutScore.p)[i]; }
     // hit_t::compareHitsByScoreAndId (scores are non-negative here)
     std::sort(out, out + m, [](const fsgpu_hit &a, const fsgpu_hit &b) {
         if (a.score != b.score) return a.score > b.score;
@@ -403,9 +462,9 @@ int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, 
 
 int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out) {
     if (!ctx || !scores_out) return FSGPU_E_ARG;
-    if (ctx->n == 0 || !ctx->scores.p) { ctx->err = "no scan results"; return FSGPU_E_NODB; }
+    if (!ctx->db || ctx->db->n == 0 || !ctx->scores.p) { ctx->err = "no scan results"; return FSGPU_E_NODB; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(scores_out, ctx->scores.p, ctx->n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(scores_out, ctx->scores.p, ctx->db->n, hipMemcpyDeviceToHost));
     return FSGPU_OK;
 }
 
@@ -464,13 +523,16 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
     const int rowDw = swRowDwords(R);
     const size_t tblDw = (size_t) kAlphabet * rowDw;
     const size_t imgDw = tblDw * (hasAA ? 2 : 1);
-    std::vector<uint32_t> img(imgDw * nTiles, 0u);
+    int rc;
+    if ((rc = ensurePinned(ctx, ctx->hImg, imgDw * nTiles * 4)) != FSGPU_OK) return rc;
+    uint32_t *img = (uint32_t *) ctx->hImg.p;
+    memset(img, 0, imgDw * nTiles * 4);
     for (int t = 0; t < nTiles; t++) {
         const int base = t * 64 * R;
         for (int tbl = 0; tbl < (hasAA ? 2 : 1); tbl++) {
             const int16_t *f = tbl == 0 ? p3_0 : pAA0;
             const int16_t *r = tbl == 0 ? p3_1 : pAA1;
-            uint32_t *dst = img.data() + imgDw * t + tblDw * tbl;
+            uint32_t *dst = img + imgDw * t + tblDw * tbl;
             for (int a = 0; a < kAlphabet; a++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int rr = 0; rr < R; rr++) {
@@ -484,11 +546,8 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
                     }
         }
     }
-    int rc;
-    if ((rc = ensure(ctx, ctx->img, img.size() * 4)) != FSGPU_OK) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->img.p, img.data(), img.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    // the staging vector must outlive the async copy: pageable memcpyAsync returns after staging, but be safe
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = ensure(ctx, ctx->img, imgDw * nTiles * 4)) != FSGPU_OK) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->img.p, img, imgDw * nTiles * 4, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t stride = (uint32_t) ((maxLt + 63) / 64 * 64);
     if (nTiles > 1) {
         const size_t bbytes = (size_t) nPairs * stride * 3 * 4;
@@ -498,7 +557,7 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
     }
     for (int t = 0; t < nTiles; t++) {
         SwArgs sa;
-        sa.aa = ctx->alnAA; sa.ss = ctx->aln3di; sa.offsets = ctx->dOffsets; sa.lengths = ctx->dLengths;
+        sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
         sa.targetIds = dTids; sa.nPairs = nPairs;
         sa.profSS = (const uint32_t *) ctx->img.p + imgDw * t;
         sa.profAA = hasAA ? sa.profSS + tblDw : nullptr;
@@ -527,8 +586,8 @@ int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_
     if (!p3Di_fwd || !p3Di_rev || L <= 0 || L > FSGPU_MAX_SEQ_LEN || n < 0 || (n > 0 && !targetIds) || ((pAA_fwd == nullptr) != (pAA_rev == nullptr))) {
         ctx->err = "fsgpu_sw_launch: bad argument"; return FSGPU_E_ARG;
     }
-    if (ctx->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
-    if (pAA_fwd && !ctx->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
+    if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (pAA_fwd && !ctx->db->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
     if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
         ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
         return FSGPU_E_UNSUPPORTED;
@@ -542,29 +601,26 @@ int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_
     if (n == 0) return FSGPU_OK;
     int maxLt = 1;
     for (int i = 0; i < n; i++) {
-        if (targetIds[i] >= ctx->n) { ctx->sw.pending = false; ctx->err = "target id out of range"; return FSGPU_E_ARG; }
-        maxLt = std::max(maxLt, ctx->hLengths[targetIds[i]]);
+        if (targetIds[i] >= ctx->db->n) { ctx->sw.pending = false; ctx->err = "target id out of range"; return FSGPU_E_ARG; }
+        maxLt = std::max(maxLt, ctx->db->hLengths[targetIds[i]]);
     }
     int rc;
     if ((rc = ensure(ctx, ctx->tids, (size_t) n * 4)) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->res0, (size_t) n * 16)) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->res1, (size_t) n * 16)) != FSGPU_OK) return rc;
-    if (ctx->hResCap < (size_t) n) {
-        hipHostFree(ctx->hRes0); hipHostFree(ctx->hRes1);
-        ctx->hRes0 = ctx->hRes1 = nullptr;
-        HIPCHK(hipHostMalloc((void **) &ctx->hRes0, (size_t) n * 16));
-        HIPCHK(hipHostMalloc((void **) &ctx->hRes1, (size_t) n * 16));
-        ctx->hResCap = n;
-    }
-    HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->sw.tids.data(), (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensurePinned(ctx, ctx->hRes0, (size_t) n * 16)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hRes1, (size_t) n * 16)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hTids, (size_t) n * 4)) != FSGPU_OK) return rc;
+    memcpy(ctx->hTids.p, ctx->sw.tids.data(), (size_t) n * 4);
+    HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->hTids.p, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     rc = runSwPass(ctx, true, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, (const uint32_t *) ctx->tids.p, n, maxLt, gapOpen, gapExtend,
                    (int32_t *) ctx->res0.p, (int32_t *) ctx->res1.p);
     if (rc != FSGPU_OK) { ctx->sw.pending = false; return rc; }
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->evValid[1] = true;
-    HIPCHK(hipMemcpyAsync(ctx->hRes0, ctx->res0.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->hRes1, ctx->res1.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hRes0.p, ctx->res0.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hRes1.p, ctx->res1.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
     return FSGPU_OK;
 }
 
@@ -574,9 +630,9 @@ int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev) {
     ctx->sw.pending = false;
     const int n = ctx->sw.n;
     if (n == 0) return FSGPU_OK;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(fwd, ctx->hRes0, (size_t) n * 16);
-    memcpy(rev, ctx->hRes1, (size_t) n * 16);
+    { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; }
+    memcpy(fwd, ctx->hRes0.p, (size_t) n * 16);
+    memcpy(rev, ctx->hRes1.p, (size_t) n * 16);
     // int16 saturation -> int32 re-run with the int32 kernel's segment length (alignScoreEndPos, :313-336)
     for (int dir = 0; dir < 2; dir++) {
         fsgpu_swres *res = dir == 0 ? fwd : rev;
@@ -586,20 +642,19 @@ int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev) {
         for (int i = 0; i < n; i++)
             if (res[i].score == 32767) {
                 ids.push_back(ctx->sw.tids[i]); where.push_back(i);
-                maxLt = std::max(maxLt, ctx->hLengths[ctx->sw.tids[i]]);
+                maxLt = std::max(maxLt, ctx->db->hLengths[ctx->sw.tids[i]]);
             }
         if (ids.empty()) continue;
         const int m = (int) ids.size();
-        HIPCHK(hipMemcpyAsync(ctx->tids.p, ids.data(), (size_t) m * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(ctx->tids.p, ids.data(), (size_t) m * 4, hipMemcpyHostToDevice));
         const int16_t *pA = dir == 0 ? ctx->sw.pAAf : ctx->sw.pAAr;
         const int16_t *p3 = dir == 0 ? ctx->sw.p3f : ctx->sw.p3r;
         int rc = runSwPass(ctx, false, pA, p3, nullptr, nullptr, ctx->sw.L, (const uint32_t *) ctx->tids.p, m, maxLt, ctx->sw.go, ctx->sw.ge,
                            (int32_t *) ctx->res0.p, nullptr);
         if (rc != FSGPU_OK) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->hRes0, ctx->res0.p, (size_t) m * 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < m; k++) memcpy(&res[where[k]], ctx->hRes0 + (size_t) k * 4, 16);
+        HIPCHK(hipMemcpyAsync(ctx->hRes0.p, ctx->res0.p, (size_t) m * 16, hipMemcpyDeviceToHost, ctx->stream));
+        { int rc2 = syncStream(ctx); if (rc2 != FSGPU_OK) return rc2; }
+        for (int k = 0; k < m; k++) memcpy(&res[where[k]], (const int32_t *) ctx->hRes0.p + (size_t) k * 4, 16);
     }
     return FSGPU_OK;
 }

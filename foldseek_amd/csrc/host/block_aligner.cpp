@@ -31,66 +31,119 @@ constexpr bool SHRINK = true;         // scan_block.rs:815
 // SHRINK_SUFFIX_LEN = STEP / 4 = 2 (scan_block.rs:816) is folded into suffixHmax2
 constexpr uint8_t AA_NULL = 26;       // b'A' + 26 - b'A'
 
+// One 16 x int16 vector.  On x86-64 with AVX2 (the configuration the reference itself is built for) every helper is
+// the very instruction the crate's avx2.rs issues; elsewhere the scalar statements below define the same lane values.
+#if defined(__AVX2__)
+#include <immintrin.h>
+struct V {
+    __m256i m;
+};
+inline V set1(int16_t x) { return V{_mm256_set1_epi16(x)}; }
+inline V load(const int16_t *p) { return V{_mm256_loadu_si256((const __m256i *) p)}; }
+inline void store(int16_t *p, const V &a) { _mm256_storeu_si256((__m256i *) p, a.m); }
+inline int16_t lane(const V &a, int i) { alignas(32) int16_t t[16]; _mm256_store_si256((__m256i *) t, a.m); return t[i]; }
+inline V withLane0(const V &a, int16_t x) { return V{_mm256_insert_epi16(a.m, x, 0)}; }
+inline V adds(const V &a, const V &b) { return V{_mm256_adds_epi16(a.m, b.m)}; }
+inline V subs(const V &a, const V &b) { return V{_mm256_subs_epi16(a.m, b.m)}; }
+inline V vmax(const V &a, const V &b) { return V{_mm256_max_epi16(a.m, b.m)}; }
+inline V cmpeq(const V &a, const V &b) { return V{_mm256_cmpeq_epi16(a.m, b.m)}; }
+inline V blend(const V &a, const V &b, const V &mask) { return V{_mm256_blendv_epi8(a.m, b.m, mask.m)}; }
+// simd_sl_i16!(a, b, 1) (avx2.rs:92-109)
+inline V sl1(const V &a, const V &b) { return V{_mm256_alignr_epi8(a.m, _mm256_permute2x128_si256(a.m, b.m, 0x03), 14)}; }
+// simd_step (avx2.rs:131-135)
+inline V step8(const V &a, const V &b) { return V{_mm256_permute2x128_si256(a.m, b.m, 0x03)}; }
+template <int N> inline V sllz(const V &a) { return V{_mm256_slli_si256(a.m, N * 2)}; }   // simd_sllz_i16! (avx2.rs:143-154)
+template <int B> inline V slli16(const V &a) { return V{_mm256_slli_epi16(a.m, B)}; }
+inline V broadcasthi(const V &a) { return V{_mm256_permute4x64_epi64(_mm256_shufflehi_epi16(a.m, 0xFF), 0xFF)}; }   // avx2.rs:156-161
+inline int16_t hmax(const V &a) {                                                           // avx2.rs:176-184
+    __m256i v2 = _mm256_max_epi16(a.m, _mm256_srli_si256(a.m, 2));
+    v2 = _mm256_max_epi16(v2, _mm256_srli_si256(v2, 4));
+    v2 = _mm256_max_epi16(v2, _mm256_srli_si256(v2, 8));
+    v2 = _mm256_max_epi16(v2, _mm256_permute2x128_si256(v2, v2, 0x03));
+    return (int16_t) _mm256_extract_epi16(v2, 0);
+}
+struct ScanConsts { V gapExtendAll, lane; };
+inline ScanConsts prefixScanConsts(const V &gap) {                                          // avx2.rs:283-297
+    __m256i shift1 = _mm256_adds_epi16(_mm256_slli_si256(gap.m, 2), gap.m);
+    __m256i shift2 = _mm256_adds_epi16(_mm256_slli_si256(shift1, 4), shift1);
+    __m256i shift4 = _mm256_adds_epi16(_mm256_slli_si256(shift2, 8), shift2);
+    __m256i correct1 = _mm256_srli_si256(_mm256_shufflehi_epi16(shift4, 0xFF), 8);
+    correct1 = _mm256_permute4x64_epi64(correct1, 0x05);
+    correct1 = _mm256_adds_epi16(correct1, shift4);
+    ScanConsts c; c.gapExtendAll = V{correct1}; c.lane = V{shift4};
+    return c;
+}
+inline V prefixScan(const V &Rmax, const V &gapCost, const V &gapCostLane) {                // avx2.rs:299-317
+    __m256i shift1 = _mm256_adds_epi16(_mm256_slli_si256(Rmax.m, 2), gapCost.m);
+    shift1 = _mm256_max_epi16(Rmax.m, shift1);
+    __m256i shift2 = _mm256_adds_epi16(_mm256_slli_si256(shift1, 4), _mm256_slli_epi16(gapCost.m, 1));
+    shift2 = _mm256_max_epi16(shift1, shift2);
+    __m256i shift4 = _mm256_adds_epi16(_mm256_slli_si256(shift2, 8), _mm256_slli_epi16(gapCost.m, 2));
+    shift4 = _mm256_max_epi16(shift2, shift4);
+    __m256i correct1 = _mm256_permute4x64_epi64(_mm256_shufflehi_epi16(shift4, 0xFF), 0x50);
+    correct1 = _mm256_adds_epi16(correct1, gapCostLane.m);
+    return V{_mm256_max_epi16(shift4, correct1)};
+}
+// simd_movemask_i8(simd_blend_i8(lo, hi, 0xFF00)): bit 2k <- lo lane k, bit 2k+1 <- hi lane k
+inline uint32_t mask2(const V &lo, const V &hi) {
+    return (uint32_t) _mm256_movemask_epi8(_mm256_blendv_epi8(lo.m, hi.m, _mm256_set1_epi16((int16_t) 0xFF00)));
+}
+// halfsimd_lookup2_i16 (avx2.rs:319-326): 32-entry int8 row looked up with two pshufb + blend, sign extended
+inline V lookup32(const int8_t *row, const uint8_t *q) {
+    const __m128i lut1 = _mm_loadu_si128((const __m128i *) row), lut2 = _mm_loadu_si128((const __m128i *) (row + 16));
+    const __m128i v = _mm_loadu_si128((const __m128i *) q);
+    const __m128i a = _mm_shuffle_epi8(lut1, v), b = _mm_shuffle_epi8(lut2, v);
+    const __m128i c = _mm_blendv_epi8(a, b, _mm_slli_epi16(v, 3));
+    return V{_mm256_cvtepi8_epi16(c)};
+}
+#else
 struct V {
     int16_t v[L];
 };
-
 inline int16_t sat16(int32_t x) { return (int16_t) (x > 32767 ? 32767 : (x < -32768 ? -32768 : x)); }
 inline V set1(int16_t x) { V r; for (int i = 0; i < L; i++) r.v[i] = x; return r; }
 inline V load(const int16_t *p) { V r; memcpy(r.v, p, sizeof(r.v)); return r; }
 inline void store(int16_t *p, const V &a) { memcpy(p, a.v, sizeof(a.v)); }
+inline int16_t lane(const V &a, int i) { return a.v[i]; }
+inline V withLane0(const V &a, int16_t x) { V r = a; r.v[0] = x; return r; }
 inline V adds(const V &a, const V &b) { V r; for (int i = 0; i < L; i++) r.v[i] = sat16((int32_t) a.v[i] + b.v[i]); return r; }
 inline V subs(const V &a, const V &b) { V r; for (int i = 0; i < L; i++) r.v[i] = sat16((int32_t) a.v[i] - b.v[i]); return r; }
 inline V vmax(const V &a, const V &b) { V r; for (int i = 0; i < L; i++) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
-// lane masks are kept as 0 / -1 like _mm256_cmpeq_epi16
 inline V cmpeq(const V &a, const V &b) { V r; for (int i = 0; i < L; i++) r.v[i] = a.v[i] == b.v[i] ? (int16_t) -1 : (int16_t) 0; return r; }
 inline V blend(const V &a, const V &b, const V &mask) { V r; for (int i = 0; i < L; i++) r.v[i] = mask.v[i] ? b.v[i] : a.v[i]; return r; }
-// simd_sl_i16!(a, b, 1): shift one lane up, the top lane of b comes in at the bottom (avx2.rs:92-109)
 inline V sl1(const V &a, const V &b) { V r; r.v[0] = b.v[L - 1]; for (int i = 1; i < L; i++) r.v[i] = a.v[i - 1]; return r; }
-// simd_step(a, b) = permute2x128(a, b, 0x03): low half <- b.high, high half <- a.low (avx2.rs:131-135)
 inline V step8(const V &a, const V &b) { V r; for (int i = 0; i < 8; i++) { r.v[i] = b.v[8 + i]; r.v[8 + i] = a.v[i]; } return r; }
-// _mm256_slli_si256 by n lanes: shifts inside each 128-bit half, zero fill (simd_sllz_i16!, avx2.rs:143-154)
-inline V sllz(const V &a, int n) {
+// _mm256_slli_si256 by N lanes: shifts inside each 128-bit half, zero fill
+template <int N> inline V sllz(const V &a) {
     V r;
     for (int h = 0; h < 2; h++)
-        for (int k = 0; k < 8; k++) r.v[h * 8 + k] = k >= n ? a.v[h * 8 + k - n] : (int16_t) 0;
+        for (int k = 0; k < 8; k++) r.v[h * 8 + k] = k >= N ? a.v[h * 8 + k - N] : (int16_t) 0;
     return r;
 }
-inline V slli16(const V &a, int bits) { V r; for (int i = 0; i < L; i++) r.v[i] = (int16_t) ((uint16_t) a.v[i] << bits); return r; }
-inline V broadcasthi(const V &a) { return set1(a.v[L - 1]); }   // avx2.rs:156-161
+template <int B> inline V slli16(const V &a) { V r; for (int i = 0; i < L; i++) r.v[i] = (int16_t) ((uint16_t) a.v[i] << B); return r; }
+inline V broadcasthi(const V &a) { return set1(a.v[L - 1]); }
 inline int16_t hmax(const V &a) { int16_t m = a.v[0]; for (int i = 1; i < L; i++) m = std::max(m, a.v[i]); return m; }
-// simd_prefix_hmax_i16!(v, STEP = 8): maximum of lanes 0..7; the shifted-in zeros only touch lanes that are not read
-inline int16_t prefixHmax8(const int16_t *p) { int16_t m = p[0]; for (int i = 1; i < 8; i++) m = std::max(m, p[i]); return m; }
-// simd_suffix_hmax_i16!(v, 2): max of the two top lanes (avx2.rs:232-256)
-inline int16_t suffixHmax2(const int16_t *p) { return std::max(p[L - 1], p[L - 2]); }
-
 struct ScanConsts { V gapExtendAll, lane; };
-// get_prefix_scan_consts (avx2.rs:283-297)
 inline ScanConsts prefixScanConsts(const V &gap) {
-    V shift1 = adds(sllz(gap, 1), gap);
-    V shift2 = adds(sllz(shift1, 2), shift1);
-    V shift4 = adds(sllz(shift2, 4), shift2);
-    // shufflehi(0xFF) -> lanes 4..7 of each half = lane 7 of that half; srli_si256 by 8 bytes -> lanes 0..3 = that value,
-    // lanes 4..7 = 0; permute4x64(0b00000101) -> low half = old q1 (zeros), high half = old q0 x2 (lane 7 of the low half)
+    V shift1 = adds(sllz<1>(gap), gap);
+    V shift2 = adds(sllz<2>(shift1), shift1);
+    V shift4 = adds(sllz<4>(shift2), shift2);
     V correct1;
     for (int k = 0; k < 8; k++) { correct1.v[k] = 0; correct1.v[8 + k] = shift4.v[7]; }
     correct1 = adds(correct1, shift4);
     ScanConsts c; c.gapExtendAll = correct1; c.lane = shift4;
     return c;
 }
-// simd_prefix_scan_i16 (avx2.rs:299-317)
 inline V prefixScan(const V &Rmax, const V &gapCost, const V &gapCostLane) {
-    V shift1 = vmax(Rmax, adds(sllz(Rmax, 1), gapCost));
-    V shift2 = vmax(shift1, adds(sllz(shift1, 2), slli16(gapCost, 1)));
-    V shift4 = vmax(shift2, adds(sllz(shift2, 4), slli16(gapCost, 2)));
-    // shufflehi(0xFF) + permute4x64(0b01010000): low half <- lanes 0..3 twice, high half <- lane 7 broadcast
+    V shift1 = vmax(Rmax, adds(sllz<1>(Rmax), gapCost));
+    V shift2 = vmax(shift1, adds(sllz<2>(shift1), slli16<1>(gapCost)));
+    V shift4 = vmax(shift2, adds(sllz<4>(shift2), slli16<2>(gapCost)));
     V correct1;
     for (int k = 0; k < 4; k++) { correct1.v[k] = shift4.v[k]; correct1.v[4 + k] = shift4.v[k]; }
     for (int k = 0; k < 8; k++) correct1.v[8 + k] = shift4.v[7];
     correct1 = adds(correct1, gapCostLane);
     return vmax(shift4, correct1);
 }
-// simd_movemask_i8(simd_blend_i8(lo, hi, 0xFF00)): bit 2k <- lo lane k, bit 2k+1 <- hi lane k
 inline uint32_t mask2(const V &lo, const V &hi) {
     uint32_t m = 0;
     for (int k = 0; k < L; k++) {
@@ -99,6 +152,19 @@ inline uint32_t mask2(const V &lo, const V &hi) {
     }
     return m;
 }
+inline V lookup32(const int8_t *row, const uint8_t *q) {
+    V r;
+    for (int k = 0; k < L; k++) {
+        const uint8_t b = q[k];
+        r.v[k] = (b & 0x80) ? 0 : row[(b & 0x0f) + ((b & 0x10) ? 16 : 0)];
+    }
+    return r;
+}
+#endif
+// simd_prefix_hmax_i16!(v, STEP = 8): maximum of lanes 0..7; the shifted-in zeros only touch lanes that are not read
+inline int16_t prefixHmax8(const int16_t *p) { int16_t m = p[0]; for (int i = 1; i < 8; i++) m = std::max(m, p[i]); return m; }
+// simd_suffix_hmax_i16!(v, 2): max of the two top lanes (avx2.rs:232-256)
+inline int16_t suffixHmax2(const int16_t *p) { return std::max(p[L - 1], p[L - 2]); }
 
 } // namespace
 
@@ -114,17 +180,7 @@ inline uint8_t upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t) (c -
 inline uint8_t convertChar(uint8_t c) { c = upper(c); assert(c >= 'A' && c <= 'A' + 26); return (uint8_t) (c - 'A'); }
 
 // AAMatrix::get_scores (scores.rs:126-140): the 32-entry row of c, looked up per query byte, sign extended
-inline V getScores(const AAMatrix *m, uint8_t c, const uint8_t *q) {
-    V r;
-    const int8_t *row = m->scores + (size_t) c * 32;
-    for (int k = 0; k < L; k++) {
-        const uint8_t b = q[k];
-        // pshufb: index = low 4 bits, zero if bit 7 set; the second table is chosen by bit 4
-        int8_t s = (b & 0x80) ? 0 : row[(b & 0x0f) + ((b & 0x10) ? 16 : 0)];
-        r.v[k] = s;
-    }
-    return r;
-}
+inline V getScores(const AAMatrix *m, uint8_t c, const uint8_t *q) { return lookup32(m->scores + (size_t) c * 32, q); }
 
 struct Trace {
     std::vector<uint32_t> trace, trace2;
@@ -219,7 +275,7 @@ struct Block {
                     scores = adds(adds(scores, s3), adds(refBias, qBias));
                 }
                 D11 = adds(D00, scores);
-                if (startI + i == 0 && startJ + j == 0) D11.v[0] = ZERO;
+                if (startI + i == 0 && startJ + j == 0) D11 = withLane0(D11, ZERO);
                 const V C11open = adds(D10, gapOpen);
                 const V C11 = vmax(adds(C10, gapExtend), C11open);
                 D11 = vmax(D11, C11);
@@ -246,8 +302,8 @@ struct Block {
                 store(CcolP + i, C11);
             }
             Dcorner = set1(MIN);
-            DrowP[j] = D11.v[L - 1];
-            RrowP[j] = R11.v[L - 1];
+            DrowP[j] = lane(D11, L - 1);
+            RrowP[j] = lane(R11, L - 1);
             if (!xdrop && startI + height > query.len() && startJ + j >= reference.len()) {
                 if (traceOn) trace.traceIdx += (width - 1 - j) * (height / L);
                 break;
@@ -262,7 +318,7 @@ struct Block {
     // shift_and_offset (scan_block.rs:1096-1123): drop the first STEP entries, append temp buffers, re-base
     static V shiftAndOffset(size_t blockSize, int16_t *b1, int16_t *b2, const int16_t *t1, const int16_t *t2, const V &offAdd) {
         V curr1 = adds(load(b1), offAdd);
-        const V Dcorner = set1(curr1.v[STEP - 1]);
+        const V Dcorner = set1(lane(curr1, STEP - 1));
         V curr2 = adds(load(b2), offAdd);
         size_t i = 0;
         while (i < blockSize - L) {
@@ -276,7 +332,7 @@ struct Block {
         store(b2 + blockSize - L, step8(load(t2), curr2));
         return Dcorner;
     }
-    static int16_t clamp16(int32_t x) { return sat16(x); }
+    static int16_t clamp16(int32_t x) { return (int16_t) (x > 32767 ? 32767 : (x < -32768 ? -32768 : x)); }
 
     // align_core (scan_block.rs:120-630)
     void align(const Seq &query, const Seq &reference, const AAMatrix *m, const AAMatrix *m3di, Gaps gaps, size_t minSize, size_t maxSize,
@@ -352,15 +408,17 @@ struct Block {
                     const V &cd = grow ? growDmax : pb.Dmax;
                     const V &ci = grow ? growArgI : pb.argI;
                     const V &cj = grow ? growArgJ : pb.argJ;
-                    for (int lane = 0; lane < L; lane++) {
-                        if (cd.v[lane] != currMax) continue;
-                        const size_t idxI = (size_t) (uint16_t) ci.v[lane], idxJ = (size_t) (uint16_t) cj.v[lane];
-                        const size_t r = idxI + lane, c = (blockSize - STEP) + idxJ;
+                    alignas(32) int16_t cdv[L], civ[L], cjv[L];
+                    store(cdv, cd); store(civ, ci); store(cjv, cj);
+                    for (int ln = 0; ln < L; ln++) {
+                        if (cdv[ln] != currMax) continue;
+                        const size_t idxI = (size_t) (uint16_t) civ[ln], idxJ = (size_t) (uint16_t) cjv[ln];
+                        const size_t r = idxI + ln, c = (blockSize - STEP) + idxJ;
                         size_t gi, gj;
-                        if (grow) { gi = si + prevSize + idxJ; gj = sj + idxI + lane; }
+                        if (grow) { gi = si + prevSize + idxJ; gj = sj + idxI + ln; }
                         else if (dir == DirRight) { gi = si + r; gj = sj + c; }
                         else if (dir == DirDown) { gi = si + c; gj = sj + r; }
-                        else { gi = si + idxI + lane; gj = sj + prevSize + idxJ; }
+                        else { gi = si + idxI + ln; gj = sj + prevSize + idxJ; }
                         const bool better = (gj != bestJ) ? (gj > bestJ) : (gi > bestI);
                         if (better) { bestI = gi; bestJ = gj; }
                     }

@@ -7,6 +7,7 @@
 #include "hostlib.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -33,7 +34,11 @@ struct fshost_search {
     std::vector<uint8_t> rAA, r3Di, tAA, t3Di;
     std::vector<fsgpu_swres> fwd, rev;
     std::string cigars;
+    // host-side wall time of the last calls, seconds: [0] prefilter profile, [1] prefilter device call (incl. wait),
+    // [2] align profiles + e-value net, [3] SW device call (incl. wait), [4] gates, [5] block-aligner backtrace
+    double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+static inline double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" {
 
@@ -83,12 +88,15 @@ const char *fshost_search_error(const fshost_search *s) { return s ? s->err.c_st
 
 int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_t identityId, fsgpu_hit *hits) {
     if (!s || !s->ctx) return FSGPU_E_ARG;
+    const double t0 = nowSec();
     s->pssm.resize((size_t) s->matPref.n * L);
     int cap = 0;
     int rc = prefilterProfile(s->matPref, q3di, L, s->par.compBiasCorrection != 0, s->par.prefCompBiasScale, s->pssm.data(), &cap);
     if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
     int nout = 0;
+    const double t1 = nowSec();
     rc = fsgpu_gapless_scan(s->ctx, s->pssm.data(), L, cap, s->par.minDiagScoreThr, identityId, s->par.maxResListLen, hits, &nout);
+    s->stats[0] = t1 - t0; s->stats[1] = nowSec() - t1;
     if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
     return nout;
 }
@@ -134,6 +142,7 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
     const int A = s->mat3Di.n;
     const bool useAA = par.alignmentType == 2;
     double lambda, mu;
+    const double t0 = nowSec();
     s->evaluer.predictMuLambda(q3di, L, A, &lambda, &mu);
     // forward and reversed-query profiles (structurealign.cpp:344-347)
     s->pAAf.resize((size_t) A * L); s->p3f.resize((size_t) A * L); s->pAAr.resize((size_t) A * L); s->p3r.resize((size_t) A * L);
@@ -148,9 +157,12 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
                            s->pAAr.data(), s->p3r.data(), nullptr, nullptr);
     if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
     s->fwd.resize(n); s->rev.resize(n);
+    const double t1 = nowSec();
     rc = fsgpu_sw_batch(s->ctx, useAA ? s->pAAf.data() : nullptr, s->p3f.data(), useAA ? s->pAAr.data() : nullptr, s->p3r.data(), L,
                         targetIds, n, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
     if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    const double t2 = nowSec();
+    double tBack = 0;
 
     s->cigars.clear();
     int passedNum = 0, rejected = 0, nres = 0;
@@ -180,8 +192,10 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
             s->tAA[i] = a > 20 ? 20 : a;
         }
         BlockAlnOut bo;
+        const double tb0 = nowSec();
         blockBacktrace(s->matAA, s->mat3Di, qAA, q3di, s->cbAA.data(), s->cbSS.data(), L, s->tAA.data(), s->t3Di.data(), Lt, f.qEnd, f.dbEnd,
                        f.score, par.gapOpen, par.gapExtend, bo);
+        tBack += nowSec() - tb0;
         fshost_result r;
         memset(&r, 0, sizeof(r));
         int qStart = -1, dbStart = -1;
@@ -215,10 +229,13 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
         }
     }
     if (nres > 1) std::sort(results, results + nres, compareHits);
+    s->stats[2] = t1 - t0; s->stats[3] = t2 - t1; s->stats[5] = tBack; s->stats[4] = nowSec() - t2 - tBack;
     return nres;
 }
 
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r) { return s->cigars.c_str() + r->backtraceOff; }
+
+void fshost_search_stats(const fshost_search *s, double *out8) { memcpy(out8, s->stats, sizeof(s->stats)); }
 
 void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev) {
     *fwd = s->fwd.data();

@@ -42,9 +42,15 @@ struct GaplessArgs {
     int cap;                    // min(cap, score)
     uint8_t *scores;            // [nTargets]
     uint32_t *queue;            // work counter, zeroed before launch
+    // query row tiles (queries longer than 16*R rows): tile t covers rows [tileBase, tileBase + 16R)
+    int tileBase;
+    int firstTile, lastTile;
+    const uint16_t *borderIn;   // S(last row of the previous tile, column) for every target column, scan-layout order
+    uint16_t *borderOut;
+    int16_t *scoreAcc;          // running maximum over tiles (biased domain), [nTargets]
 };
 
-template <int R>
+template <int R, bool TILED>
 __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
     static_assert(R % 4 == 0 && R >= 4 && R <= kGaplessMaxR, "R must be a multiple of 4");
     constexpr int ROWB = gaplessRowBytes(R);
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
             int w = idx & 3, g = (idx >> 2) & 7, copy = (idx >> 5) & 1;
             int k = (idx >> 6) % (R / 4), row = (idx >> 6) / (R / 4);
             int r = 4 * k + w;
-            int qlo = g * 2 * R + r, qhi = qlo + R;
+            int qlo = a.tileBase + g * 2 * R + r, qhi = qlo + R;
             uint32_t v;
             if (row == kDeadCode) {
                 v = kFloor2;
@@ -87,7 +93,12 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
         if (w >= a.nStripes) break;
         const uint32_t stripe = a.order[w];
         const uint32_t len16 = a.stripeLen[stripe];
-        const uint4 *src = a.scan + a.stripeOff[stripe] + j;
+        const uint64_t soff = a.stripeOff[stripe];
+        const uint4 *src = a.scan + soff + j;
+        // border arrays use the scan layout at 2 bytes per residue: 32 bytes per (chunk, target)
+        const uint4 *bin = TILED ? (const uint4 *) a.borderIn + (soff + j) * 2 : nullptr;
+        uint4 *bout = TILED ? (uint4 *) a.borderOut + (soff + j) * 2 : nullptr;
+        uint32_t carryPrevChunk = kFloor2 & 0xffffu;      // border value of the column before this chunk (biased)
 
         uint32_t S[R];
         uint32_t M = kFloor2;
@@ -99,6 +110,18 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
             const uint4 cur = nxt;
             if (c + 1 < len16) nxt = src[(size_t) (c + 1) * 8];
             const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t bi[8], bo[8];
+            if constexpr (TILED) {
+                if (!a.firstTile && g == 0) {
+                    const uint4 x0 = bin[(size_t) c * 16], x1 = bin[(size_t) c * 16 + 1];
+                    bi[0] = x0.x; bi[1] = x0.y; bi[2] = x0.z; bi[3] = x0.w; bi[4] = x1.x; bi[5] = x1.y; bi[6] = x1.z; bi[7] = x1.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) bi[k] = kFloor2;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) bo[k] = 0;
+            }
 #pragma unroll
             for (int b = 0; b < 16; b++) {
                 const uint32_t code = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
@@ -111,7 +134,13 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                 }
                 // diagonal hand-off
                 uint32_t prev = __builtin_amdgcn_update_dpp(kFloor2, S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, false);
-                prev = (g == 0) ? kFloor2 : prev;
+                if constexpr (TILED) {
+                    // first lane: the diagonal enters from the previous row tile, column b - 1
+                    const uint32_t fromTile = (b == 0) ? carryPrevChunk : ((b & 1) ? (bi[(b - 1) >> 1] & 0xffffu) : (bi[(b - 1) >> 1] >> 16));
+                    prev = (g == 0) ? (fromTile << 16) : prev;
+                } else {
+                    prev = (g == 0) ? kFloor2 : prev;
+                }
                 const uint32_t in = __builtin_amdgcn_perm(prev, S[R - 1], sel);
 #pragma unroll
                 for (int r = R - 1; r >= 1; r--) {
@@ -120,6 +149,18 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                 }
                 S[0] = pk_adds_i16(in, P[0]);
                 M = pk_max_i16(M, S[0]);
+                if constexpr (TILED) {
+                    // last lane: its bottom row (high half of the last register) is the next tile's input
+                    const uint32_t v = S[R - 1] >> 16;
+                    bo[b >> 1] |= (b & 1) ? (v << 16) : v;
+                }
+            }
+            if constexpr (TILED) {
+                carryPrevChunk = bi[7] >> 16;
+                if (!a.lastTile && g == 7) {
+                    bout[(size_t) c * 16] = make_uint4(bo[0], bo[1], bo[2], bo[3]);
+                    bout[(size_t) c * 16 + 1] = make_uint4(bo[4], bo[5], bo[6], bo[7]);
+                }
             }
         }
         // max over both strips and the 8 lanes of the group
@@ -129,9 +170,15 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
         m = max(m, __shfl_xor(m, 4));
         const uint32_t tid = stripe * kStripeTargets + j;
         if (g == 0 && tid < a.nTargets) {
-            int sc = m + 32768;
-            sc = sc < a.cap ? sc : a.cap;
-            a.scores[tid] = (uint8_t) sc;
+            if constexpr (TILED) {
+                if (!a.firstTile) m = max(m, (int) a.scoreAcc[tid]);
+                if (!a.lastTile) a.scoreAcc[tid] = (int16_t) m;
+            }
+            if (!TILED || a.lastTile) {
+                int sc = m + 32768;
+                sc = sc < a.cap ? sc : a.cap;
+                a.scores[tid] = (uint8_t) sc;
+            }
         }
     }
 }

@@ -129,6 +129,9 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
         }
     }
     __syncthreads();
+    // The wavefront is a long dependent chain with little work per step: when a throughput kernel (the gapless scan
+    // of another query) shares the SIMD, win the issue arbitration so this kernel's latency does not stretch.
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wavesPerBlock = blockDim.x >> 6;
     const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6));

@@ -66,6 +66,10 @@ typedef struct {
 int fsgpu_create(int device, fsgpu_ctx **out);
 void fsgpu_destroy(fsgpu_ctx *ctx);
 const char *fsgpu_last_error(const fsgpu_ctx *ctx); /* ctx may be NULL: returns the last creation error */
+/* A second context on the same GPU with its own HIP stream and scratch buffers that SHARES the resident database of
+ * `src` (reference counted): lets several host threads keep the device busy, the way the reference runs one aligner
+ * object per OpenMP thread over one shared DBReader (F/src/strucclustutils/structurealign.cpp:284-321). */
+int fsgpu_clone(const fsgpu_ctx *src, fsgpu_ctx **out);
 int fsgpu_device(const fsgpu_ctx *ctx);
 /* HIP stream all kernels of this context are launched on (a hipStream_t), for callers that time with events */
 void *fsgpu_stream(const fsgpu_ctx *ctx);
@@ -88,8 +92,8 @@ uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx);  /* sum of lengths */
 /* ---- prefilter: exhaustive gapless diagonal scan ----------------------------------------------------------- */
 /* pssm: int8 [21][L] row-major, pssm[a*L+i] = subMat[a][q_i] + round(compBias_i) -- what runFilterOnGpu hands to
  *       Marv::scan (ungappedprefilter.cpp:195-203).
- * scoreCap: 255 - bias of the CPU path (StripedSmithWaterman.cpp:1397-1406); scores are min(cap, best diagonal run),
- *       which is exactly what the uint8 striped kernel returns.  Pass 0x7fff for uncapped (Marv-like) scores.
+ * scoreCap: 255 - bias of the CPU path (StripedSmithWaterman.cpp:1397-1406), 0..255; scores are
+ *       min(cap, best diagonal run), which is exactly what the uint8 striped kernel returns.
  * Keeps targets with score > minScore (plus identityId if >= 0), orders them by (score desc, id asc)
  * (hit_t::compareHitsByScoreAndId, QueryMatcher.h:38-48) and returns the first maxRes in out[0..*nout). */
 int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore,

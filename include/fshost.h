@@ -120,6 +120,10 @@ int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_
 int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
                         const uint32_t *targetIds, int n, fshost_result *results);
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r);
+/* Host wall time (seconds) spent in the stages of the last prefilter/align calls: [0] prefilter profile build,
+ * [1] fsgpu_gapless_scan incl. wait, [2] align profiles + e-value net, [3] fsgpu_sw_batch incl. wait, [4] gates,
+ * [5] block-aligner backtrace; [6..7] reserved. */
+void fshost_search_stats(const fshost_search *s, double *out8);
 /* Raw per-pair device results of the last fshost_search_align (n entries each), for tests. */
 void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev);
 

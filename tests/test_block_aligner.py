@@ -23,9 +23,19 @@ class AlignResult(C.Structure):
     _fields_ = [("score", C.c_int32), ("query_idx", C.c_size_t), ("reference_idx", C.c_size_t)]
 
 
-@pytest.fixture(scope="module")
-def ba():
-    L = C.CDLL(api.LIB_PATH)
+def _scalar_build():
+    """the portable (non-AVX2) statement of the same lane semantics, compiled on the fly with g++"""
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.gettempdir(), f"fs_block_aligner_scalar_{os.getuid()}.so")
+    src = os.path.join(root, "foldseek_amd", "csrc", "host", "block_aligner.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-mno-avx2", "-o", out, src])
+    return out
+
+
+@pytest.fixture(scope="module", params=["avx2-product", "scalar"])
+def ba(request):
+    L = C.CDLL(api.LIB_PATH if request.param == "avx2-product" else _scalar_build())
     vp = C.c_void_p
     L.block_new_simple_aamatrix.restype = vp
     L.block_new_simple_aamatrix.argtypes = [C.c_int8, C.c_int8]

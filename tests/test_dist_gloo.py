@@ -1,0 +1,62 @@
+"""world_size-2 gloo test (CPU): the N>1 path of bench.py -- one DB broadcast, query sharding, rank-order gather -- gives
+the same per-query results as a single process.  The per-query compute is the oracle here (no GPU in this container);
+what is under test is foldseek_amd/dist.py."""
+import os
+import sys
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, ws, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from foldseek_amd import synth, dist as fdist
+    import helpers
+    q3, qa = synth.make_queries(5, seed=3, mean_len=80, lo=40, hi=120)
+    db = synth.make_db(60, (q3, qa), seed=4, homologs_per_query=5, mean_len=80, lo=30, hi=150) if rank == 0 else None
+    tensors, hdb = fdist.broadcast_db(db, torch.device("cpu"))
+    assert tensors[0].numel() == hdb.data3di.size and tensors[3].numel() == hdb.n
+    lo, hi = fdist.shard_range(len(q3), rank, ws)
+    mine = []
+    for qi in range(lo, hi):
+        sc = helpers.o_ungapped_scores(q3[qi], hdb, True)
+        sel = helpers.o_prefilter_select(sc, 30, -1, 10)
+        mine.append((qi, sel["key"].tolist(), sel["score"].tolist()))
+    allr = fdist.gather_objects(mine)
+    t = fdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    assert t == float(ws)
+    if rank == 0:
+        flat = [x for part in allr for x in part]
+        ret.put(flat)
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_query_sharding_world2():
+    sys.path.insert(0, ROOT)
+    from foldseek_amd import synth, dist as fdist
+    import helpers
+    assert [fdist.shard_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [fdist.shard_range(8, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 8)]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat = ret.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q3, qa = synth.make_queries(5, seed=3, mean_len=80, lo=40, hi=120)
+    db = synth.make_db(60, (q3, qa), seed=4, homologs_per_query=5, mean_len=80, lo=30, hi=150)
+    assert [x[0] for x in flat] == list(range(5))
+    for qi, keys, scores in flat:
+        sel = helpers.o_prefilter_select(helpers.o_ungapped_scores(q3[qi], db, True), 30, -1, 10)
+        assert keys == sel["key"].tolist() and scores == sel["score"].tolist()

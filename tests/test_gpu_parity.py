@@ -104,6 +104,27 @@ def test_sw_long_query_row_tiles():
     ctx.close()
 
 
+def test_gapless_long_query_row_tiles():
+    """queries longer than 512 residues: 512-row tiles, diagonals continue through border arrays in HBM"""
+    rng = np.random.default_rng(321)
+    lens = (513, 700, 1024, 1300, 2100)
+    q3 = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    qa = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    db = synth.make_db(500, (q3, qa), seed=12, homologs_per_query=25, hi=2400, mask_frac=0.02)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m = api.Matrix(0, 2.0)
+    for qi in range(len(lens)):
+        pssm, cap = api.prefilter_profile(m, q3[qi], True, 0.15)
+        hits = ctx.gapless_scan(pssm, cap, min_score=30, max_res=200)
+        want = helpers.o_ungapped_scores(q3[qi], db, True)
+        got = ctx.gapless_scores().astype(np.int32)
+        assert (got == want).all(), (lens[qi], np.flatnonzero(got != want)[:10])
+        sel = helpers.o_prefilter_select(want, 30, -1, 200)
+        assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
+    ctx.close()
+
+
 def _manual_db(seqs3, seqsa):
     lens = np.array([len(x) for x in seqs3], dtype=np.int32)
     order = np.argsort(lens, kind="stable")
