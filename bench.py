@@ -27,8 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1]), 2: 3Di+AA")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
@@ -171,6 +171,13 @@ def main():
         alg_bytes = residues + db.n                       # every target residue read once (1 B) + 1 score byte written
         mean_lq = float(np.mean([len(q3[i]) for i in range(args.warmup, nq)]))
         cells = mean_lq * residues
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same DB)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.targets == 100000:
+                traffic = tj["fetch_correction"] * tj["fetch_size_kb"] * 1024 + tj["write_size_kb"] * 1024
+        except Exception:
+            traffic = None
         out = {
             "metric": "residues aligned/sec (prefilter+align)",
             "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,7 +192,7 @@ def main():
             "queries_per_s": world * args.steps / dt,
             "hits_per_query": nh / args.steps, "alignments_per_query": nr / args.steps,
             "roofline": {"bound": "hbm", "achieved": alg_bytes / kavg / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_bytes / kavg / 1e9 / 8000.0, "traffic": None,
+                         "frac": alg_bytes / kavg / 1e9 / 8000.0, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                          "kernel": "k_gapless", "kernel_ms": kavg * 1e3,
                          "note": "the scan is VALU/LDS bound (Lq cell updates per target byte), see valu/lds below and DESIGN.md",
                          # 1 packed VALU lane-op per DP cell: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz cells/s at best

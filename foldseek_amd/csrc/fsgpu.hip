@@ -51,6 +51,7 @@ struct DbStore {
 struct fsgpu_ctx {
     int device = 0;
     int numCU = 256;
+    int gaplessBlocksPerCU = 2;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gapless start/stop, sw start/stop
     bool evValid[2] = {false, false};
@@ -144,6 +145,7 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     ctx->numCU = prop.multiProcessorCount;
+    if (const char *e2 = getenv("FSGPU_GAPLESS_BLOCKS_PER_CU")) ctx->gaplessBlocksPerCU = std::max(1, atoi(e2));
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     for (int i = 0; i < 4; i++)
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
@@ -344,7 +346,9 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
         attrSet = true;
     }
     int perCU = perCUcached;
-    perCU = std::max(1, std::min(perCU, 4));
+    // 2 workgroups (16 waves, <= 90 KB LDS) per CU already saturate VALU issue (profiles/r01_valu_lds_issue_rate_ubench.txt) and
+    // leave wave slots + LDS for the latency-bound SW wavefront kernel of another in-flight query to co-reside
+    perCU = std::max(1, std::min(perCU, ctx->gaplessBlocksPerCU));
     // one wave needs one stripe at a time: do not launch more waves than stripes
     uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nStripes + 7) / 8);
     blocks = std::max(blocks, 1u);

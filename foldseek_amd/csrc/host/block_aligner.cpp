@@ -620,7 +620,7 @@ PosBias *block_new_pos_bias(uintptr_t len, uintptr_t maxSize) {
 }
 void block_set_pos_bias(PosBias *b, const int16_t *v, uintptr_t len) {
     if (b->bias.size() < len + 1 + L) b->bias.resize(len + 1 + L, 0);
-    std::fill(b->bias.begin(), b->bias.end(), 0);
+    std::fill(b->bias.begin(), b->bias.end(), 0);        // PosBias::set_biases zero-fills the whole vector (scores.rs:721-725)
     memcpy(b->bias.data() + 1, v, len * sizeof(int16_t));
     b->len = len;
 }

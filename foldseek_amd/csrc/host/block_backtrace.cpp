@@ -15,9 +15,25 @@ namespace {
 struct Scratch {
     BlockHandle block = nullptr;
     size_t capQ = 0, capT = 0;
-    ~Scratch() { if (block) block_free_aa_trace_xdrop(block); }
+    // per-thread reusable inputs: the reference allocates these per call (StructureSmithWaterman.cpp:387-449)
+    PaddedBytes *pqAA = nullptr, *pq3 = nullptr, *ptAA = nullptr, *pt3 = nullptr;
+    PosBias *pqB = nullptr, *ptB = nullptr;
+    AAMatrix *maa = nullptr, *m3 = nullptr;
+    uint64_t maaKey = 0, m3Key = 0;                   // content hash of the fsh::Matrix the cached block matrices hold
+    ~Scratch() {
+        if (block) block_free_aa_trace_xdrop(block);
+        if (pqAA) { block_free_padded_aa(pqAA); block_free_padded_aa(pq3); block_free_padded_aa(ptAA); block_free_padded_aa(pt3); }
+        if (pqB) { block_free_pos_bias(pqB); block_free_pos_bias(ptB); }
+        if (maa) { block_free_aamatrix(maa); block_free_aamatrix(m3); }
+    }
 };
 thread_local Scratch g_scratch;
+uint64_t matrixHash(const Matrix &m) {
+    uint64_t h = 1469598103934665603ull;
+    for (short v : m.sub) { h ^= (uint16_t) v; h *= 1099511628211ull; }
+    for (char c : m.letters) { h ^= (uint8_t) c; h *= 1099511628211ull; }
+    return h | 1;
+}
 constexpr size_t MAX_SIZE = 4096;
 }
 
@@ -50,9 +66,13 @@ void blockBacktrace(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, c
         t3s[i] = m3Di.letters[t3Di[dbEnd - (int) i]];
     }
     (void) Lq;
-    PaddedBytes *pqAA = block_new_padded_aa(queryAlnLen, MAX_SIZE), *pq3 = block_new_padded_aa(queryAlnLen, MAX_SIZE);
-    PaddedBytes *ptAA = block_new_padded_aa(targetAlnLen, MAX_SIZE), *pt3 = block_new_padded_aa(targetAlnLen, MAX_SIZE);
-    PosBias *pqB = block_new_pos_bias(queryAlnLen, MAX_SIZE), *ptB = block_new_pos_bias(targetAlnLen, MAX_SIZE);
+    if (!sc.pqAA) {
+        sc.pqAA = block_new_padded_aa(queryAlnLen, MAX_SIZE); sc.pq3 = block_new_padded_aa(queryAlnLen, MAX_SIZE);
+        sc.ptAA = block_new_padded_aa(targetAlnLen, MAX_SIZE); sc.pt3 = block_new_padded_aa(targetAlnLen, MAX_SIZE);
+        sc.pqB = block_new_pos_bias(queryAlnLen, MAX_SIZE); sc.ptB = block_new_pos_bias(targetAlnLen, MAX_SIZE);
+    }
+    PaddedBytes *pqAA = sc.pqAA, *pq3 = sc.pq3, *ptAA = sc.ptAA, *pt3 = sc.pt3;
+    PosBias *pqB = sc.pqB, *ptB = sc.ptB;
     block_set_bytes_padded_aa(pqAA, (const uint8_t *) qAAs.data(), queryAlnLen, MAX_SIZE);
     block_set_bytes_padded_aa(pq3, (const uint8_t *) q3s.data(), queryAlnLen, MAX_SIZE);
     block_set_pos_bias(pqB, qBias.data(), queryAlnLen);
@@ -60,11 +80,19 @@ void blockBacktrace(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, c
     block_set_bytes_padded_aa(pt3, (const uint8_t *) t3s.data(), targetAlnLen, MAX_SIZE);
     block_set_pos_bias(ptB, tBias.data(), targetAlnLen);
     // matrices keyed by letter, filled from the short substitution scores cast to int8 (:428-447)
-    AAMatrix *maa = block_new_simple_aamatrix(1, -1), *m3 = block_new_simple_aamatrix(1, -1);
-    for (int a = 0; a < mAA.n; a++)
-        for (int b = 0; b < mAA.n; b++) block_set_aamatrix(maa, (uint8_t) mAA.letters[a], (uint8_t) mAA.letters[b], (int8_t) mAA.sub[a * mAA.n + b]);
-    for (int a = 0; a < m3Di.n; a++)
-        for (int b = 0; b < m3Di.n; b++) block_set_aamatrix(m3, (uint8_t) m3Di.letters[a], (uint8_t) m3Di.letters[b], (int8_t) m3Di.sub[a * m3Di.n + b]);
+    if (!sc.maa) { sc.maa = block_new_simple_aamatrix(1, -1); sc.m3 = block_new_simple_aamatrix(1, -1); }
+    AAMatrix *maa = sc.maa, *m3 = sc.m3;
+    const uint64_t hA = matrixHash(mAA), h3 = matrixHash(m3Di);
+    if (sc.maaKey != hA) {
+        for (int a = 0; a < mAA.n; a++)
+            for (int b = 0; b < mAA.n; b++) block_set_aamatrix(maa, (uint8_t) mAA.letters[a], (uint8_t) mAA.letters[b], (int8_t) mAA.sub[a * mAA.n + b]);
+        sc.maaKey = hA;
+    }
+    if (sc.m3Key != h3) {
+        for (int a = 0; a < m3Di.n; a++)
+            for (int b = 0; b < m3Di.n; b++) block_set_aamatrix(m3, (uint8_t) m3Di.letters[a], (uint8_t) m3Di.letters[b], (int8_t) m3Di.sub[a * m3Di.n + b]);
+        sc.m3Key = h3;
+    }
 
     AlignResult res;
     res.score = -1000000000; res.query_idx = (uintptr_t) -1; res.reference_idx = (uintptr_t) -1;
@@ -104,9 +132,6 @@ void blockBacktrace(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, c
         out.ok = true;
         block_free_cigar(cigar);
     }
-    block_free_padded_aa(pqAA); block_free_padded_aa(pq3); block_free_padded_aa(ptAA); block_free_padded_aa(pt3);
-    block_free_pos_bias(pqB); block_free_pos_bias(ptB);
-    block_free_aamatrix(maa); block_free_aamatrix(m3);
 }
 
 } // namespace fsh
