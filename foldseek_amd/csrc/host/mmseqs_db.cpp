@@ -1,0 +1,142 @@
+// mmseqs_db.cpp -- see mmseqs_db.h
+#include "mmseqs_db.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace fsh {
+
+static bool fileSize(const std::string &p, uint64_t &sz) {
+    struct stat st;
+    if (stat(p.c_str(), &st) != 0) return false;
+    sz = (uint64_t) st.st_size;
+    return true;
+}
+
+DbReader::~DbReader() {
+    if (mapped && base) munmap((void *) base, bytes);
+}
+
+bool DbReader::open(const std::string &path, std::string &err) {
+    // .dbtype
+    {
+        FILE *f = fopen((path + ".dbtype").c_str(), "rb");
+        if (!f) { err = "cannot open " + path + ".dbtype"; return false; }
+        int32_t t = 0;
+        if (fread(&t, 4, 1, f) != 1) { fclose(f); err = "short read on " + path + ".dbtype"; return false; }
+        fclose(f);
+        type = t;
+        if (extended() & DBTYPE_EXTENDED_COMPRESSED) { err = path + ": compressed databases are not supported by this module"; return false; }
+    }
+    // .index
+    {
+        FILE *f = fopen((path + ".index").c_str(), "rb");
+        if (!f) { err = "cannot open " + path + ".index"; return false; }
+        uint64_t isz = 0;
+        fileSize(path + ".index", isz);
+        std::vector<char> buf(isz + 1);
+        if (isz && fread(buf.data(), 1, isz, f) != isz) { fclose(f); err = "short read on " + path + ".index"; return false; }
+        fclose(f);
+        buf[isz] = 0;
+        const char *p = buf.data(), *end = buf.data() + isz;
+        while (p < end) {
+            char *q;
+            Entry e;
+            e.key = (uint32_t) strtoul(p, &q, 10);
+            if (q == p) break;
+            e.offset = strtoull(q, &q, 10);
+            e.length = (uint32_t) strtoul(q, &q, 10);
+            entries.push_back(e);
+            while (q < end && *q != '\n') q++;
+            p = q + 1;
+        }
+        std::stable_sort(entries.begin(), entries.end(), [](const Entry &a, const Entry &b) { return a.key < b.key; });
+    }
+    // data: <db> or <db>.0, <db>.1, ...
+    uint64_t sz = 0;
+    if (fileSize(path, sz)) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { err = "cannot open " + path; return false; }
+        bytes = sz;
+        if (sz) {
+            void *m = mmap(NULL, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); err = "mmap failed for " + path; return false; }
+            base = (const char *) m;
+            mapped = true;
+        }
+        ::close(fd);
+    } else {
+        for (int k = 0;; k++) {
+            const std::string part = path + "." + std::to_string(k);
+            uint64_t psz = 0;
+            if (!fileSize(part, psz)) break;
+            FILE *f = fopen(part.c_str(), "rb");
+            if (!f) { err = "cannot open " + part; return false; }
+            const size_t old = owned.size();
+            owned.resize(old + psz);
+            if (psz && fread(owned.data() + old, 1, psz, f) != psz) { fclose(f); err = "short read on " + part; return false; }
+            fclose(f);
+        }
+        if (owned.empty() && !entries.empty()) { err = "cannot find data file for " + path; return false; }
+        base = owned.data();
+        bytes = owned.size();
+    }
+    // padded GPU databases store L residues (+ padding) but index L + 2 (makepaddedseqdb.cpp:96-104)
+    const bool gpuDb = (extended() & DBTYPE_EXTENDED_GPU) != 0;
+    for (const Entry &e : entries) {
+        const uint64_t need = gpuDb ? (e.length >= 2 ? e.length - 2 : 0) : e.length;
+        if (e.offset + need > bytes) { err = path + ": index entry beyond end of data file"; return false; }
+    }
+    return true;
+}
+
+int64_t DbReader::idOf(uint32_t k) const {
+    auto it = std::lower_bound(entries.begin(), entries.end(), k, [](const Entry &e, uint32_t v) { return e.key < v; });
+    if (it == entries.end() || it->key != k) return -1;
+    return (int64_t) (it - entries.begin());
+}
+
+uint64_t DbReader::residues() const {
+    uint64_t r = 0;
+    for (const Entry &e : entries) r += e.length >= 2 ? e.length - 2 : 0;
+    return r;
+}
+
+bool DbWriter::open(const std::string &p, int dbtype, std::string &err) {
+    path = p; type = dbtype; off = 0; entries.clear();
+    f = fopen(p.c_str(), "wb");
+    if (!f) { err = "cannot create " + p; return false; }
+    return true;
+}
+
+void DbWriter::write(uint32_t key, const char *data, size_t size) {
+    if (size) fwrite(data, 1, size, f);
+    const char nul = 0;
+    fwrite(&nul, 1, 1, f);
+    DbReader::Entry e; e.key = key; e.offset = off; e.length = (uint32_t) (size + 1);
+    entries.push_back(e);
+    off += size + 1;
+}
+
+bool DbWriter::close(std::string &err) {
+    if (f) { fclose(f); f = nullptr; }
+    std::stable_sort(entries.begin(), entries.end(), [](const DbReader::Entry &a, const DbReader::Entry &b) { return a.key < b.key; });
+    FILE *fi = fopen((path + ".index").c_str(), "wb");
+    if (!fi) { err = "cannot create " + path + ".index"; return false; }
+    for (const auto &e : entries) fprintf(fi, "%u\t%llu\t%u\n", e.key, (unsigned long long) e.offset, e.length);
+    fclose(fi);
+    FILE *ft = fopen((path + ".dbtype").c_str(), "wb");
+    if (!ft) { err = "cannot create " + path + ".dbtype"; return false; }
+    int32_t t = type;
+    fwrite(&t, 4, 1, ft);
+    fclose(ft);
+    return true;
+}
+
+} // namespace fsh

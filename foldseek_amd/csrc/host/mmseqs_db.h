@@ -1,0 +1,58 @@
+// mmseqs_db.h -- minimal reader / writer for the MMseqs2 on-disk database layout the hot-path modules exchange
+// (reference: DBReader / DBWriter, M/src/commons/DBReader.{h,cpp}, DBWriter.cpp:331-428; layout summary SURVEY.md 8b):
+//   <db>         entries back to back, each terminated by '\0' (sequence entries: residues + '\n' + '\0')
+//   <db>.index   one line per entry: key \t offset \t length   (length counts the terminator bytes), sorted by key
+//   <db>.dbtype  int32: low 16 bits = type (0 amino acids, 5 alignment results, 7 prefilter results),
+//                high 16 bits = extended flags (8 = padded GPU database)
+// Only what the two modules need: uncompressed, single data file (or <db>.0, <db>.1 ... concatenated by offset).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace fsh {
+
+enum { DBTYPE_AMINO_ACIDS = 0, DBTYPE_ALIGNMENT_RES = 5, DBTYPE_PREFILTER_RES = 7 };
+enum { DBTYPE_EXTENDED_COMPRESSED = 1, DBTYPE_EXTENDED_GPU = 8 };
+
+class DbReader {
+public:
+    struct Entry { uint32_t key; uint64_t offset; uint32_t length; };
+    ~DbReader();
+    bool open(const std::string &path, std::string &err);
+    size_t size() const { return entries.size(); }
+    uint32_t key(size_t id) const { return entries[id].key; }
+    const char *data(size_t id) const { return base + entries[id].offset; }
+    uint32_t entryLen(size_t id) const { return entries[id].length; }        // as in the index
+    uint32_t seqLen(size_t id) const { return entries[id].length >= 2 ? entries[id].length - 2 : 0; }   // DBReader::getSeqLen
+    uint64_t offset(size_t id) const { return entries[id].offset; }
+    int64_t idOf(uint32_t key) const;                                         // DBReader::getId, -1 if absent
+    int dbtype() const { return type & 0xffff; }
+    int extended() const { return (int) ((uint32_t) type >> 16); }
+    const char *dataBase() const { return base; }
+    uint64_t dataSize() const { return bytes; }
+    uint64_t residues() const;                                                // getAminoAcidDBSize: sum of seqLen
+private:
+    std::vector<Entry> entries;                                               // sorted by key
+    const char *base = nullptr;
+    uint64_t bytes = 0;
+    int type = 0;
+    bool mapped = false;
+    std::vector<char> owned;                                                  // multi-file DBs are read into memory
+};
+
+class DbWriter {
+public:
+    bool open(const std::string &path, int dbtype, std::string &err);
+    // appends data + '\0' and remembers (key, offset, size + 1)   (DBWriter::writeData with addNullByte)
+    void write(uint32_t key, const char *data, size_t size);
+    bool close(std::string &err);                                             // index sorted by key + .dbtype
+private:
+    std::string path;
+    int type = 0;
+    FILE *f = nullptr;
+    uint64_t off = 0;
+    std::vector<DbReader::Entry> entries;
+};
+
+} // namespace fsh

@@ -1,0 +1,318 @@
+// modules.cpp -- the three sub-commands of the hot path with the reference's module contract
+// ("int f(int argc, const char **argv)", DBs in -> DBs out, EXIT_SUCCESS / message + EXIT_FAILURE):
+//   ungappedprefilter <queryDB_ss> <targetDB_ss[_pad]> <outPrefDB>          M/src/prefiltering/ungappedprefilter.cpp:484-595
+//   structurealign    <queryDB> <targetDB[_pad]> <prefDB> <outAlnDB>         F/src/strucclustutils/structurealign.cpp:141-481
+//   makepaddedseqdb   <seqDB> <outPaddedDB>                                  M/src/util/makepaddedseqdb.cpp:14-154
+// They read and write the same on-disk databases as the reference modules, so the shell workflows
+// (F/data/structuresearch.sh:41-53,116-143) can call them in place of the originals.  All DP work is done by the
+// device library (fsgpu_*), this file is DB plumbing + option parsing.
+#include "hostlib.h"
+#include "mmseqs_db.h"
+
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace fsh;
+
+namespace {
+
+struct Options {
+    std::vector<std::string> pos;
+    std::map<std::string, std::string> kv;
+    bool has(const std::string &k) const { return kv.count(k) != 0; }
+    int geti(const std::string &k, int d) const { auto it = kv.find(k); return it == kv.end() ? d : atoi(it->second.c_str()); }
+    double getd(const std::string &k, double d) const { auto it = kv.find(k); return it == kv.end() ? d : atof(it->second.c_str()); }
+};
+
+// flags of the reference modules that take no value (M/src/commons/Parameters.cpp); everything else is "--flag value"
+const char *kBoolFlags[] = {"-a", "--add-backtrace", "-h", "--help", nullptr};
+
+Options parseArgs(int argc, const char **argv) {
+    Options o;
+    for (int i = 0; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() > 1 && a[0] == '-' && !(a.size() > 1 && isdigit((unsigned char) a[1]))) {
+            bool isBool = false;
+            for (int k = 0; kBoolFlags[k]; k++) isBool = isBool || a == kBoolFlags[k];
+            if (isBool) { o.kv[a] = "1"; continue; }
+            if (i + 1 < argc) { o.kv[a] = argv[++i]; } else { o.kv[a] = "1"; }
+        } else {
+            o.pos.push_back(a);
+        }
+    }
+    return o;
+}
+
+int fail(const std::string &msg) {
+    fprintf(stderr, "%s\n", msg.c_str());
+    return EXIT_FAILURE;
+}
+
+// Target database in the padded GPU layout, either taken as is from disk or built in memory from an ASCII DB.
+struct PaddedTarget {
+    std::vector<uint8_t> own3di, ownAA;
+    const uint8_t *d3 = nullptr, *dA = nullptr;
+    std::vector<uint64_t> offsets;
+    std::vector<int32_t> lengths;
+    std::vector<uint32_t> keys;
+    uint64_t bytes = 0;
+};
+
+bool loadPadded(const DbReader &r3, const DbReader *rA, const Matrix &m3, const Matrix *mA, PaddedTarget &t, std::string &err) {
+    const size_t n = r3.size();
+    t.offsets.resize(n + 1); t.lengths.resize(n); t.keys.resize(n);
+    const bool padded = (r3.extended() & DBTYPE_EXTENDED_GPU) != 0;
+    if (rA && rA->size() != n) { err = "AA and 3Di target databases differ in size"; return false; }
+    if (padded) {
+        for (size_t i = 0; i < n; i++) {
+            t.offsets[i] = r3.offset(i); t.lengths[i] = (int32_t) r3.seqLen(i); t.keys[i] = r3.key(i);
+            if (rA && (rA->offset(i) != r3.offset(i) || rA->seqLen(i) != r3.seqLen(i))) { err = "padded AA and 3Di databases are not aligned"; return false; }
+        }
+        t.offsets[n] = r3.dataSize();
+        t.d3 = (const uint8_t *) r3.dataBase();
+        t.dA = rA ? (const uint8_t *) rA->dataBase() : nullptr;
+        t.bytes = r3.dataSize();
+        return true;
+    }
+    // ASCII database: encode in index order (lower case = soft-masked -> code + 32), pad each entry to a multiple of 4
+    uint64_t off = 0;
+    for (size_t i = 0; i < n; i++) {
+        t.offsets[i] = off; t.lengths[i] = (int32_t) r3.seqLen(i); t.keys[i] = r3.key(i);
+        off += ((uint64_t) t.lengths[i] + 3) / 4 * 4;
+        if (rA && rA->seqLen(i) != r3.seqLen(i)) { err = "AA and 3Di entries differ in length"; return false; }
+    }
+    t.offsets[n] = off; t.bytes = off;
+    t.own3di.assign(off, 20);
+    if (rA) t.ownAA.assign(off, 20);
+    for (size_t i = 0; i < n; i++) {
+        const char *s = r3.data(i);
+        for (int k = 0; k < t.lengths[i]; k++) {
+            uint8_t c = m3.aa2num[(unsigned char) s[k]];
+            t.own3di[t.offsets[i] + k] = (uint8_t) (islower((unsigned char) s[k]) ? c + 32 : c);
+        }
+        if (rA) {
+            const char *a = rA->data(i);
+            for (int k = 0; k < t.lengths[i]; k++) t.ownAA[t.offsets[i] + k] = mA->aa2num[(unsigned char) a[k]];
+        }
+    }
+    t.d3 = t.own3di.data();
+    t.dA = rA ? t.ownAA.data() : nullptr;
+    return true;
+}
+
+void fillParams(const Options &o, fshost_params &p) {
+    fshost_params_default(&p);
+    p.maxResListLen = o.geti("--max-seqs", p.maxResListLen);
+    p.minDiagScoreThr = o.geti("--min-ungapped-score", p.minDiagScoreThr);
+    p.compBiasCorrection = o.geti("--comp-bias-corr", p.compBiasCorrection);
+    p.alignmentType = o.geti("--alignment-type", p.alignmentType);
+    p.gapOpen = o.geti("--gap-open", p.gapOpen);
+    p.gapExtend = o.geti("--gap-extend", p.gapExtend);
+    p.evalThr = o.getd("-e", p.evalThr);
+    p.covThr = (float) o.getd("-c", p.covThr);
+    p.covMode = o.geti("--cov-mode", p.covMode);
+    p.addBacktrace = (o.has("-a") || o.has("--add-backtrace")) ? 1 : 0;
+    p.maxAccept = o.geti("--max-accept", p.maxAccept);
+    p.maxRejected = o.geti("--max-rejected", p.maxRejected);
+    p.seqIdThr = (float) o.getd("--min-seq-id", p.seqIdThr);
+    p.alnLenThr = o.geti("--min-aln-len", p.alnLenThr);
+}
+
+} // namespace
+
+extern "C" {
+
+int fsmod_makepaddedseqdb(int argc, const char **argv) {
+    Options o = parseArgs(argc, argv);
+    if (o.pos.size() != 2) return fail("usage: makepaddedseqdb <sequenceDB> <outPaddedDB>");
+    DbReader r;
+    std::string err;
+    if (!r.open(o.pos[0], err)) return fail(err);
+    Matrix m;
+    if (!m.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f)) return fail("matrix construction failed");
+    const size_t n = r.size();
+    // DBReader SORT_BY_LENGTH = descending length, ties ascending id (M/src/commons/DBReader.h:436-448), iterated backwards
+    std::vector<size_t> ord(n);
+    for (size_t i = 0; i < n; i++) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return r.seqLen(a) > r.seqLen(b); });
+    std::reverse(ord.begin(), ord.end());
+    FILE *fd = fopen(o.pos[1].c_str(), "wb");
+    FILE *fi = fopen((o.pos[1] + ".index").c_str(), "wb");
+    FILE *fl = fopen((o.pos[1] + ".lookup").c_str(), "wb");
+    if (!fd || !fi || !fl) return fail("cannot create " + o.pos[1]);
+    uint64_t off = 0;
+    std::string out;
+    for (size_t k = 0; k < n; k++) {
+        const size_t id = ord[k];
+        const char *s = r.data(id);
+        const uint32_t L = r.seqLen(id);
+        out.clear();
+        for (uint32_t i = 0; i < L; i++) {
+            const uint8_t c = m.aa2num[(unsigned char) s[i]];
+            out.push_back((char) (islower((unsigned char) s[i]) ? c + 32 : c));
+        }
+        out.append((L % 4 == 0) ? 0 : 4 - L % 4, (char) 20);
+        fwrite(out.data(), 1, out.size(), fd);
+        fprintf(fi, "%zu\t%llu\t%u\n", k, (unsigned long long) off, L + 2);
+        fprintf(fl, "%zu\t%u\t%u\n", k, r.key(id), r.key(id));   // new key -> original key (name column unknown here)
+        off += out.size();
+    }
+    fclose(fd); fclose(fi); fclose(fl);
+    FILE *ft = fopen((o.pos[1] + ".dbtype").c_str(), "wb");
+    if (!ft) return fail("cannot create dbtype");
+    int32_t t = (int32_t) ((uint32_t) r.dbtype() | ((uint32_t) (r.extended() | DBTYPE_EXTENDED_GPU) << 16));
+    fwrite(&t, 4, 1, ft);
+    fclose(ft);
+    return EXIT_SUCCESS;
+}
+
+int fsmod_ungappedprefilter(int argc, const char **argv) {
+    Options o = parseArgs(argc, argv);
+    if (o.pos.size() != 3) return fail("usage: ungappedprefilter <queryDB_ss> <targetDB_ss> <outPrefDB> [--max-seqs N] [--min-ungapped-score S] [--comp-bias-corr 0|1] [--threads T]");
+    std::string err;
+    DbReader q, t;
+    if (!q.open(o.pos[0], err) || !t.open(o.pos[1], err)) return fail(err);
+    const bool sameDB = o.pos[0] == o.pos[1];
+    fshost_params par;
+    fillParams(o, par);
+    par.prefCompBiasScale = (float) o.getd("--comp-bias-corr-scale", 0.15);
+    Matrix m3;
+    m3.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f);
+    PaddedTarget pt;
+    if (!loadPadded(t, nullptr, m3, nullptr, pt, err)) return fail(err);
+    fsgpu_ctx *ctx0 = nullptr;
+    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
+    if (fsgpu_db_load(ctx0, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
+        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    DbWriter w;
+    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) return fail(err);
+    const int nthreads = std::max(1, std::min(o.geti("--threads", 3), 16));
+    std::vector<std::string> results(q.size());
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    std::string firstErr;
+    auto work = [&](int tix) {
+        fsgpu_ctx *ctx = ctx0;
+        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data());
+        std::vector<fsgpu_hit> hits(par.maxResListLen);
+        std::vector<uint8_t> codes;
+        char line[128];
+        for (;;) {
+            const size_t id = next++;
+            if (id >= q.size() || bad) break;
+            const uint32_t L = q.seqLen(id);
+            if (L == 0) continue;
+            codes.resize(L);
+            const char *sq = q.data(id);
+            for (uint32_t i = 0; i < L; i++) codes[i] = m3.aa2num[(unsigned char) sq[i]];
+            const int64_t identity = sameDB ? t.idOf(q.key(id)) : -1;
+            const int n = fshost_search_prefilter(s, codes.data(), (int) L, identity, hits.data());
+            if (n < 0) { if (!bad++) firstErr = fshost_search_error(s); break; }
+            std::string &out = results[id];
+            for (int k = 0; k < n; k++) out.append(line, fshost_format_prefilter_hit(line, pt.keys[hits[k].id], hits[k].score, 0));
+        }
+        fshost_search_free(s);
+        if (tix > 0) fsgpu_destroy(ctx);
+    };
+    std::vector<std::thread> ths;
+    for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
+    work(0);
+    for (auto &th : ths) th.join();
+    if (bad) { fsgpu_destroy(ctx0); return fail("ungappedprefilter failed: " + firstErr); }
+    for (size_t id = 0; id < q.size(); id++) w.write(q.key(id), results[id].data(), results[id].size());   // empty entries too
+    fsgpu_destroy(ctx0);
+    if (!w.close(err)) return fail(err);
+    return EXIT_SUCCESS;
+}
+
+int fsmod_structurealign(int argc, const char **argv) {
+    Options o = parseArgs(argc, argv);
+    if (o.pos.size() != 4) return fail("usage: structurealign <queryDB> <targetDB> <prefDB> <outAlnDB> [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
+    std::string err;
+    DbReader qA, q3, tA, t3, pref;
+    if (!qA.open(o.pos[0], err) || !q3.open(o.pos[0] + "_ss", err) || !tA.open(o.pos[1], err) || !t3.open(o.pos[1] + "_ss", err) ||
+        !pref.open(o.pos[2], err))
+        return fail(err);
+    const bool sameDB = o.pos[0] == o.pos[1];
+    fshost_params par;
+    fillParams(o, par);
+    par.alnCompBiasScale = (float) o.getd("--comp-bias-corr-scale", 0.5);
+    Matrix m3, mA;
+    m3.builtin(FSHOST_MAT_3DI, 2.1f, 0.0f);
+    mA.builtin(FSHOST_MAT_BLOSUM62, par.alignmentType == 2 ? 1.4f : 0.0f, 0.0f);
+    PaddedTarget pt;
+    if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
+    fsgpu_ctx *ctx0 = nullptr;
+    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
+    if (fsgpu_db_load(ctx0, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
+        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    DbWriter w;
+    if (!w.open(o.pos[3], DBTYPE_ALIGNMENT_RES, err)) return fail(err);
+    const int nthreads = std::max(1, std::min(o.geti("--threads", 3), 16));
+    std::vector<std::string> results(pref.size());
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    std::string firstErr;
+    auto work = [&](int tix) {
+        fsgpu_ctx *ctx = ctx0;
+        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data());
+        std::vector<uint8_t> cA, c3;
+        std::vector<uint32_t> ids;
+        std::vector<fshost_result> res;
+        std::vector<char> line(1024 + 2 * 65536 * 2);
+        for (;;) {
+            const size_t id = next++;
+            if (id >= pref.size() || bad) break;
+            const uint32_t queryKey = pref.key(id);
+            const char *data = pref.data(id);
+            if (*data == '\0') continue;
+            const int64_t qid = q3.idOf(queryKey);
+            if (qid < 0 || qA.idOf(queryKey) < 0) { if (!bad++) firstErr = "query key missing in query database"; break; }
+            const uint32_t L = q3.seqLen((size_t) qid);
+            cA.resize(L); c3.resize(L);
+            const char *sA = qA.data((size_t) qA.idOf(queryKey)), *s3 = q3.data((size_t) qid);
+            for (uint32_t i = 0; i < L; i++) { cA[i] = mA.aa2num[(unsigned char) sA[i]]; c3[i] = m3.aa2num[(unsigned char) s3[i]]; }
+            // prefilter entry: lines "targetKey \t score \t diagonal" (Util::parseKey, structurealign.cpp:351-355)
+            ids.clear();
+            while (*data != '\0') {
+                const uint32_t dbKey = (uint32_t) strtoul(data, nullptr, 10);
+                const int64_t tid = t3.idOf(dbKey);
+                if (tid < 0) { if (!bad++) firstErr = "target key missing in target database"; break; }
+                ids.push_back((uint32_t) tid);
+                while (*data != '\n' && *data != '\0') data++;
+                if (*data == '\n') data++;
+            }
+            if (bad) break;
+            res.resize(ids.size() + 1);
+            const int64_t identity = sameDB ? t3.idOf(queryKey) : -1;
+            const int n = fshost_search_align(s, cA.data(), c3.data(), (int) L, identity, ids.data(), (int) ids.size(), res.data());
+            if (n < 0) { if (!bad++) firstErr = fshost_search_error(s); break; }
+            std::string &out = results[id];
+            for (int k = 0; k < n; k++)
+                out.append(line.data(), fshost_format_result(line.data(), &res[k], fshost_search_backtrace(s, &res[k]), par.addBacktrace));
+        }
+        fshost_search_free(s);
+        if (tix > 0) fsgpu_destroy(ctx);
+    };
+    std::vector<std::thread> ths;
+    for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
+    work(0);
+    for (auto &th : ths) th.join();
+    if (bad) { fsgpu_destroy(ctx0); return fail("structurealign failed: " + firstErr); }
+    for (size_t id = 0; id < pref.size(); id++) w.write(pref.key(id), results[id].data(), results[id].size());
+    fsgpu_destroy(ctx0);
+    if (!w.close(err)) return fail(err);
+    return EXIT_SUCCESS;
+}
+
+} // extern "C"

@@ -141,6 +141,16 @@ int fshost_block_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, 
 size_t fshost_format_prefilter_hit(char *buf, uint32_t key, int score, int diagonal);
 size_t fshost_format_result(char *buf, const fshost_result *r, const char *backtrace, int addBacktrace);
 
+/* ---- module entry points with the reference's sub-command contract (argv without the program / command name) ----
+ * They read and write MMseqs2 databases on disk exactly like the reference modules they stand in for:
+ *   fsmod_ungappedprefilter  <queryDB_ss> <targetDB_ss> <outPrefDB>       M/src/prefiltering/ungappedprefilter.cpp:484-595
+ *   fsmod_structurealign     <queryDB> <targetDB> <prefDB> <outAlnDB>     F/src/strucclustutils/structurealign.cpp:141-481
+ *   fsmod_makepaddedseqdb    <seqDB> <outPaddedDB>                        M/src/util/makepaddedseqdb.cpp:14-154
+ * Return EXIT_SUCCESS or print a message to stderr and return EXIT_FAILURE. */
+int fsmod_ungappedprefilter(int argc, const char **argv);
+int fsmod_structurealign(int argc, const char **argv);
+int fsmod_makepaddedseqdb(int argc, const char **argv);
+
 #ifdef __cplusplus
 }
 #endif
