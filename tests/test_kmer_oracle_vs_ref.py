@@ -1,0 +1,106 @@
+"""Pins oracle/fs_kmer_oracle.c (the C restatement of the k-mer prefilter) to the
+reference's own classes compiled into oracle/_ref (ref_kmer_harness.cpp): index table, masked sequence lookup,
+extended 3-mer matrix rows, similar-k-mer lists and complete per-query hit lists, including the
+databaseHits-overflow path, every BINSIZE-dependent ordering and the score-255 rescoring path.
+Skipped where oracle/_ref could not be built (no /root/reference)."""
+import numpy as np
+import pytest
+
+import helpers as H
+import kmer_lib as K
+from foldseek_amd import synth
+
+N, NQ = 1500, 5
+
+
+@pytest.fixture(scope="module")
+def world():
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    O = K.load_ora()
+    q3, qa = synth.make_queries(NQ, seed=3)
+    db = synth.make_db(N, (q3, qa), seed=11, homologs_per_query=25, mask_frac=0.02)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    # a few hand-made edge cases: leading run of code 0 (never masked), long repeats, all-X, too short for a k-mer
+    targets[0] = np.array([0] * 12 + [3, 4, 5, 6, 7, 8, 9, 10, 11, 12] * 3, np.uint8)
+    targets[1] = np.array([5] * 9 + [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13] + [7] * 7 + [2, 3], np.uint8)
+    targets[2] = np.full(40, 20, np.uint8)
+    targets[3] = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9], np.uint8)
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    r = K.RefKpf(R, targets)
+    o = K.OraKpf(O, ksub, pb, usub, targets)
+    yield dict(r=r, o=o, q3=q3, targets=targets, ksub=ksub, usub=usub)
+    r.close(); o.close()
+
+
+def test_matrices(world):
+    assert (world["r"].submat(0).ravel() == world["ksub"]).all()
+    assert (world["r"].submat(1).ravel() == world["usub"]).all()
+
+
+def test_index_and_lookup(world):
+    r, o = world["r"], world["o"]
+    ro, oo = r.offsets(), o.offsets()
+    assert (ro == oo).all() and ro[-1] > 0
+    for i in list(range(8)) + list(range(8, N, 37)):
+        L = len(world["targets"][i])
+        assert (r.masked(i, L) == o.masked(i, L)).all(), i
+    rng = np.random.default_rng(5)
+    nz = np.nonzero(np.diff(ro.astype(np.int64)))[0]
+    for k in rng.choice(nz, 300):
+        a, b = r.index_list(k), o.index_list(k)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), k
+
+
+def test_extended_matrix_rows(world):
+    r, o = world["r"], world["o"]
+    for idx in [0, 1, 19, 20, 399, 400, 7999, 1234, 4321, 6789]:
+        a, b = r.row(3, idx), o.row(3, idx)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), idx
+    for idx in [0, 7, 399]:
+        a, b = r.row(2, idx), o.row(2, idx)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), idx
+
+
+def test_similar_kmer_lists(world):
+    r, o = world["r"], world["o"]
+    rng = np.random.default_rng(9)
+    for t in range(40):
+        km = rng.integers(0, 20, 6).astype(np.uint8)
+        thr = int(rng.integers(30, 130)) if t else 0
+        a, b = r.kmer_list(km, thr), o.kmer_list(km, thr)
+        assert len(a) == len(b) and (a == b).all(), (km, thr)
+
+
+VARIANTS = [
+    dict(),
+    dict(maxResListLen=40),
+    dict(maxResListLen=40, bins=4),
+    dict(maxResListLen=40, bins=32),
+    dict(maxResListLen=4),                                        # >= maxHits hits at 255 -> rescoreHits path
+    dict(maxResListLen=300, maxDbMatches=9000),                   # several databaseHits overflows
+    dict(maxResListLen=60, maxDbMatches=4000, bins=8),
+    dict(maxResListLen=300, maxDbMatches=3000, foundDiagonalsSize=2500),
+    dict(compBias=0, maxResListLen=25, maxDbMatches=7000),
+    dict(minDiagScoreThr=12, maxResListLen=1500),
+]
+
+
+@pytest.mark.parametrize("kw", VARIANTS)
+def test_hit_lists(world, kw):
+    r, o, q3 = world["r"], world["o"], world["q3"]
+    base = dict(maxResListLen=1000, bins=0, maxDbMatches=0, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=30)
+    base.update(kw)
+    r.set(**base); o.set(**base)
+    ident = np.array([-1, 7, -1, 100, -1], np.int64)
+    rr, rs, _ = r.run(q3, ident)
+    orr, os_ = o.run(q3, ident)
+    for q in range(NQ):
+        assert orr[q] is not None
+        assert len(rr[q]) == len(orr[q]) and (rr[q] == orr[q]).all(), (q, kw)
+        assert np.allclose(rs[q], os_[q]), (q, rs[q], os_[q])
+    assert sum(len(x) for x in rr) > 0
+    if "maxDbMatches" in kw:
+        assert rs[:, 2].sum() > 0     # the overflow path was really taken
