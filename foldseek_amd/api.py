@@ -27,6 +27,24 @@ class Params(C.Structure):
                 ("seqIdThr", C.c_float), ("alnLenThr", C.c_int)]
 
 
+class KmerIndexParams(C.Structure):
+    _fields_ = [("kmerSize", C.c_int32), ("spaced", C.c_int32), ("kmerThr", C.c_int32), ("maskLowerCase", C.c_int32),
+                ("maskNrepeats", C.c_int32)]
+
+
+class KmerSearchParams(C.Structure):
+    _fields_ = [("maxResListLen", C.c_int32), ("minDiagScoreThr", C.c_int32), ("bins", C.c_int32), ("reserved", C.c_int32),
+                ("maxDbMatches", C.c_int64), ("foundDiagonalsSize", C.c_int64), ("l2CacheSize", C.c_uint64)]
+
+
+class KmerQuery(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("kmerThr", C.c_void_p), ("profile", C.c_void_p), ("L", C.c_int32),
+                ("reserved", C.c_int32), ("identity", C.c_int64)]
+
+
+KMER_HIT_DT = np.dtype([("id", np.uint32), ("score", np.int32), ("diag", np.uint16), ("pad", np.uint16)])
+
+
 class FsgpuError(RuntimeError):
     pass
 
@@ -62,6 +80,13 @@ def lib():
         "fsgpu_sw_launch": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32]),
         "fsgpu_sw_finish": (i32, [vp, vp, vp]),
         "fsgpu_last_kernel_ms": (f64, [vp, i32]),
+        "fsgpu_kmer_index_build": (i32, [vp, vp, vp]),
+        "fsgpu_kmer_index_entries": (u64, [vp]),
+        "fsgpu_kmer_search": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+        "fsgpu_kmer_index_copy": (i32, [vp, vp, vp, vp]),
+        "fsgpu_kmer_row_copy": (i32, [vp, i32, vp, vp]),
+        "fshost_kmer_query_prepare": (i32, [vp, vp, vp, i32, i32, f32, i32, i32, i32, vp, vp]),
+        "fshost_kmer_threshold": (i32, [f32, i32]),
         "fshost_matrix_create": (vp, [i32, f32, f32]),
         "fshost_matrix_from_text": (vp, [C.c_char_p, f32, f32]),
         "fshost_matrix_free": (None, [vp]),
@@ -104,7 +129,8 @@ def exported_symbols():
     return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_launch", "fsgpu_sw_finish",
-            "fsgpu_last_kernel_ms"]
+            "fsgpu_last_kernel_ms", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
+            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy"]
 
 
 def _ptr(a):
@@ -168,6 +194,23 @@ def align_profiles(mAA, m3Di, qAA, q3Di, comp_bias=True, scale=0.5):
     if rc != 0:
         raise FsgpuError(f"fshost_align_profiles rc={rc}")
     return pAA, p3, cbA, cbS
+
+
+def kmer_threshold(sensitivity=9.5, kmer_size=6):
+    return lib().fshost_kmer_threshold(sensitivity, kmer_size)
+
+
+def kmer_query_prepare(m_kmer, m_ungapped, q3di, comp_bias=True, scale=0.15, kmer_thr=78, kmer_size=6, spaced=1):
+    """-> (seq, kmerThr[nPos], profile[L,21]) for Context.kmer_search"""
+    q = np.ascontiguousarray(q3di, np.uint8)
+    L_ = len(q)
+    thr = np.zeros(max(L_, 1), np.int16)
+    prof = np.zeros((max(L_, 1), 21), np.int8)
+    n = lib().fshost_kmer_query_prepare(m_kmer.h, m_ungapped.h, _ptr(q), L_, int(comp_bias), scale, kmer_thr, kmer_size, spaced,
+                                        _ptr(thr), _ptr(prof))
+    if n < 0:
+        raise FsgpuError("fshost_kmer_query_prepare failed")
+    return q, thr[:n].copy(), prof[:L_].copy()
 
 
 class Evaluer:
@@ -244,6 +287,56 @@ class Context:
         self._chk(lib().fsgpu_gapless_scan(self.h, _ptr(pssm), pssm.shape[1], cap, min_score, identity, max_res, _ptr(out),
                                            C.byref(nout)), "fsgpu_gapless_scan")
         return out[:nout.value]
+
+    # ---- k-mer prefilter ------------------------------------------------------------------------------------
+    def kmer_index_build(self, kmer_matrix, kmer_thr=78, kmer_size=6, spaced=1, mask_lower_case=1, mask_n_repeats=6):
+        """kmer_matrix: Matrix(FSHOST_MAT_3DI, 8.0, -0.2) -- the prefilter's seeding matrix"""
+        p = KmerIndexParams(kmer_size, spaced, kmer_thr, mask_lower_case, mask_n_repeats)
+        sub = np.ascontiguousarray(kmer_matrix.scores(), np.int16)
+        self._kmer_ip = p
+        self._chk(lib().fsgpu_kmer_index_build(self.h, C.byref(p), _ptr(sub)), "fsgpu_kmer_index_build")
+
+    @property
+    def kmer_index_entries(self):
+        return lib().fsgpu_kmer_index_entries(self.h)
+
+    def kmer_index_copy(self, nbytes_db):
+        off = np.zeros(64000001, np.uint32)
+        ent = np.zeros(max(1, self.kmer_index_entries), np.uint64)
+        msk = np.zeros(max(1, nbytes_db), np.uint8)
+        self._chk(lib().fsgpu_kmer_index_copy(self.h, _ptr(off), _ptr(ent), _ptr(msk)), "fsgpu_kmer_index_copy")
+        return off, ent[:self.kmer_index_entries], msk[:nbytes_db]
+
+    def kmer_row(self, row):
+        s = np.zeros(8000, np.int16); ix = np.zeros(8000, np.uint16)
+        self._chk(lib().fsgpu_kmer_row_copy(self.h, row, _ptr(s), _ptr(ix)), "fsgpu_kmer_row_copy")
+        return s, ix
+
+    def kmer_search(self, prepared, identity=None, max_res=1000, min_diag=30, bins=0, max_db_matches=0,
+                    found_diagonals_size=0, l2_cache_size=0, want_stats=False):
+        """prepared: list of (seq uint8[L], thr int16[nPos], profile int8[L,21]) from kmer_query_prepare."""
+        nq = len(prepared)
+        sp = KmerSearchParams(max_res, min_diag, bins, 0, max_db_matches, found_diagonals_size, l2_cache_size)
+        qs = (KmerQuery * max(nq, 1))()
+        keep = []
+        for i, (seq, thr, prof) in enumerate(prepared):
+            seq = np.ascontiguousarray(seq, np.uint8); thr = np.ascontiguousarray(thr, np.int16); prof = np.ascontiguousarray(prof, np.int8)
+            keep.append((seq, thr, prof))
+            qs[i].seq = seq.ctypes.data; qs[i].kmerThr = thr.ctypes.data; qs[i].profile = prof.ctypes.data
+            qs[i].L = len(seq); qs[i].reserved = 0
+            qs[i].identity = -1 if identity is None else int(identity[i])
+        out = np.zeros((max(nq, 1), max_res), KMER_HIT_DT)
+        nout = np.zeros(max(nq, 1), np.int32)
+        status = np.zeros(max(nq, 1), np.int32)
+        stats = np.zeros((max(nq, 1), 4))
+        self._chk(lib().fsgpu_kmer_search(self.h, C.byref(sp), C.cast(qs, C.c_void_p), nq, _ptr(out), _ptr(nout), _ptr(status), _ptr(stats)),
+                  "fsgpu_kmer_search")
+        res = [out[q, :nout[q]].copy() for q in range(nq)]
+        return (res, status[:nq], stats[:nq]) if want_stats else (res, status[:nq])
+
+    def kmer_stage_ms(self):
+        """device ms of the last k-mer batch: total, count, lists, emit, sort, dupflags, score, walk, select"""
+        return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(9)]
 
     def gapless_scores(self):
         s = np.zeros(self.n, np.uint8)

@@ -9,118 +9,12 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/fsgpu.h"
-#include "fs_kernels.h"
-#include "k_gapless.hpp"
+#include "fsgpu_ctx.h"
 #include "k_select.hpp"
+#include "k_gapless.hpp"
 #include "k_sw.hpp"
 
-using namespace fs;
-
 static thread_local std::string g_createError;
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-struct PinBuf {          // pinned host staging
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-// Device-resident target database; shared (ref-counted) between a context and its clones.
-struct DbStore {
-    uint64_t n = 0, residues = 0, bytes = 0;
-    bool hasAA = false;
-    int maxLen = 0;
-    uint4 *scan = nullptr;
-    uint64_t *stripeOff = nullptr;
-    uint32_t *stripeLen = nullptr, *order = nullptr;
-    uint32_t nStripes = 0;
-    uint64_t scanU4 = 0;          // size of `scan` in uint4 units
-    uint8_t *aln3di = nullptr, *alnAA = nullptr;
-    uint64_t *dOffsets = nullptr;
-    int32_t *dLengths = nullptr;
-    std::vector<int32_t> hLengths;
-    ~DbStore() {
-        (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(order);
-        (void) hipFree(aln3di); (void) hipFree(alnAA); (void) hipFree(dOffsets); (void) hipFree(dLengths);
-    }
-};
-
-struct fsgpu_ctx {
-    int device = 0;
-    int numCU = 256;
-    int gaplessBlocksPerCU = 2;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gapless start/stop, sw start/stop
-    bool evValid[2] = {false, false};
-    std::string err;
-
-    // database (shared with clones)
-    std::shared_ptr<DbStore> db;
-
-    // gapless scratch
-    DevBuf pssm, scores, chunkHist, baseGt, baseTie, outId, outScore, gBorder0, gBorder1, scoreAcc;
-    SelMeta *dMeta = nullptr;
-    uint32_t *queue = nullptr;
-    PinBuf hPssm, hImg, hTids;           // pinned staging for per-query uploads (no sync needed to reuse host vectors)
-    SelMeta *hMeta = nullptr;            // pinned
-    PinBuf hOutId, hOutScore;            // pinned
-    int pendingMaxRes = 0;
-    bool gaplessPending = false;
-
-    // sw scratch
-    DevBuf img, tids, res0, res1, border0, border1, keys;
-    PinBuf hRes0, hRes1;                           // pinned result staging
-    struct {
-        bool pending = false;
-        int n = 0, L = 0, go = 0, ge = 0;
-        bool hasAA = false;
-        std::vector<uint32_t> tids;
-        const int16_t *pAAf = nullptr, *p3f = nullptr, *pAAr = nullptr, *p3r = nullptr;
-    } sw;
-};
-
-#define HIPCHK(call)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (call);                                                                        \
-        if (e_ != hipSuccess) {                                                                        \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
-            return FSGPU_E_HIP;                                                                        \
-        }                                                                                              \
-    } while (0)
-
-// Wait for the context stream by polling: hipStreamSynchronize from a non-main host thread falls back to a blocking
-// wait that costs ~0.2 ms per call on this stack, more than the kernels it waits for.
-static int syncStream(fsgpu_ctx *ctx) {
-    for (unsigned spins = 0;; spins++) {
-        hipError_t e = hipStreamQuery(ctx->stream);
-        if (e == hipSuccess) return FSGPU_OK;
-        if (e != hipErrorNotReady) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
-        if (spins > 200000) { std::this_thread::yield(); }
-    }
-}
-
-static int ensurePinned(fsgpu_ctx *ctx, PinBuf &b, size_t bytes) {
-    if (b.cap >= bytes && b.p) return FSGPU_OK;
-    if (b.p) { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; (void) hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
-    // grow geometrically in whole 64 KiB granules so steady-state queries never reallocate
-    size_t want = ((std::max(bytes * 2, (size_t) 65536) + 65535) / 65536) * 65536;
-    hipError_t e = hipHostMalloc(&b.p, want);
-    if (e != hipSuccess) { ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
-    b.cap = want;
-    return FSGPU_OK;
-}
-
-static int ensure(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
-    if (b.cap >= bytes && b.p) return FSGPU_OK;
-    if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-    size_t want = std::max(bytes, (size_t) 256);
-    HIPCHK(hipMalloc(&b.p, want));
-    b.cap = want;
-    return FSGPU_OK;
-}
 
 extern "C" {
 
@@ -156,13 +50,14 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     return FSGPU_OK;
 }
 
-static void freeDb(fsgpu_ctx *ctx) { ctx->db.reset(); }
+static void freeDb(fsgpu_ctx *ctx) { ctx->db.reset(); ctx->kidx.reset(); }
 
 int fsgpu_clone(const fsgpu_ctx *src, fsgpu_ctx **out) {
     if (!src || !out) return FSGPU_E_ARG;
     int rc = fsgpu_create(src->device, out);
     if (rc != FSGPU_OK) return rc;
     (*out)->db = src->db;
+    (*out)->kidx = src->kidx;
     return FSGPU_OK;
 }
 
@@ -171,6 +66,8 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     freeDb(ctx);
+    ctx->kidx.reset();
+    if (ctx->kmer) fsgpu_kmer_free_scratch(ctx->kmer);
     DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
                       &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
@@ -278,6 +175,8 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
         HIPCHK(hipGetLastError());
     }
     if (bytes) {
+        HIPCHK(hipMalloc((void **) &ctx->db->raw3di, bytes));
+        HIPCHK(hipMemcpyAsync(ctx->db->raw3di, dRaw3di, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(k_db_unmask, dim3(2048), dim3(256), 0, ctx->stream, dRaw3di, ctx->db->aln3di, bytes);
         HIPCHK(hipGetLastError());
         if (dRawAA) {
@@ -473,6 +372,7 @@ int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out) {
 }
 
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which) {
+    if (ctx && which >= 2 && which < 12) return ctx->kmerMs[which - 2];
     if (!ctx || which < 0 || which > 1 || !ctx->evValid[which]) return -1.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]) != hipSuccess) return -1.0;

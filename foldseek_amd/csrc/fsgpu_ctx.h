@@ -1,0 +1,127 @@
+// fsgpu_ctx.h -- private: the context / database structures shared by the translation units of libfsgpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fsgpu.h"
+#include "fs_kernels.h"
+namespace fs {
+#include "fs_selmeta.h"
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+struct PinBuf {          // pinned host staging
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct KmerIndex;        // fsgpu_kmer.hip
+struct KmerScratch;      // fsgpu_kmer.hip
+void fsgpu_kmer_free_scratch(KmerScratch *s);
+
+using namespace fs;
+
+// Device-resident target database; shared (ref-counted) between a context and its clones.
+struct DbStore {
+    uint64_t n = 0, residues = 0, bytes = 0;
+    bool hasAA = false;
+    int maxLen = 0;
+    uint4 *scan = nullptr;
+    uint64_t *stripeOff = nullptr;
+    uint32_t *stripeLen = nullptr, *order = nullptr;
+    uint32_t nStripes = 0;
+    uint64_t scanU4 = 0;          // size of `scan` in uint4 units
+    uint8_t *aln3di = nullptr, *alnAA = nullptr;
+    uint8_t *raw3di = nullptr;    // codes with the soft-mask flag (+32) kept: input of the k-mer index build
+    uint64_t *dOffsets = nullptr;
+    int32_t *dLengths = nullptr;
+    std::vector<int32_t> hLengths;
+    ~DbStore() {
+        (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(order);
+        (void) hipFree(aln3di); (void) hipFree(alnAA); (void) hipFree(raw3di); (void) hipFree(dOffsets); (void) hipFree(dLengths);
+    }
+};
+
+struct fsgpu_ctx {
+    int device = 0;
+    int numCU = 256;
+    int gaplessBlocksPerCU = 2;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gapless start/stop, sw start/stop
+    bool evValid[2] = {false, false};
+    std::string err;
+
+    // database (shared with clones)
+    std::shared_ptr<DbStore> db;
+    std::shared_ptr<KmerIndex> kidx;   // k-mer prefilter index (shared with clones)
+    KmerScratch *kmer = nullptr;       // per-context k-mer prefilter scratch
+    double kmerMs[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // device ms of the last k-mer batch: [0] total, [1..] stages
+
+    // gapless scratch
+    DevBuf pssm, scores, chunkHist, baseGt, baseTie, outId, outScore, gBorder0, gBorder1, scoreAcc;
+    SelMeta *dMeta = nullptr;
+    uint32_t *queue = nullptr;
+    PinBuf hPssm, hImg, hTids;           // pinned staging for per-query uploads (no sync needed to reuse host vectors)
+    SelMeta *hMeta = nullptr;            // pinned
+    PinBuf hOutId, hOutScore;            // pinned
+    int pendingMaxRes = 0;
+    bool gaplessPending = false;
+
+    // sw scratch
+    DevBuf img, tids, res0, res1, border0, border1, keys;
+    PinBuf hRes0, hRes1;                           // pinned result staging
+    struct {
+        bool pending = false;
+        int n = 0, L = 0, go = 0, ge = 0;
+        bool hasAA = false;
+        std::vector<uint32_t> tids;
+        const int16_t *pAAf = nullptr, *p3f = nullptr, *pAAr = nullptr, *p3r = nullptr;
+    } sw;
+};
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return FSGPU_E_HIP;                                                                        \
+        }                                                                                              \
+    } while (0)
+
+// Wait for the context stream by polling: hipStreamSynchronize from a non-main host thread falls back to a blocking
+// wait that costs ~0.2 ms per call on this stack, more than the kernels it waits for.
+inline int syncStream(fsgpu_ctx *ctx) {
+    for (unsigned spins = 0;; spins++) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return FSGPU_OK;
+        if (e != hipErrorNotReady) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
+        if (spins > 200000) { std::this_thread::yield(); }
+    }
+}
+
+inline int ensurePinned(fsgpu_ctx *ctx, PinBuf &b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return FSGPU_OK;
+    if (b.p) { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; (void) hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    // grow geometrically in whole 64 KiB granules so steady-state queries never reallocate
+    size_t want = ((std::max(bytes * 2, (size_t) 65536) + 65535) / 65536) * 65536;
+    hipError_t e = hipHostMalloc(&b.p, want);
+    if (e != hipSuccess) { ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
+    b.cap = want;
+    return FSGPU_OK;
+}
+
+inline int ensure(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return FSGPU_OK;
+    if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max(bytes, (size_t) 256);
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return FSGPU_OK;
+}
+

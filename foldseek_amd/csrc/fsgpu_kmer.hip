@@ -1,0 +1,580 @@
+// fsgpu_kmer.hip -- C ABI of the k-mer prefilter (include/fsgpu.h: fsgpu_kmer_index_build / fsgpu_kmer_search).
+// Host side: HIP runtime + rocPRIM's device radix sort / scan (AMD's native primitives; the order-defining work is in
+// k_kmer.hpp).  No CPU fallback: everything below fails with FSGPU_E_* when there is no device.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
+
+#include "fsgpu_ctx.h"
+#include "k_kmer.hpp"
+
+struct KmerIndex {
+    fsgpu_kmer_index_params p{};
+    KmerPattern pat{};
+    std::shared_ptr<DbStore> db;          // keeps offsets / lengths alive
+    uint64_t n = 0;
+    int tbits = 1;
+    uint8_t *masked = nullptr;            // SequenceLookup: masked codes in the padded layout of the DB
+    uint32_t *offsets = nullptr;          // 20^6 + 1
+    uint64_t *entries = nullptr;          // seqId << 16 | first position
+    uint64_t nEntries = 0;
+    int16_t *s3 = nullptr;                // extended 3-mer matrix, rows sorted descending
+    uint16_t *i3 = nullptr;
+    ~KmerIndex() { (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(entries); (void) hipFree(s3); (void) hipFree(i3); }
+};
+
+struct KmerScratch {
+    DevBuf qs, posQuery, seqs, thrs, profiles, K, Kbase, listStart, listSize, listPos, listP, chunks,
+           keys0, keys1, vals0, vals1, flags, scan, ckeys, cvals, kept, score, scrA, scrB, best,
+           ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand;
+    PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc;
+    hipEvent_t ev[12] = {};
+    bool evInit = false;
+};
+
+void fsgpu_kmer_free_scratch(KmerScratch *s) {
+    if (!s) return;
+    DevBuf *d[] = {&s->qs, &s->posQuery, &s->seqs, &s->thrs, &s->profiles, &s->K, &s->Kbase, &s->listStart, &s->listSize, &s->listPos, &s->listP,
+                   &s->chunks, &s->keys0, &s->keys1, &s->vals0, &s->vals1, &s->flags, &s->scan, &s->ckeys, &s->cvals, &s->kept, &s->score,
+                   &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand};
+    for (DevBuf *b : d) if (b->p) (void) hipFree(b->p);
+    PinBuf *h[] = {&s->hQs, &s->hPosQuery, &s->hSeqs, &s->hThrs, &s->hProfiles, &s->hChunks, &s->hEc, &s->hRounds, &s->hResSize, &s->hThr,
+                   &s->hOutCount, &s->hOut, &s->hMisc};
+    for (PinBuf *b : h) if (b->p) (void) hipHostFree(b->p);
+    if (s->evInit) for (hipEvent_t e : s->ev) (void) hipEventDestroy(e);
+    delete s;
+}
+
+#define RPCHK(call)                                                                                    \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return FSGPU_E_HIP;                                                                        \
+        }                                                                                              \
+    } while (0)
+
+static inline unsigned gridFor(uint64_t n, unsigned block) { return (unsigned) std::max<uint64_t>(1, (n + block - 1) / block); }
+
+template <class T>
+static int scanExclusive(fsgpu_ctx *ctx, DevBuf &tmp, const T *in, T *out, size_t n) {
+    size_t bytes = 0;
+    RPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, (T) 0, n, rocprim::plus<T>(), ctx->stream));
+    int rc = ensure(ctx, tmp, bytes);
+    if (rc != FSGPU_OK) return rc;
+    RPCHK(rocprim::exclusive_scan(tmp.p, bytes, in, out, (T) 0, n, rocprim::plus<T>(), ctx->stream));
+    return FSGPU_OK;
+}
+// u32 sizes -> u64 exclusive prefix
+struct U32to64 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
+static int scanExclusive32to64(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *in, uint64_t *out, size_t n) {
+    auto it = rocprim::make_transform_iterator(in, U32to64());
+    size_t bytes = 0;
+    RPCHK(rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    int rc = ensure(ctx, tmp, bytes);
+    if (rc != FSGPU_OK) return rc;
+    RPCHK(rocprim::exclusive_scan(tmp.p, bytes, it, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    return FSGPU_OK;
+}
+static int sortPairs(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout, size_t n, int bits) {
+    size_t bytes = 0;
+    RPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
+    int rc = ensure(ctx, tmp, bytes);
+    if (rc != FSGPU_OK) return rc;
+    RPCHK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
+    return FSGPU_OK;
+}
+
+static int bitsFor(uint64_t n) { int b = 1; while (b < 32 && (1ull << b) < n) b++; return b; }
+
+extern "C" {
+
+uint64_t fsgpu_kmer_index_entries(const fsgpu_ctx *ctx) { return ctx && ctx->kidx ? ctx->kidx->nEntries : 0; }
+
+int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, const int16_t *kmerSub) {
+    if (!ctx || !p || !kmerSub) return FSGPU_E_ARG;
+    if (!ctx->db || !ctx->db->raw3di) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (p->kmerSize != 6) { ctx->err = "k-mer prefilter: only k = 6 is implemented on the device"; return FSGPU_E_UNSUPPORTED; }
+    RPCHK(hipSetDevice(ctx->device));
+    std::shared_ptr<KmerIndex> ix = std::make_shared<KmerIndex>();
+    ix->p = *p; ix->db = ctx->db; ix->n = ctx->db->n;
+    ix->tbits = bitsFor(std::max<uint64_t>(ix->n, 2));
+    static const int s6[10] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 1};
+    ix->pat.size = p->spaced ? 10 : 6;
+    for (int i = 0, k = 0; i < ix->pat.size; i++) if (!p->spaced || s6[i]) ix->pat.pos[k++] = i;
+    const DbStore &db = *ctx->db;
+    const uint64_t n = db.n, bytes = std::max<uint64_t>(db.bytes, 1);
+    const uint64_t tableSize = 64000000ull;
+
+    // extended 3-mer matrix
+    int16_t *dSub = nullptr;
+    RPCHK(hipMalloc((void **) &dSub, 441 * sizeof(int16_t)));
+    RPCHK(hipMemcpy(dSub, kmerSub, 441 * sizeof(int16_t), hipMemcpyHostToDevice));
+    RPCHK(hipMalloc((void **) &ix->s3, (size_t) kRow3 * kRow3 * sizeof(int16_t)));
+    RPCHK(hipMalloc((void **) &ix->i3, (size_t) kRow3 * kRow3 * sizeof(uint16_t)));
+    hipLaunchKernelGGL(k_kmer_rows3, dim3(kRow3), dim3(1024), 0, ctx->stream, dSub, ix->s3, ix->i3);
+    RPCHK(hipGetLastError());
+
+    // masked lookup
+    RPCHK(hipMalloc((void **) &ix->masked, bytes));
+    RPCHK(hipMemsetAsync(ix->masked, 20, bytes, ctx->stream));
+    if (n) {
+        hipLaunchKernelGGL(k_kmer_mask, dim3(gridFor(n, 128)), dim3(128), 0, ctx->stream, db.raw3di, db.dOffsets, db.dLengths, n,
+                           p->maskLowerCase, p->maskNrepeats, ix->masked);
+        RPCHK(hipGetLastError());
+    }
+    // k-mer extraction in (seqId, pos) order
+    std::vector<uint64_t> resOff(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) resOff[i + 1] = resOff[i] + (uint64_t) db.hLengths[i];
+    const uint64_t R = resOff[n];
+    if (R >= 0xFFFFFFF0ull) { ctx->err = "k-mer index: more than 2^32 residues"; return FSGPU_E_UNSUPPORTED; }
+    RPCHK(hipMalloc((void **) &ix->offsets, (tableSize + 1) * sizeof(uint32_t)));
+    RPCHK(hipMemsetAsync(ix->offsets, 0, (tableSize + 1) * sizeof(uint32_t), ctx->stream));
+    uint64_t *dResOff = nullptr, *v0 = nullptr, *v1 = nullptr;
+    uint32_t *k0 = nullptr, *k1 = nullptr, *flags = nullptr, *scan = nullptr;
+    int8_t *dSelf = nullptr;
+    DevBuf tmp;
+    int rc = FSGPU_OK;
+    auto cleanup = [&]() {
+        (void) hipFree(dResOff); (void) hipFree(v0); (void) hipFree(v1); (void) hipFree(k0); (void) hipFree(k1);
+        (void) hipFree(flags); (void) hipFree(scan); (void) hipFree(dSelf); (void) hipFree(tmp.p); (void) hipFree(dSub);
+    };
+#define IXCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return FSGPU_E_HIP; } } while (0)
+    if (R > 0) {
+        int8_t self[21];
+        for (int a = 0; a < 21; a++) self[a] = (int8_t) kmerSub[a * 21 + a];
+        IXCHK(hipMalloc((void **) &dSelf, 32));
+        IXCHK(hipMemcpy(dSelf, self, 21, hipMemcpyHostToDevice));
+        IXCHK(hipMalloc((void **) &dResOff, (n + 1) * sizeof(uint64_t)));
+        IXCHK(hipMemcpy(dResOff, resOff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        IXCHK(hipMalloc((void **) &k0, R * sizeof(uint32_t)));
+        IXCHK(hipMalloc((void **) &k1, R * sizeof(uint32_t)));
+        IXCHK(hipMalloc((void **) &v0, R * sizeof(uint64_t)));
+        IXCHK(hipMalloc((void **) &v1, R * sizeof(uint64_t)));
+        IXCHK(hipMalloc((void **) &flags, (R + 1) * sizeof(uint32_t)));
+        IXCHK(hipMalloc((void **) &scan, (R + 1) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_kmer_extract, dim3((unsigned) std::min<uint64_t>(n, 65535 * 16)), dim3(256), 0, ctx->stream, ix->masked, db.dOffsets, db.dLengths,
+                           dResOff, n, ix->pat, p->kmerThr, dSelf, k0, v0);
+        IXCHK(hipGetLastError());
+        // stable sort by k-mer keeps the (seqId, pos) order inside every k-mer: IndexEntryLocalTmp::comapreByIdAndPos
+        rc = sortPairs(ctx, tmp, k0, k1, v0, v1, R, 26);
+        if (rc != FSGPU_OK) { cleanup(); return rc; }
+        IXCHK(hipMemsetAsync(flags + R, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_kmer_unique_flags, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, k1, v1, R, flags, ix->offsets);
+        IXCHK(hipGetLastError());
+        rc = scanExclusive<uint32_t>(ctx, tmp, flags, scan, R + 1);
+        if (rc != FSGPU_OK) { cleanup(); return rc; }
+        uint32_t ne = 0;
+        IXCHK(hipMemcpyAsync(&ne, scan + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        IXCHK(hipStreamSynchronize(ctx->stream));
+        ix->nEntries = ne;
+        IXCHK(hipMalloc((void **) &ix->entries, std::max<uint64_t>(ne, 1) * sizeof(uint64_t)));
+        hipLaunchKernelGGL(k_kmer_compact_entries, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, v1, flags, scan, R, ix->entries);
+        IXCHK(hipGetLastError());
+    } else {
+        IXCHK(hipMalloc((void **) &ix->entries, sizeof(uint64_t)));
+    }
+    // counts -> offsets (in place)
+    rc = scanExclusive<uint32_t>(ctx, tmp, ix->offsets, ix->offsets, tableSize + 1);
+    if (rc != FSGPU_OK) { cleanup(); return rc; }
+    IXCHK(hipStreamSynchronize(ctx->stream));
+    cleanup();
+#undef IXCHK
+    ctx->kidx = ix;
+    return FSGPU_OK;
+}
+
+// Test / inspection accessors: copy parts of the resident index to host memory (any pointer may be NULL).
+int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets /*64e6+1*/, uint64_t *entries /*nEntries*/, uint8_t *masked /*db bytes*/) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (!ctx->kidx) { ctx->err = "k-mer index not built"; return FSGPU_E_NODB; }
+    const KmerIndex &ix = *ctx->kidx;
+    if (offsets) RPCHK(hipMemcpy(offsets, ix.offsets, (64000000ull + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (entries && ix.nEntries) RPCHK(hipMemcpy(entries, ix.entries, ix.nEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (masked && ix.db->bytes) RPCHK(hipMemcpy(masked, ix.masked, ix.db->bytes, hipMemcpyDeviceToHost));
+    return FSGPU_OK;
+}
+int fsgpu_kmer_row_copy(fsgpu_ctx *ctx, int row, int16_t *score /*8000*/, uint16_t *index /*8000*/) {
+    if (!ctx || row < 0 || row >= kRow3) return FSGPU_E_ARG;
+    if (!ctx->kidx) { ctx->err = "k-mer index not built"; return FSGPU_E_NODB; }
+    RPCHK(hipMemcpy(score, ctx->kidx->s3 + (size_t) row * kRow3, kRow3 * sizeof(int16_t), hipMemcpyDeviceToHost));
+    RPCHK(hipMemcpy(index, ctx->kidx->i3 + (size_t) row * kRow3, kRow3 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return FSGPU_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct HostOut { uint32_t id, count, diag; int32_t score; uint64_t g; };
+static_assert(sizeof(HostOut) == sizeof(KmerOut), "layout");
+
+unsigned pickBins(const fsgpu_kmer_search_params &p, uint64_t n) {
+    if (p.bins) return (unsigned) p.bins;
+    uint64_t l2 = p.l2CacheSize;
+    if (l2 == 0) {
+        long v = sysconf(_SC_LEVEL2_CACHE_SIZE);      // Util::getL2CacheSize (M/src/commons/Util.cpp:346-361)
+        l2 = v > 0 ? (uint64_t) v : 262144;
+    }
+    for (unsigned x = 2; x <= 1024; x *= 2) if (n / x < l2) return x;
+    return 2048;
+}
+
+int scalarDiag(const int8_t *profile, int len, const uint8_t *db) {
+    int mx = 0, s = 0;
+    for (int pos = 0; pos < len; pos++) { s += profile[pos * 21 + db[pos]]; s = s < 0 ? 0 : s; mx = s > mx ? s : mx; }
+    return mx;
+}
+
+// The tail of QueryMatcher::matchQuery (:146-239) on the elements at or above the cut: array order of the reference
+// = (bin = id & (B-1), then the order the overflow rounds left the elements in), radix by score, getResult, final sort.
+int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer_query &q, const KmerChunks &ck, const uint32_t *ec, const uint32_t *rounds,
+                uint64_t resultSize, uint32_t thr, std::vector<HostOut> &el, fsgpu_kmer_hit *out, int32_t *nout) {
+    const uint64_t big = std::max<uint64_t>(n, 1000000);
+    const uint64_t foundSize = sp.foundDiagonalsSize ? (uint64_t) sp.foundDiagonalsSize : big;
+    const size_t maxHits = (size_t) std::min<uint64_t>((uint64_t) sp.maxResListLen, n);
+    const unsigned B = pickBins(sp, n);
+    const uint32_t C = ck.nChunks - 1;
+    int status = FSGPU_KMER_OK;
+    bool empty = false;
+    if (ck.aborted == 2) status = FSGPU_KMER_E_CHUNKS;
+    if (ck.aborted == 1) empty = true;
+    const bool lastEmpty = ck.start[ck.nChunks] == ck.start[ck.nChunks - 1];
+    if (C >= 1 && lastEmpty) empty = true;
+    // findDuplicates output capacity (CacheFriendlyOperations.cpp:217-219): conservative replay
+    for (uint32_t c = 0; c <= C && status == FSGPU_KMER_OK && !empty; c++) {
+        if (c == C && lastEmpty) break;
+        const uint64_t before = c == 0 ? 0 : rounds[c];
+        if ((uint64_t) ec[c] + before >= foundSize) status = FSGPU_KMER_E_OUTPUT;
+    }
+    size_t cur = 0;
+    if (q.identity >= 0 && maxHits > 0) { out[0].id = (uint32_t) q.identity; out[0].score = 65535; out[0].diagonal = 0; out[0].pad = 0; cur = 1; }
+    if (status < 0) { *nout = 0; return status; }
+    if (!empty && resultSize >= foundSize / 2) status = FSGPU_KMER_UNSTABLE;
+    if (!empty && !el.empty()) {
+        // order of the chunk runs in foundDiagonals after the overflow rounds (k-mer prefilter)
+        std::vector<int> rank(C + 1, 0), dir(C + 1, 1);
+        {
+            std::vector<std::pair<int, int>> order;       // (chunk, direction)
+            order.push_back({0, 1});
+            for (uint32_t j = 2; j <= C; j++) {
+                std::vector<std::pair<int, int>> nx;
+                nx.push_back({(int) j - 1, -1});
+                for (size_t z = order.size(); z-- > 0;) nx.push_back({order[z].first, -order[z].second});
+                order.swap(nx);
+            }
+            if (C >= 1) order.push_back({(int) C, 1});
+            for (size_t z = 0; z < order.size(); z++) { rank[order[z].first] = (int) z; dir[order[z].first] = order[z].second; }
+        }
+        struct Key { uint32_t count; uint32_t bin; uint64_t ok; const HostOut *e; };
+        std::vector<Key> ks(el.size());
+        for (size_t i = 0; i < el.size(); i++) {
+            uint32_t c = 0;
+            while (c + 1 < ck.nChunks && ck.start[c + 1] <= el[i].g) c++;
+            const uint64_t gg = dir[c] > 0 ? el[i].g : ((1ull << 40) - 1 - el[i].g);
+            ks[i] = {el[i].count, el[i].id & (B - 1), ((uint64_t) rank[c] << 40) | gg, &el[i]};
+        }
+        auto arrayOrder = [](const Key &a, const Key &b) { return a.bin != b.bin ? a.bin < b.bin : a.ok < b.ok; };
+        const bool truncated = thr >= 255;
+        unsigned rescale = 0;
+        if (truncated) {
+            // rescoreHits (QueryMatcher.cpp:563-589): only the 255-capped hits survive, re-ranked by their real score
+            std::sort(ks.begin(), ks.end(), arrayOrder);
+            int maxSelf = scalarDiag(q.profile, q.L, q.seq) - 255;
+            maxSelf = std::max(1, maxSelf);
+            maxSelf = std::min(maxSelf, 65535);
+            const float fmax = (float) maxSelf;
+            for (Key &k : ks) {
+                unsigned ns = (unsigned) k.e->score - 255u;
+                float sc = (float) std::min(ns, 65535u);
+                k.count = (uint8_t) ((sc / fmax) * (float) 255 + 0.5);
+            }
+            rescale = (unsigned) maxSelf;
+            std::stable_sort(ks.begin(), ks.end(), [](const Key &a, const Key &b) { return a.count > b.count; });
+        } else {
+            std::sort(ks.begin(), ks.end(), [&](const Key &a, const Key &b) { return a.count != b.count ? a.count > b.count : arrayOrder(a, b); });
+        }
+        for (size_t i = 0; i < ks.size() && cur < maxHits; i++) {
+            if (q.identity >= 0 && (uint32_t) q.identity == ks[i].e->id) continue;
+            fsgpu_kmer_hit &h = out[cur];
+            h.id = ks[i].e->id; h.diagonal = (uint16_t) ks[i].e->diag; h.pad = 0;
+            h.score = (int32_t) ks[i].count;
+            if (rescale != 0) h.score = (int32_t) (255u + ks[i].count * rescale / 255u);
+            else if (ks[i].count >= 255) h.score = ks[i].e->score;
+            cur++;
+        }
+    }
+    if (cur > 1) {
+        auto cmp = [](const fsgpu_kmer_hit &a, const fsgpu_kmer_hit &b) {
+            const int aa = abs(a.score), bb = abs(b.score);
+            return aa != bb ? aa > bb : a.id < b.id;
+        };
+        std::sort(out + (q.identity >= 0 ? 1 : 0), out + cur, cmp);
+    }
+    *nout = (int32_t) cur;
+    return status;
+}
+
+} // namespace
+
+static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const fsgpu_kmer_query *queries, int nq,
+                     fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats) {
+    KmerIndex &ix = *ctx->kidx;
+    if (!ctx->kmer) ctx->kmer = new KmerScratch();
+    KmerScratch &S = *ctx->kmer;
+    if (!S.evInit) { for (hipEvent_t &e : S.ev) RPCHK(hipEventCreate(&e)); S.evInit = true; }
+    const DbStore &db = *ix.db;
+    const uint64_t n = ix.n;
+    const int tbits = ix.tbits;
+    const uint64_t big = std::max<uint64_t>(n, 1000000);
+    const uint64_t maxDbMatches = sp.maxDbMatches ? (uint64_t) sp.maxDbMatches : big * 2;
+    const uint32_t maxHits = (uint32_t) std::min<uint64_t>((uint64_t) sp.maxResListLen, n);
+    int rc;
+#define CHK(x) do { rc = (x); if (rc != FSGPU_OK) return rc; } while (0)
+
+    // ---- stage the batch ------------------------------------------------------------------------------------
+    uint64_t nPos = 0, seqBytes = 0, profBytes = 0;
+    for (int q = 0; q < nq; q++) {
+        const int L = queries[q].L;
+        if (L < 0 || L > FSGPU_MAX_SEQ_LEN || (L > 0 && (!queries[q].seq || !queries[q].profile))) { ctx->err = "k-mer search: bad query"; return FSGPU_E_ARG; }
+        nPos += (uint64_t) std::max(0, L - ix.pat.size + 1);
+        seqBytes += (uint64_t) L + 16;
+        profBytes += (uint64_t) L * 21 + 16;
+    }
+    CHK(ensurePinned(ctx, S.hQs, (size_t) nq * sizeof(KmerQ)));
+    CHK(ensurePinned(ctx, S.hPosQuery, (nPos + 1) * sizeof(uint16_t)));
+    CHK(ensurePinned(ctx, S.hSeqs, seqBytes));
+    CHK(ensurePinned(ctx, S.hThrs, (nPos + 1) * sizeof(int16_t)));
+    CHK(ensurePinned(ctx, S.hProfiles, profBytes));
+    KmerQ *hq = (KmerQ *) S.hQs.p;
+    {
+        uint64_t pb = 0, so = 0, po = 0;
+        for (int q = 0; q < nq; q++) {
+            const int L = queries[q].L;
+            const uint32_t np = (uint32_t) std::max(0, L - ix.pat.size + 1);
+            hq[q].posBase = (uint32_t) pb; hq[q].nPos = np; hq[q].seqOff = (uint32_t) so; hq[q].L = (uint32_t) L; hq[q].profOff = (uint32_t) po;
+            hq[q].pad = 0; hq[q].hitBase = 0; hq[q].listBase = 0;
+            uint8_t *sd = (uint8_t *) S.hSeqs.p + so;
+            for (int i = 0; i < L; i++) { uint8_t c = queries[q].seq[i]; c = c >= 32 ? c - 32 : c; sd[i] = c > 20 ? 20 : c; }
+            memset(sd + L, 20, 16);
+            if (L) memcpy((int8_t *) S.hProfiles.p + po, queries[q].profile, (size_t) L * 21);
+            for (uint32_t i = 0; i < np; i++) { ((uint16_t *) S.hPosQuery.p)[pb + i] = (uint16_t) q; ((int16_t *) S.hThrs.p)[pb + i] = queries[q].kmerThr ? queries[q].kmerThr[i] : (int16_t) ix.p.kmerThr; }
+            pb += np; so += (uint64_t) L + 16; po += (uint64_t) L * 21 + 16;
+        }
+    }
+    CHK(ensure(ctx, S.qs, (size_t) nq * sizeof(KmerQ)));
+    CHK(ensure(ctx, S.posQuery, (nPos + 1) * sizeof(uint16_t)));
+    CHK(ensure(ctx, S.seqs, seqBytes));
+    CHK(ensure(ctx, S.thrs, (nPos + 1) * sizeof(int16_t)));
+    CHK(ensure(ctx, S.profiles, profBytes));
+    CHK(ensure(ctx, S.K, (nPos + 1) * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.Kbase, (nPos + 1) * sizeof(uint64_t)));
+    CHK(ensure(ctx, S.chunks, (size_t) nq * sizeof(KmerChunks)));
+    CHK(ensure(ctx, S.ec, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.rounds, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.resSize, (size_t) nq * sizeof(uint64_t)));
+    CHK(ensure(ctx, S.hist, (size_t) nq * 256 * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.thr, (size_t) nq * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.outCount, (size_t) nq * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.nCand, 64));
+    CHK(ensurePinned(ctx, S.hMisc, 256));
+    CHK(ensurePinned(ctx, S.hChunks, (size_t) nq * sizeof(KmerChunks)));
+    CHK(ensurePinned(ctx, S.hEc, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+    CHK(ensurePinned(ctx, S.hRounds, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+    CHK(ensurePinned(ctx, S.hResSize, (size_t) nq * sizeof(uint64_t)));
+    CHK(ensurePinned(ctx, S.hThr, (size_t) nq * sizeof(uint32_t)));
+    CHK(ensurePinned(ctx, S.hOutCount, (size_t) nq * sizeof(uint32_t)));
+    hipStream_t st = ctx->stream;
+    RPCHK(hipEventRecord(S.ev[0], st));
+    RPCHK(hipMemcpyAsync(S.qs.p, S.hQs.p, (size_t) nq * sizeof(KmerQ), hipMemcpyHostToDevice, st));
+    RPCHK(hipMemcpyAsync(S.posQuery.p, S.hPosQuery.p, (nPos + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    RPCHK(hipMemcpyAsync(S.seqs.p, S.hSeqs.p, seqBytes, hipMemcpyHostToDevice, st));
+    RPCHK(hipMemcpyAsync(S.thrs.p, S.hThrs.p, (nPos + 1) * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    RPCHK(hipMemcpyAsync(S.profiles.p, S.hProfiles.p, profBytes, hipMemcpyHostToDevice, st));
+    RPCHK(hipMemsetAsync(S.ec.p, 0, (size_t) nq * kMaxChunks * sizeof(uint32_t), st));
+    RPCHK(hipMemsetAsync(S.rounds.p, 0, (size_t) nq * kMaxChunks * sizeof(uint32_t), st));
+    RPCHK(hipMemsetAsync(S.resSize.p, 0, (size_t) nq * sizeof(uint64_t), st));
+    RPCHK(hipMemsetAsync(S.hist.p, 0, (size_t) nq * 256 * sizeof(uint32_t), st));
+    RPCHK(hipMemsetAsync(S.outCount.p, 0, (size_t) nq * sizeof(uint32_t), st));
+
+    uint64_t *misc = (uint64_t *) S.hMisc.p;
+    uint64_t nLists = 0, nHits = 0;
+    uint32_t nCand = 0;
+    // ---- stage 1: similar k-mers -> lists ---------------------------------------------------------------------
+    if (nPos) {
+        hipLaunchKernelGGL(k_kmer_count, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                           (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, (uint32_t *) S.K.p);
+        RPCHK(hipGetLastError());
+    }
+    RPCHK(hipMemsetAsync((uint32_t *) S.K.p + nPos, 0, sizeof(uint32_t), st));
+    CHK(scanExclusive32to64(ctx, S.tmp, (const uint32_t *) S.K.p, (uint64_t *) S.Kbase.p, nPos + 1));
+    RPCHK(hipMemcpyAsync(&misc[0], (uint64_t *) S.Kbase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    CHK(syncStream(ctx));
+    nLists = misc[0];
+    RPCHK(hipEventRecord(S.ev[1], st));
+    CHK(ensure(ctx, S.listStart, (nLists + 1) * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.listSize, (nLists + 1) * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.listPos, (nLists + 1) * sizeof(uint32_t)));
+    CHK(ensure(ctx, S.listP, (nLists + 1) * sizeof(uint64_t)));
+    if (nLists) {
+        hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                           (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
+                           (const uint64_t *) S.Kbase.p, ix.offsets, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+        RPCHK(hipGetLastError());
+    }
+    RPCHK(hipMemsetAsync((uint32_t *) S.listSize.p + nLists, 0, sizeof(uint32_t), st));
+    CHK(scanExclusive32to64(ctx, S.tmp, (const uint32_t *) S.listSize.p, (uint64_t *) S.listP.p, nLists + 1));
+    hipLaunchKernelGGL(k_kmer_qbases, dim3(gridFor(nq, 64)), dim3(64), 0, st, (KmerQ *) S.qs.p, nq, (const uint64_t *) S.Kbase.p, (const uint64_t *) S.listP.p);
+    hipLaunchKernelGGL(k_kmer_chunks, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.Kbase.p, (const uint64_t *) S.listP.p, maxDbMatches, (KmerChunks *) S.chunks.p);
+    RPCHK(hipGetLastError());
+    RPCHK(hipMemcpyAsync(&misc[1], (uint64_t *) S.listP.p + nLists, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    RPCHK(hipMemcpyAsync(S.hChunks.p, S.chunks.p, (size_t) nq * sizeof(KmerChunks), hipMemcpyDeviceToHost, st));
+    RPCHK(hipMemcpyAsync(S.hQs.p, S.qs.p, (size_t) nq * sizeof(KmerQ), hipMemcpyDeviceToHost, st));
+    CHK(syncStream(ctx));
+    nHits = misc[1];
+    RPCHK(hipEventRecord(S.ev[2], st));
+    if (nHits >= 0xFFFFFF00ull) {
+        if (nq > 1) return 1;                                // caller halves the batch
+        ctx->err = "k-mer search: a single query produces more than 2^32 index hits"; return FSGPU_E_UNSUPPORTED;
+    }
+    const KmerChunks *hck = (const KmerChunks *) S.hChunks.p;
+    const uint32_t cap = (uint32_t) std::max<uint64_t>(1, n);
+    // ---- stage 2: hit stream, stable sort by (query, target) ---------------------------------------------------
+    if (nHits) {
+        CHK(ensure(ctx, S.keys0, nHits * sizeof(uint32_t)));
+        CHK(ensure(ctx, S.keys1, nHits * sizeof(uint32_t)));
+        CHK(ensure(ctx, S.vals0, nHits * sizeof(uint64_t)));
+        CHK(ensure(ctx, S.vals1, nHits * sizeof(uint64_t)));
+        CHK(ensure(ctx, S.flags, (nHits + 1) * sizeof(uint32_t)));
+        CHK(ensure(ctx, S.scan, (nHits + 1) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, 2048)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p,
+                           (const uint16_t *) S.posQuery.p, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
+                           (const uint32_t *) S.listPos.p, ix.entries, nHits, tbits, (uint32_t *) S.keys0.p, (uint64_t *) S.vals0.p);
+        RPCHK(hipGetLastError());
+        RPCHK(hipEventRecord(S.ev[3], st));
+        CHK(sortPairs(ctx, S.tmp, (const uint32_t *) S.keys0.p, (uint32_t *) S.keys1.p, (const uint64_t *) S.vals0.p, (uint64_t *) S.vals1.p, nHits,
+                      std::min(32, tbits + bitsFor(std::max(nq, 2)))));
+        RPCHK(hipEventRecord(S.ev[4], st));
+        // ---- stage 3: double-diagonal candidates ----------------------------------------------------------------
+        RPCHK(hipMemsetAsync((uint32_t *) S.flags.p + nHits, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_kmer_dupflags, dim3(gridFor(nHits, 256)), dim3(256), 0, st, (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p, nHits, tbits,
+                           (uint32_t *) S.flags.p, (uint32_t *) S.ec.p);
+        RPCHK(hipGetLastError());
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.flags.p, (uint32_t *) S.scan.p, nHits + 1));
+        RPCHK(hipMemcpyAsync(S.nCand.p, (uint32_t *) S.scan.p + nHits, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        RPCHK(hipMemcpyAsync(&misc[2], (uint32_t *) S.scan.p + nHits, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CHK(syncStream(ctx));
+        nCand = (uint32_t) misc[2];
+    }
+    RPCHK(hipEventRecord(S.ev[5], st));
+    if (nCand) {
+        CHK(ensure(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
+        CHK(ensure(ctx, S.cvals, (size_t) nCand * sizeof(uint64_t)));
+        CHK(ensure(ctx, S.kept, (size_t) nCand));
+        CHK(ensure(ctx, S.score, (size_t) nCand * sizeof(int32_t)));
+        CHK(ensure(ctx, S.scrA, (size_t) nCand * sizeof(uint64_t)));
+        CHK(ensure(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
+        CHK(ensure(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
+        CHK(ensure(ctx, S.out, (size_t) nq * cap * sizeof(KmerOut)));
+        hipLaunchKernelGGL(k_kmer_compact_cands, dim3(gridFor(nHits, 256)), dim3(256), 0, st, (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p,
+                           (const uint32_t *) S.flags.p, (const uint32_t *) S.scan.p, nHits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p);
+        RPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                           (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
+                           (uint8_t *) S.kept.p, (int32_t *) S.score.p);
+        RPCHK(hipGetLastError());
+        RPCHK(hipEventRecord(S.ev[6], st));
+        // ---- stage 4: per-target replay ----------------------------------------------------------------------
+        hipLaunchKernelGGL(k_kmer_walk, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                           (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
+                           (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
+        RPCHK(hipGetLastError());
+        RPCHK(hipEventRecord(S.ev[7], st));
+        // ---- stage 5: histogram, cut, hand-over --------------------------------------------------------------
+        hipLaunchKernelGGL(k_kmer_hist, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const KmerBest *) S.best.p,
+                           (const uint32_t *) S.nCand.p, tbits, (uint32_t *) S.hist.p);
+        hipLaunchKernelGGL(k_kmer_cut, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const uint32_t *) S.hist.p, nq, maxHits, (uint32_t) sp.minDiagScoreThr, (uint32_t *) S.thr.p);
+        hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
+                           (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, cap, (uint32_t *) S.outCount.p, (KmerOut *) S.out.p);
+        RPCHK(hipGetLastError());
+    } else {
+        for (int e = 6; e <= 7; e++) RPCHK(hipEventRecord(S.ev[e], st));
+        RPCHK(hipMemsetAsync(S.thr.p, 0, (size_t) nq * sizeof(uint32_t), st));
+    }
+    RPCHK(hipMemcpyAsync(S.hEc.p, S.ec.p, (size_t) nq * kMaxChunks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RPCHK(hipMemcpyAsync(S.hRounds.p, S.rounds.p, (size_t) nq * kMaxChunks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RPCHK(hipMemcpyAsync(S.hResSize.p, S.resSize.p, (size_t) nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    RPCHK(hipMemcpyAsync(S.hThr.p, S.thr.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RPCHK(hipMemcpyAsync(S.hOutCount.p, S.outCount.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RPCHK(hipEventRecord(S.ev[8], st));
+    CHK(syncStream(ctx));
+    const uint32_t *hOutCount = (const uint32_t *) S.hOutCount.p;
+    size_t totalOut = 0;
+    std::vector<size_t> outOff(nq + 1, 0);
+    for (int q = 0; q < nq; q++) { outOff[q] = totalOut; totalOut += std::min(hOutCount[q], cap); }
+    outOff[nq] = totalOut;
+    CHK(ensurePinned(ctx, S.hOut, std::max<size_t>(1, totalOut) * sizeof(KmerOut)));
+    for (int q = 0; q < nq; q++) {
+        const size_t c = std::min(hOutCount[q], cap);
+        if (c) RPCHK(hipMemcpyAsync((KmerOut *) S.hOut.p + outOff[q], (KmerOut *) S.out.p + (size_t) q * cap, c * sizeof(KmerOut), hipMemcpyDeviceToHost, st));
+    }
+    RPCHK(hipEventRecord(S.ev[9], st));
+    CHK(syncStream(ctx));
+    {
+        float ms = 0;
+        static const int a[9] = {0, 0, 1, 2, 3, 4, 5, 6, 7}, b[9] = {9, 1, 2, 3, 4, 5, 6, 7, 8};
+        // [0] total, [1] count+scan, [2] lists+chunks, [3] emit, [4] sort, [5] dup flags+scan, [6] compact+score, [7] walk, [8] hist/cut/out
+        for (int i = 0; i < 9; i++) ctx->kmerMs[i] = hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess ? (double) ms : -1.0;
+    }
+    // ---- host tail ---------------------------------------------------------------------------------------------
+    const KmerQ *hq2 = (const KmerQ *) S.hQs.p;
+    std::vector<HostOut> el;
+    for (int q = 0; q < nq; q++) {
+        const size_t c = outOff[q + 1] - outOff[q];
+        el.resize(c);
+        if (c) memcpy(el.data(), (const HostOut *) S.hOut.p + outOff[q], c * sizeof(HostOut));
+        status[q] = finishQuery(sp, n, queries[q], hck[q], (const uint32_t *) S.hEc.p + (size_t) q * kMaxChunks, (const uint32_t *) S.hRounds.p + (size_t) q * kMaxChunks,
+                                ((const uint64_t *) S.hResSize.p)[q], ((const uint32_t *) S.hThr.p)[q], el, out + (size_t) q * sp.maxResListLen, &nout[q]);
+        if (stats) {
+            uint64_t le = nLists;
+            for (int r = q + 1; r < nq; r++) { le = hq2[r].listBase; break; }
+            stats[q * 4 + 0] = queries[q].L > 0 ? (double) (le - hq2[q].listBase) / (double) queries[q].L : 0.0;
+            stats[q * 4 + 1] = (double) hck[q].total;
+            stats[q * 4 + 2] = hck[q].nChunks > 1 ? 1.0 : 0.0;
+            stats[q * 4 + 3] = (double) pickBins(sp, n);
+        }
+    }
+#undef CHK
+    return FSGPU_OK;
+}
+
+extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params *p, const fsgpu_kmer_query *queries, int nq,
+                                 fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats) {
+    if (!ctx || !p || (nq > 0 && (!queries || !out || !nout || !status))) return FSGPU_E_ARG;
+    if (!ctx->kidx) { ctx->err = "k-mer index not built"; return FSGPU_E_NODB; }
+    if (p->maxResListLen <= 0 || p->minDiagScoreThr < 1) { ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 1 required"; return FSGPU_E_UNSUPPORTED; }
+    if (p->bins && (p->bins & (p->bins - 1))) { ctx->err = "k-mer search: bins must be a power of two"; return FSGPU_E_ARG; }
+    RPCHK(hipSetDevice(ctx->device));
+    const int qbitsMax = 32 - ctx->kidx->tbits;
+    const int maxBatch = std::max(1, std::min(32, qbitsMax >= 5 ? 32 : (1 << std::max(0, qbitsMax))));
+    int q0 = 0;
+    int batch = maxBatch;
+    while (q0 < nq) {
+        const int m = std::min(batch, nq - q0);
+        int rc = kmerBatch(ctx, *p, queries + q0, m, out + (size_t) q0 * p->maxResListLen, nout + q0, status + q0, stats ? stats + (size_t) q0 * 4 : nullptr);
+        if (rc == 1) { batch = std::max(1, m / 2); continue; }
+        if (rc != FSGPU_OK) return rc;
+        q0 += m;
+    }
+    return FSGPU_OK;
+}

@@ -274,3 +274,45 @@ int fshost_block_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, 
 }
 
 } // extern "C"
+
+// ---- k-mer prefilter query side -------------------------------------------------------------------------------
+extern "C" int fshost_kmer_threshold(float sensitivity, int kmerSize) {
+    // Prefiltering::getKmerThreshold, non-profile branch; Foldseek overrides k = 7 (FoldseekBase.cpp:585)
+    float best;
+    if (kmerSize == 5) best = 160.75f - (sensitivity * 12.75f);
+    else if (kmerSize == 6) best = 163.2f - (sensitivity * 8.917f);
+    else if (kmerSize == 7) return (int) (197.0 - (11.22 * sensitivity));
+    else return -1;
+    return (int) best;
+}
+
+extern "C" int fshost_kmer_query_prepare(const fshost_matrix *mKmer, const fshost_matrix *mUngapped, const uint8_t *q3di, int L,
+                                         int compBias, float scale, int kmerThrBase, int kmerSize, int spaced,
+                                         int16_t *kmerThr, int8_t *profile) {
+    static const int s6[10] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 1};
+    static const int s7[12] = {1, 1, 0, 1, 0, 1, 0, 0, 1, 0, 1, 1};
+    if (!mKmer || !mUngapped || L < 0 || (kmerSize != 6 && kmerSize != 7)) return -1;
+    int pos[8], psize = spaced ? (kmerSize == 6 ? 10 : 12) : kmerSize, np = 0;
+    for (int i = 0; i < psize; i++) if (!spaced || (kmerSize == 6 ? s6[i] : s7[i])) pos[np++] = i;
+    std::vector<uint8_t> q(L);
+    for (int i = 0; i < L; i++) { uint8_t c = q3di[i]; c = c >= 32 ? c - 32 : c; q[i] = c > 20 ? 20 : c; }
+    std::vector<float> bias(L + 1, 0.0f);
+    if (compBias) fshost_comp_bias(mKmer, q.data(), L, scale, bias.data());
+    const int n = fshost_matrix_size(mUngapped);
+    const int16_t *us = fshost_matrix_scores(mUngapped);
+    for (int p = 0; p < L; p++) {
+        float c = bias[p];
+        c = (c < 0.0) ? c / 4 - 0.5 : c / 4 + 0.5;                 // UngappedAlignment.cpp:399-403
+        const char corr = (char) c;
+        for (int a = 0; a < 21; a++) profile[p * 21 + a] = (int8_t) (us[q[p] * n + a] + corr);
+    }
+    const int nPos = L - psize + 1;
+    for (int i = 0; i < nPos; i++) {
+        float bc = 0;
+        for (int z = 0; z < kmerSize; z++) bc += bias[i + pos[z]];
+        const short b = (short) ((bc < 0.0) ? bc - 0.5 : bc + 0.5);   // QueryMatcher.cpp:267-268
+        const int t = kmerThrBase - b;
+        kmerThr[i] = (int16_t) (t > 0 ? t : 0);
+    }
+    return nPos > 0 ? nPos : 0;
+}

@@ -14,12 +14,7 @@ namespace fs {
 constexpr int kSelChunk = 4096;     // targets per workgroup
 constexpr int kSelThreads = 256;    // 16 consecutive targets per thread -> id order is preserved
 
-struct SelMeta {
-    int32_t T;         // cut score: score > T always taken, score == T taken for the first `mTies` ids
-    uint32_t nGt;      // number of hits with score > T
-    uint32_t mTies;    // number of ties at T that are taken
-    uint32_t nOut;     // nGt + mTies
-};
+
 
 __device__ __forceinline__ bool selPasses(int score, uint32_t id, int minScore, int64_t identityId) {
     return score > minScore || (int64_t) id == identityId;

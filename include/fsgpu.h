@@ -19,6 +19,10 @@
  *   fsgpu_sw_batch                    StructureSmithWaterman::alignScoreEndPos x2 (forward query, reversed query)
  *                                     F/src/commons/StructureSmithWaterman.cpp:263-362, call sites
  *                                     F/src/strucclustutils/structurealign.cpp:46-47,65-67
+ *   fsgpu_kmer_index_build            Prefiltering::getIndexTable -> IndexBuilder::fillDatabase + the extended 3-mer matrix
+ *                                     M/src/prefiltering/Prefiltering.cpp:544-583,220-225, IndexBuilder.cpp:56-271
+ *   fsgpu_kmer_search                 the per-query body of Prefiltering::runSplit = QueryMatcher::matchQuery
+ *                                     M/src/prefiltering/Prefiltering.cpp:847-917, QueryMatcher.cpp:103-376
  *   fshost_*                          host-side pieces of the same path that stay on the CPU, exported so the
  *                                     reference-side adapter and the tests can reach them.
  */
@@ -123,9 +127,72 @@ int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_
                     const uint32_t *targetIds, int n, int gapOpen, int gapExtend);
 int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev);
 
+/* ---- prefilter: k-mer matching with double-diagonal hits + ungapped diagonal scoring ------------------------- */
+/* Index parameters == the subset of Prefiltering's members that shape IndexTable / SequenceLookup.  Sequence-
+ * sequence searches with k = 6 only (what setupSplit picks below 3.35e9 residues, IndexTable.h:456-458). */
+typedef struct {
+    int32_t kmerSize;       /* 6 */
+    int32_t spaced;         /* 1: pattern 1101010011 (M/src/commons/Sequence.h:25), 0: contiguous */
+    int32_t kmerThr;        /* Prefiltering::getKmerThreshold (Prefiltering.cpp:1036-1096); 78 at -s 9.5 */
+    int32_t maskLowerCase;  /* --mask-lower-case (Foldseek: 1) */
+    int32_t maskNrepeats;   /* --mask-n-repeat   (Foldseek: 6); tantan masking (--mask 1) is not available */
+} fsgpu_kmer_index_params;
+/* Builds, in HBM and from the resident 3Di database (fsgpu_db_load / fsgpu_db_adopt_device), the masked sequence
+ * lookup, the k-mer index (offset table over 20^6 k-mers + one (seqId, first position) entry per distinct k-mer of
+ * every target, lists ordered by seqId) and the sorted 8000 x 8000 extended 3-mer matrix of kmerSubMat21x21
+ * (the 8-bit "k-mer" matrix of the prefilter: SubstitutionMatrix(3di.out, 8.0, -0.2), int16 row-major 21x21). */
+int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, const int16_t *kmerSubMat21x21);
+uint64_t fsgpu_kmer_index_entries(const fsgpu_ctx *ctx);
+/* Inspection (tests): copy the offset table (64e6+1 uint32), the entries (seqId << 16 | position) and/or the masked
+ * sequence lookup (padded DB layout) to host memory; any pointer may be NULL.  Row `row` of the extended 3-mer matrix. */
+int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets, uint64_t *entries, uint8_t *masked);
+int fsgpu_kmer_row_copy(fsgpu_ctx *ctx, int row, int16_t *score, uint16_t *index);
+
+typedef struct {
+    int32_t maxResListLen;      /* --max-seqs */
+    int32_t minDiagScoreThr;    /* --min-ungapped-score, >= 1 */
+    int32_t bins;               /* BINSIZE of CacheFriendlyOperations; 0 = derive from l2CacheSize like initDiagonalMatcher */
+    int32_t reserved;
+    int64_t maxDbMatches;       /* 0 = 2*max(1e6,N) (QueryMatcher.cpp:45) */
+    int64_t foundDiagonalsSize; /* 0 = max(1e6,N)   (QueryMatcher.cpp:44) */
+    uint64_t l2CacheSize;       /* Util::getL2CacheSize() of the host whose tie order is to be reproduced; 0 = this host */
+} fsgpu_kmer_search_params;
+/* One query: numeric codes seq[L]; kmerThr[i] for every k-mer start i in [0, L - patternSize] =
+ * max(kmerThr - round(sum of the composition bias over the k-mer), 0) (QueryMatcher.cpp:262-270);
+ * profile[L][21] = ungappedSubMat[q_i][a] + round(bias_i / 4) (UngappedAlignment::createProfile).
+ * fshost_kmer_query_prepare fills both.  identity = target id that is the query itself, or -1. */
+typedef struct {
+    const uint8_t *seq;
+    const int16_t *kmerThr;
+    const int8_t *profile;
+    int32_t L;
+    int32_t reserved;
+    int64_t identity;
+} fsgpu_kmer_query;
+/* == hit_t (QueryMatcher.h:31-48) with the target's DB index instead of its key */
+typedef struct {
+    uint32_t id;
+    int32_t score;
+    uint16_t diagonal;
+    uint16_t pad;
+} fsgpu_kmer_hit;
+enum {
+    FSGPU_KMER_OK = 0,
+    FSGPU_KMER_UNSTABLE = 1,     /* >= foundDiagonalsSize/2 targets carried a diagonal: the reference orders equal scores
+                                    with an unstable std::sort there (QueryMatcher.cpp:205-215); we return the stable order */
+    FSGPU_KMER_E_OUTPUT = -1,    /* the reference would have cut findDuplicates short (output array full); not replayed */
+    FSGPU_KMER_E_CHUNKS = -2     /* more than 255 databaseHits refills */
+};
+/* Runs nq queries (batched on the device), writes per query q up to maxResListLen hits to out[q*maxResListLen ..],
+ * their number to nout[q] and a FSGPU_KMER_* code to status[q]; hits are bit-identical to QueryMatcher::matchQuery
+ * (order included) whenever status[q] == 0.  stats (may be NULL): per query kmersPerPos, dbMatches, overflowed, bins. */
+int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params *p, const fsgpu_kmer_query *queries, int nq,
+                      fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats);
+
 /* ---- instrumentation -------------------------------------------------------------------------------------- */
 /* Device time (ms, HIP events on the context stream) of the dominant kernel of the last _finish()ed call:
- * which = 0 gapless scan kernel, 1 SW kernel.  Returns < 0 if nothing was recorded. */
+ * which = 0 gapless scan kernel, 1 SW kernel, 2 whole device part of the last fsgpu_kmer_search batch.
+ * Returns < 0 if nothing was recorded. */
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which);
 
 #ifdef __cplusplus

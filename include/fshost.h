@@ -57,6 +57,18 @@ int fshost_prefilter_profile(const fshost_matrix *m3di, const uint8_t *q3di, int
 int fshost_align_profiles(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di,
                           int L, int compBias, float scale3Di, int16_t *pAA, int16_t *p3Di, int8_t *cbAA, int8_t *cbSS);
 
+/* ---- k-mer prefilter query side (QueryMatcher::matchQuery :108-124 + match :262-270, UngappedAlignment::createProfile) ----
+ * mKmer = SubstitutionMatrix(3di.out, 8.0, -0.2) (the seeding matrix), mUngapped = SubstitutionMatrix(3di.out, 2.0, -0.2).
+ * kmerThr[i], i in [0, L - patternSize]: max(kmerThrBase - round(sum of bias over the k-mer's residues), 0);
+ * profile[L][21] = mUngapped[q_i][a] + round(bias_i / 4).  patternSize/kmerSize as in fsgpu_kmer_index_params.
+ * Returns the number of k-mer start positions written (0 when the query is shorter than the pattern). */
+int fshost_kmer_query_prepare(const fshost_matrix *mKmer, const fshost_matrix *mUngapped, const uint8_t *q3di, int L,
+                              int compBias, float scale, int kmerThrBase, int kmerSize, int spaced,
+                              int16_t *kmerThr, int8_t *profile);
+/* Prefiltering::getKmerThreshold for sequence-sequence searches (Prefiltering.cpp:1036-1096, externalThreshold of
+ * F/src/FoldseekBase.cpp:585): -s sensitivity -> k-mer score threshold; < 0 for an unsupported k */
+int fshost_kmer_threshold(float sensitivity, int kmerSize);
+
 /* nnPath NULL: evalue_nn.bin next to libfsgpu.so (foldseek_amd/data/) */
 fshost_evaluer *fshost_evaluer_create(const char *nnPath, uint64_t dbResidues);
 void fshost_evaluer_free(fshost_evaluer *e);

@@ -1,0 +1,120 @@
+"""GPU parity of the k-mer prefilter (fsgpu_kmer_index_build / fsgpu_kmer_search through the C ABI) against the
+C oracle (oracle/fs_kmer_oracle.c, itself pinned to the compiled reference by test_kmer_oracle_vs_ref.py):
+index table, masked lookup, extended 3-mer rows and complete hit lists (ids, scores, diagonals, order), bit-exact,
+over the option space that changes the reference's arrival-order rules (BINSIZE, databaseHits refills, result
+truncation, 255-capped rescoring, identity hit)."""
+import numpy as np
+import pytest
+
+import helpers as H
+import kmer_lib as K
+from foldseek_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+N, NQ = 3000, 6
+
+
+@pytest.fixture(scope="module")
+def world():
+    O = K.load_ora()
+    q3, qa = synth.make_queries(NQ, seed=1)
+    db = synth.make_db(N, (q3, qa), homologs_per_query=30, mask_frac=0.02)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    o = K.OraKpf(O, ksub, pb, usub, targets)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8 = api.Matrix(0, 8.0, -0.2)
+    m2 = api.Matrix(0, 2.0, -0.2)
+    assert (m8.scores().ravel() == ksub).all() and (m2.scores().ravel() == usub).all()
+    ctx.kmer_index_build(m8, kmer_thr=78)
+    yield dict(o=o, ctx=ctx, db=db, q3=q3, m8=m8, m2=m2, targets=targets)
+    o.close()
+
+
+def test_index_matches_oracle(world):
+    o, ctx, db = world["o"], world["ctx"], world["db"]
+    ooff, oseq, opos = o.index()
+    off, ent, msk = ctx.kmer_index_copy(db.data3di.size)
+    assert ctx.kmer_index_entries == int(ooff[-1])
+    assert (off.astype(np.uint64) == ooff).all()
+    assert ((ent >> np.uint64(16)).astype(np.uint32) == oseq).all()
+    assert ((ent & np.uint64(0xffff)).astype(np.uint16) == opos).all()
+    for i in range(0, db.n, 17):
+        L = int(db.lengths[i])
+        assert (msk[db.offsets[i]:db.offsets[i] + L] == o.masked(i, L)).all(), i
+
+
+def test_extended_rows(world):
+    o, ctx = world["o"], world["ctx"]
+    for idx in [0, 1, 19, 20, 399, 400, 7999, 1234, 4321, 6789]:
+        s, ix = ctx.kmer_row(idx)
+        os_, oi = o.row(3, idx)
+        assert (s == os_).all() and (ix.astype(np.uint32) == oi).all(), idx
+
+
+VARIANTS = [
+    dict(),
+    dict(maxResListLen=50),
+    dict(maxResListLen=50, bins=4),
+    dict(maxResListLen=50, bins=16),
+    dict(maxResListLen=5),
+    dict(maxResListLen=300, maxDbMatches=20000),
+    dict(maxResListLen=100, maxDbMatches=9000, bins=8),
+    dict(maxResListLen=300, maxDbMatches=5000, foundDiagonalsSize=40000),
+    dict(compBias=0, maxResListLen=20, maxDbMatches=15000),
+    dict(minDiagScoreThr=15, maxResListLen=2000),
+]
+
+
+def run_gpu(world, kw, queries, ident):
+    ctx, m8, m2 = world["ctx"], world["m8"], world["m2"]
+    prep = [api.kmer_query_prepare(m8, m2, q, comp_bias=bool(kw.get("compBias", 1)), scale=0.15, kmer_thr=78) for q in queries]
+    return ctx.kmer_search(prep, identity=ident, max_res=kw.get("maxResListLen", 1000), min_diag=kw.get("minDiagScoreThr", 30),
+                           bins=kw.get("bins", 0), max_db_matches=kw.get("maxDbMatches", 0),
+                           found_diagonals_size=kw.get("foundDiagonalsSize", 0), l2_cache_size=2 * 1024 * 1024, want_stats=True)
+
+
+@pytest.mark.parametrize("kw", VARIANTS)
+def test_hit_lists(world, kw):
+    o, q3 = world["o"], world["q3"]
+    base = dict(maxResListLen=1000, bins=0, maxDbMatches=0, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=30)
+    base.update(kw)
+    o.set(**base)
+    ident = np.array([-1, 7, -1, 100, -1, -1], np.int64)
+    orr, os_ = o.run(q3, ident)
+    res, status, stats = run_gpu(world, kw, q3, ident)
+    for q in range(NQ):
+        assert status[q] == 0, (q, status[q])
+        assert np.allclose(stats[q], os_[q]), (q, stats[q], os_[q])
+        a, b = res[q], orr[q]
+        assert len(a) == len(b), (q, kw, len(a), len(b))
+        assert (a["id"] == b["id"]).all() and (a["score"] == b["score"]).all() and (a["diag"] == b["diag"]).all(), (q, kw)
+    if "maxDbMatches" in kw:
+        assert os_[:, 2].sum() > 0
+
+
+def test_batching_is_transparent(world):
+    """one query per call == all queries in one batch"""
+    q3 = world["q3"]
+    res_all, st_all, _ = run_gpu(world, {}, q3, None)
+    for q in range(NQ):
+        r1, s1, _ = run_gpu(world, {}, [q3[q]], None)
+        assert (r1[0] == res_all[q]).all()
+
+
+def test_degenerate_queries(world):
+    """shorter than the spaced pattern, all X, and a query with masked (lower-case) residues"""
+    o = world["o"]
+    o.set(maxResListLen=1000, bins=0, maxDbMatches=0, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=30)
+    qs = [np.array([1, 2, 3, 4, 5], np.uint8), np.full(50, 20, np.uint8), world["targets"][40].copy(), np.zeros(0, np.uint8)]
+    ident = np.array([-1, 3, 40, -1], np.int64)
+    res, status, _ = run_gpu(world, {}, qs, ident)
+    for i, q in enumerate(qs):
+        if len(q) == 0:
+            assert len(res[i]) == 0
+            continue
+        b, _ = o.query(q, int(ident[i]))
+        assert status[i] == 0 and len(res[i]) == len(b) and (res[i] == b).all(), i
