@@ -2,6 +2,7 @@
 // ("int f(int argc, const char **argv)", DBs in -> DBs out, EXIT_SUCCESS / message + EXIT_FAILURE):
 //   ungappedprefilter <queryDB_ss> <targetDB_ss[_pad]> <outPrefDB>          M/src/prefiltering/ungappedprefilter.cpp:484-595
 //   structurealign    <queryDB> <targetDB[_pad]> <prefDB> <outAlnDB>         F/src/strucclustutils/structurealign.cpp:141-481
+//   prefilter         <queryDB_ss> <targetDB_ss[_pad]> <outPrefDB>          M/src/prefiltering/Main.cpp -> Prefiltering.cpp:22-245,755-982
 //   makepaddedseqdb   <seqDB> <outPaddedDB>                                  M/src/util/makepaddedseqdb.cpp:14-154
 // They read and write the same on-disk databases as the reference modules, so the shell workflows
 // (F/data/structuresearch.sh:41-53,116-143) can call them in place of the originals.  All DP work is done by the
@@ -229,6 +230,119 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
     for (auto &th : ths) th.join();
     if (bad) { fsgpu_destroy(ctx0); return fail("ungappedprefilter failed: " + firstErr); }
     for (size_t id = 0; id < q.size(); id++) w.write(q.key(id), results[id].data(), results[id].size());   // empty entries too
+    fsgpu_destroy(ctx0);
+    if (!w.close(err)) return fail(err);
+    return EXIT_SUCCESS;
+}
+
+// Util::canBeCovered (M/src/commons/Util.cpp:542-559) for the three modes runSplit applies it to (Prefiltering.cpp:880-887)
+static bool canBeCovered(float covThr, int covMode, float q, float t) {
+    switch (covMode) {
+        case 0: return (q / t >= covThr) && (t / q >= covThr);
+        case 2: return (t / q) >= covThr;
+        case 5: return (std::min(t, q) / std::max(t, q)) >= covThr;
+        default: return true;
+    }
+}
+
+int fsmod_prefilter(int argc, const char **argv) {
+    Options o = parseArgs(argc, argv);
+    if (o.pos.size() != 3) return fail("usage: prefilter <queryDB_ss> <targetDB_ss> <outPrefDB> [-s S] [-k 6] [--k-score T] [--max-seqs N] [--min-ungapped-score S] "
+                                       "[--comp-bias-corr 0|1] [--comp-bias-corr-scale F] [--mask-lower-case 0|1] [--mask-n-repeat N] [--spaced-kmer-mode 0|1] "
+                                       "[--add-self-matches 0|1] [-c F --cov-mode M] [--threads T]");
+    std::string err;
+    DbReader q, t;
+    if (!q.open(o.pos[0], err) || !t.open(o.pos[1], err)) return fail(err);
+    const bool sameDB = o.pos[0] == o.pos[1];
+    const bool includeIdentical = o.geti("--add-self-matches", 0) != 0;
+    // defaults as Foldseek sets them for its prefilter call (F/src/workflow/StructureSearch.cpp:101, F/src/commons/LocalParameters.cpp:382-412)
+    const int kmerSize = o.geti("-k", 0) == 0 ? 6 : o.geti("-k", 6);     // k = 0: auto -> 6 below 3.35e9 residues (IndexTable.h:456-458)
+    if (kmerSize != 6) return fail("prefilter: only -k 6 is implemented on the device path");
+    if (t.residues() >= 3350000000ull && o.geti("-k", 0) == 0) return fail("prefilter: database needs k = 7, which is not implemented on the device path");
+    if (o.geti("--diag-score", 1) != 1 || o.geti("--exact-kmer-matching", 0) != 0 || o.geti("--mask", 0) != 0)
+        return fail("prefilter: --diag-score 0, --exact-kmer-matching 1 and --mask 1 are not implemented on the device path");
+    const float sens = (float) o.getd("-s", 9.5);
+    const int kmerThr = o.has("--k-score") ? o.geti("--k-score", 0) : fshost_kmer_threshold(sens, kmerSize);
+    const int spaced = o.geti("--spaced-kmer-mode", 1);
+    const int maxRes = (int) std::min<uint64_t>((uint64_t) o.geti("--max-seqs", 1000), std::max<uint64_t>(t.size(), 1));
+    const int compBias = o.geti("--comp-bias-corr", 1);
+    const float cbScale = (float) o.getd("--comp-bias-corr-scale", 0.15);
+    const float covThr = (float) o.getd("-c", 0.0);
+    const int covMode = o.geti("--cov-mode", 0);
+    fshost_matrix *m8 = fshost_matrix_create(FSHOST_MAT_3DI, 8.0f, -0.2f), *m2 = fshost_matrix_create(FSHOST_MAT_3DI, 2.0f, -0.2f);
+    Matrix m3;
+    if (!m8 || !m2 || !m3.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f)) return fail("matrix construction failed");
+    PaddedTarget pt;
+    if (!loadPadded(t, nullptr, m3, nullptr, pt, err)) return fail(err);
+    fsgpu_ctx *ctx0 = nullptr;
+    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
+    if (fsgpu_db_load(ctx0, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
+        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    fsgpu_kmer_index_params ip;
+    ip.kmerSize = kmerSize; ip.spaced = spaced; ip.kmerThr = kmerThr;
+    ip.maskLowerCase = o.geti("--mask-lower-case", 1); ip.maskNrepeats = o.geti("--mask-n-repeat", 6);
+    if (fsgpu_kmer_index_build(ctx0, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    fsgpu_kmer_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.maxResListLen = maxRes; sp.minDiagScoreThr = o.geti("--min-ungapped-score", 30);
+    DbWriter w;
+    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) return fail(err);
+    const int nthreads = std::max(1, std::min(o.geti("--threads", 2), 16));
+    const size_t batch = 32;
+    std::vector<std::string> results(q.size());
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0), unstable(0);
+    std::string firstErr;
+    auto work = [&](int tix) {
+        fsgpu_ctx *ctx = ctx0;
+        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        std::vector<std::vector<uint8_t>> codes(batch);
+        std::vector<std::vector<int16_t>> thr(batch);
+        std::vector<std::vector<int8_t>> prof(batch);
+        std::vector<fsgpu_kmer_query> qs(batch);
+        std::vector<fsgpu_kmer_hit> hits(batch * (size_t) maxRes);
+        std::vector<int32_t> nout(batch), status(batch);
+        char line[128];
+        for (;;) {
+            const size_t b0 = next.fetch_add(batch);
+            if (b0 >= q.size() || bad) break;
+            const size_t nb = std::min(batch, q.size() - b0);
+            for (size_t k = 0; k < nb; k++) {
+                const size_t id = b0 + k;
+                const uint32_t L = q.seqLen(id);
+                codes[k].resize(L + 1); thr[k].resize(L + 1); prof[k].resize((size_t) L * 21 + 1);
+                const char *sq = q.data(id);
+                for (uint32_t i = 0; i < L; i++) codes[k][i] = m3.aa2num[(unsigned char) sq[i]];
+                fshost_kmer_query_prepare(m8, m2, codes[k].data(), (int) L, compBias, cbScale, kmerThr, kmerSize, spaced, thr[k].data(), prof[k].data());
+                qs[k].seq = codes[k].data(); qs[k].kmerThr = thr[k].data(); qs[k].profile = prof[k].data(); qs[k].L = (int32_t) L; qs[k].reserved = 0;
+                qs[k].identity = (sameDB || includeIdentical) ? t.idOf(q.key(id)) : -1;
+            }
+            if (fsgpu_kmer_search(ctx, &sp, qs.data(), (int) nb, hits.data(), nout.data(), status.data(), nullptr) != FSGPU_OK) {
+                if (!bad++) firstErr = fsgpu_last_error(ctx);
+                break;
+            }
+            for (size_t k = 0; k < nb; k++) {
+                if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q.key(b0 + k)) + ": hit buffers of the reference would overflow (status " + std::to_string(status[k]) + ")"; break; }
+                if (status[k] == FSGPU_KMER_UNSTABLE) unstable++;
+                std::string &out = results[b0 + k];
+                const float qLen = (float) q.seqLen(b0 + k);
+                for (int h = 0; h < nout[k]; h++) {
+                    const fsgpu_kmer_hit &hit = hits[k * (size_t) maxRes + h];
+                    if (covThr > 0.0 && (covMode == 0 || covMode == 2 || covMode == 5) && !canBeCovered(covThr, covMode, qLen, (float) pt.lengths[hit.id])) continue;
+                    out.append(line, fshost_format_prefilter_hit(line, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
+                }
+            }
+        }
+        if (tix > 0) fsgpu_destroy(ctx);
+    };
+    std::vector<std::thread> ths;
+    for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
+    work(0);
+    for (auto &th : ths) th.join();
+    fshost_matrix_free(m8); fshost_matrix_free(m2);
+    if (bad) { fsgpu_destroy(ctx0); return fail("prefilter failed: " + firstErr); }
+    if (unstable) fprintf(stderr, "prefilter: %d queries matched more than half of the diagonal buffer; equal scores at the --max-seqs cut are ordered deterministically there (the reference's order is unspecified)\n", (int) unstable);
+    for (size_t id = 0; id < q.size(); id++) w.write(q.key(id), results[id].data(), results[id].size());   // empty entries too (Prefiltering.cpp:900)
     fsgpu_destroy(ctx0);
     if (!w.close(err)) return fail(err);
     return EXIT_SUCCESS;

@@ -156,10 +156,12 @@ size_t fshost_format_result(char *buf, const fshost_result *r, const char *backt
 /* ---- module entry points with the reference's sub-command contract (argv without the program / command name) ----
  * They read and write MMseqs2 databases on disk exactly like the reference modules they stand in for:
  *   fsmod_ungappedprefilter  <queryDB_ss> <targetDB_ss> <outPrefDB>       M/src/prefiltering/ungappedprefilter.cpp:484-595
+ *   fsmod_prefilter          <queryDB_ss> <targetDB_ss> <outPrefDB>       M/src/prefiltering/Prefiltering.cpp:22-245,755-982 (k-mer prefilter)
  *   fsmod_structurealign     <queryDB> <targetDB> <prefDB> <outAlnDB>     F/src/strucclustutils/structurealign.cpp:141-481
  *   fsmod_makepaddedseqdb    <seqDB> <outPaddedDB>                        M/src/util/makepaddedseqdb.cpp:14-154
  * Return EXIT_SUCCESS or print a message to stderr and return EXIT_FAILURE. */
 int fsmod_ungappedprefilter(int argc, const char **argv);
+int fsmod_prefilter(int argc, const char **argv);
 int fsmod_structurealign(int argc, const char **argv);
 int fsmod_makepaddedseqdb(int argc, const char **argv);
 
