@@ -335,8 +335,8 @@ class Context:
         return (res, status[:nq], stats[:nq]) if want_stats else (res, status[:nq])
 
     def kmer_stage_ms(self):
-        """device ms of the last k-mer batch: total, count, lists, emit, sort, dupflags, score, walk, select"""
-        return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(9)]
+        """ms of the last k-mer batch: device total, count, lists, emit, sort, dupflags, score, walk, select; [9] host tail"""
+        return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(10)]
 
     def gapless_scores(self):
         s = np.zeros(self.n, np.uint8)

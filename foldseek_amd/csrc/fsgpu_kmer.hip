@@ -8,6 +8,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <unistd.h>
@@ -489,9 +490,12 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         hipLaunchKernelGGL(k_kmer_compact_cands, dim3(gridFor(nHits, 256)), dim3(256), 0, st, (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p,
                            (const uint32_t *) S.flags.p, (const uint32_t *) S.scan.p, nHits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p);
         RPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+        int maxL = 0;
+        for (int q = 0; q < nq; q++) maxL = std::max(maxL, queries[q].L);
+        const int ldsBytes = std::min(maxL * 21, 60 * 1024);
+        hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), (size_t) ldsBytes, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
                            (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
-                           (uint8_t *) S.kept.p, (int32_t *) S.score.p);
+                           ldsBytes, (uint8_t *) S.kept.p, (int32_t *) S.score.p);
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[6], st));
         // ---- stage 4: per-target replay ----------------------------------------------------------------------
@@ -537,6 +541,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         for (int i = 0; i < 9; i++) ctx->kmerMs[i] = hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess ? (double) ms : -1.0;
     }
     // ---- host tail ---------------------------------------------------------------------------------------------
+    const auto tTail = std::chrono::steady_clock::now();
     const KmerQ *hq2 = (const KmerQ *) S.hQs.p;
     std::vector<HostOut> el;
     for (int q = 0; q < nq; q++) {
@@ -554,6 +559,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             stats[q * 4 + 3] = (double) pickBins(sp, n);
         }
     }
+    ctx->kmerMs[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTail).count();
 #undef CHK
     return FSGPU_OK;
 }

@@ -230,7 +230,10 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_count(const KmerQ *qs, cons
 }
 
 // pass 2: enumerate the similar k-mers of position p in the reference's order, probe the index table and write one
-// (entry start, size, position) triple per k-mer into the list arrays at Kbase[p].
+// (entry start, size, position) triple per k-mer into the list arrays at Kbase[p].  The part of the two sorted 3-mer
+// rows that can pass the threshold (typically a few hundred entries) is staged in LDS, so the only HBM traffic left is
+// the random 8-byte probe of the offset table per k-mer -- the roofline of this kernel.
+constexpr int kStage = 2048;
 __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
                                                            uint32_t nPos, KmerPattern pat, const int16_t *s3, const uint16_t *i3,
                                                            const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets,
@@ -241,20 +244,34 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     if (Kp == 0) return;
     const KmerQ q = qs[posQuery[p]];
     __shared__ KmerPosInfo info;
+    __shared__ int c0s;
     __shared__ uint32_t ox[kRow3 + 1];        // exclusive prefix of c_x
     __shared__ uint32_t part[kKmerBlock + 1];
-    if (threadIdx.x == 0) info = kmerPosInfo(q, seqs, thrs, p, pat, s3);
+    __shared__ int16_t s1[kStage], s2[kStage];
+    __shared__ uint16_t j1[kStage], j2[kStage];
+    if (threadIdx.x == 0) {
+        info = kmerPosInfo(q, seqs, thrs, p, pat, s3);
+        // longest inner list: c_0 = #{S2 >= thr - S1[0]}
+        c0s = countGE(s3 + (size_t) info.b * kRow3, kRow3, (int) (int16_t) (info.thr - s3[(size_t) info.a * kRow3]));
+    }
     __syncthreads();
     const int16_t *S1 = s3 + (size_t) info.a * kRow3, *S2 = s3 + (size_t) info.b * kRow3;
     const uint16_t *I1 = i3 + (size_t) info.a * kRow3, *I2 = i3 + (size_t) info.b * kRow3;
-    const int n1 = info.n1;
+    const int n1 = info.n1, c0 = c0s;
+    const bool staged = n1 <= kStage && c0 <= kStage;
+    if (staged) {
+        for (int i = threadIdx.x; i < n1; i += kKmerBlock) { s1[i] = S1[i]; j1[i] = I1[i]; }
+        for (int i = threadIdx.x; i < c0; i += kKmerBlock) { s2[i] = S2[i]; j2[i] = I2[i]; }
+        __syncthreads();
+    }
     // each thread owns a contiguous slice of x so that a two-level scan gives the exclusive prefix
     const int per = (n1 + kKmerBlock - 1) / kKmerBlock;
-    const int x0 = threadIdx.x * per, x1 = min(n1, x0 + per);
+    const int x0 = min(n1, (int) threadIdx.x * per), x1 = min(n1, x0 + per);
     uint32_t sum = 0;
     for (int x = x0; x < x1; x++) {
-        const int cutoff2 = (int) (int16_t) (info.thr - S1[x]);
-        const uint32_t c = (uint32_t) countGE(S2, kRow3, cutoff2);
+        uint32_t c;
+        if (staged) c = (uint32_t) countGE(s2, c0, (int) (int16_t) (info.thr - s1[x]));
+        else c = (uint32_t) countGE(S2, kRow3, (int) (int16_t) (info.thr - S1[x]));
         ox[x] = sum;
         sum += c;
     }
@@ -270,17 +287,26 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     if (threadIdx.x == 0) ox[n1] = part[kKmerBlock];
     __syncthreads();
     const uint64_t base = Kbase[p];
-    for (uint32_t r = threadIdx.x; r < Kp; r += blockDim.x) {
-        int lo = 0, hi = n1;                  // last x with ox[x] <= r  (c_x > 0 for every x < n1 is not guaranteed)
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ox[mid] <= r) lo = mid; else hi = mid; }
-        // skip empty rows: ox[lo] <= r < ox[lo+1] must hold; rows with c_x == 0 share ox with their successor
-        while (ox[lo + 1] <= r) lo++;
-        const uint32_t y = r - ox[lo];
-        const uint32_t kmer = (uint32_t) I1[lo] + (uint32_t) kRow3 * (uint32_t) I2[y];
-        const uint32_t st = offsets[kmer], en = offsets[kmer + 1];
-        listStart[base + r] = st;
-        listSize[base + r] = en - st;
-        listPos[base + r] = p;
+    for (uint32_t r0 = threadIdx.x; r0 < Kp; r0 += 4 * kKmerBlock) {
+        uint32_t kmer[4], st[4], en[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * kKmerBlock;
+            kmer[u] = 0;
+            if (r < Kp) {
+                int lo = 0, hi = n1;          // last x with ox[x] <= r (c_x >= 1 for every x < n1)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ox[mid] <= r) lo = mid; else hi = mid; }
+                const uint32_t y = r - ox[lo];
+                kmer[u] = staged ? (uint32_t) j1[lo] + (uint32_t) kRow3 * (uint32_t) j2[y] : (uint32_t) I1[lo] + (uint32_t) kRow3 * (uint32_t) I2[y];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { st[u] = offsets[kmer[u]]; en[u] = offsets[kmer[u] + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = r0 + u * kKmerBlock;
+            if (r < Kp) { listStart[base + r] = st[u]; listSize[base + r] = en[u] - st[u]; listPos[base + r] = p; }
+        }
     }
 }
 
@@ -326,28 +352,46 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
 // --------------------------------------------------------------------------------------------------------------
 // search, stage 2: the hit stream.  Output-balanced gather: one thread per hit, list found by binary search.
 // --------------------------------------------------------------------------------------------------------------
+constexpr int kEmitStage = 8192;
 __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerChunks *chunks, const uint16_t *posQuery, uint64_t nLists, const uint64_t *listP,
                                                    const uint32_t *listStart, const uint32_t *listPos, const uint64_t *entries,
                                                    uint64_t nHits, int tbits, uint32_t *keys, uint64_t *vals) {
     __shared__ uint64_t range[2];
+    __shared__ uint32_t rel[kEmitStage + 1];  // list prefix relative to the block's first list
     const uint64_t o0 = (uint64_t) blockIdx.x * 2048;
     if (o0 >= nHits) return;
     const uint64_t o1 = min(nHits, o0 + 2048);
     if (threadIdx.x < 2) {
         const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
-        uint64_t lo = 0, hi = nLists;         // last l with listP[l] <= o
+        uint64_t lo = 0, hi = nLists;         // last l with listP[l] <= o (that list is non-empty and contains o)
         while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
         range[threadIdx.x] = lo;
     }
     __syncthreads();
+    const uint64_t l0 = range[0], l1 = range[1];
+    const uint64_t p0 = listP[l0];
+    const int nl = (int) min<uint64_t>(l1 - l0 + 1, (uint64_t) kEmitStage + 1);
+    const bool staged = l1 - l0 + 1 <= (uint64_t) kEmitStage;
+    if (staged) {
+        for (int i = threadIdx.x; i < nl; i += 256) rel[i] = (uint32_t) (listP[l0 + i] - p0);
+        __syncthreads();
+    }
     for (uint64_t o = o0 + threadIdx.x; o < o1; o += blockDim.x) {
-        uint64_t lo = range[0], hi = range[1] + 1;
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
-        while (listP[lo + 1] <= o) lo++;      // empty lists share their prefix with the successor
-        const uint32_t p = listPos[lo];
+        uint64_t l;
+        if (staged) {
+            const uint32_t ro = (uint32_t) (o - p0);
+            int lo = 0, hi = nl;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rel[mid] <= ro) lo = mid; else hi = mid; }
+            l = l0 + lo;
+        } else {
+            uint64_t lo = l0, hi = l1 + 1;
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
+            l = lo;
+        }
+        const uint32_t p = listPos[l];
         const uint32_t qi = posQuery[p];
         const KmerQ &q = qs[qi];
-        const uint64_t e = entries[(uint64_t) listStart[lo] + (o - listP[lo])];
+        const uint64_t e = entries[(uint64_t) listStart[l] + (o - listP[l])];
         const uint32_t seqId = (uint32_t) (e >> 16), posj = (uint32_t) e & 0xffffu;
         const uint32_t i = p - q.posBase;
         const uint64_t g = o - q.hitBase;
@@ -395,11 +439,48 @@ __global__ void k_kmer_compact_cands(const uint32_t *keys, const uint64_t *vals,
 
 // findDuplicates pass 2 (collapse runs of equal 8-bit diagonals among the candidates of one target and chunk) fused
 // with UngappedAlignment scoring of the survivors: score32 = uncapped best ungapped run on the 16-bit diagonal.
-// kept[j] = 0 dropped, 1 kept.
-__global__ void k_kmer_score(const uint32_t *ckeys, const uint64_t *cvals, const uint32_t *nCandPtr, int tbits, const KmerQ *qs, const int8_t *profiles,
-                             const uint8_t *masked, const uint64_t *offsets, const int32_t *lengths, uint8_t *kept, int32_t *score) {
-    const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= *nCandPtr) return;
+// kept[j] = 0 dropped, 1 kept.  One thread per candidate; the candidates are sorted by query, so a workgroup stages the
+// int8 profile of its first query in LDS (other queries of a straddling workgroup read theirs from global memory) and
+// every lane walks its diagonal with aligned 8-byte target loads: 8 cells per memory round trip.
+template <bool LDS>
+__device__ inline int kmerDiagScore(const int8_t *prof, const uint8_t *db, int len) {
+    int mx = 0, s = 0, pos = 0;
+    // head: up to the first 8-byte boundary of the target
+    const int head = min(len, (int) ((8 - ((uintptr_t) db & 7)) & 7));
+    for (; pos < head; pos++) { s += prof[pos * 21 + db[pos]]; s = s < 0 ? 0 : s; mx = s > mx ? s : mx; }
+    for (; pos + 8 <= len; pos += 8) {
+        const uint64_t w = *reinterpret_cast<const uint64_t *>(db + pos);
+        const int8_t *p = prof + pos * 21;
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[k * 21 + (int) ((w >> (8 * k)) & 0xff)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s += v[k]; s = s < 0 ? 0 : s; mx = s > mx ? s : mx; }
+    }
+    for (; pos < len; pos++) { s += prof[pos * 21 + db[pos]]; s = s < 0 ? 0 : s; mx = s > mx ? s : mx; }
+    return mx;
+}
+
+__global__ __launch_bounds__(256) void k_kmer_score(const uint32_t *ckeys, const uint64_t *cvals, const uint32_t *nCandPtr, int tbits, const KmerQ *qs,
+                                                    const int8_t *profiles, const uint8_t *masked, const uint64_t *offsets, const int32_t *lengths,
+                                                    int ldsBytes, uint8_t *kept, int32_t *score) {
+    extern __shared__ int8_t sprof[];
+    __shared__ uint32_t q0s;
+    const uint64_t nCand = *nCandPtr;
+    const uint64_t j0 = (uint64_t) blockIdx.x * 256, j = j0 + threadIdx.x;
+    if (j0 >= nCand) return;
+    if (threadIdx.x == 0) q0s = ckeys[j0] >> tbits;
+    __syncthreads();
+    const uint32_t q0 = q0s;
+    const int L0 = (int) qs[q0].L;
+    const bool staged = L0 * 21 <= ldsBytes;
+    if (staged) {
+        const int8_t *src = profiles + qs[q0].profOff;       // profOff is a multiple of 1 byte only: copy bytewise in 4-byte lanes when aligned
+        const int nb = L0 * 21;
+        for (int i = threadIdx.x; i < nb; i += 256) sprof[i] = src[i];
+    }
+    __syncthreads();
+    if (j >= nCand) return;
     const uint32_t k = ckeys[j];
     const uint64_t v = cvals[j];
     bool keep = true;
@@ -407,22 +488,19 @@ __global__ void k_kmer_score(const uint32_t *ckeys, const uint64_t *cvals, const
     kept[j] = keep ? 1 : 0;
     if (!keep) { score[j] = 0; return; }
     const uint32_t t = k & ((1u << tbits) - 1u);
-    const KmerQ &q = qs[k >> tbits];
-    const int8_t *prof = profiles + q.profOff;
+    const uint32_t qi = k >> tbits;
+    const KmerQ &q = qs[qi];
     const uint8_t *db = masked + offsets[t];
     const int dbLen = lengths[t], qLen = (int) q.L;
-    const int diagonal = (int) (int16_t) (uint16_t) hitDiag(v);
     const uint32_t d = hitDiag(v);
+    const int diagonal = (int) (int16_t) (uint16_t) d;
     const int minDist = (int) min((0u - d) & 0xffffu, d);
-    int len = 0;
-    if (diagonal >= 0 && minDist < qLen) { len = min(dbLen, qLen - minDist); prof += (size_t) minDist * 21; }
+    int len = 0, poff = 0;
+    if (diagonal >= 0 && minDist < qLen) { len = min(dbLen, qLen - minDist); poff = minDist * 21; }
     else if (diagonal < 0 && minDist < dbLen) { len = min(dbLen - minDist, qLen); db += minDist; }
-    int mx = 0, s = 0;
-    for (int pos = 0; pos < len; pos++) {
-        s += prof[pos * 21 + db[pos]];
-        s = s < 0 ? 0 : s;
-        mx = s > mx ? s : mx;
-    }
+    int mx;
+    if (staged && qi == q0) mx = kmerDiagScore<true>(sprof + poff, db, len);
+    else mx = kmerDiagScore<false>(profiles + q.profOff + poff, db, len);
     score[j] = mx;
 }
 
@@ -573,16 +651,34 @@ __global__ void k_kmer_cut(const uint32_t *hist, int nq, uint32_t maxHits, uint3
     thr[q] = t < minDiag ? minDiag : t;
 }
 struct KmerOut { uint32_t id; uint32_t count; uint32_t diag; int32_t score; uint64_t g; };
-__global__ void k_kmer_out(const uint32_t *ckeys, const uint64_t *cvals, const int32_t *score, const KmerBest *best, const uint32_t *nCandPtr, int tbits,
-                           const uint32_t *thr, uint32_t cap, uint32_t *outCount /*[nq]*/, KmerOut *out /*[nq][cap]*/) {
+__global__ __launch_bounds__(256) void k_kmer_out(const uint32_t *ckeys, const uint64_t *cvals, const int32_t *score, const KmerBest *best, const uint32_t *nCandPtr, int tbits,
+                                                  const uint32_t *thr, uint32_t cap, uint32_t *outCount /*[nq]*/, KmerOut *out /*[nq][cap]*/) {
     const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= *nCandPtr) return;
-    const KmerBest b = best[s];
-    if (b.nElems == 0xFFFFFFFFu || b.nElems == 0) return;
-    const uint32_t qi = ckeys[s] >> tbits;
-    if (b.count < thr[qi] || b.count == 0) return;
-    const uint32_t slot = atomicAdd(&outCount[qi], 1u);
-    if (slot >= cap) return;
+    bool take = false;
+    uint32_t qi = 0;
+    KmerBest b{};
+    if (s < *nCandPtr) {
+        b = best[s];
+        if (b.nElems != 0xFFFFFFFFu && b.nElems != 0) {
+            qi = ckeys[s] >> tbits;
+            take = b.count >= thr[qi] && b.count != 0;
+        }
+    }
+    // one atomic per (wave, query) instead of one per element: same-address atomics serialise in L2
+    uint32_t slot = 0;
+    const int lane = (int) (threadIdx.x & 63);
+    unsigned long long pending = __ballot(take);
+    while (pending) {
+        const int leader = __ffsll((long long) pending) - 1;
+        const uint32_t q = (uint32_t) __shfl((int) qi, leader);
+        const unsigned long long grp = __ballot(take && qi == q);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&outCount[q], (uint32_t) __popcll(grp));
+        base = (uint32_t) __shfl((int) base, leader);
+        if (take && qi == q) slot = base + (uint32_t) __popcll(grp & ((1ull << lane) - 1ull));
+        pending &= ~grp;
+    }
+    if (!take || slot >= cap) return;
     const uint64_t v = cvals[b.cand];
     KmerOut o;
     o.id = ckeys[s] & ((1u << tbits) - 1u); o.count = b.count; o.diag = hitDiag(v); o.score = score[b.cand]; o.g = hitG(v);
