@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1]), 2: 3Di+AA")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
+    ap.add_argument("--kmer-queries", type=int, default=128, help="queries of the k-mer prefilter section (batches of 32)")
+    ap.add_argument("--kmer-cpu-queries", type=int, default=256, help="queries the reference k-mer prefilter is timed on")
     ap.add_argument("--cpu-sample-targets", type=int, default=20000)
     return ap.parse_args()
 
@@ -82,6 +85,116 @@ def cpu_baseline(db, q3, qa, hits_ids, atype, sample_targets):
             "sample": f"gapless prefilter timed on {ns} of {db.n} targets ({sample_res} residues, scaled linearly) + "
                       f"fwd/rev structure SW on the {len(hits_ids)} prefilter hits, {threads} host threads",
             "prefilter_s_sample": t_pref, "align_s": t_aln}
+
+
+def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdist):
+    """k-mer prefilter (Foldseek's default prefilter on CPUs) + structure SW on its hits, same resident DB.
+    Every rank builds its own index from the broadcast DB (no collective) and searches its own queries."""
+    import threading
+    nqk = max(32, args.kmer_queries // 32 * 32)
+    q3, qa = synth.make_queries(nqk, seed=5000 + rank, lo=250, hi=450)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    thr = api.kmer_threshold(9.5, 6)
+    t0 = time.perf_counter()
+    ctx0.kmer_index_build(m8, kmer_thr=thr)
+    t_index = time.perf_counter() - t0
+    # a clone made now shares the resident DB and the index; two host threads keep the device busy during the host tails
+    kctx = [ctx0, ctx0.clone()]
+    ksearch = [search0, api.Search(kctx[1], par)]
+    prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in q3]
+    batches = [list(range(b, b + 32)) for b in range(0, nqk, 32)]
+    stat = {"dev": [], "lists": [], "counts": [], "hits": 0, "aln": 0, "t_pref": 0.0, "t_aln": 0.0, "hq": 0}
+    lock = threading.Lock()
+
+    def run(t, ids, timed):
+        tp = time.perf_counter()
+        res, status = kctx[t].kmer_search([prep[i] for i in ids], max_res=1000)
+        tp = time.perf_counter() - tp
+        ms, cnt = kctx[t].kmer_stage_ms(), kctx[t].kmer_counts()
+        ta = time.perf_counter()
+        na = 0
+        for k, i in enumerate(ids):
+            na += len(ksearch[t].align(qa[i], q3[i], res[k]["id"]))
+        ta = time.perf_counter() - ta
+        if timed:
+            with lock:
+                stat["dev"].append(ms[0]); stat["lists"].append(ms[10]); stat["counts"].append(cnt)
+                stat["hits"] += sum(len(r) for r in res); stat["aln"] += na; stat["t_pref"] += tp; stat["t_aln"] += ta
+                stat["bad"] = stat.get("bad", 0) + int((status < 0).sum())
+        return res
+
+    run(0, batches[0], False); run(1, batches[0], False)          # warm both host threads / contexts
+    ready, go = threading.Barrier(3), threading.Barrier(3)
+
+    def worker(t):
+        ready.wait(); go.wait()
+        for b in range(t, len(batches), 2):
+            run(t, batches[b], True)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    ready.wait()
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go.wait()
+    for th in ths:
+        th.join()
+    torch.cuda.synchronize()
+    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    # solo batch on an idle GPU for the roofline of the dominant kernel
+    run(0, batches[-1], False)
+    solo_ms, solo_cnt = kctx[0].kmer_stage_ms(), kctx[0].kmer_counts()
+    ksearch[1].close(); kctx[1].close()
+    if rank != 0:
+        return None
+    probes = float(solo_cnt[0])
+    lists_s = solo_ms[10] * 1e-3
+    alg = probes * 8.0                                         # two uint32 offsets per similar k-mer
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json")))
+        if args.targets == 100000:
+            traffic = tj["k_kmer_lists_bytes_per_probe"] * probes
+    except Exception:
+        traffic = None
+    out = {"workload": f"{nqk} queries in batches of 32 vs the same {db.n}-structure DB: k-mer prefilter (-s 9.5, k=6 spaced, "
+                       f"--max-seqs 1000, double-diagonal + ungapped scoring) + fwd/rev structure SW on its hits",
+           "value": world * nqk * db.residues / dt, "unit": "residues/s", "queries_per_s": world * nqk / dt,
+           "ms_per_query": 1e3 * dt / nqk, "prefilter_ms_per_query_host_wall": 1e3 * stat["t_pref"] / nqk,
+           "align_ms_per_query_host_wall": 1e3 * stat["t_aln"] / nqk, "prefilter_device_ms_per_query": float(np.sum(stat["dev"])) / nqk,
+           "index_build_s": t_index, "index_entries": int(ctx0.kmer_index_entries), "kmer_threshold": thr,
+           "similar_kmers_per_query": float(np.mean([c[0] for c in stat["counts"]])) / 32, "index_hits_per_query": float(np.mean([c[1] for c in stat["counts"]])) / 32,
+           "candidates_per_query": float(np.mean([c[2] for c in stat["counts"]])) / 32,
+           "hits_per_query": stat["hits"] / nqk, "alignments_per_query": stat["aln"] / nqk, "unsupported_queries": stat.get("bad", 0),
+           "stage_ms_per_batch32_solo": {k: solo_ms[i] for i, k in enumerate(["device_total", "count", "lists", "emit", "sort", "dupflags", "score", "replay", "select", "host_tail", "k_kmer_lists"])},
+           "roofline": {"bound": "hbm", "kernel": "k_kmer_lists", "kernel_ms": solo_ms[10], "achieved": alg / lists_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": alg / lists_s / 1e9 / 8000.0, "traffic": traffic, "algorithmic_bytes": alg,
+                        "probes_per_launch": probes, "probes_per_s": probes / lists_s,
+                        "note": "random 8-byte probes of the 256 MB k-mer offset table: each one costs a whole HBM sector, see DESIGN.md"}}
+    return out
+
+
+def kmer_cpu_baseline(args, synth, db):
+    """the reference's own k-mer prefilter classes (oracle/_ref) on all host cores: index build + matchQuery"""
+    import kmer_lib as K
+    R = K.load_ref()
+    if R is None:
+        return None
+    threads = os.cpu_count() or 1
+    nq = args.kmer_cpu_queries
+    q3, _ = synth.make_queries(nq, seed=5000, lo=250, hi=450)
+    t0 = time.perf_counter()
+    r = K.RefKpf(R, [db.seq(i, "3di", unmask=False) for i in range(db.n)], threads=threads)
+    t_build = time.perf_counter() - t0
+    _, _, secs = r.run(q3, None, threads=threads)
+    _, _, secs = r.run(q3, None, threads=threads)
+    r.close()
+    return {"value": nq * db.residues / secs, "unit": "residues/s", "queries_per_s": nq / secs, "cores": threads, "kind": "reference",
+            "sample": f"QueryMatcher::matchQuery of the reference on {nq} queries vs the same {db.n}-target DB, {threads} OpenMP threads "
+                      f"(dynamic,1), second of two runs; index build {t_build:.1f}s not included; prefilter only (no alignment)",
+            "index_build_s": t_build}
 
 
 def main():
@@ -214,6 +327,19 @@ def main():
         if not args.no_cpu_baseline:
             hits, _ = step(0, args.warmup)
             out["cpu_baseline"] = cpu_baseline(db, q3[args.warmup], qa[args.warmup], hits["id"], args.alignment_type, args.cpu_sample_targets)
+    for x in searches[1:]:
+        x.close()
+    for c in ctxs[1:]:
+        c.close()
+    searches, ctxs = searches[:1], ctxs[:1]
+    kout = None
+    if not args.no_kmer:
+        kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist)
+    if rank == 0:
+        if kout is not None:
+            if not args.no_cpu_baseline:
+                kout["cpu_baseline"] = kmer_cpu_baseline(args, synth, db)
+            out["kmer_prefilter"] = kout
         print(json.dumps(out))
     for x in searches:
         x.close()

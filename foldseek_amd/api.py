@@ -85,6 +85,7 @@ def lib():
         "fsgpu_kmer_search": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
         "fsgpu_kmer_index_copy": (i32, [vp, vp, vp, vp]),
         "fsgpu_kmer_row_copy": (i32, [vp, i32, vp, vp]),
+        "fsgpu_kmer_last_counts": (None, [vp, vp]),
         "fshost_kmer_query_prepare": (i32, [vp, vp, vp, i32, i32, f32, i32, i32, i32, vp, vp]),
         "fshost_kmer_threshold": (i32, [f32, i32]),
         "fshost_matrix_create": (vp, [i32, f32, f32]),
@@ -130,7 +131,7 @@ def exported_symbols():
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_last_kernel_ms", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
-            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy"]
+            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts"]
 
 
 def _ptr(a):
@@ -307,6 +308,23 @@ class Context:
         self._chk(lib().fsgpu_kmer_index_copy(self.h, _ptr(off), _ptr(ent), _ptr(msk)), "fsgpu_kmer_index_copy")
         return off, ent[:self.kmer_index_entries], msk[:nbytes_db]
 
+    def kmer_index_reference_order(self, nbytes_db):
+        """(offsets uint64[64e6+1], seqId uint32[], pos uint16[], masked) re-ordered to the reference's k-mer numbering
+        (first3 + 8000*last3); the device keeps its table first-3-mer major (kmerDeviceIndex)."""
+        off, ent, msk = self.kmer_index_copy(nbytes_db)
+        k = np.arange(64000000, dtype=np.int64)
+        kdev = (k % 8000) * 8000 + k // 8000
+        size_dev = np.diff(off.astype(np.int64))
+        size_ref = size_dev[kdev]
+        roff = np.zeros(64000001, np.uint64)
+        roff[1:] = np.cumsum(size_ref)
+        nz = np.nonzero(size_ref)[0]
+        starts = off.astype(np.int64)[kdev[nz]]
+        lens = size_ref[nz]
+        idx = np.repeat(starts - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+        e = ent[idx]
+        return roff, (e >> np.uint64(16)).astype(np.uint32), (e & np.uint64(0xffff)).astype(np.uint16), msk
+
     def kmer_row(self, row):
         s = np.zeros(8000, np.int16); ix = np.zeros(8000, np.uint16)
         self._chk(lib().fsgpu_kmer_row_copy(self.h, row, _ptr(s), _ptr(ix)), "fsgpu_kmer_row_copy")
@@ -334,9 +352,15 @@ class Context:
         res = [out[q, :nout[q]].copy() for q in range(nq)]
         return (res, status[:nq], stats[:nq]) if want_stats else (res, status[:nq])
 
+    def kmer_counts(self):
+        """last batch: similar k-mers probed, index hits, double-diagonal candidates, elements handed to the host"""
+        out = np.zeros(4, np.uint64)
+        lib().fsgpu_kmer_last_counts(self.h, _ptr(out))
+        return out
+
     def kmer_stage_ms(self):
-        """ms of the last k-mer batch: device total, count, lists, emit, sort, dupflags, score, walk, select; [9] host tail"""
-        return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(10)]
+        """ms of the last k-mer batch: device total, count, lists, emit, sort, dupflags, score, walk, select; [9] host tail; [10] k_kmer_lists kernel alone"""
+        return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(11)]
 
     def gapless_scores(self):
         s = np.zeros(self.n, np.uint8)

@@ -372,7 +372,7 @@ int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out) {
 }
 
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which) {
-    if (ctx && which >= 2 && which < 12) return ctx->kmerMs[which - 2];
+    if (ctx && which >= 2 && which < 14) return ctx->kmerMs[which - 2];
     if (!ctx || which < 0 || which > 1 || !ctx->evValid[which]) return -1.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]) != hipSuccess) return -1.0;

@@ -61,7 +61,8 @@ struct fsgpu_ctx {
     std::shared_ptr<DbStore> db;
     std::shared_ptr<KmerIndex> kidx;   // k-mer prefilter index (shared with clones)
     KmerScratch *kmer = nullptr;       // per-context k-mer prefilter scratch
-    double kmerMs[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // device ms of the last k-mer batch: [0] total, [1..] stages
+    double kmerMs[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // ms of the last k-mer batch: [0] device total, [1..8] stages, [9] host tail, [10] k_kmer_lists alone
+    uint64_t kmerCounts[4] = {0, 0, 0, 0};   // last batch: k-mer lists probed, index hits, double-diagonal candidates, elements handed to the host
 
     // gapless scratch
     DevBuf pssm, scores, chunkHist, baseGt, baseTie, outId, outScore, gBorder0, gBorder1, scoreAcc;

@@ -23,12 +23,13 @@ struct KmerIndex {
     uint64_t n = 0;
     int tbits = 1;
     uint8_t *masked = nullptr;            // SequenceLookup: masked codes in the padded layout of the DB
-    uint32_t *offsets = nullptr;          // 20^6 + 1
+    uint32_t *offsets = nullptr;          // 20^6 + 1, in device k-mer order (kmerDeviceIndex)
+    uint32_t *bitmap = nullptr;           // 20^6 bits: list non-empty
     uint64_t *entries = nullptr;          // seqId << 16 | first position
     uint64_t nEntries = 0;
     int16_t *s3 = nullptr;                // extended 3-mer matrix, rows sorted descending
     uint16_t *i3 = nullptr;
-    ~KmerIndex() { (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(entries); (void) hipFree(s3); (void) hipFree(i3); }
+    ~KmerIndex() { (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(bitmap); (void) hipFree(entries); (void) hipFree(s3); (void) hipFree(i3); }
 };
 
 struct KmerScratch {
@@ -36,7 +37,7 @@ struct KmerScratch {
            keys0, keys1, vals0, vals1, flags, scan, ckeys, cvals, kept, score, scrA, scrB, best,
            ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand;
     PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc;
-    hipEvent_t ev[12] = {};
+    hipEvent_t ev[14] = {};
     bool evInit = false;
 };
 
@@ -64,11 +65,17 @@ void fsgpu_kmer_free_scratch(KmerScratch *s) {
 
 static inline unsigned gridFor(uint64_t n, unsigned block) { return (unsigned) std::max<uint64_t>(1, (n + block - 1) / block); }
 
+// scratch grows geometrically: batch sizes differ from call to call and a hipFree/hipMalloc pair costs milliseconds
+static int ensureK(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return FSGPU_OK;
+    return ensure(ctx, b, bytes + bytes / 2 + (1u << 20));
+}
+
 template <class T>
 static int scanExclusive(fsgpu_ctx *ctx, DevBuf &tmp, const T *in, T *out, size_t n) {
     size_t bytes = 0;
     RPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, (T) 0, n, rocprim::plus<T>(), ctx->stream));
-    int rc = ensure(ctx, tmp, bytes);
+    int rc = ensureK(ctx, tmp, bytes);
     if (rc != FSGPU_OK) return rc;
     RPCHK(rocprim::exclusive_scan(tmp.p, bytes, in, out, (T) 0, n, rocprim::plus<T>(), ctx->stream));
     return FSGPU_OK;
@@ -79,7 +86,7 @@ static int scanExclusive32to64(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *in, 
     auto it = rocprim::make_transform_iterator(in, U32to64());
     size_t bytes = 0;
     RPCHK(rocprim::exclusive_scan(nullptr, bytes, it, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
-    int rc = ensure(ctx, tmp, bytes);
+    int rc = ensureK(ctx, tmp, bytes);
     if (rc != FSGPU_OK) return rc;
     RPCHK(rocprim::exclusive_scan(tmp.p, bytes, it, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
     return FSGPU_OK;
@@ -87,7 +94,7 @@ static int scanExclusive32to64(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *in, 
 static int sortPairs(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout, size_t n, int bits) {
     size_t bytes = 0;
     RPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
-    int rc = ensure(ctx, tmp, bytes);
+    int rc = ensureK(ctx, tmp, bytes);
     if (rc != FSGPU_OK) return rc;
     RPCHK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
     return FSGPU_OK;
@@ -185,6 +192,9 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     // counts -> offsets (in place)
     rc = scanExclusive<uint32_t>(ctx, tmp, ix->offsets, ix->offsets, tableSize + 1);
     if (rc != FSGPU_OK) { cleanup(); return rc; }
+    IXCHK(hipMalloc((void **) &ix->bitmap, (tableSize / 32) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_kmer_bitmap, dim3(gridFor(tableSize / 32, 256)), dim3(256), 0, ctx->stream, ix->offsets, (uint32_t) (tableSize / 32), ix->bitmap);
+    IXCHK(hipGetLastError());
     IXCHK(hipStreamSynchronize(ctx->stream));
     cleanup();
 #undef IXCHK
@@ -201,6 +211,9 @@ int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets /*64e6+1*/, uint64_t
     if (entries && ix.nEntries) RPCHK(hipMemcpy(entries, ix.entries, ix.nEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (masked && ix.db->bytes) RPCHK(hipMemcpy(masked, ix.masked, ix.db->bytes, hipMemcpyDeviceToHost));
     return FSGPU_OK;
+}
+void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4) {
+    for (int i = 0; i < 4; i++) out4[i] = ctx ? ctx->kmerCounts[i] : 0;
 }
 int fsgpu_kmer_row_copy(fsgpu_ctx *ctx, int row, int16_t *score /*8000*/, uint16_t *index /*8000*/) {
     if (!ctx || row < 0 || row >= kRow3) return FSGPU_E_ARG;
@@ -277,19 +290,20 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
             if (C >= 1) order.push_back({(int) C, 1});
             for (size_t z = 0; z < order.size(); z++) { rank[order[z].first] = (int) z; dir[order[z].first] = order[z].second; }
         }
+        auto chunkOf = [&](uint64_t g) { uint32_t c = 0; while (c + 1 < ck.nChunks && ck.start[c + 1] <= g) c++; return c; };
+        // array order of the reference inside one score bucket: (bin, order the overflow rounds left the elements in)
+        auto orderKey = [&](const HostOut &e, uint32_t &bin) {
+            const uint32_t c = chunkOf(e.g);
+            bin = e.id & (B - 1);
+            return ((uint64_t) rank[c] << 40) | (dir[c] > 0 ? e.g : ((1ull << 40) - 1 - e.g));
+        };
         struct Key { uint32_t count; uint32_t bin; uint64_t ok; const HostOut *e; };
-        std::vector<Key> ks(el.size());
-        for (size_t i = 0; i < el.size(); i++) {
-            uint32_t c = 0;
-            while (c + 1 < ck.nChunks && ck.start[c + 1] <= el[i].g) c++;
-            const uint64_t gg = dir[c] > 0 ? el[i].g : ((1ull << 40) - 1 - el[i].g);
-            ks[i] = {el[i].count, el[i].id & (B - 1), ((uint64_t) rank[c] << 40) | gg, &el[i]};
-        }
         auto arrayOrder = [](const Key &a, const Key &b) { return a.bin != b.bin ? a.bin < b.bin : a.ok < b.ok; };
         const bool truncated = thr >= 255;
-        unsigned rescale = 0;
         if (truncated) {
             // rescoreHits (QueryMatcher.cpp:563-589): only the 255-capped hits survive, re-ranked by their real score
+            std::vector<Key> ks(el.size());
+            for (size_t i = 0; i < el.size(); i++) { uint32_t bin; const uint64_t ok = orderKey(el[i], bin); ks[i] = {el[i].count, bin, ok, &el[i]}; }
             std::sort(ks.begin(), ks.end(), arrayOrder);
             int maxSelf = scalarDiag(q.profile, q.L, q.seq) - 255;
             maxSelf = std::max(1, maxSelf);
@@ -300,19 +314,38 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
                 float sc = (float) std::min(ns, 65535u);
                 k.count = (uint8_t) ((sc / fmax) * (float) 255 + 0.5);
             }
-            rescale = (unsigned) maxSelf;
+            const unsigned rescale = (unsigned) maxSelf;
             std::stable_sort(ks.begin(), ks.end(), [](const Key &a, const Key &b) { return a.count > b.count; });
+            for (size_t i = 0; i < ks.size() && cur < maxHits; i++) {
+                if (q.identity >= 0 && (uint32_t) q.identity == ks[i].e->id) continue;
+                fsgpu_kmer_hit &h = out[cur++];
+                h.id = ks[i].e->id; h.diagonal = (uint16_t) ks[i].e->diag; h.pad = 0;
+                h.score = (int32_t) (255u + ks[i].count * rescale / 255u);
+            }
         } else {
-            std::sort(ks.begin(), ks.end(), [&](const Key &a, const Key &b) { return a.count != b.count ? a.count > b.count : arrayOrder(a, b); });
-        }
-        for (size_t i = 0; i < ks.size() && cur < maxHits; i++) {
-            if (q.identity >= 0 && (uint32_t) q.identity == ks[i].e->id) continue;
-            fsgpu_kmer_hit &h = out[cur];
-            h.id = ks[i].e->id; h.diagonal = (uint16_t) ks[i].e->diag; h.pad = 0;
-            h.score = (int32_t) ks[i].count;
-            if (rescale != 0) h.score = (int32_t) (255u + ks[i].count * rescale / 255u);
-            else if (ks[i].count >= 255) h.score = ks[i].e->score;
-            cur++;
+            // everything above the cut is taken (computeScoreThreshold leaves fewer than maxHits of them); the ties at the
+            // cut fill the remaining slots in the reference's array order, so only they need the (bin, order) key
+            std::vector<Key> ties;
+            for (const HostOut &e : el) {
+                if (q.identity >= 0 && (uint32_t) q.identity == e.id) continue;
+                if (e.count > thr) {
+                    if (cur < maxHits) {
+                        fsgpu_kmer_hit &h = out[cur++];
+                        h.id = e.id; h.diagonal = (uint16_t) e.diag; h.pad = 0;
+                        h.score = e.count >= 255 ? e.score : (int32_t) e.count;
+                    }
+                } else if (e.count == thr) {
+                    uint32_t bin; const uint64_t ok = orderKey(e, bin);
+                    ties.push_back({e.count, bin, ok, &e});
+                }
+            }
+            const size_t room = maxHits - cur;
+            if (ties.size() > room) { std::nth_element(ties.begin(), ties.begin() + room, ties.end(), arrayOrder); ties.resize(room); }
+            for (const Key &k : ties) {
+                fsgpu_kmer_hit &h = out[cur++];
+                h.id = k.e->id; h.diagonal = (uint16_t) k.e->diag; h.pad = 0;
+                h.score = k.e->count >= 255 ? k.e->score : (int32_t) k.e->count;
+            }
         }
     }
     if (cur > 1) {
@@ -373,21 +406,21 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             pb += np; so += (uint64_t) L + 16; po += (uint64_t) L * 21 + 16;
         }
     }
-    CHK(ensure(ctx, S.qs, (size_t) nq * sizeof(KmerQ)));
-    CHK(ensure(ctx, S.posQuery, (nPos + 1) * sizeof(uint16_t)));
-    CHK(ensure(ctx, S.seqs, seqBytes));
-    CHK(ensure(ctx, S.thrs, (nPos + 1) * sizeof(int16_t)));
-    CHK(ensure(ctx, S.profiles, profBytes));
-    CHK(ensure(ctx, S.K, (nPos + 1) * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.Kbase, (nPos + 1) * sizeof(uint64_t)));
-    CHK(ensure(ctx, S.chunks, (size_t) nq * sizeof(KmerChunks)));
-    CHK(ensure(ctx, S.ec, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.rounds, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.resSize, (size_t) nq * sizeof(uint64_t)));
-    CHK(ensure(ctx, S.hist, (size_t) nq * 256 * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.thr, (size_t) nq * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.outCount, (size_t) nq * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.nCand, 64));
+    CHK(ensureK(ctx, S.qs, (size_t) nq * sizeof(KmerQ)));
+    CHK(ensureK(ctx, S.posQuery, (nPos + 1) * sizeof(uint16_t)));
+    CHK(ensureK(ctx, S.seqs, seqBytes));
+    CHK(ensureK(ctx, S.thrs, (nPos + 1) * sizeof(int16_t)));
+    CHK(ensureK(ctx, S.profiles, profBytes));
+    CHK(ensureK(ctx, S.K, (nPos + 1) * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.Kbase, (nPos + 1) * sizeof(uint64_t)));
+    CHK(ensureK(ctx, S.chunks, (size_t) nq * sizeof(KmerChunks)));
+    CHK(ensureK(ctx, S.ec, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.rounds, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.resSize, (size_t) nq * sizeof(uint64_t)));
+    CHK(ensureK(ctx, S.hist, (size_t) nq * 256 * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.thr, (size_t) nq * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.outCount, (size_t) nq * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.nCand, 64));
     CHK(ensurePinned(ctx, S.hMisc, 256));
     CHK(ensurePinned(ctx, S.hChunks, (size_t) nq * sizeof(KmerChunks)));
     CHK(ensurePinned(ctx, S.hEc, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
@@ -423,15 +456,20 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     CHK(syncStream(ctx));
     nLists = misc[0];
     RPCHK(hipEventRecord(S.ev[1], st));
-    CHK(ensure(ctx, S.listStart, (nLists + 1) * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.listSize, (nLists + 1) * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.listPos, (nLists + 1) * sizeof(uint32_t)));
-    CHK(ensure(ctx, S.listP, (nLists + 1) * sizeof(uint64_t)));
+    CHK(ensureK(ctx, S.listStart, (nLists + 1) * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.listSize, (nLists + 1) * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.listPos, (nLists + 1) * sizeof(uint32_t)));
+    CHK(ensureK(ctx, S.listP, (nLists + 1) * sizeof(uint64_t)));
     if (nLists) {
-        hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+        RPCHK(hipEventRecord(S.ev[10], st));
+        hipLaunchKernelGGL(k_kmer_lists<false>, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
                            (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
-                           (const uint64_t *) S.Kbase.p, ix.offsets, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+                           (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+        hipLaunchKernelGGL(k_kmer_lists<true>, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                           (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
+                           (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
         RPCHK(hipGetLastError());
+        RPCHK(hipEventRecord(S.ev[11], st));
     }
     RPCHK(hipMemsetAsync((uint32_t *) S.listSize.p + nLists, 0, sizeof(uint32_t), st));
     CHK(scanExclusive32to64(ctx, S.tmp, (const uint32_t *) S.listSize.p, (uint64_t *) S.listP.p, nLists + 1));
@@ -452,12 +490,12 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     const uint32_t cap = (uint32_t) std::max<uint64_t>(1, n);
     // ---- stage 2: hit stream, stable sort by (query, target) ---------------------------------------------------
     if (nHits) {
-        CHK(ensure(ctx, S.keys0, nHits * sizeof(uint32_t)));
-        CHK(ensure(ctx, S.keys1, nHits * sizeof(uint32_t)));
-        CHK(ensure(ctx, S.vals0, nHits * sizeof(uint64_t)));
-        CHK(ensure(ctx, S.vals1, nHits * sizeof(uint64_t)));
-        CHK(ensure(ctx, S.flags, (nHits + 1) * sizeof(uint32_t)));
-        CHK(ensure(ctx, S.scan, (nHits + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.keys0, nHits * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.keys1, nHits * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.vals0, nHits * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.vals1, nHits * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.flags, (nHits + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.scan, (nHits + 1) * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, 2048)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p,
                            (const uint16_t *) S.posQuery.p, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
                            (const uint32_t *) S.listPos.p, ix.entries, nHits, tbits, (uint32_t *) S.keys0.p, (uint64_t *) S.vals0.p);
@@ -479,14 +517,14 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     }
     RPCHK(hipEventRecord(S.ev[5], st));
     if (nCand) {
-        CHK(ensure(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
-        CHK(ensure(ctx, S.cvals, (size_t) nCand * sizeof(uint64_t)));
-        CHK(ensure(ctx, S.kept, (size_t) nCand));
-        CHK(ensure(ctx, S.score, (size_t) nCand * sizeof(int32_t)));
-        CHK(ensure(ctx, S.scrA, (size_t) nCand * sizeof(uint64_t)));
-        CHK(ensure(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
-        CHK(ensure(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
-        CHK(ensure(ctx, S.out, (size_t) nq * cap * sizeof(KmerOut)));
+        CHK(ensureK(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.cvals, (size_t) nCand * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.kept, (size_t) nCand));
+        CHK(ensureK(ctx, S.score, (size_t) nCand * sizeof(int32_t)));
+        CHK(ensureK(ctx, S.scrA, (size_t) nCand * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
+        CHK(ensureK(ctx, S.out, (size_t) nq * cap * sizeof(KmerOut)));
         hipLaunchKernelGGL(k_kmer_compact_cands, dim3(gridFor(nHits, 256)), dim3(256), 0, st, (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p,
                            (const uint32_t *) S.flags.p, (const uint32_t *) S.scan.p, nHits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p);
         RPCHK(hipGetLastError());
@@ -539,6 +577,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         static const int a[9] = {0, 0, 1, 2, 3, 4, 5, 6, 7}, b[9] = {9, 1, 2, 3, 4, 5, 6, 7, 8};
         // [0] total, [1] count+scan, [2] lists+chunks, [3] emit, [4] sort, [5] dup flags+scan, [6] compact+score, [7] walk, [8] hist/cut/out
         for (int i = 0; i < 9; i++) ctx->kmerMs[i] = hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess ? (double) ms : -1.0;
+        ctx->kmerMs[10] = nLists && hipEventElapsedTime(&ms, S.ev[10], S.ev[11]) == hipSuccess ? (double) ms : -1.0;
+        ctx->kmerCounts[0] = nLists; ctx->kmerCounts[1] = nHits; ctx->kmerCounts[2] = nCand; ctx->kmerCounts[3] = totalOut;
     }
     // ---- host tail ---------------------------------------------------------------------------------------------
     const auto tTail = std::chrono::steady_clock::now();

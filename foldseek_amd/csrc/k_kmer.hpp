@@ -32,6 +32,12 @@ __host__ __device__ inline uint32_t hitChunk(uint64_t v) { return (uint32_t) v &
 
 struct KmerPattern { int size; int pos[6]; };
 
+// Device order of the 20^6 k-mer table: first 3-mer (letters 0..2 of the k-mer) MAJOR.  The reference's index is
+// first3 + 8000*last3; KmerGenerator walks "for every similar first 3-mer x: all similar last 3-mers y", so with the
+// first 3-mer major all probes of one x fall into one 32 KB row of the offset table (and one 1000-byte bitmap row)
+// instead of being spread over the whole 256 MB table.
+__host__ __device__ inline uint32_t kmerDeviceIndex(uint32_t first3, uint32_t last3) { return first3 * 8000u + last3; }
+
 // per-query constants of one batch
 struct KmerQ {
     uint32_t posBase, nPos;        // k-mer start positions [posBase, posBase+nPos) of the batch position arrays
@@ -95,17 +101,17 @@ __global__ __launch_bounds__(256) void k_kmer_extract(const uint8_t *masked, con
         for (int pos = threadIdx.x; pos < L; pos += blockDim.x) {
             uint32_t key = kKmerInvalid;
             if (pos + pat.size <= L) {
-                uint32_t idx = 0, pw = 1;
+                uint32_t half[2] = {0, 0}, pw = 1;
                 int score = 0;
                 bool x = false;
 #pragma unroll
                 for (int z = 0; z < 6; z++) {
                     const uint32_t c = s[pos + pat.pos[z]];
                     x |= c >= 20;
-                    idx += c * pw; pw *= kKA;
+                    half[z / 3] += c * pw; pw = (z == 2) ? 1 : pw * kKA;
                     score += selfScore[c > 20 ? 20 : c];
                 }
-                if (!x && !(kmerThr > 0 && score < kmerThr)) key = idx;
+                if (!x && !(kmerThr > 0 && score < kmerThr)) key = kmerDeviceIndex(half[0], half[1]);
             }
             keys[base + pos] = key;
             vals[base + pos] = (t << 16) | (uint32_t) pos;
@@ -129,6 +135,16 @@ __global__ void k_kmer_compact_entries(const uint64_t *vals, const uint32_t *fla
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (flags[i]) entries[scan[i]] = vals[i];
+}
+
+// one bit per k-mer: list non-empty (8 MB instead of 256 MB: most probes of the search never reach the offset table)
+__global__ void k_kmer_bitmap(const uint32_t *offsets, uint32_t nWords, uint32_t *bitmap) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nWords) return;
+    uint32_t bits = 0, prev = offsets[(size_t) w * 32];
+#pragma unroll 8
+    for (int b = 0; b < 32; b++) { const uint32_t nx = offsets[(size_t) w * 32 + b + 1]; bits |= (nx != prev ? 1u : 0u) << b; prev = nx; }
+    bitmap[w] = bits;
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -233,22 +249,28 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_count(const KmerQ *qs, cons
 // (entry start, size, position) triple per k-mer into the list arrays at Kbase[p].  The part of the two sorted 3-mer
 // rows that can pass the threshold (typically a few hundred entries) is staged in LDS, so the only HBM traffic left is
 // the random 8-byte probe of the offset table per k-mer -- the roofline of this kernel.
-constexpr int kStage = 2048;
+// Two instantiations: STAGE = 1024 covers practically every position (a few hundred row entries pass the threshold)
+// with 12 KB of LDS, so 8 workgroups per CU hide the probe latency; BIG handles the rare positions whose passing row
+// prefix is longer (very low thresholds) straight from global memory with the full 8001-entry prefix array.
+constexpr int kStage = 1024;
+template <bool BIG>
 __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
                                                            uint32_t nPos, KmerPattern pat, const int16_t *s3, const uint16_t *i3,
-                                                           const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets,
+                                                           const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets, const uint32_t *bitmap,
                                                            uint32_t *listStart, uint32_t *listSize, uint32_t *listPos) {
     const uint32_t p = blockIdx.x;
     if (p >= nPos) return;
     const uint32_t Kp = Kcount[p];
     if (Kp == 0) return;
     const KmerQ q = qs[posQuery[p]];
+    constexpr int NOX = BIG ? kRow3 : kStage;
+    constexpr int NST = BIG ? 1 : kStage;
     __shared__ KmerPosInfo info;
     __shared__ int c0s;
-    __shared__ uint32_t ox[kRow3 + 1];        // exclusive prefix of c_x
+    __shared__ uint32_t ox[NOX + 1];          // exclusive prefix of c_x
     __shared__ uint32_t part[kKmerBlock + 1];
-    __shared__ int16_t s1[kStage], s2[kStage];
-    __shared__ uint16_t j1[kStage], j2[kStage];
+    __shared__ int16_t s1[NST], s2[NST];
+    __shared__ uint16_t j1[NST], j2[NST];
     if (threadIdx.x == 0) {
         info = kmerPosInfo(q, seqs, thrs, p, pat, s3);
         // longest inner list: c_0 = #{S2 >= thr - S1[0]}
@@ -258,8 +280,9 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     const int16_t *S1 = s3 + (size_t) info.a * kRow3, *S2 = s3 + (size_t) info.b * kRow3;
     const uint16_t *I1 = i3 + (size_t) info.a * kRow3, *I2 = i3 + (size_t) info.b * kRow3;
     const int n1 = info.n1, c0 = c0s;
-    const bool staged = n1 <= kStage && c0 <= kStage;
-    if (staged) {
+    const bool small = n1 <= kStage && c0 <= kStage;
+    if (small == BIG) return;                 // the other instantiation owns this position
+    if (!BIG) {
         for (int i = threadIdx.x; i < n1; i += kKmerBlock) { s1[i] = S1[i]; j1[i] = I1[i]; }
         for (int i = threadIdx.x; i < c0; i += kKmerBlock) { s2[i] = S2[i]; j2[i] = I2[i]; }
         __syncthreads();
@@ -270,7 +293,7 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     uint32_t sum = 0;
     for (int x = x0; x < x1; x++) {
         uint32_t c;
-        if (staged) c = (uint32_t) countGE(s2, c0, (int) (int16_t) (info.thr - s1[x]));
+        if (!BIG) c = (uint32_t) countGE(s2, c0, (int) (int16_t) (info.thr - s1[x]));
         else c = (uint32_t) countGE(S2, kRow3, (int) (int16_t) (info.thr - S1[x]));
         ox[x] = sum;
         sum += c;
@@ -297,11 +320,17 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
                 int lo = 0, hi = n1;          // last x with ox[x] <= r (c_x >= 1 for every x < n1)
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ox[mid] <= r) lo = mid; else hi = mid; }
                 const uint32_t y = r - ox[lo];
-                kmer[u] = staged ? (uint32_t) j1[lo] + (uint32_t) kRow3 * (uint32_t) j2[y] : (uint32_t) I1[lo] + (uint32_t) kRow3 * (uint32_t) I2[y];
+                kmer[u] = !BIG ? kmerDeviceIndex(j1[lo], j2[y]) : kmerDeviceIndex(I1[lo], I2[y]);
             }
         }
+        uint32_t bm[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { st[u] = offsets[kmer[u]]; en[u] = offsets[kmer[u] + 1]; }
+        for (int u = 0; u < 4; u++) bm[u] = bitmap[kmer[u] >> 5];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            st[u] = 0; en[u] = 0;
+            if ((bm[u] >> (kmer[u] & 31)) & 1u) { st[u] = offsets[kmer[u]]; en[u] = offsets[kmer[u] + 1]; }
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t r = r0 + u * kKmerBlock;

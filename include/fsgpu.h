@@ -144,7 +144,8 @@ typedef struct {
 int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, const int16_t *kmerSubMat21x21);
 uint64_t fsgpu_kmer_index_entries(const fsgpu_ctx *ctx);
 /* Inspection (tests): copy the offset table (64e6+1 uint32), the entries (seqId << 16 | position) and/or the masked
- * sequence lookup (padded DB layout) to host memory; any pointer may be NULL.  Row `row` of the extended 3-mer matrix. */
+ * sequence lookup (padded DB layout) to host memory; any pointer may be NULL.  The table is kept in the DEVICE k-mer
+ * order: index = first3mer * 8000 + last3mer (the reference numbers k-mers first3mer + 8000 * last3mer).  Row `row` of the extended 3-mer matrix. */
 int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets, uint64_t *entries, uint8_t *masked);
 int fsgpu_kmer_row_copy(fsgpu_ctx *ctx, int row, int16_t *score, uint16_t *index);
 
@@ -189,9 +190,15 @@ enum {
 int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params *p, const fsgpu_kmer_query *queries, int nq,
                       fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats);
 
+/* Work counters of the last fsgpu_kmer_search batch: [0] similar k-mers probed in the index table, [1] index hits,
+ * [2] double-diagonal candidates, [3] elements handed to the host tail. */
+void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4);
+
 /* ---- instrumentation -------------------------------------------------------------------------------------- */
 /* Device time (ms, HIP events on the context stream) of the dominant kernel of the last _finish()ed call:
- * which = 0 gapless scan kernel, 1 SW kernel, 2 whole device part of the last fsgpu_kmer_search batch.
+ * which = 0 gapless scan kernel, 1 SW kernel, 2 whole device part of the last fsgpu_kmer_search batch,
+ * 3..10 its stages (similar-k-mer count, index probes, hit gather, sort, double-diagonal flags, scoring, replay,
+ * selection), 11 host tail, 12 the index-probe kernel (k_kmer_lists) alone.
  * Returns < 0 if nothing was recorded. */
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which);
 

@@ -86,12 +86,11 @@ def gpu():
 def test_gpu_index_against_golden(gpu):
     ctx = gpu[0]
     assert ctx.kmer_index_entries == int(G["index_entries"][0])
-    off, ent, _ = ctx.kmer_index_copy(G["db_data3di"].size)
-    off = off.astype(np.uint64)
+    off, seq, pos, _ = ctx.kmer_index_reference_order(G["db_data3di"].size)
     assert np.bitwise_xor.reduce(off * np.arange(1, len(off) + 1, dtype=np.uint64)) == G["index_offsets_sum"][0]
     for k, s, p in zip(G["il_kmers"], _split(G["il_seq"], G["il_len"]), _split(G["il_pos"], G["il_len"])):
-        e = ent[off[int(k)]:off[int(k) + 1]]
-        assert ((e >> np.uint64(16)).astype(np.uint32) == s).all() and ((e & np.uint64(0xffff)).astype(np.uint16) == p).all()
+        lo, hi = int(off[int(k)]), int(off[int(k) + 1])
+        assert (seq[lo:hi] == s).all() and (pos[lo:hi] == p).all()
     for k, idx in enumerate(G["rows"]):
         s, ix = ctx.kmer_row(int(idx))
         assert (s == G["row_scores"][k]).all() and (ix == G["row_index"][k]).all()

@@ -37,11 +37,10 @@ def world():
 def test_index_matches_oracle(world):
     o, ctx, db = world["o"], world["ctx"], world["db"]
     ooff, oseq, opos = o.index()
-    off, ent, msk = ctx.kmer_index_copy(db.data3di.size)
+    off, seq, pos, msk = ctx.kmer_index_reference_order(db.data3di.size)
     assert ctx.kmer_index_entries == int(ooff[-1])
-    assert (off.astype(np.uint64) == ooff).all()
-    assert ((ent >> np.uint64(16)).astype(np.uint32) == oseq).all()
-    assert ((ent & np.uint64(0xffff)).astype(np.uint16) == opos).all()
+    assert (off == ooff).all()
+    assert (seq == oseq).all() and (pos == opos).all()
     for i in range(0, db.n, 17):
         L = int(db.lengths[i])
         assert (msk[db.offsets[i]:db.offsets[i] + L] == o.masked(i, L)).all(), i
@@ -118,3 +117,30 @@ def test_degenerate_queries(world):
             continue
         b, _ = o.query(q, int(ident[i]))
         assert status[i] == 0 and len(res[i]) == len(b) and (res[i] == b).all(), i
+
+
+def test_low_threshold_long_row_prefixes():
+    """a low k-mer threshold makes more than 1024 entries of the sorted 3-mer rows pass: the global-memory instantiation of
+    the list kernel (k_kmer_lists<true>) and the k-mer cap (MAX_KMER_RESULT_SIZE) path against the oracle"""
+    O = K.load_ora()
+    q3, qa = synth.make_queries(3, seed=77, mean_len=60, lo=40, hi=80)
+    db = synth.make_db(400, (q3, qa), seed=78, homologs_per_query=10, mean_len=120, lo=30, hi=300)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    for thr in (25, 0):
+        o = K.OraKpf(O, ksub, pb, usub, targets, kmerThr=thr, maxResListLen=100)
+        ctx = api.Context(0)
+        ctx.load_db(db)
+        m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+        ctx.kmer_index_build(m8, kmer_thr=thr)
+        qs = q3 if thr else [q3[0][:16]]
+        prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in qs]
+        res, status, stats = ctx.kmer_search(prep, max_res=100, l2_cache_size=2 << 20, want_stats=True)
+        for i, q in enumerate(qs):
+            b, st = o.query(q, -1)
+            assert status[i] == 0 and np.allclose(stats[i], st), (thr, i, stats[i], st)
+            assert len(res[i]) == len(b) and (res[i] == b).all(), (thr, i)
+        assert stats[:, 0].max() > 1e5
+        o.close()
+        ctx.close()

@@ -12,7 +12,7 @@ m8 = api.Matrix(0, 8.0, -0.2); m2 = api.Matrix(0, 2.0, -0.2)
 t = time.time(); ctx.kmer_index_build(m8, kmer_thr=78); print("index build %.3fs entries=%d" % (time.time() - t, ctx.kmer_index_entries), flush=True)
 t = time.time(); prep = [api.kmer_query_prepare(m8, m2, q) for q in q3]; print("host prepare %.3f ms/query" % ((time.time() - t) / NQ * 1e3))
 for rep in range(REPS):
-    stages = np.zeros(10); t = time.time(); hits = 0
+    stages = np.zeros(11); t = time.time(); hits = 0
     for b in range(0, NQ, 32):
         res, status, stats = ctx.kmer_search(prep[b:b + 32], max_res=1000, want_stats=True)
         stages += np.array(ctx.kmer_stage_ms()); hits += stats[:, 1].sum()

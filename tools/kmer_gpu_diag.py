@@ -15,10 +15,10 @@ ctx = api.Context(0); ctx.load_db(db)
 m8 = api.Matrix(0, 8.0, -0.2); m2 = api.Matrix(0, 2.0, -0.2)
 t = time.time(); ctx.kmer_index_build(m8, kmer_thr=78); print("gpu index build %.2fs entries=%d" % (time.time() - t, ctx.kmer_index_entries), flush=True)
 ooff, oseq, opos = o.index()
-off, ent, msk = ctx.kmer_index_copy(db.data3di.size)
-print("entries", ctx.kmer_index_entries, int(ooff[-1]), "offsets equal:", bool((off.astype(np.uint64) == ooff).all()))
-if len(ent) == len(oseq):
-    print("entry seq equal:", bool(((ent >> np.uint64(16)).astype(np.uint32) == oseq).all()), "pos equal:", bool(((ent & np.uint64(0xffff)).astype(np.uint16) == opos).all()))
+off, seq, pos, msk = ctx.kmer_index_reference_order(db.data3di.size)
+print("entries", ctx.kmer_index_entries, int(ooff[-1]), "offsets equal:", bool((off == ooff).all()))
+if len(seq) == len(oseq):
+    print("entry seq equal:", bool((seq == oseq).all()), "pos equal:", bool((pos == opos).all()))
 bad = [i for i in range(db.n) if not (msk[db.offsets[i]:db.offsets[i] + db.lengths[i]] == o.masked(i, int(db.lengths[i]))).all()]
 print("masked mismatches:", len(bad), bad[:5])
 badrows = []
