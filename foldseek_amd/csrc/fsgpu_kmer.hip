@@ -300,7 +300,21 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
         struct Key { uint32_t count; uint32_t bin; uint64_t ok; const HostOut *e; };
         auto arrayOrder = [](const Key &a, const Key &b) { return a.bin != b.bin ? a.bin < b.bin : a.ok < b.ok; };
         const bool truncated = thr >= 255;
-        if (truncated) {
+        if (status == FSGPU_KMER_UNSTABLE) {
+            // resultSize >= foundDiagonalsSize/2 (QueryMatcher.cpp:205-215): the reference compacts the elements at or above
+            // the cut in array order and orders them with std::sort(sortScore), which is not stable.  The same call on the
+            // same sequence reproduces its permutation wherever both sides use libstdc++'s introsort.
+            std::vector<Key> ks(el.size());
+            for (size_t i = 0; i < el.size(); i++) { uint32_t bin; const uint64_t ok = orderKey(el[i], bin); ks[i] = {el[i].count, bin, ok, &el[i]}; }
+            std::sort(ks.begin(), ks.end(), arrayOrder);
+            std::sort(ks.begin(), ks.end(), [](const Key &a, const Key &b) { return a.count > b.count; });
+            for (size_t i = 0; i < ks.size() && cur < maxHits; i++) {
+                if (q.identity >= 0 && (uint32_t) q.identity == ks[i].e->id) continue;
+                fsgpu_kmer_hit &h = out[cur++];
+                h.id = ks[i].e->id; h.diagonal = (uint16_t) ks[i].e->diag; h.pad = 0;
+                h.score = ks[i].e->count >= 255 ? ks[i].e->score : (int32_t) ks[i].e->count;
+            }
+        } else if (truncated) {
             // rescoreHits (QueryMatcher.cpp:563-589): only the 255-capped hits survive, re-ranked by their real score
             std::vector<Key> ks(el.size());
             for (size_t i = 0; i < el.size(); i++) { uint32_t bin; const uint64_t ok = orderKey(el[i], bin); ks[i] = {el[i].count, bin, ok, &el[i]}; }

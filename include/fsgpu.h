@@ -179,8 +179,9 @@ typedef struct {
 } fsgpu_kmer_hit;
 enum {
     FSGPU_KMER_OK = 0,
-    FSGPU_KMER_UNSTABLE = 1,     /* >= foundDiagonalsSize/2 targets carried a diagonal: the reference orders equal scores
-                                    with an unstable std::sort there (QueryMatcher.cpp:205-215); we return the stable order */
+    FSGPU_KMER_UNSTABLE = 1,     /* >= foundDiagonalsSize/2 targets carried a diagonal: the reference orders equal scores with an
+                                    unstable std::sort there (QueryMatcher.cpp:205-215); replayed with the same call on the same
+                                    sequence, identical wherever both builds use libstdc++'s introsort (informational) */
     FSGPU_KMER_E_OUTPUT = -1,    /* the reference would have cut findDuplicates short (output array full); not replayed */
     FSGPU_KMER_E_CHUNKS = -2     /* more than 255 databaseHits refills */
 };

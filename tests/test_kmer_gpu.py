@@ -144,3 +144,36 @@ def test_low_threshold_long_row_prefixes():
         assert stats[:, 0].max() > 1e5
         o.close()
         ctx.close()
+
+
+def test_unstable_sort_branch_matches_compiled_reference():
+    """resultSize >= foundDiagonalsSize/2: the reference leaves its radix path for std::sort (QueryMatcher.cpp:205-215).
+    The C oracle does not model libstdc++'s introsort, so this one is checked against the compiled reference itself
+    (oracle/_ref travels to the GPU box as a built .so); skipped where it was not built.  A database without planted
+    homologs keeps the candidates per target near one, which is what lets the buffer sit between the two limits."""
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    q3, qa = synth.make_queries(4, seed=91)
+    db = synth.make_db(4000, None, seed=92, mask_frac=0.0)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=78)
+    w = dict(ctx=ctx, m8=m8, m2=m2)
+    # find a foundDiagonalsSize with  candidates < size <= 2 * (targets carrying a diagonal)  for at least one query
+    pick = None
+    for size in range(8000, 400, -100):
+        res, status, stats = run_gpu(w, dict(maxResListLen=60, foundDiagonalsSize=size, bins=2), q3, None)
+        if (status >= 0).all() and (status == 1).any():
+            pick = (size, res, status)
+            break
+    assert pick is not None, "no buffer size puts this workload into the std::sort branch"
+    size, res, status = pick
+    r = K.RefKpf(R, targets, threads=8, maxResListLen=60, foundDiagonalsSize=size, bins=2)
+    rr, rs, _ = r.run(q3, None)
+    r.close()
+    for q in range(len(q3)):
+        assert len(res[q]) == len(rr[q]) and (res[q] == rr[q]).all(), (q, size, status[q])
+    ctx.close()
