@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -110,6 +112,8 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     if (!ctx || !p || !kmerSub) return FSGPU_E_ARG;
     if (!ctx->db || !ctx->db->raw3di) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (p->kmerSize != 6) { ctx->err = "k-mer prefilter: only k = 6 is implemented on the device"; return FSGPU_E_UNSUPPORTED; }
+    // UngappedAlignment switches to computeLongScore (wrapped 16-bit diagonals) from 32768 residues on (UngappedAlignment.cpp:198,295-312)
+    if (ctx->db->maxLen >= 32768) { ctx->err = "k-mer prefilter: targets of 32768 residues or more are not supported on the device"; return FSGPU_E_UNSUPPORTED; }
     RPCHK(hipSetDevice(ctx->device));
     std::shared_ptr<KmerIndex> ix = std::make_shared<KmerIndex>();
     ix->p = *p; ix->db = ctx->db; ix->n = ctx->db->n;
@@ -395,6 +399,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     for (int q = 0; q < nq; q++) {
         const int L = queries[q].L;
         if (L < 0 || L > FSGPU_MAX_SEQ_LEN || (L > 0 && (!queries[q].seq || !queries[q].profile))) { ctx->err = "k-mer search: bad query"; return FSGPU_E_ARG; }
+        if (L >= 32768) { ctx->err = "k-mer search: queries of 32768 residues or more are not supported on the device"; return FSGPU_E_UNSUPPORTED; }
         nPos += (uint64_t) std::max(0, L - ix.pat.size + 1);
         seqBytes += (uint64_t) L + 16;
         profBytes += (uint64_t) L * 21 + 16;
@@ -508,7 +513,6 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(ensureK(ctx, S.keys1, nHits * sizeof(uint32_t)));
         CHK(ensureK(ctx, S.vals0, nHits * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.vals1, nHits * sizeof(uint64_t)));
-        CHK(ensureK(ctx, S.flags, (nHits + 1) * sizeof(uint32_t)));
         CHK(ensureK(ctx, S.scan, (nHits + 1) * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, 2048)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p,
                            (const uint16_t *) S.posQuery.p, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
@@ -518,14 +522,15 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(sortPairs(ctx, S.tmp, (const uint32_t *) S.keys0.p, (uint32_t *) S.keys1.p, (const uint64_t *) S.vals0.p, (uint64_t *) S.vals1.p, nHits,
                       std::min(32, tbits + bitsFor(std::max(nq, 2)))));
         RPCHK(hipEventRecord(S.ev[4], st));
-        // ---- stage 3: double-diagonal candidates ----------------------------------------------------------------
-        RPCHK(hipMemsetAsync((uint32_t *) S.flags.p + nHits, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_kmer_dupflags, dim3(gridFor(nHits, 256)), dim3(256), 0, st, (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p, nHits, tbits,
-                           (uint32_t *) S.flags.p, (uint32_t *) S.ec.p);
-        RPCHK(hipGetLastError());
-        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.flags.p, (uint32_t *) S.scan.p, nHits + 1));
-        RPCHK(hipMemcpyAsync(S.nCand.p, (uint32_t *) S.scan.p + nHits, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        RPCHK(hipMemcpyAsync(&misc[2], (uint32_t *) S.scan.p + nHits, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        // ---- stage 3: double-diagonal candidates: single-pass ordered compaction of the hit indices ---------------------
+        {
+            KmerDupPred pred{(const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p};
+            size_t bytes = 0;
+            RPCHK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), (uint32_t *) S.scan.p, (uint32_t *) S.nCand.p, (size_t) nHits, pred, st));
+            CHK(ensureK(ctx, S.tmp, bytes));
+            RPCHK(rocprim::select(S.tmp.p, bytes, rocprim::counting_iterator<uint32_t>(0), (uint32_t *) S.scan.p, (uint32_t *) S.nCand.p, (size_t) nHits, pred, st));
+        }
+        RPCHK(hipMemcpyAsync(&misc[2], S.nCand.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CHK(syncStream(ctx));
         nCand = (uint32_t) misc[2];
     }
@@ -539,8 +544,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(ensureK(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
         CHK(ensureK(ctx, S.out, (size_t) nq * cap * sizeof(KmerOut)));
-        hipLaunchKernelGGL(k_kmer_compact_cands, dim3(gridFor(nHits, 256)), dim3(256), 0, st, (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p,
-                           (const uint32_t *) S.flags.p, (const uint32_t *) S.scan.p, nHits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p);
+        hipLaunchKernelGGL(k_kmer_gather_cands, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.scan.p, (const uint32_t *) S.nCand.p,
+                           (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p, tbits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
         RPCHK(hipGetLastError());
         int maxL = 0;
         for (int q = 0; q < nq; q++) maxL = std::max(maxL, queries[q].L);

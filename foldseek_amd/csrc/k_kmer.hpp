@@ -436,34 +436,40 @@ __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerCh
 // search, stage 3 (after the stable sort by (query, target)): double-diagonal detection
 // --------------------------------------------------------------------------------------------------------------
 // findDuplicates pass 1: a hit is a candidate iff its 8-bit diagonal equals that of the previous hit of the same
-// target in the same chunk (the byte array starts at 0, so a first hit on diagonal 0 also counts).
-__global__ __launch_bounds__(256) void k_kmer_dupflags(const uint32_t *keys, const uint64_t *vals, uint64_t n, int tbits, uint32_t *flags, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
-    __shared__ uint32_t h[kMaxChunks];        // per-chunk candidate counts of the block's first query
-    __shared__ uint32_t q0;
-    const uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x;
-    h[threadIdx.x] = 0;
-    if (threadIdx.x == 0) q0 = keys[(uint64_t) blockIdx.x * 256] >> tbits;
-    __syncthreads();
-    if (i < n) {
+// target in the same chunk (the byte array starts at 0, so a first hit on diagonal 0 also counts).  Used as the
+// predicate of a single-pass ordered stream compaction (rocprim::select over the hit indices).
+struct KmerDupPred {
+    const uint32_t *keys;
+    const uint64_t *vals;
+    __device__ bool operator()(uint32_t i) const {
         const uint32_t k = keys[i];
         const uint64_t v = vals[i];
         uint32_t prev = 0;
         if (i > 0 && keys[i - 1] == k) { const uint64_t pv = vals[i - 1]; if (hitChunk(pv) == hitChunk(v)) prev = hitD8(pv); }
-        const uint32_t f = hitD8(v) == prev ? 1u : 0u;
-        flags[i] = f;
-        if (f) {
-            if ((k >> tbits) == q0) atomicAdd(&h[hitChunk(v)], 1u);
-            else atomicAdd(&ecCount[(size_t) (k >> tbits) * kMaxChunks + hitChunk(v)], 1u);
-        }
+        return hitD8(v) == prev;
+    }
+};
+// gather the selected hits into the candidate arrays; per (query, chunk) candidate counts for the output-capacity check
+__global__ __launch_bounds__(256) void k_kmer_gather_cands(const uint32_t *idx, const uint32_t *nCandPtr, const uint32_t *keys, const uint64_t *vals, int tbits,
+                                                           uint32_t *ckeys, uint64_t *cvals, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
+    __shared__ uint32_t h[kMaxChunks];        // per-chunk candidate counts of the block's first query
+    __shared__ uint32_t q0;
+    const uint64_t nCand = *nCandPtr;
+    const uint64_t j0 = (uint64_t) blockIdx.x * 256, j = j0 + threadIdx.x;
+    if (j0 >= nCand) return;
+    h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) q0 = keys[idx[j0]] >> tbits;
+    __syncthreads();
+    if (j < nCand) {
+        const uint32_t i = idx[j];
+        const uint32_t k = keys[i];
+        const uint64_t v = vals[i];
+        ckeys[j] = k; cvals[j] = v;
+        if ((k >> tbits) == q0) atomicAdd(&h[hitChunk(v)], 1u);
+        else atomicAdd(&ecCount[(size_t) (k >> tbits) * kMaxChunks + hitChunk(v)], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&ecCount[(size_t) q0 * kMaxChunks + threadIdx.x], h[threadIdx.x]);
-}
-__global__ void k_kmer_compact_cands(const uint32_t *keys, const uint64_t *vals, const uint32_t *flags, const uint32_t *scan, uint64_t n,
-                                     uint32_t *ckeys, uint64_t *cvals) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flags[i]) { ckeys[scan[i]] = keys[i]; cvals[scan[i]] = vals[i]; }
 }
 
 // findDuplicates pass 2 (collapse runs of equal 8-bit diagonals among the candidates of one target and chunk) fused
