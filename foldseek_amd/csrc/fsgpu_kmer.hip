@@ -5,8 +5,6 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_select.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
@@ -513,8 +511,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(ensureK(ctx, S.keys1, nHits * sizeof(uint32_t)));
         CHK(ensureK(ctx, S.vals0, nHits * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.vals1, nHits * sizeof(uint64_t)));
-        CHK(ensureK(ctx, S.scan, (nHits + 1) * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, 2048)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p,
+        CHK(ensureK(ctx, S.scan, (nHits / kDupTile + 4) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, kEmitTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p,
                            (const uint16_t *) S.posQuery.p, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
                            (const uint32_t *) S.listPos.p, ix.entries, nHits, tbits, (uint32_t *) S.keys0.p, (uint64_t *) S.vals0.p);
         RPCHK(hipGetLastError());
@@ -522,15 +520,16 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(sortPairs(ctx, S.tmp, (const uint32_t *) S.keys0.p, (uint32_t *) S.keys1.p, (const uint64_t *) S.vals0.p, (uint64_t *) S.vals1.p, nHits,
                       std::min(32, tbits + bitsFor(std::max(nq, 2)))));
         RPCHK(hipEventRecord(S.ev[4], st));
-        // ---- stage 3: double-diagonal candidates: single-pass ordered compaction of the hit indices ---------------------
-        {
-            KmerDupPred pred{(const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p};
-            size_t bytes = 0;
-            RPCHK(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), (uint32_t *) S.scan.p, (uint32_t *) S.nCand.p, (size_t) nHits, pred, st));
-            CHK(ensureK(ctx, S.tmp, bytes));
-            RPCHK(rocprim::select(S.tmp.p, bytes, rocprim::counting_iterator<uint32_t>(0), (uint32_t *) S.scan.p, (uint32_t *) S.nCand.p, (size_t) nHits, pred, st));
-        }
-        RPCHK(hipMemcpyAsync(&misc[2], S.nCand.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        // ---- stage 3: double-diagonal candidates: tile counts, scan ------------------------------------------------------
+        const uint64_t nTiles = (nHits + kDupTile - 1) / kDupTile;
+        const KmerDupPred pred{(const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p};
+        CHK(ensureK(ctx, S.flags, (nTiles + 1) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_kmer_dupcount, dim3((unsigned) nTiles), dim3(256), 0, st, pred, nHits, (uint32_t *) S.flags.p);
+        RPCHK(hipGetLastError());
+        RPCHK(hipMemsetAsync((uint32_t *) S.flags.p + nTiles, 0, sizeof(uint32_t), st));
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.flags.p, (uint32_t *) S.scan.p, nTiles + 1));
+        RPCHK(hipMemcpyAsync(S.nCand.p, (uint32_t *) S.scan.p + nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        RPCHK(hipMemcpyAsync(&misc[2], (uint32_t *) S.scan.p + nTiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CHK(syncStream(ctx));
         nCand = (uint32_t) misc[2];
     }
@@ -544,8 +543,11 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(ensureK(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
         CHK(ensureK(ctx, S.out, (size_t) nq * cap * sizeof(KmerOut)));
-        hipLaunchKernelGGL(k_kmer_gather_cands, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.scan.p, (const uint32_t *) S.nCand.p,
-                           (const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p, tbits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
+        {
+            const KmerDupPred pred{(const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p};
+            hipLaunchKernelGGL(k_kmer_dupscatter, dim3(gridFor(nHits, kDupTile)), dim3(256), 0, st, pred, nHits, (const uint32_t *) S.scan.p, tbits,
+                               (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
+        }
         RPCHK(hipGetLastError());
         int maxL = 0;
         for (int q = 0; q < nq; q++) maxL = std::max(maxL, queries[q].L);
@@ -630,8 +632,12 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
     if (p->maxResListLen <= 0 || p->minDiagScoreThr < 1) { ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 1 required"; return FSGPU_E_UNSUPPORTED; }
     if (p->bins && (p->bins & (p->bins - 1))) { ctx->err = "k-mer search: bins must be a power of two"; return FSGPU_E_ARG; }
     RPCHK(hipSetDevice(ctx->device));
-    const int qbitsMax = 32 - ctx->kidx->tbits;
-    const int maxBatch = std::max(1, std::min(32, qbitsMax >= 5 ? 32 : (1 << std::max(0, qbitsMax))));
+    // queries per device batch: the stable sort runs over tbits + qbits key bits in 8-bit passes, so stay at or below
+    // 24 bits (3 passes) while at least 8 queries fit; never more than 32 (5 bits)
+    const int tb = ctx->kidx->tbits;
+    int qbits = std::min(5, 32 - tb);
+    if (tb + qbits > 24 && 24 - tb >= 3) qbits = 24 - tb;
+    const int maxBatch = std::max(1, 1 << std::max(0, qbits));
     int q0 = 0;
     int batch = maxBatch;
     while (q0 < nq) {

@@ -381,15 +381,16 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
 // --------------------------------------------------------------------------------------------------------------
 // search, stage 2: the hit stream.  Output-balanced gather: one thread per hit, list found by binary search.
 // --------------------------------------------------------------------------------------------------------------
-constexpr int kEmitStage = 8192;
+constexpr int kEmitTile = 2048;               // outputs per workgroup
+constexpr int kEmitStage = 6144;              // list prefixes staged in LDS (24 KB -> 6 workgroups per CU)
 __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerChunks *chunks, const uint16_t *posQuery, uint64_t nLists, const uint64_t *listP,
                                                    const uint32_t *listStart, const uint32_t *listPos, const uint64_t *entries,
                                                    uint64_t nHits, int tbits, uint32_t *keys, uint64_t *vals) {
     __shared__ uint64_t range[2];
     __shared__ uint32_t rel[kEmitStage + 1];  // list prefix relative to the block's first list
-    const uint64_t o0 = (uint64_t) blockIdx.x * 2048;
+    const uint64_t o0 = (uint64_t) blockIdx.x * kEmitTile;
     if (o0 >= nHits) return;
-    const uint64_t o1 = min(nHits, o0 + 2048);
+    const uint64_t o1 = min(nHits, o0 + kEmitTile);
     if (threadIdx.x < 2) {
         const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
         uint64_t lo = 0, hi = nLists;         // last l with listP[l] <= o (that list is non-empty and contains o)
@@ -405,29 +406,50 @@ __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerCh
         for (int i = threadIdx.x; i < nl; i += 256) rel[i] = (uint32_t) (listP[l0 + i] - p0);
         __syncthreads();
     }
-    for (uint64_t o = o0 + threadIdx.x; o < o1; o += blockDim.x) {
-        uint64_t l;
-        if (staged) {
-            const uint32_t ro = (uint32_t) (o - p0);
-            int lo = 0, hi = nl;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rel[mid] <= ro) lo = mid; else hi = mid; }
-            l = l0 + lo;
-        } else {
-            uint64_t lo = l0, hi = l1 + 1;
-            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
-            l = lo;
+    // 8 outputs per thread, handled phase by phase so that the dependent loads of all 8 are in flight together
+    constexpr int U = kEmitTile / 256;
+    uint64_t l[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t o = o0 + threadIdx.x + 256 * u;
+        l[u] = l0;
+        if (o < o1) {
+            if (staged) {
+                const uint32_t ro = (uint32_t) (o - p0);
+                int lo = 0, hi = nl;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rel[mid] <= ro) lo = mid; else hi = mid; }
+                l[u] = l0 + lo;
+            } else {
+                uint64_t lo = l0, hi = l1 + 1;
+                while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
+                l[u] = lo;
+            }
         }
-        const uint32_t p = listPos[l];
-        const uint32_t qi = posQuery[p];
-        const KmerQ &q = qs[qi];
-        const uint64_t e = entries[(uint64_t) listStart[l] + (o - listP[l])];
-        const uint32_t seqId = (uint32_t) (e >> 16), posj = (uint32_t) e & 0xffffu;
-        const uint32_t i = p - q.posBase;
+    }
+    uint32_t p[U], st[U];
+    uint64_t lp[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { p[u] = listPos[l[u]]; st[u] = listStart[l[u]]; lp[u] = listP[l[u]]; }
+    uint64_t e[U];
+    uint32_t qi[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t o = o0 + threadIdx.x + 256 * u;
+        e[u] = o < o1 ? entries[(uint64_t) st[u] + (o - lp[u])] : 0;
+        qi[u] = posQuery[p[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t o = o0 + threadIdx.x + 256 * u;
+        if (o >= o1) continue;
+        const KmerQ &q = qs[qi[u]];
+        const uint32_t seqId = (uint32_t) (e[u] >> 16), posj = (uint32_t) e[u] & 0xffffu;
+        const uint32_t i = p[u] - q.posBase;
         const uint64_t g = o - q.hitBase;
-        const KmerChunks &ck = chunks[qi];
+        const KmerChunks &ck = chunks[qi[u]];
         uint32_t c = 0;
         while (c + 1 < ck.nChunks && ck.start[c + 1] <= g) c++;
-        keys[o] = ((uint32_t) qi << tbits) | seqId;
+        keys[o] = (qi[u] << tbits) | seqId;
         vals[o] = hitPack(g, (i - posj) & 0xffffu, c);
     }
 }
@@ -436,8 +458,8 @@ __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerCh
 // search, stage 3 (after the stable sort by (query, target)): double-diagonal detection
 // --------------------------------------------------------------------------------------------------------------
 // findDuplicates pass 1: a hit is a candidate iff its 8-bit diagonal equals that of the previous hit of the same
-// target in the same chunk (the byte array starts at 0, so a first hit on diagonal 0 also counts).  Used as the
-// predicate of a single-pass ordered stream compaction (rocprim::select over the hit indices).
+// target in the same chunk (the byte array starts at 0, so a first hit on diagonal 0 also counts).  Predicate of the
+// ordered candidate compaction below.
 struct KmerDupPred {
     const uint32_t *keys;
     const uint64_t *vals;
@@ -449,24 +471,61 @@ struct KmerDupPred {
         return hitD8(v) == prev;
     }
 };
-// gather the selected hits into the candidate arrays; per (query, chunk) candidate counts for the output-capacity check
-__global__ __launch_bounds__(256) void k_kmer_gather_cands(const uint32_t *idx, const uint32_t *nCandPtr, const uint32_t *keys, const uint64_t *vals, int tbits,
-                                                           uint32_t *ckeys, uint64_t *cvals, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
+// Ordered compaction of the candidates in two coalesced passes over the sorted hit stream (24 B per hit in total):
+// pass 1 counts the candidates of every 2048-hit tile, a scan over the tile counts gives the tile bases, pass 2
+// re-evaluates the predicate, ranks the candidates inside the tile with wave ballots and writes them in order.
+constexpr int kDupTile = 2048;
+__global__ __launch_bounds__(256) void k_kmer_dupcount(KmerDupPred pred, uint64_t n, uint32_t *tileCount) {
+    __shared__ uint32_t wsum[4];
+    const uint64_t base = (uint64_t) blockIdx.x * kDupTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < kDupTile / 256; u++) {
+        const uint64_t i = base + u * 256 + threadIdx.x;
+        const bool f = i < n && pred((uint32_t) i);
+        c += (uint32_t) __popcll(__ballot(f));
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tileCount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_kmer_dupscatter(KmerDupPred pred, uint64_t n, const uint32_t *tileBase, int tbits,
+                                                         uint32_t *ckeys, uint64_t *cvals, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
+    constexpr int U = kDupTile / 256;
+    __shared__ uint32_t wcnt[U][4];
     __shared__ uint32_t h[kMaxChunks];        // per-chunk candidate counts of the block's first query
     __shared__ uint32_t q0;
-    const uint64_t nCand = *nCandPtr;
-    const uint64_t j0 = (uint64_t) blockIdx.x * 256, j = j0 + threadIdx.x;
-    if (j0 >= nCand) return;
+    const uint64_t base = (uint64_t) blockIdx.x * kDupTile;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     h[threadIdx.x] = 0;
-    if (threadIdx.x == 0) q0 = keys[idx[j0]] >> tbits;
+    if (threadIdx.x == 0) q0 = pred.keys[base] >> tbits;
+    uint32_t mine = 0, rank[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t i = base + u * 256 + threadIdx.x;
+        const bool f = i < n && pred((uint32_t) i);
+        const unsigned long long m = __ballot(f);
+        rank[u] = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        if (f) mine |= 1u << u;
+        if (lane == 0) wcnt[u][wave] = (uint32_t) __popcll(m);
+    }
     __syncthreads();
-    if (j < nCand) {
-        const uint32_t i = idx[j];
-        const uint32_t k = keys[i];
-        const uint64_t v = vals[i];
-        ckeys[j] = k; cvals[j] = v;
-        if ((k >> tbits) == q0) atomicAdd(&h[hitChunk(v)], 1u);
-        else atomicAdd(&ecCount[(size_t) (k >> tbits) * kMaxChunks + hitChunk(v)], 1u);
+    uint32_t run = tileBase[blockIdx.x];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) before += w < wave ? wcnt[u][w] : 0;
+        if ((mine >> u) & 1u) {
+            const uint64_t i = base + u * 256 + threadIdx.x;
+            const uint32_t j = run + before + rank[u];
+            const uint32_t k = pred.keys[i];
+            const uint64_t v = pred.vals[i];
+            ckeys[j] = k; cvals[j] = v;
+            if ((k >> tbits) == q0) atomicAdd(&h[hitChunk(v)], 1u);
+            else atomicAdd(&ecCount[(size_t) (k >> tbits) * kMaxChunks + hitChunk(v)], 1u);
+        }
+        run += wcnt[u][0] + wcnt[u][1] + wcnt[u][2] + wcnt[u][3];
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&ecCount[(size_t) q0 * kMaxChunks + threadIdx.x], h[threadIdx.x]);
