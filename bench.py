@@ -27,11 +27,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1]), 2: 3Di+AA")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
+    ap.add_argument("--group", type=int, default=8, help="queries a host thread prefilters back to back before ONE multi-query SW launch (0: one SW launch per query)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
     ap.add_argument("--kmer-queries", type=int, default=128, help="queries of the k-mer prefilter section (batches of 32)")
@@ -112,13 +113,13 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
         tp = time.perf_counter() - tp
         ms, cnt = kctx[t].kmer_stage_ms(), kctx[t].kmer_counts()
         ta = time.perf_counter()
-        na = 0
-        for k, i in enumerate(ids):
-            na += len(ksearch[t].align(qa[i], q3[i], res[k]["id"]))
+        aln = ksearch[t].align_batch([qa[i] for i in ids], [q3[i] for i in ids], [r["id"] for r in res])
+        na = sum(len(a) for a in aln)
         ta = time.perf_counter() - ta
+        swms = kctx[t].kernel_ms(1)
         if timed:
             with lock:
-                stat["dev"].append(ms[0]); stat["lists"].append(ms[10]); stat["counts"].append(cnt)
+                stat["dev"].append(ms[0]); stat["lists"].append(ms[10]); stat["counts"].append(cnt); stat.setdefault("sw", []).append(swms)
                 stat["hits"] += sum(len(r) for r in res); stat["aln"] += na; stat["t_pref"] += tp; stat["t_aln"] += ta
                 stat["bad"] = stat.get("bad", 0) + int((status < 0).sum())
         return res
@@ -160,10 +161,10 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     except Exception:
         traffic = None
     out = {"workload": f"{nqk} queries in batches of 32 vs the same {db.n}-structure DB: k-mer prefilter (-s 9.5, k=6 spaced, "
-                       f"--max-seqs 1000, double-diagonal + ungapped scoring) + fwd/rev structure SW on its hits",
+                       f"--max-seqs 1000, double-diagonal + ungapped scoring) + fwd/rev structure SW on its hits (one multi-query SW launch per register class)",
            "value": world * nqk * db.residues / dt, "unit": "residues/s", "queries_per_s": world * nqk / dt,
            "ms_per_query": 1e3 * dt / nqk, "prefilter_ms_per_query_host_wall": 1e3 * stat["t_pref"] / nqk,
-           "align_ms_per_query_host_wall": 1e3 * stat["t_aln"] / nqk, "prefilter_device_ms_per_query": float(np.sum(stat["dev"])) / nqk,
+           "align_ms_per_query_host_wall": 1e3 * stat["t_aln"] / nqk, "sw_kernels_ms_per_batch32": float(np.mean(stat["sw"])), "prefilter_device_ms_per_query": float(np.sum(stat["dev"])) / nqk,
            "index_build_s": t_index, "index_entries": int(ctx0.kmer_index_entries), "kmer_threshold": thr,
            "similar_kmers_per_query": float(np.mean([c[0] for c in stat["counts"]])) / 32, "index_hits_per_query": float(np.mean([c[1] for c in stat["counts"]])) / 32,
            "candidates_per_query": float(np.mean([c[2] for c in stat["counts"]])) / 32,
@@ -245,19 +246,37 @@ def main():
     ready = threading.Barrier(nthreads + 1)
     go = threading.Barrier(nthreads + 1)
 
+    G = max(1, args.group)
+
+    def steps(t, ids):
+        """G queries: G gapless scans back to back, then ONE multi-query SW launch over all their hit lists"""
+        hl, km = [], []
+        for i in ids:
+            hl.append(searches[t].prefilter(q3[i]))
+            km.append(ctxs[t].kernel_ms(0))
+        rs = searches[t].align_batch([qa[i] for i in ids], [q3[i] for i in ids], [h["id"] for h in hl])
+        return hl, rs, km
+
     def worker(t):
         # untimed warmup inside the worker: the first HIP calls of a host thread initialise per-thread state
         for i in range(t, args.warmup, nthreads):
             step(t, i)
         if args.warmup < nthreads:
             step(t, 0)
+        steps(t, list(range(min(G, nq))))
         ready.wait()
         go.wait()
-        for i in range(args.warmup + t, nq, nthreads):
-            hits, res = step(t, i)
+        mine = list(range(args.warmup, nq))
+        groups = [mine[k:k + G] for k in range(0, len(mine), G)]
+        for g in groups[t::nthreads]:
+            if args.group == 0:                       # per-query path: fsgpu_sw_batch per query
+                h1, r1 = step(t, g[0])
+                hl, rs, km = [h1], [r1], [ctxs[t].kernel_ms(0)]
+            else:
+                hl, rs, km = steps(t, g)
             with lock:
-                kms.append(ctxs[t].kernel_ms(0)); sms.append(ctxs[t].kernel_ms(1))
-                counts[0] += len(hits); counts[1] += len(res)
+                kms.extend(km); sms.append(ctxs[t].kernel_ms(1) / len(g))
+                counts[0] += sum(len(h) for h in hl); counts[1] += sum(len(r) for r in rs)
 
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
     for th in ths:
@@ -306,9 +325,10 @@ def main():
             "dtype": "i16", "data": "synthetic",
             "config": {"workload": f"1 query/step vs {db.n}-structure synthetic 3Di DB (mean len {residues / db.n:.0f}), "
                                    f"gapless prefilter (all targets) + top-1000 + fwd/rev structure SW "
-                                   f"(--alignment-type {args.alignment_type}) + host gates/backtrace",
+                                   f"(--alignment-type {args.alignment_type}) + host gates/backtrace; each host thread prefilters "
+                                   f"{G} queries back to back, then aligns their hit lists with one multi-query SW launch",
                        "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "max_seqs": 1000,
-                       "queries_per_rank": args.steps, "host_threads_per_gpu": nthreads,
+                       "queries_per_rank": args.steps, "host_threads_per_gpu": nthreads, "queries_per_sw_launch": G,
                        "parallelism": f"query-shard x{world}, DB replicated by one RCCL broadcast"},
             "queries_per_s": world * args.steps / dt,
             "hits_per_query": nh / args.steps, "alignments_per_query": nr / args.steps,

@@ -110,6 +110,8 @@ def lib():
         "fshost_search_error": (C.c_char_p, [vp]),
         "fshost_search_prefilter": (i32, [vp, vp, i32, i64, vp]),
         "fshost_search_align": (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
+        "fshost_search_align_batch": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "fsgpu_sw_multi": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
         "fshost_search_stats": (None, [vp, vp]),
         "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -129,7 +131,7 @@ def lib():
 def exported_symbols():
     return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
-            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_launch", "fsgpu_sw_finish",
+            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_last_kernel_ms", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
             "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts"]
 
@@ -426,6 +428,29 @@ class Search:
             bts = [lib().fshost_search_backtrace(self.h, C.c_void_p(res[i:i + 1].ctypes.data)).decode() for i in range(n)]
             return res, bts
         return res
+
+    def align_batch(self, qAAs, q3dis, target_id_lists, identity=None, with_backtrace=False):
+        """several queries, one device call (fsgpu_sw_multi); returns a list of result arrays (and backtrace lists)"""
+        nq = len(q3dis)
+        qa = [np.ascontiguousarray(x, np.uint8) for x in qAAs]
+        q3 = [np.ascontiguousarray(x, np.uint8) for x in q3dis]
+        ts = [np.ascontiguousarray(x, np.uint32) for x in target_id_lists]
+        res = [np.zeros(max(1, len(t)), RESULT_DT) for t in ts]
+        P = C.c_void_p * max(nq, 1)
+        pa, p3, pt, pr = P(*[x.ctypes.data for x in qa]), P(*[x.ctypes.data for x in q3]), P(*[x.ctypes.data for x in ts]), P(*[x.ctypes.data for x in res])
+        Ls = np.array([len(x) for x in q3], np.int32)
+        ns = np.array([len(x) for x in ts], np.int32)
+        ident = None if identity is None else np.ascontiguousarray(identity, np.int64)
+        nres = np.zeros(max(nq, 1), np.int32)
+        rc = lib().fshost_search_align_batch(self.h, nq, C.cast(pa, C.c_void_p), C.cast(p3, C.c_void_p), _ptr(Ls), _ptr(ident), C.cast(pt, C.c_void_p),
+                                             _ptr(ns), C.cast(pr, C.c_void_p), _ptr(nres))
+        if rc != 0:
+            raise FsgpuError(f"align_batch rc={rc}: {lib().fshost_search_error(self.h).decode()}")
+        out = [res[i][:nres[i]] for i in range(nq)]
+        if with_backtrace:
+            bts = [[lib().fshost_search_backtrace(self.h, C.c_void_p(out[i][k:k + 1].ctypes.data)).decode() for k in range(len(out[i]))] for i in range(nq)]
+            return out, bts
+        return out
 
     def stats(self):
         out = np.zeros(8)

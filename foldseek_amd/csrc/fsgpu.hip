@@ -417,6 +417,28 @@ static int launchSw(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nPa
 #undef FS_SW_CASE
 }
 
+// multi-query launch: one workgroup (4 waves) per SwBlockDesc
+template <int R, bool HAS_AA>
+static int launchSwBlocksT(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks) {
+    const int lds = (HAS_AA ? 2 : 1) * kAlphabet * swRowDwords(R) * 4;
+    static thread_local bool attrSet = false;
+    if (!attrSet) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_sw<R, HAS_AA, Pk16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL((k_sw<R, HAS_AA, Pk16>), dim3(nBlocks), dim3(256), lds, ctx->stream, sa);
+    HIPCHK(hipGetLastError());
+    return FSGPU_OK;
+}
+static int launchSwBlocks(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks) {
+#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocksT<RR, true>(ctx, sa, nBlocks) : launchSwBlocksT<RR, false>(ctx, sa, nBlocks);
+    switch (R) {
+        FS_SW_CASE(1) FS_SW_CASE(2) FS_SW_CASE(3) FS_SW_CASE(4) FS_SW_CASE(6) FS_SW_CASE(8)
+        default: ctx->err = "internal: bad SW R"; return FSGPU_E_ARG;
+    }
+#undef FS_SW_CASE
+}
+
 // Builds the per-tile LDS images (host) and runs all row tiles of one pass.
 //   packed:  value = (fwd int16) | (rev int16) << 16;   int32: value = the selected direction's score
 static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int16_t *p3_0, const int16_t *pAA1, const int16_t *p3_1,
@@ -476,6 +498,7 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
         sa.borderStride = stride;
         sa.keys = (uint64_t *) ctx->keys.p;
         sa.res0 = dRes0; sa.res1 = dRes1;
+        sa.blocks = nullptr;
         rc = packed ? launchSw<Pk16>(ctx, R, hasAA, sa, nPairs) : launchSw<I32>(ctx, R, hasAA, sa, nPairs);
         if (rc != FSGPU_OK) return rc;
     }
@@ -568,6 +591,159 @@ int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_f
     int rc = fsgpu_sw_launch(ctx, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, targetIds, n, gapOpen, gapExtend);
     if (rc != FSGPU_OK) return rc;
     return fsgpu_sw_finish(ctx, fwd, rev);
+}
+
+// Several queries in one go: all single-tile queries (L <= 512) of one register class R share ONE launch -- workgroups
+// of 4 waves, each workgroup serving pairs of a single query and loading that query's LDS image -- so the device sees
+// tens of thousands of independent waves instead of ~1000 per launch and the long-target tail of one query overlaps
+// the bulk of the others.  Longer queries and int16-saturated pairs go through the single-query path.
+int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev) {
+    if (!ctx || nq < 0 || (nq > 0 && (!q || !fwd || !rev))) return FSGPU_E_ARG;
+    if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
+        ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
+        return FSGPU_E_UNSUPPORTED;
+    }
+    if (ctx->sw.pending) { ctx->err = "previous SW batch not finished"; return FSGPU_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<size_t> base(nq + 1, 0);
+    bool hasAA = false, anyAA = false, allAA = true;
+    for (int i = 0; i < nq; i++) {
+        if (!q[i].p3Di_fwd || !q[i].p3Di_rev || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN || q[i].n < 0 || (q[i].n > 0 && !q[i].targetIds) ||
+            ((q[i].pAA_fwd == nullptr) != (q[i].pAA_rev == nullptr))) { ctx->err = "fsgpu_sw_multi: bad query"; return FSGPU_E_ARG; }
+        anyAA = anyAA || q[i].pAA_fwd != nullptr; allAA = allAA && q[i].pAA_fwd != nullptr;
+        base[i + 1] = base[i] + (size_t) q[i].n;
+        for (int k = 0; k < q[i].n; k++) if (q[i].targetIds[k] >= ctx->db->n) { ctx->err = "target id out of range"; return FSGPU_E_ARG; }
+    }
+    if (anyAA != allAA) { ctx->err = "fsgpu_sw_multi: either all or none of the queries carry AA profiles"; return FSGPU_E_ARG; }
+    hasAA = anyAA;
+    if (hasAA && !ctx->db->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
+    const size_t total = base[nq];
+    int rc;
+    std::vector<uint32_t> perm;
+    std::vector<uint64_t> lkey;
+    // ---- launch groups by register class ----
+    const int classes[6] = {1, 2, 3, 4, 6, 8};
+    std::vector<int> cls(nq, -1);
+    for (int i = 0; i < nq; i++) if (q[i].L <= 64 * kSwMaxR && q[i].n > 0) cls[i] = swPickR(q[i].L);
+    size_t imgDwTotal = 0, nBlocks = 0;
+    for (int i = 0; i < nq; i++) if (cls[i] > 0) { imgDwTotal += (size_t) kAlphabet * swRowDwords(cls[i]) * (hasAA ? 2 : 1); nBlocks += ((size_t) q[i].n + 3) / 4; }
+    if (total) {
+        if ((rc = ensure(ctx, ctx->tids, total * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->res0, total * 16)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->res1, total * 16)) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hRes0, total * 16)) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hRes1, total * 16)) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hTids, total * 4)) != FSGPU_OK) return rc;
+        // inside every query the pairs are issued longest target first (perm), and the workgroups of a launch are ordered
+        // by their longest target: the long wavefronts start early and the short ones fill the tail (LPT)
+        perm.resize(total);
+        for (int i = 0; i < nq; i++) {
+            uint32_t *p = perm.data() + base[i];
+            const uint32_t *ids = q[i].targetIds;
+            const std::vector<int32_t> &len = ctx->db->hLengths;
+            lkey.resize(q[i].n);
+            for (int k = 0; k < q[i].n; k++) lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[k]]) << 32) | (uint32_t) k;
+            std::sort(lkey.begin(), lkey.end());
+            uint32_t *dst = (uint32_t *) ctx->hTids.p + base[i];
+            for (int k = 0; k < q[i].n; k++) { p[k] = (uint32_t) lkey[k]; dst[k] = ids[p[k]]; }
+        }
+        HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->hTids.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (nBlocks) {
+        if ((rc = ensurePinned(ctx, ctx->hImg, imgDwTotal * 4 + nBlocks * sizeof(SwBlockDesc) + 64)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->img, imgDwTotal * 4 + nBlocks * sizeof(SwBlockDesc) + 64)) != FSGPU_OK) return rc;
+        uint32_t *img = (uint32_t *) ctx->hImg.p;
+        SwBlockDesc *hb = (SwBlockDesc *) ((unsigned char *) ctx->hImg.p + ((imgDwTotal * 4 + 15) / 16) * 16);
+        const size_t descOff = ((imgDwTotal * 4 + 15) / 16) * 16;
+        size_t imgPos = 0, blkPos = 0;
+        struct Group { int R; size_t blk0, nblk; };
+        std::vector<Group> groups;
+        for (int R : classes) {
+            Group g{R, blkPos, 0};
+            const int rowDw = swRowDwords(R);
+            const size_t tblDw = (size_t) kAlphabet * rowDw;
+            for (int i = 0; i < nq; i++) {
+                if (cls[i] != R) continue;
+                const int L = q[i].L;
+                uint32_t *dst0 = img + imgPos;
+                for (int tbl = 0; tbl < (hasAA ? 2 : 1); tbl++) {
+                    const int16_t *f = tbl == 0 ? q[i].p3Di_fwd : q[i].pAA_fwd;
+                    const int16_t *r = tbl == 0 ? q[i].p3Di_rev : q[i].pAA_rev;
+                    uint32_t *dst = dst0 + tblDw * tbl;
+                    for (int a = 0; a < kAlphabet; a++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int rr = 0; rr < R; rr++) {
+                                const int row = lane * R + rr;
+                                uint32_t v = 0;
+                                if (row < L) v = (uint32_t) (uint16_t) f[(size_t) a * L + row] | ((uint32_t) (uint16_t) r[(size_t) a * L + row] << 16);
+                                dst[(size_t) a * rowDw + swDwordIndex(R, lane, rr)] = v;
+                            }
+                }
+                for (int p0 = 0; p0 < q[i].n; p0 += 4) {
+                    SwBlockDesc &d = hb[blkPos++];
+                    d.imgOff = (uint32_t) imgPos; d.firstPair = (uint32_t) (base[i] + p0); d.nPairs = (uint16_t) std::min(4, q[i].n - p0);
+                    d.rowsInTile = (uint16_t) L; d.segLen = (uint32_t) ((L + 15) / 16);
+                    g.nblk++;
+                }
+                imgPos += tblDw * (hasAA ? 2 : 1);
+            }
+            if (g.nblk) {
+                // first pair of a workgroup is its longest (pairs are length-sorted inside the query)
+                const uint32_t *ht = (const uint32_t *) ctx->hTids.p;
+                const std::vector<int32_t> &len = ctx->db->hLengths;
+                std::stable_sort(hb + g.blk0, hb + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return len[ht[x.firstPair]] > len[ht[y.firstPair]]; });
+                groups.push_back(g);
+            }
+        }
+        HIPCHK(hipMemcpyAsync(ctx->img.p, ctx->hImg.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
+        for (const Group &g : groups) {
+            SwArgs sa;
+            sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
+            sa.targetIds = (const uint32_t *) ctx->tids.p; sa.nPairs = (int) total;
+            sa.profSS = (const uint32_t *) ctx->img.p; sa.profAA = nullptr;
+            sa.tileBase = 0; sa.rowsInTile = 0; sa.segLen = 1;
+            sa.go = (uint32_t) gapOpen | ((uint32_t) gapOpen << 16);
+            sa.ge = (uint32_t) gapExtend | ((uint32_t) gapExtend << 16);
+            sa.tileIn = 0; sa.tileOut = 0; sa.borderIn = nullptr; sa.borderOut = nullptr; sa.borderStride = 0; sa.keys = nullptr;
+            sa.res0 = (int32_t *) ctx->res0.p; sa.res1 = (int32_t *) ctx->res1.p;
+            sa.blocks = (const SwBlockDesc *) ((const unsigned char *) ctx->img.p + descOff) + g.blk0;
+            rc = launchSwBlocks(ctx, g.R, hasAA, sa, (int) g.nblk);
+            if (rc != FSGPU_OK) return rc;
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->evValid[1] = true;
+    if (total) {
+        HIPCHK(hipMemcpyAsync(ctx->hRes0.p, ctx->res0.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->hRes1.p, ctx->res1.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
+        const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hRes0.p, *r1 = (const fsgpu_swres *) ctx->hRes1.p;
+        for (int i = 0; i < nq; i++)
+            for (int k = 0; k < q[i].n; k++) { fwd[base[i] + perm[base[i] + k]] = r0[base[i] + k]; rev[base[i] + perm[base[i] + k]] = r1[base[i] + k]; }
+    }
+    // long (row-tiled) queries and int16-saturated pairs: the single-query path
+    for (int i = 0; i < nq; i++) {
+        if (q[i].n == 0) continue;
+        if (cls[i] < 0) {
+            rc = fsgpu_sw_batch(ctx, q[i].pAA_fwd, q[i].p3Di_fwd, q[i].pAA_rev, q[i].p3Di_rev, q[i].L, q[i].targetIds, q[i].n, gapOpen, gapExtend,
+                                fwd + base[i], rev + base[i]);
+            if (rc != FSGPU_OK) return rc;
+            continue;
+        }
+        std::vector<uint32_t> ids;
+        std::vector<int> where;
+        for (int k = 0; k < q[i].n; k++)
+            if (fwd[base[i] + k].score == 32767 || rev[base[i] + k].score == 32767) { ids.push_back(q[i].targetIds[k]); where.push_back(k); }
+        if (ids.empty()) continue;
+        std::vector<fsgpu_swres> f2(ids.size()), r2(ids.size());
+        rc = fsgpu_sw_batch(ctx, q[i].pAA_fwd, q[i].p3Di_fwd, q[i].pAA_rev, q[i].p3Di_rev, q[i].L, ids.data(), (int) ids.size(), gapOpen, gapExtend,
+                            f2.data(), r2.data());
+        if (rc != FSGPU_OK) return rc;
+        for (size_t k = 0; k < ids.size(); k++) { fwd[base[i] + where[k]] = f2[k]; rev[base[i] + where[k]] = r2[k]; }
+    }
+    return FSGPU_OK;
 }
 
 } // extern "C"

@@ -135,36 +135,43 @@ static bool compareHits(const fshost_result &first, const fshost_result &second)
 
 extern "C" {
 
-int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
-                        const uint32_t *targetIds, int n, fshost_result *results) {
-    if (!s || !s->ctx || !qAA || !q3di || L <= 0 || n < 0) return FSGPU_E_ARG;
-    const fshost_params &par = s->par;
-    const int A = s->mat3Di.n;
-    const bool useAA = par.alignmentType == 2;
-    double lambda, mu;
-    const double t0 = nowSec();
-    s->evaluer.predictMuLambda(q3di, L, A, &lambda, &mu);
-    // forward and reversed-query profiles (structurealign.cpp:344-347)
-    s->pAAf.resize((size_t) A * L); s->p3f.resize((size_t) A * L); s->pAAr.resize((size_t) A * L); s->p3r.resize((size_t) A * L);
-    s->cbAA.resize(L); s->cbSS.resize(L);
-    s->rAA.assign(qAA, qAA + L); s->r3Di.assign(q3di, q3di + L);
-    std::reverse(s->rAA.begin(), s->rAA.end());
-    std::reverse(s->r3Di.begin(), s->r3Di.end());
-    int rc = alignProfiles(s->matAA, s->mat3Di, qAA, q3di, L, par.compBiasCorrection != 0, par.alnCompBiasScale, s->pAAf.data(), s->p3f.data(),
-                           s->cbAA.data(), s->cbSS.data());
-    if (rc == FSGPU_OK)
-        rc = alignProfiles(s->matAA, s->mat3Di, s->rAA.data(), s->r3Di.data(), L, par.compBiasCorrection != 0, par.alnCompBiasScale,
-                           s->pAAr.data(), s->p3r.data(), nullptr, nullptr);
-    if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
-    s->fwd.resize(n); s->rev.resize(n);
-    const double t1 = nowSec();
-    rc = fsgpu_sw_batch(s->ctx, useAA ? s->pAAf.data() : nullptr, s->p3f.data(), useAA ? s->pAAr.data() : nullptr, s->p3r.data(), L,
-                        targetIds, n, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
-    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
-    const double t2 = nowSec();
-    double tBack = 0;
+} // extern "C"
 
-    s->cigars.clear();
+namespace {
+
+// per-query state of the alignment stage: profiles of the forward and the reversed query, biases, e-value parameters
+struct AlignQuery {
+    const uint8_t *qAA = nullptr, *q3di = nullptr;
+    int L = 0;
+    std::vector<int16_t> pAAf, p3f, pAAr, p3r;
+    std::vector<int8_t> cbAA, cbSS;
+    double lambda = 0, mu = 0;
+};
+
+// structurealign.cpp:322-347: e-value network + forward / reversed-query profiles
+int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, std::vector<uint8_t> &r3Di) {
+    const fshost_params &par = s->par;
+    const int A = s->mat3Di.n, L = aq.L;
+    s->evaluer.predictMuLambda(aq.q3di, L, A, &aq.lambda, &aq.mu);
+    aq.pAAf.resize((size_t) A * L); aq.p3f.resize((size_t) A * L); aq.pAAr.resize((size_t) A * L); aq.p3r.resize((size_t) A * L);
+    aq.cbAA.resize(L); aq.cbSS.resize(L);
+    rAA.assign(aq.qAA, aq.qAA + L); r3Di.assign(aq.q3di, aq.q3di + L);
+    std::reverse(rAA.begin(), rAA.end());
+    std::reverse(r3Di.begin(), r3Di.end());
+    int rc = alignProfiles(s->matAA, s->mat3Di, aq.qAA, aq.q3di, L, par.compBiasCorrection != 0, par.alnCompBiasScale, aq.pAAf.data(), aq.p3f.data(),
+                           aq.cbAA.data(), aq.cbSS.data());
+    if (rc == FSGPU_OK)
+        rc = alignProfiles(s->matAA, s->mat3Di, rAA.data(), r3Di.data(), L, par.compBiasCorrection != 0, par.alnCompBiasScale,
+                           aq.pAAr.data(), aq.p3r.data(), nullptr, nullptr);
+    if (rc != FSGPU_OK) s->err = "bad query residue code";
+    return rc;
+}
+
+// alignStructure gates + backtrace + checkCriteria + ordering for one query (structurealign.cpp:37-112,350-445)
+int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const uint32_t *targetIds, int n, const fsgpu_swres *fwd,
+              const fsgpu_swres *rev, fshost_result *results, double &tBack) {
+    const fshost_params &par = s->par;
+    const int L = aq.L;
     int passedNum = 0, rejected = 0, nres = 0;
     for (int k = 0; k < n && passedNum < par.maxAccept && rejected < par.maxRejected; k++) {
         const uint32_t tid = targetIds[k];
@@ -173,13 +180,13 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
         const int Lt = s->lengths[tid];
         if (!canBeCovered(par.covThr, par.covMode, (float) L, (float) Lt)) { rejected++; continue; }
         // ---- alignStructure ----
-        const fsgpu_swres &f = s->fwd[k];
+        const fsgpu_swres &f = fwd[k];
         float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
         if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) { rejected++; continue; }
-        double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, lambda, mu);
+        double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, aq.lambda, aq.mu);
         if (evalue > par.evalThr) { rejected++; continue; }
-        const int32_t score = f.score - s->rev[k].score;
-        evalue = s->evaluer.computeEvalueCorr(score, lambda, mu);
+        const int32_t score = f.score - rev[k].score;
+        evalue = s->evaluer.computeEvalueCorr(score, aq.lambda, aq.mu);
         if (evalue > par.evalThr) { rejected++; continue; }
         // start position + backtrace on the host (block aligner), only for hits that survived both gates
         s->tAA.resize(Lt); s->t3Di.resize(Lt);
@@ -193,7 +200,7 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
         }
         BlockAlnOut bo;
         const double tb0 = nowSec();
-        blockBacktrace(s->matAA, s->mat3Di, qAA, q3di, s->cbAA.data(), s->cbSS.data(), L, s->tAA.data(), s->t3Di.data(), Lt, f.qEnd, f.dbEnd,
+        blockBacktrace(s->matAA, s->mat3Di, aq.qAA, aq.q3di, aq.cbAA.data(), aq.cbSS.data(), L, s->tAA.data(), s->t3Di.data(), Lt, f.qEnd, f.dbEnd,
                        f.score, par.gapOpen, par.gapExtend, bo);
         tBack += nowSec() - tb0;
         fshost_result r;
@@ -229,8 +236,73 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
         }
     }
     if (nres > 1) std::sort(results, results + nres, compareHits);
+    return nres;
+}
+
+} // namespace
+
+extern "C" {
+
+int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
+                        const uint32_t *targetIds, int n, fshost_result *results) {
+    if (!s || !s->ctx || !qAA || !q3di || L <= 0 || n < 0) return FSGPU_E_ARG;
+    const fshost_params &par = s->par;
+    const bool useAA = par.alignmentType == 2;
+    const double t0 = nowSec();
+    AlignQuery aq;
+    aq.qAA = qAA; aq.q3di = q3di; aq.L = L;
+    int rc = prepareAlign(s, aq, s->rAA, s->r3Di);
+    if (rc != FSGPU_OK) return rc;
+    s->fwd.resize(n); s->rev.resize(n);
+    const double t1 = nowSec();
+    rc = fsgpu_sw_batch(s->ctx, useAA ? aq.pAAf.data() : nullptr, aq.p3f.data(), useAA ? aq.pAAr.data() : nullptr, aq.p3r.data(), L,
+                        targetIds, n, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
+    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    const double t2 = nowSec();
+    double tBack = 0;
+    s->cigars.clear();
+    const int nres = gateAlign(s, aq, identityId, targetIds, n, s->fwd.data(), s->rev.data(), results, tBack);
     s->stats[2] = t1 - t0; s->stats[3] = t2 - t1; s->stats[5] = tBack; s->stats[4] = nowSec() - t2 - tBack;
     return nres;
+}
+
+// The same for nq queries with ONE device call (fsgpu_sw_multi): results[q] must hold n[q] entries, nres[q] receives the
+// number of accepted alignments of query q.  Backtraces of all queries stay valid until the next align call.
+int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
+                              const int64_t *identityId, const uint32_t *const *targetIds, const int *n,
+                              fshost_result *const *results, int *nres) {
+    if (!s || !s->ctx || nq < 0 || (nq > 0 && (!qAA || !q3di || !L || !targetIds || !n || !results || !nres))) return FSGPU_E_ARG;
+    const fshost_params &par = s->par;
+    const bool useAA = par.alignmentType == 2;
+    const double t0 = nowSec();
+    std::vector<AlignQuery> aq(nq);
+    std::vector<fsgpu_sw_query> dq(nq);
+    size_t total = 0;
+    for (int i = 0; i < nq; i++) {
+        if (!qAA[i] || !q3di[i] || L[i] <= 0 || n[i] < 0) return FSGPU_E_ARG;
+        aq[i].qAA = qAA[i]; aq[i].q3di = q3di[i]; aq[i].L = L[i];
+        const int rc = prepareAlign(s, aq[i], s->rAA, s->r3Di);
+        if (rc != FSGPU_OK) return rc;
+        dq[i].pAA_fwd = useAA ? aq[i].pAAf.data() : nullptr; dq[i].p3Di_fwd = aq[i].p3f.data();
+        dq[i].pAA_rev = useAA ? aq[i].pAAr.data() : nullptr; dq[i].p3Di_rev = aq[i].p3r.data();
+        dq[i].L = L[i]; dq[i].n = n[i]; dq[i].targetIds = targetIds[i];
+        total += (size_t) n[i];
+    }
+    s->fwd.resize(total); s->rev.resize(total);
+    const double t1 = nowSec();
+    int rc = fsgpu_sw_multi(s->ctx, dq.data(), nq, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
+    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    const double t2 = nowSec();
+    double tBack = 0;
+    s->cigars.clear();
+    size_t base = 0;
+    for (int i = 0; i < nq; i++) {
+        nres[i] = gateAlign(s, aq[i], identityId ? identityId[i] : -1, targetIds[i], n[i], s->fwd.data() + base, s->rev.data() + base, results[i], tBack);
+        if (nres[i] < 0) return nres[i];
+        base += (size_t) n[i];
+    }
+    s->stats[2] = t1 - t0; s->stats[3] = t2 - t1; s->stats[5] = tBack; s->stats[4] = nowSec() - t2 - tBack;
+    return FSGPU_OK;
 }
 
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r) { return s->cigars.c_str() + r->backtraceOff; }

@@ -79,6 +79,17 @@ struct SwArgs {
     uint64_t *keys;               // [nPairs][2] running best across tiles (packed: fwd, rev; int32: slot 0)
     int32_t *res0;                // fsgpu_swres[nPairs] as int32 x4 (packed: forward; int32: the direction re-run)
     int32_t *res1;                // packed only: reversed query
+    // multi-query launches (single-tile queries of one R class): workgroup b serves blocks[b]; NULL = one query per launch
+    const struct SwBlockDesc *blocks;
+};
+
+// One workgroup of a multi-query launch: up to (blockDim.x / 64) consecutive pairs of one query.
+struct SwBlockDesc {
+    uint32_t imgOff;              // dword offset of this query's LDS image inside SwArgs::profSS ([SS table][AA table])
+    uint32_t firstPair;           // global pair index of wave 0 (targetIds / result arrays are concatenated over queries)
+    uint16_t nPairs;              // live waves of this workgroup
+    uint16_t rowsInTile;          // query length (<= 64R)
+    uint32_t segLen;
 };
 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
@@ -118,12 +129,20 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     constexpr int ROWB = swRowDwords(R) * 4;
     constexpr int TBL = kAlphabet * ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t *profSS = a.profSS, *profAA = a.profAA;
+    int rowsInTile = a.rowsInTile, segLen = a.segLen, pairBase = -1, pairsHere = 0;
+    if (a.blocks) {               // multi-query launch: this workgroup's query
+        const SwBlockDesc bd = a.blocks[blockIdx.x];
+        profSS = a.profSS + bd.imgOff;
+        profAA = profSS + TBL / 4;
+        rowsInTile = bd.rowsInTile; segLen = (int) bd.segLen; pairBase = (int) bd.firstPair; pairsHere = bd.nPairs;
+    }
     {
-        const uint4 *s3 = (const uint4 *) a.profSS;
+        const uint4 *s3 = (const uint4 *) profSS;
         uint4 *d3 = (uint4 *) smem;
         for (int i = threadIdx.x; i < TBL / 16; i += blockDim.x) d3[i] = s3[i];
         if constexpr (HAS_AA) {
-            const uint4 *sa = (const uint4 *) a.profAA;
+            const uint4 *sa = (const uint4 *) profAA;
             uint4 *da = (uint4 *) (smem + TBL);
             for (int i = threadIdx.x; i < TBL / 16; i += blockDim.x) da[i] = sa[i];
         }
@@ -134,8 +153,9 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wavesPerBlock = blockDim.x >> 6;
-    const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6));
-    if (pair >= a.nPairs) return;
+    const int waveInBlock = (int) (threadIdx.x >> 6);
+    const int pair = __builtin_amdgcn_readfirstlane(pairBase >= 0 ? pairBase + waveInBlock : blockIdx.x * wavesPerBlock + waveInBlock);
+    if (pairBase >= 0 ? waveInBlock >= pairsHere : pair >= a.nPairs) return;
 
     // wave-uniform pair parameters -> SGPRs, scalar loop control
     const uint32_t tid = __builtin_amdgcn_readfirstlane(a.targetIds[pair]);
@@ -143,14 +163,14 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     const uint64_t off64 = a.offsets[tid];
     const uint64_t off = ((uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) (off64 >> 32)) << 32) |
                          (uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) off64);
-    const int nLanes = a.tileOut ? 64 : (a.rowsInTile + R - 1) / R;
+    const int nLanes = a.tileOut ? 64 : (rowsInTile + R - 1) / R;
     const int steps = Lt > 0 ? Lt + nLanes - 1 : 0;
     const bool laneActive = lane < nLanes;
 
     // segment-start masks for my rows
     uint32_t segmask[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) segmask[r] = ((a.tileBase + lane * R + r) % a.segLen == 0) ? 0u : 0xffffffffu;
+    for (int r = 0; r < R; r++) segmask[r] = ((a.tileBase + lane * R + r) % segLen == 0) ? 0u : 0xffffffffu;
 
     uint32_t E[R], Hp[R], snap[R];
 #pragma unroll

@@ -23,6 +23,7 @@
  *                                     M/src/prefiltering/Prefiltering.cpp:544-583,220-225, IndexBuilder.cpp:56-271
  *   fsgpu_kmer_search                 the per-query body of Prefiltering::runSplit = QueryMatcher::matchQuery
  *                                     M/src/prefiltering/Prefiltering.cpp:847-917, QueryMatcher.cpp:103-376
+ *   fsgpu_sw_multi                    the same for a batch of queries in one device launch per register class
  *   fshost_*                          host-side pieces of the same path that stay on the CPU, exported so the
  *                                     reference-side adapter and the tests can reach them.
  */
@@ -121,6 +122,18 @@ int fsgpu_gapless_finish(fsgpu_ctx *ctx, fsgpu_hit *out, int *nout);
 int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
                    const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,
                    const uint32_t *targetIds, int n, int gapOpen, int gapExtend,
+                   fsgpu_swres *fwd, fsgpu_swres *rev);
+/* Several queries per call (what a host thread of structurealign would do one after the other, structurealign.cpp:322-452):
+ * same semantics per query as fsgpu_sw_batch; results are concatenated in query order (sum of n entries).  All queries of
+ * at most 512 residues that share a register class run in ONE launch, which fills the device where a single query's
+ * ~1000 pairs cannot.  Either all or none of the queries carry AA profiles. */
+typedef struct {
+    const int16_t *pAA_fwd, *p3Di_fwd, *pAA_rev, *p3Di_rev;
+    int32_t L;
+    int32_t n;
+    const uint32_t *targetIds;
+} fsgpu_sw_query;
+int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *queries, int nq, int gapOpen, int gapExtend,
                    fsgpu_swres *fwd, fsgpu_swres *rev);
 int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
                     const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,

@@ -131,6 +131,11 @@ int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_
  * Returns number of accepted alignments or < 0. */
 int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
                         const uint32_t *targetIds, int n, fshost_result *results);
+/* The same for nq queries with one device call (fsgpu_sw_multi): results[q] has room for n[q] entries, nres[q] receives
+ * the number of accepted alignments of query q; identityId may be NULL.  Returns 0 or < 0. */
+int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
+                              const int64_t *identityId, const uint32_t *const *targetIds, const int *n,
+                              fshost_result *const *results, int *nres);
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r);
 /* Host wall time (seconds) spent in the stages of the last prefilter/align calls: [0] prefilter profile build,
  * [1] fsgpu_gapless_scan incl. wait, [2] align profiles + e-value net, [3] fsgpu_sw_batch incl. wait, [4] gates,

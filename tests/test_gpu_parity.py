@@ -215,3 +215,41 @@ def test_ragged_and_tiny_database():
     fwd, rev = ctx.sw_batch(pAf, p3f, pAr, p3r, np.zeros(0, np.uint32))
     assert len(fwd) == 0
     ctx.close()
+
+
+def test_align_batch_equals_per_query_align():
+    """fshost_search_align_batch / fsgpu_sw_multi (one launch per register class for many queries) returns exactly what the
+    per-query calls return: mixed lengths across all register classes, a row-tiled long query, an empty hit list, a pair
+    that saturates int16 (int32 re-run), both alignment types; complete result records and backtraces."""
+    rng = np.random.default_rng(123)
+    lens = [40, 70, 130, 200, 260, 350, 380, 500, 512, 700, 33]
+    q3 = [rng.choice(20, size=L, p=synth.BACK_3DI / synth.BACK_3DI.sum()).astype(np.uint8) for L in lens]
+    qa = [rng.choice(20, size=L, p=synth.BACK_AA / synth.BACK_AA.sum()).astype(np.uint8) for L in lens]
+    # a self-scoring monster: 3Di 'M' / AA 'W' repeated -> int16 saturation against its planted copy
+    q3.append(np.full(3000, 10, np.uint8)); qa.append(np.full(3000, 18, np.uint8))
+    db = synth.make_db(1500, (q3, qa), seed=321, homologs_per_query=12, mask_frac=0.01, hi=3200)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    for atype in (2, 0):
+        par = api.default_params()
+        par.alignmentType = atype
+        par.addBacktrace = 1
+        s = api.Search(ctx, par)
+        hit_lists = []
+        for i in range(len(q3)):
+            ids = rng.choice(db.n, size=int(rng.integers(60, 400)), replace=False).astype(np.uint32)
+            hit_lists.append(ids)
+        hit_lists[3] = np.zeros(0, np.uint32)
+        single = [s.align(qa[i], q3[i], hit_lists[i], with_backtrace=True) for i in range(len(q3))]
+        batch, bts = s.align_batch(qa, q3, hit_lists, with_backtrace=True)
+        total = 0
+        for i in range(len(q3)):
+            r1, b1 = single[i]
+            assert len(batch[i]) == len(r1), (atype, i)
+            for f in ("dbKey", "score", "qcov", "dbcov", "seqId", "eval", "alnLength", "qStartPos", "qEndPos", "qLen", "dbStartPos", "dbEndPos", "dbLen"):
+                assert (batch[i][f] == r1[f]).all(), (atype, i, f)
+            assert bts[i] == b1, (atype, i)
+            total += len(r1)
+        assert total > 20
+        s.close()
+    ctx.close()
