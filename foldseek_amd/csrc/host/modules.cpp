@@ -376,44 +376,64 @@ int fsmod_structurealign(int argc, const char **argv) {
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     std::string firstErr;
+    // each host thread takes groups of prefilter entries: their hit lists go through ONE multi-query SW launch
+    // (fshost_search_align_batch), then gates / backtrace / formatting per query
+    const size_t group = (size_t) std::max(1, std::min(o.geti("--align-batch", 8), 64));
     auto work = [&](int tix) {
         fsgpu_ctx *ctx = ctx0;
         if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
         fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data());
-        std::vector<uint8_t> cA, c3;
-        std::vector<uint32_t> ids;
-        std::vector<fshost_result> res;
+        std::vector<std::vector<uint8_t>> cA(group), c3(group);
+        std::vector<std::vector<uint32_t>> ids(group);
+        std::vector<std::vector<fshost_result>> res(group);
+        std::vector<size_t> entry(group);
+        std::vector<const uint8_t *> pA(group), p3(group);
+        std::vector<const uint32_t *> pT(group);
+        std::vector<fshost_result *> pR(group);
+        std::vector<int> Ls(group), ns(group), nres(group);
+        std::vector<int64_t> ident(group);
         std::vector<char> line(1024 + 2 * 65536 * 2);
         for (;;) {
-            const size_t id = next++;
-            if (id >= pref.size() || bad) break;
-            const uint32_t queryKey = pref.key(id);
-            const char *data = pref.data(id);
-            if (*data == '\0') continue;
-            const int64_t qid = q3.idOf(queryKey);
-            if (qid < 0 || qA.idOf(queryKey) < 0) { if (!bad++) firstErr = "query key missing in query database"; break; }
-            const uint32_t L = q3.seqLen((size_t) qid);
-            cA.resize(L); c3.resize(L);
-            const char *sA = qA.data((size_t) qA.idOf(queryKey)), *s3 = q3.data((size_t) qid);
-            for (uint32_t i = 0; i < L; i++) { cA[i] = mA.aa2num[(unsigned char) sA[i]]; c3[i] = m3.aa2num[(unsigned char) s3[i]]; }
-            // prefilter entry: lines "targetKey \t score \t diagonal" (Util::parseKey, structurealign.cpp:351-355)
-            ids.clear();
-            while (*data != '\0') {
-                const uint32_t dbKey = (uint32_t) strtoul(data, nullptr, 10);
-                const int64_t tid = t3.idOf(dbKey);
-                if (tid < 0) { if (!bad++) firstErr = "target key missing in target database"; break; }
-                ids.push_back((uint32_t) tid);
-                while (*data != '\n' && *data != '\0') data++;
-                if (*data == '\n') data++;
+            const size_t b0 = next.fetch_add(group);
+            if (b0 >= pref.size() || bad) break;
+            size_t m = 0;
+            for (size_t id = b0; id < std::min(pref.size(), b0 + group) && !bad; id++) {
+                const uint32_t queryKey = pref.key(id);
+                const char *data = pref.data(id);
+                if (*data == '\0') continue;
+                const int64_t qid = q3.idOf(queryKey);
+                if (qid < 0 || qA.idOf(queryKey) < 0) { if (!bad++) firstErr = "query key missing in query database"; break; }
+                const uint32_t L = q3.seqLen((size_t) qid);
+                cA[m].resize(L); c3[m].resize(L);
+                const char *sA = qA.data((size_t) qA.idOf(queryKey)), *s3 = q3.data((size_t) qid);
+                for (uint32_t i = 0; i < L; i++) { cA[m][i] = mA.aa2num[(unsigned char) sA[i]]; c3[m][i] = m3.aa2num[(unsigned char) s3[i]]; }
+                // prefilter entry: lines "targetKey \t score \t diagonal" (Util::parseKey, structurealign.cpp:351-355)
+                ids[m].clear();
+                while (*data != '\0') {
+                    const uint32_t dbKey = (uint32_t) strtoul(data, nullptr, 10);
+                    const int64_t tid = t3.idOf(dbKey);
+                    if (tid < 0) { if (!bad++) firstErr = "target key missing in target database"; break; }
+                    ids[m].push_back((uint32_t) tid);
+                    while (*data != '\n' && *data != '\0') data++;
+                    if (*data == '\n') data++;
+                }
+                if (bad) break;
+                res[m].resize(ids[m].size() + 1);
+                entry[m] = id; pA[m] = cA[m].data(); p3[m] = c3[m].data(); pT[m] = ids[m].data(); pR[m] = res[m].data();
+                Ls[m] = (int) L; ns[m] = (int) ids[m].size(); ident[m] = sameDB ? t3.idOf(queryKey) : -1;
+                m++;
             }
             if (bad) break;
-            res.resize(ids.size() + 1);
-            const int64_t identity = sameDB ? t3.idOf(queryKey) : -1;
-            const int n = fshost_search_align(s, cA.data(), c3.data(), (int) L, identity, ids.data(), (int) ids.size(), res.data());
-            if (n < 0) { if (!bad++) firstErr = fshost_search_error(s); break; }
-            std::string &out = results[id];
-            for (int k = 0; k < n; k++)
-                out.append(line.data(), fshost_format_result(line.data(), &res[k], fshost_search_backtrace(s, &res[k]), par.addBacktrace));
+            if (m == 0) continue;
+            if (fshost_search_align_batch(s, (int) m, pA.data(), p3.data(), Ls.data(), ident.data(), pT.data(), ns.data(), pR.data(), nres.data()) != FSGPU_OK) {
+                if (!bad++) firstErr = fshost_search_error(s);
+                break;
+            }
+            for (size_t k = 0; k < m; k++) {
+                std::string &out = results[entry[k]];
+                for (int r = 0; r < nres[k]; r++)
+                    out.append(line.data(), fshost_format_result(line.data(), &res[k][r], fshost_search_backtrace(s, &res[k][r]), par.addBacktrace));
+            }
         }
         fshost_search_free(s);
         if (tix > 0) fsgpu_destroy(ctx);
