@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--group", type=int, default=8, help="queries a host thread prefilters back to back before ONE multi-query SW launch (0: one SW launch per query)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
-    ap.add_argument("--kmer-queries", type=int, default=128, help="queries of the k-mer prefilter section (batches of 32)")
+    ap.add_argument("--kmer-threads", type=int, default=3, help="host threads (context clones) of the k-mer section")
+    ap.add_argument("--kmer-queries", type=int, default=384, help="queries of the k-mer prefilter section (batches of 32)")
     ap.add_argument("--kmer-cpu-queries", type=int, default=256, help="queries the reference k-mer prefilter is timed on")
     ap.add_argument("--cpu-sample-targets", type=int, default=20000)
     return ap.parse_args()
@@ -93,6 +94,7 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     Every rank builds its own index from the broadcast DB (no collective) and searches its own queries."""
     import threading
     nqk = max(32, args.kmer_queries // 32 * 32)
+
     q3, qa = synth.make_queries(nqk, seed=5000 + rank, lo=250, hi=450)
     m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
     thr = api.kmer_threshold(9.5, 6)
@@ -100,8 +102,9 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     ctx0.kmer_index_build(m8, kmer_thr=thr)
     t_index = time.perf_counter() - t0
     # a clone made now shares the resident DB and the index; two host threads keep the device busy during the host tails
-    kctx = [ctx0, ctx0.clone()]
-    ksearch = [search0, api.Search(kctx[1], par)]
+    KT = max(1, args.kmer_threads)
+    kctx = [ctx0] + [ctx0.clone() for _ in range(KT - 1)]
+    ksearch = [search0] + [api.Search(c, par) for c in kctx[1:]]
     prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in q3]
     batches = [list(range(b, b + 32)) for b in range(0, nqk, 32)]
     stat = {"dev": [], "lists": [], "counts": [], "hits": 0, "aln": 0, "t_pref": 0.0, "t_aln": 0.0, "hq": 0}
@@ -124,15 +127,16 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
                 stat["bad"] = stat.get("bad", 0) + int((status < 0).sum())
         return res
 
-    run(0, batches[0], False); run(1, batches[0], False)          # warm both host threads / contexts
-    ready, go = threading.Barrier(3), threading.Barrier(3)
+    for t in range(KT):
+        run(t, batches[0], False)                                 # warm every host thread's context
+    ready, go = threading.Barrier(KT + 1), threading.Barrier(KT + 1)
 
     def worker(t):
         ready.wait(); go.wait()
-        for b in range(t, len(batches), 2):
+        for b in range(t, len(batches), KT):
             run(t, batches[b], True)
 
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(KT)]
     for th in ths:
         th.start()
     ready.wait()
@@ -147,7 +151,10 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     # solo batch on an idle GPU for the roofline of the dominant kernel
     run(0, batches[-1], False)
     solo_ms, solo_cnt = kctx[0].kmer_stage_ms(), kctx[0].kmer_counts()
-    ksearch[1].close(); kctx[1].close()
+    for x in ksearch[1:]:
+        x.close()
+    for c in kctx[1:]:
+        c.close()
     if rank != 0:
         return None
     probes = float(solo_cnt[0])
@@ -165,7 +172,7 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
            "value": world * nqk * db.residues / dt, "unit": "residues/s", "queries_per_s": world * nqk / dt,
            "ms_per_query": 1e3 * dt / nqk, "prefilter_ms_per_query_host_wall": 1e3 * stat["t_pref"] / nqk,
            "align_ms_per_query_host_wall": 1e3 * stat["t_aln"] / nqk, "sw_kernels_ms_per_batch32": float(np.mean(stat["sw"])), "prefilter_device_ms_per_query": float(np.sum(stat["dev"])) / nqk,
-           "index_build_s": t_index, "index_entries": int(ctx0.kmer_index_entries), "kmer_threshold": thr,
+           "host_threads": KT, "index_build_s": t_index, "index_entries": int(ctx0.kmer_index_entries), "kmer_threshold": thr,
            "similar_kmers_per_query": float(np.mean([c[0] for c in stat["counts"]])) / 32, "index_hits_per_query": float(np.mean([c[1] for c in stat["counts"]])) / 32,
            "candidates_per_query": float(np.mean([c[2] for c in stat["counts"]])) / 32,
            "hits_per_query": stat["hits"] / nqk, "alignments_per_query": stat["aln"] / nqk, "unsupported_queries": stat.get("bad", 0),
