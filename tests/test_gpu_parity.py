@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def small_db():
-    q3, qa = synth.make_queries(6, seed=5, mean_len=250, lo=20, hi=500)
+    q3, qa = synth.make_queries(8, seed=5, mean_len=250, lo=20, hi=500)
     # force a spread of query lengths over the kernel's register-tile variants
     rng = np.random.default_rng(77)
-    for i, L in enumerate((20, 64, 130, 260, 390, 512)):
+    for i, L in enumerate((20, 100, 130, 230, 260, 350, 390, 512)):      # SW register classes R = 1,2,3,4,6,8 (two lengths each for 6 and 8)
         q3[i] = rng.choice(20, size=L).astype(np.uint8)
         qa[i] = rng.choice(20, size=L).astype(np.uint8)
     db = synth.make_db(2500, (q3, qa), seed=7, homologs_per_query=40, mask_frac=0.02)
@@ -30,7 +30,7 @@ def test_db_bookkeeping(small_db):
     assert ctx.residues == db.residues
 
 
-@pytest.mark.parametrize("qi", range(6))
+@pytest.mark.parametrize("qi", range(8))
 @pytest.mark.parametrize("comp_bias", [True, False])
 def test_gapless_scores_and_hits(small_db, qi, comp_bias):
     ctx, db, q3, _ = small_db
@@ -62,7 +62,7 @@ def test_gapless_identity_and_truncation(small_db):
 
 
 @pytest.mark.parametrize("atype", [2, 0])
-@pytest.mark.parametrize("qi", range(6))
+@pytest.mark.parametrize("qi", range(8))
 def test_sw_score_endpos(small_db, qi, atype):
     ctx, db, q3, qa = small_db
     mAA = api.Matrix(1, 1.4 if atype == 2 else 0.0)
@@ -222,7 +222,7 @@ def test_align_batch_equals_per_query_align():
     per-query calls return: mixed lengths across all register classes, a row-tiled long query, an empty hit list, a pair
     that saturates int16 (int32 re-run), both alignment types; complete result records and backtraces."""
     rng = np.random.default_rng(123)
-    lens = [40, 70, 130, 200, 260, 350, 380, 500, 512, 700, 33]
+    lens = [40, 70, 130, 200, 260, 300, 350, 380, 420, 447, 500, 512, 700, 33]
     q3 = [rng.choice(20, size=L, p=synth.BACK_3DI / synth.BACK_3DI.sum()).astype(np.uint8) for L in lens]
     qa = [rng.choice(20, size=L, p=synth.BACK_AA / synth.BACK_AA.sum()).astype(np.uint8) for L in lens]
     # a self-scoring monster: 3Di 'M' / AA 'W' repeated -> int16 saturation against its planted copy
