@@ -76,6 +76,8 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p);
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamDestroy(ctx->swAux[i]);
+    for (int i = 0; i < 7; i++) if (ctx->swAuxEv[i]) (void) hipEventDestroy(ctx->swAuxEv[i]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -419,19 +421,19 @@ static int launchSw(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nPa
 
 // multi-query launch: one workgroup (4 waves) per SwBlockDesc
 template <int R, bool HAS_AA>
-static int launchSwBlocksT(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks) {
+static int launchSwBlocksT(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
     const int lds = (HAS_AA ? 2 : 1) * kAlphabet * swRowDwords(R) * 4;
     static thread_local bool attrSet = false;
     if (!attrSet) {
         HIPCHK(hipFuncSetAttribute((const void *) k_sw<R, HAS_AA, Pk16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_sw<R, HAS_AA, Pk16>), dim3(nBlocks), dim3(256), lds, ctx->stream, sa);
+    hipLaunchKernelGGL((k_sw<R, HAS_AA, Pk16>), dim3(nBlocks), dim3(256), lds, stream, sa);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
-static int launchSwBlocks(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks) {
-#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocksT<RR, true>(ctx, sa, nBlocks) : launchSwBlocksT<RR, false>(ctx, sa, nBlocks);
+static int launchSwBlocks(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks, hipStream_t stream) {
+#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocksT<RR, true>(ctx, sa, nBlocks, stream) : launchSwBlocksT<RR, false>(ctx, sa, nBlocks, stream);
     switch (R) {
         FS_SW_CASE(1) FS_SW_CASE(2) FS_SW_CASE(3) FS_SW_CASE(4) FS_SW_CASE(6) FS_SW_CASE(8)
         default: ctx->err = "internal: bad SW R"; return FSGPU_E_ARG;
@@ -698,7 +700,17 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
             }
         }
         HIPCHK(hipMemcpyAsync(ctx->img.p, ctx->hImg.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
+        // every register-class group gets its own stream: their long-target tails overlap instead of queueing up
+        if (groups.size() > 1) {
+            if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
+            for (size_t gi = 1; gi < groups.size(); gi++)
+                if (!ctx->swAux[gi]) HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[gi], hipStreamNonBlocking));
+            HIPCHK(hipEventRecord(ctx->swAuxEv[6], ctx->stream));          // inputs (ids, images, descriptors) are on their way
+        }
+        size_t gi = 0;
         for (const Group &g : groups) {
+            hipStream_t gs = gi == 0 ? ctx->stream : ctx->swAux[gi];
+            if (gi > 0) HIPCHK(hipStreamWaitEvent(gs, ctx->swAuxEv[6], 0));
             SwArgs sa;
             sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
             sa.targetIds = (const uint32_t *) ctx->tids.p; sa.nPairs = (int) total;
@@ -709,8 +721,10 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
             sa.tileIn = 0; sa.tileOut = 0; sa.borderIn = nullptr; sa.borderOut = nullptr; sa.borderStride = 0; sa.keys = nullptr;
             sa.res0 = (int32_t *) ctx->res0.p; sa.res1 = (int32_t *) ctx->res1.p;
             sa.blocks = (const SwBlockDesc *) ((const unsigned char *) ctx->img.p + descOff) + g.blk0;
-            rc = launchSwBlocks(ctx, g.R, hasAA, sa, (int) g.nblk);
+            rc = launchSwBlocks(ctx, g.R, hasAA, sa, (int) g.nblk, gs);
             if (rc != FSGPU_OK) return rc;
+            if (gi > 0) { HIPCHK(hipEventRecord(ctx->swAuxEv[gi], gs)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[gi], 0)); }
+            gi++;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));

@@ -75,6 +75,8 @@ struct fsgpu_ctx {
     bool gaplessPending = false;
 
     // sw scratch
+    hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
+    hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf img, tids, res0, res1, border0, border1, keys;
     PinBuf hRes0, hRes1;                           // pinned result staging
     struct {
