@@ -321,7 +321,9 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
             std::vector<Key> ks(el.size());
             for (size_t i = 0; i < el.size(); i++) { uint32_t bin; const uint64_t ok = orderKey(el[i], bin); ks[i] = {el[i].count, bin, ok, &el[i]}; }
             std::sort(ks.begin(), ks.end(), arrayOrder);
-            int maxSelf = scalarDiag(q.profile, q.L, q.seq) - 255;
+            std::vector<uint8_t> clean(q.L);       // Sequence::numSequence of the query: soft-mask flag dropped
+            for (int i = 0; i < q.L; i++) { uint8_t c = q.seq[i]; c = c >= 32 ? c - 32 : c; clean[i] = c > 20 ? 20 : c; }
+            int maxSelf = scalarDiag(q.profile, q.L, clean.data()) - 255;
             maxSelf = std::max(1, maxSelf);
             maxSelf = std::min(maxSelf, 65535);
             const float fmax = (float) maxSelf;

@@ -177,3 +177,18 @@ def test_unstable_sort_branch_matches_compiled_reference():
     for q in range(len(q3)):
         assert len(res[q]) == len(rr[q]) and (res[q] == rr[q]).all(), (q, size, status[q])
     ctx.close()
+
+
+def test_masked_query_through_the_rescoring_path(world):
+    """a database member carrying soft-mask flags (+32) as query with --max-seqs 1: the cut sits at 255, so rescoreHits
+    computes the query's self score from its UNMASKED codes (found by tools/kmer_fuzz.py)"""
+    o = world["o"]
+    o.set(maxResListLen=1, bins=0, maxDbMatches=3000, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=30)
+    cands = [i for i, t in enumerate(world["targets"]) if (t >= 32).any() and len(t) > 200][:4]
+    assert cands
+    qs = [world["targets"][i].copy() for i in cands]
+    res, status, _ = run_gpu(world, dict(maxResListLen=1, maxDbMatches=3000), qs, None)
+    for k, q in enumerate(qs):
+        b, _ = o.query(q, -1)
+        assert status[k] == 0 and len(res[k]) == len(b) == 1 and (res[k] == b).all(), (k, res[k], b)
+        assert res[k][0]["id"] == cands[k] and res[k][0]["score"] > 255
