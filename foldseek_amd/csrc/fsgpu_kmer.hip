@@ -481,10 +481,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     CHK(ensureK(ctx, S.listP, (nLists + 1) * sizeof(uint64_t)));
     if (nLists) {
         RPCHK(hipEventRecord(S.ev[10], st));
-        hipLaunchKernelGGL(k_kmer_lists<false>, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
-                           (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
-                           (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
-        hipLaunchKernelGGL(k_kmer_lists<true>, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+        hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
                            (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
                            (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
         RPCHK(hipGetLastError());

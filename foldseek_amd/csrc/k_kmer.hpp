@@ -201,7 +201,16 @@ __device__ inline int countGE(const int16_t *row, int n, int cut) {
     return lo;
 }
 
-struct KmerPosInfo { int a, b, thr, n1; bool skip; };
+// Similar k-mers of one query position (KmerGenerator::generateKmerList for k = 6 = 3 + 3): with S1 / S2 the sorted
+// score rows of the first / last 3-mer, the list is  { (x, y) : S1[x] >= thr - S2[0],  S2[y] >= thr - S1[x] }  in
+// x-major order.  The inner bound depends on x only through the VALUE S1[x], and a row holds a few dozen distinct values
+// among its passing entries, so the staircase is described by one RUN per distinct value v (from S1[0] downwards):
+//   xs(v) = #{S1 > v},  len(v) = #{S1 == v},  c(v) = #{S2 >= thr - v}.
+// One thread per value builds the runs with three binary searches; the r-th k-mer of the position is then found by a
+// search over at most a few hundred run offsets in LDS (3 KB per workgroup instead of staged row prefixes).
+constexpr int kMaxRuns = 1024;                // distinct score values between cutoff and row maximum (< 3 * 256)
+
+struct KmerPosInfo { int a, b, thr, vmax, nV; bool skip; };
 
 __device__ inline KmerPosInfo kmerPosInfo(const KmerQ &q, const uint8_t *seqs, const int16_t *thrs, uint32_t p, KmerPattern pat, const int16_t *s3) {
     KmerPosInfo r;
@@ -215,12 +224,20 @@ __device__ inline KmerPosInfo kmerPosInfo(const KmerQ &q, const uint8_t *seqs, c
     r.a = (int) (c[0] + 20 * c[1] + 400 * c[2]);
     r.b = (int) (c[3] + 20 * c[4] + 400 * c[5]);
     r.thr = thrs[p];
-    r.n1 = 0;
+    r.vmax = 0; r.nV = 0;
     if (!x) {
-        const int cutoff1 = (int) (int16_t) (r.thr - s3[(size_t) r.b * kRow3]);
-        r.n1 = countGE(s3 + (size_t) r.a * kRow3, kRow3, cutoff1);
+        const int cutoff1 = (int) (int16_t) (r.thr - s3[(size_t) r.b * kRow3]);      // short cutoff1 = threshold - possibleRest[0]
+        r.vmax = s3[(size_t) r.a * kRow3];
+        r.nV = r.vmax >= cutoff1 ? min(r.vmax - cutoff1 + 1, kMaxRuns) : 0;
     }
     return r;
+}
+
+// run of value v = vmax - t: first x, number of x, inner list length c
+__device__ inline void kmerRun(const int16_t *S1, const int16_t *S2, int thr, int v, int &xs, int &len, int &c) {
+    xs = countGE(S1, kRow3, v + 1);
+    len = countGE(S1, kRow3, v) - xs;
+    c = len ? countGE(S2, kRow3, (int) (int16_t) (thr - v)) : 0;                       // short cutoff2 = threshold - score_i - possibleRest
 }
 
 // pass 1: K_p = number of similar k-mers of position p (capped like calculateArrayProduct)
@@ -233,27 +250,22 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_count(const KmerQ *qs, cons
     __shared__ unsigned long long total;
     if (threadIdx.x == 0) { info = kmerPosInfo(q, seqs, thrs, p, pat, s3); total = 0; }
     __syncthreads();
-    if (info.skip) { if (threadIdx.x == 0) K[p] = 0; return; }
+    if (info.skip || info.nV == 0) { if (threadIdx.x == 0) K[p] = 0; return; }
     const int16_t *S1 = s3 + (size_t) info.a * kRow3, *S2 = s3 + (size_t) info.b * kRow3;
     unsigned long long mine = 0;
-    for (int x = threadIdx.x; x < info.n1; x += blockDim.x) {
-        const int cutoff2 = (int) (int16_t) (info.thr - S1[x]);
-        mine += (unsigned) countGE(S2, kRow3, cutoff2);
+    for (int t = threadIdx.x; t < info.nV; t += blockDim.x) {
+        int xs, len, c;
+        kmerRun(S1, S2, info.thr, info.vmax - t, xs, len, c);
+        mine += (unsigned long long) len * (unsigned) c;
     }
-    atomicAdd(&total, mine);
+    if (mine) atomicAdd(&total, mine);
     __syncthreads();
     if (threadIdx.x == 0) K[p] = (uint32_t) (total < (unsigned long long) (kMaxKmerResult - 1) ? total : (kMaxKmerResult - 1));
 }
 
-// pass 2: enumerate the similar k-mers of position p in the reference's order, probe the index table and write one
-// (entry start, size, position) triple per k-mer into the list arrays at Kbase[p].  The part of the two sorted 3-mer
-// rows that can pass the threshold (typically a few hundred entries) is staged in LDS, so the only HBM traffic left is
-// the random 8-byte probe of the offset table per k-mer -- the roofline of this kernel.
-// Two instantiations: STAGE = 1024 covers practically every position (a few hundred row entries pass the threshold)
-// with 12 KB of LDS, so 8 workgroups per CU hide the probe latency; BIG handles the rare positions whose passing row
-// prefix is longer (very low thresholds) straight from global memory with the full 8001-entry prefix array.
-constexpr int kStage = 1024;
-template <bool BIG>
+// pass 2: enumerate the similar k-mers of position p in the reference's order, probe bitmap + offset table and write one
+// (entry start, size, position) triple per k-mer into the list arrays at Kbase[p].  HBM traffic = one sector per
+// non-empty list + the list arrays; everything else is served by LDS / L1 / L2.
 __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
                                                            uint32_t nPos, KmerPattern pat, const int16_t *s3, const uint16_t *i3,
                                                            const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets, const uint32_t *bitmap,
@@ -263,51 +275,36 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     const uint32_t Kp = Kcount[p];
     if (Kp == 0) return;
     const KmerQ q = qs[posQuery[p]];
-    constexpr int NOX = BIG ? kRow3 : kStage;
-    constexpr int NST = BIG ? 1 : kStage;
     __shared__ KmerPosInfo info;
-    __shared__ int c0s;
-    __shared__ uint32_t ox[NOX + 1];          // exclusive prefix of c_x
-    __shared__ uint32_t part[kKmerBlock + 1];
-    __shared__ int16_t s1[NST], s2[NST];
-    __shared__ uint16_t j1[NST], j2[NST];
-    if (threadIdx.x == 0) {
-        info = kmerPosInfo(q, seqs, thrs, p, pat, s3);
-        // longest inner list: c_0 = #{S2 >= thr - S1[0]}
-        c0s = countGE(s3 + (size_t) info.b * kRow3, kRow3, (int) (int16_t) (info.thr - s3[(size_t) info.a * kRow3]));
-    }
+    __shared__ uint32_t runOx[kMaxRuns + 1];  // exclusive prefix of len * c over the runs
+    __shared__ uint16_t runXs[kMaxRuns], runC[kMaxRuns];
+    __shared__ uint32_t wsum[kKmerBlock / 64];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) { info = kmerPosInfo(q, seqs, thrs, p, pat, s3); carry = 0; }
     __syncthreads();
     const int16_t *S1 = s3 + (size_t) info.a * kRow3, *S2 = s3 + (size_t) info.b * kRow3;
     const uint16_t *I1 = i3 + (size_t) info.a * kRow3, *I2 = i3 + (size_t) info.b * kRow3;
-    const int n1 = info.n1, c0 = c0s;
-    const bool small = n1 <= kStage && c0 <= kStage;
-    if (small == BIG) return;                 // the other instantiation owns this position
-    if (!BIG) {
-        for (int i = threadIdx.x; i < n1; i += kKmerBlock) { s1[i] = S1[i]; j1[i] = I1[i]; }
-        for (int i = threadIdx.x; i < c0; i += kKmerBlock) { s2[i] = S2[i]; j2[i] = I2[i]; }
+    const int nV = info.nV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t0 = 0; t0 < nV; t0 += kKmerBlock) {
+        const int t = t0 + threadIdx.x;
+        int xs = 0, len = 0, c = 0;
+        if (t < nV) kmerRun(S1, S2, info.thr, info.vmax - t, xs, len, c);
+        const uint32_t prod = (uint32_t) len * (uint32_t) c;
+        // block exclusive scan of prod in thread order
+        uint32_t incl = prod;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (t < nV) { runOx[t] = before + incl - prod; runXs[t] = (uint16_t) xs; runC[t] = (uint16_t) c; }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t sum = carry; for (int w = 0; w < kKmerBlock / 64; w++) sum += wsum[w]; carry = sum; }
         __syncthreads();
     }
-    // each thread owns a contiguous slice of x so that a two-level scan gives the exclusive prefix
-    const int per = (n1 + kKmerBlock - 1) / kKmerBlock;
-    const int x0 = min(n1, (int) threadIdx.x * per), x1 = min(n1, x0 + per);
-    uint32_t sum = 0;
-    for (int x = x0; x < x1; x++) {
-        uint32_t c;
-        if (!BIG) c = (uint32_t) countGE(s2, c0, (int) (int16_t) (info.thr - s1[x]));
-        else c = (uint32_t) countGE(S2, kRow3, (int) (int16_t) (info.thr - S1[x]));
-        ox[x] = sum;
-        sum += c;
-    }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int t = 0; t < kKmerBlock; t++) { const uint32_t v = part[t]; part[t] = acc; acc += v; }
-        part[kKmerBlock] = acc;
-    }
-    __syncthreads();
-    for (int x = x0; x < x1; x++) ox[x] += part[threadIdx.x];
-    if (threadIdx.x == 0) ox[n1] = part[kKmerBlock];
+    if (threadIdx.x == 0) runOx[nV] = carry;
     __syncthreads();
     const uint64_t base = Kbase[p];
     for (uint32_t r0 = threadIdx.x; r0 < Kp; r0 += 4 * kKmerBlock) {
@@ -317,10 +314,11 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
             const uint32_t r = r0 + u * kKmerBlock;
             kmer[u] = 0;
             if (r < Kp) {
-                int lo = 0, hi = n1;          // last x with ox[x] <= r (c_x >= 1 for every x < n1)
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ox[mid] <= r) lo = mid; else hi = mid; }
-                const uint32_t y = r - ox[lo];
-                kmer[u] = !BIG ? kmerDeviceIndex(j1[lo], j2[y]) : kmerDeviceIndex(I1[lo], I2[y]);
+                int lo = 0, hi = nV;          // last run with runOx <= r (empty runs share their offset with the successor)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (runOx[mid] <= r) lo = mid; else hi = mid; }
+                const uint32_t d = r - runOx[lo], c = runC[lo];
+                const uint32_t dx = d / c;
+                kmer[u] = kmerDeviceIndex(I1[runXs[lo] + dx], I2[d - dx * c]);
             }
         }
         uint32_t bm[4];
