@@ -107,6 +107,38 @@ def test_prefilter_module_matches_oracle(tmp_path, padded):
         exp = "".join(api.format_prefilter_hit(int(keys_t[h["id"]]), int(h["score"]), int(np.int16(h["diag"]))) for h in hits)
         assert d[k].decode() == exp, i
         assert len(hits) > 0
+    # the workflow chain of structuresearch.sh with the k-mer prefilter: prefilter -> structurealign (3Di+AA) on disk
+    qa_db = str(tmp_path / "query")
+    dbio.write_seq_db(qa_db, qa, qkeys)
+    os.rename(qdb, qa_db + "_ss"); os.rename(qdb + ".index", qa_db + "_ss.index"); os.rename(qdb + ".dbtype", qa_db + "_ss.dbtype")
+    ta_db = str(tmp_path / "target")
+    if padded:
+        dbio.write_padded_db(ta_db, db, "aa")
+    else:
+        dbio.write_seq_db(ta_db, [db.dataaa[db.offsets[i]:db.offsets[i] + db.lengths[i]] for i in range(db.n)], keys_t)
+    for ext in ("", ".index", ".dbtype"):
+        os.rename(tdb + ext, ta_db + "_ss" + ext)
+    tdb = ta_db + "_ss"
+    aln = str(tmp_path / "aln")
+    subprocess.check_call([BIN, "structurealign", qa_db, ta_db, out, aln, "--alignment-type", "2", "-a", "--threads", "2", "-e", "10"])
+    ta_, da_ = dbio.read_db(aln)
+    assert ta_ & 0xffff == 5
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    par = api.default_params()
+    par.alignmentType = 2
+    par.addBacktrace = 1
+    s = api.Search(ctx, par, keys=keys_t)
+    naln = 0
+    for i, k in enumerate(qkeys):
+        hits, _ = o.query(q3[i], -1)
+        res, bts = s.align(qa[i], q3[i], hits["id"], with_backtrace=True)
+        exp = "".join(s.format_result(res[j:j + 1], bts[j], True) for j in range(len(res)))
+        assert da_[k].decode() == exp, i
+        naln += len(res)
+    assert naln > 0
+    s.close()
+    ctx.close()
     if not padded:
         # all-vs-all on the first 200 targets' worth of queries is too slow for the oracle; check identity handling on 3
         out2 = str(tmp_path / "pref_self")
