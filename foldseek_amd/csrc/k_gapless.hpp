@@ -153,6 +153,10 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                     // last lane: its bottom row (high half of the last register) is the next tile's input
                     const uint32_t v = S[R - 1] >> 16;
                     bo[b >> 1] |= (b & 1) ? (v << 16) : v;
+                    // Without an ordering point per column the compiler hoists the LDS profile reads of all 16 unrolled
+                    // columns above the border bookkeeping: 256 VGPRs + 346 spilled (kernel 12x slower).  An empty asm that
+                    // ties the border word to the running maximum pins each column's work in place: 92 VGPRs, no scratch.
+                    asm volatile("" : "+v"(bo[b >> 1]), "+v"(M));
                 }
             }
             if constexpr (TILED) {
