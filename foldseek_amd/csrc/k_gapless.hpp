@@ -7,8 +7,12 @@
 //
 // Mapping (not the CPU's striping, not a CUDA warp tiling):
 //   * 8 lanes x 2 strips x R registers hold one target's DP column; 8 targets per wave64.
-//   * scores live in packed int16 pairs biased by INT16_MIN: v_pk_add_i16 clamp performs "add, floor at zero"
-//     in ONE instruction, v_pk_max_i16 the running maximum -> 2 VALU ops per 2 cells.
+//   * scores live in packed FP16 pairs scaled by 2^-11 (score s is stored as s/2048): every integer 0..2048 and every
+//     profile entry is exact in FP16, "v_pk_add_f16 clamp" performs add + floor at zero (+ cap at 2048, far above the
+//     255 - bias the result is cut to) in ONE instruction, and gfx950's three-operand v_pk_maximum3_f16 folds TWO score
+//     registers into the running maximum per instruction -> 3 VALU ops per 4 cells (the int16 formulation needs 4:
+//     there is no packed integer max3).  Exactness: a diagonal that ever exceeds 2048 already pins its target at the
+//     cap, below that all sums are exact, so the result equals the integer recurrence bit for bit (tests).
 //   * the 22 x (16R) int16 profile sits in LDS in a 2-copy, bank-row aligned image: all ds_read_b128 are
 //     conflict free (fs_kernels.h).  LDS bytes/cell = 2, VALU ops/cell = 1: the two CU resources are balanced.
 //   * the target DB is pre-tiled in HBM as 8-target stripes interleaved at 16-byte granularity: one wave-level
@@ -17,6 +21,7 @@
 //   * waves pull stripes from an atomic queue ordered by descending length (LPT), so the tail is short.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include "fs_kernels.h"
 
 namespace fs {
@@ -29,6 +34,23 @@ __device__ __forceinline__ uint32_t pk_adds_i16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+
+// FP16-domain helpers (scores scaled by 2^-11)
+__device__ __forceinline__ uint32_t pk_addc_f16(uint32_t a, uint32_t b) {      // clamp(a + b, 0, 1) per half
+    uint32_t d;
+    asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// bits of the FP16 value i / 2048 for a small integer i (|i| <= 2048): exact
+__device__ __forceinline__ uint32_t f16ScaledBits(int i) {
+    return (uint32_t) __half_as_ushort(__float2half_rn((float) i * (1.0f / 2048.0f)));
+}
+constexpr uint32_t kDead2 = 0xBC00BC00u;     // packed (-1.0, -1.0): a dead profile row forces the cell to zero
 
 struct GaplessArgs {
     const uint4 *scan;          // stripe-interleaved target residues (codes 0..20, 21 = past end)
@@ -67,11 +89,11 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
             int qlo = a.tileBase + g * 2 * R + r, qhi = qlo + R;
             uint32_t v;
             if (row == kDeadCode) {
-                v = kFloor2;
+                v = kDead2;
             } else {
                 int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
                 int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
-                v = ((uint32_t) (uint16_t) (int16_t) lo) | (((uint32_t) (uint16_t) (int16_t) hi) << 16);
+                v = f16ScaledBits(lo) | (f16ScaledBits(hi) << 16);
             }
             *(uint32_t *) (smem + row * ROWB + k * 256 + copy * 128 + g * 16 + w * 4) = v;
         }
@@ -98,12 +120,12 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
         // border arrays use the scan layout at 2 bytes per residue: 32 bytes per (chunk, target)
         const uint4 *bin = TILED ? (const uint4 *) a.borderIn + (soff + j) * 2 : nullptr;
         uint4 *bout = TILED ? (uint4 *) a.borderOut + (soff + j) * 2 : nullptr;
-        uint32_t carryPrevChunk = kFloor2 & 0xffffu;      // border value of the column before this chunk (biased)
+        uint32_t carryPrevChunk = 0;                      // border value of the column before this chunk
 
         uint32_t S[R];
-        uint32_t M = kFloor2;
+        uint32_t M = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) S[r] = kFloor2;
+        for (int r = 0; r < R; r++) S[r] = 0;
 
         uint4 nxt = src[0];
         for (uint32_t c = 0; c < len16; c++) {
@@ -117,7 +139,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                     bi[0] = x0.x; bi[1] = x0.y; bi[2] = x0.z; bi[3] = x0.w; bi[4] = x1.x; bi[5] = x1.y; bi[6] = x1.z; bi[7] = x1.w;
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) bi[k] = kFloor2;
+                    for (int k = 0; k < 8; k++) bi[k] = 0;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) bo[k] = 0;
@@ -133,22 +155,20 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                     P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
                 }
                 // diagonal hand-off
-                uint32_t prev = __builtin_amdgcn_update_dpp(kFloor2, S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+                uint32_t prev = __builtin_amdgcn_update_dpp(0u, S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, false);
                 if constexpr (TILED) {
                     // first lane: the diagonal enters from the previous row tile, column b - 1
                     const uint32_t fromTile = (b == 0) ? carryPrevChunk : ((b & 1) ? (bi[(b - 1) >> 1] & 0xffffu) : (bi[(b - 1) >> 1] >> 16));
                     prev = (g == 0) ? (fromTile << 16) : prev;
                 } else {
-                    prev = (g == 0) ? kFloor2 : prev;
+                    prev = (g == 0) ? 0u : prev;
                 }
                 const uint32_t in = __builtin_amdgcn_perm(prev, S[R - 1], sel);
 #pragma unroll
-                for (int r = R - 1; r >= 1; r--) {
-                    S[r] = pk_adds_i16(S[r - 1], P[r]);
-                    M = pk_max_i16(M, S[r]);
-                }
-                S[0] = pk_adds_i16(in, P[0]);
-                M = pk_max_i16(M, S[0]);
+                for (int r = R - 1; r >= 1; r--) S[r] = pk_addc_f16(S[r - 1], P[r]);
+                S[0] = pk_addc_f16(in, P[0]);
+#pragma unroll
+                for (int r = 0; r < R; r += 2) M = pk_max3_f16(M, S[r], S[r + 1]);
                 if constexpr (TILED) {
                     // last lane: its bottom row (high half of the last register) is the next tile's input
                     const uint32_t v = S[R - 1] >> 16;
@@ -167,8 +187,8 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                 }
             }
         }
-        // max over both strips and the 8 lanes of the group
-        int m = max((int) (int16_t) (M & 0xffff), (int) (int16_t) (M >> 16));
+        // max over both strips and the 8 lanes of the group; non-negative FP16 values order like their bit patterns
+        int m = max((int) (M & 0xffff), (int) (M >> 16));
         m = max(m, __shfl_xor(m, 1));
         m = max(m, __shfl_xor(m, 2));
         m = max(m, __shfl_xor(m, 4));
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                 if (!a.lastTile) a.scoreAcc[tid] = (int16_t) m;
             }
             if (!TILED || a.lastTile) {
-                int sc = m + 32768;
+                int sc = (int) (__half2float(__ushort_as_half((unsigned short) m)) * 2048.0f + 0.5f);
                 sc = sc < a.cap ? sc : a.cap;
                 a.scores[tid] = (uint8_t) sc;
             }

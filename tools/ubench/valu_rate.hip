@@ -40,6 +40,15 @@ KERNEL(k_sad_u8, OP8_3("v_sad_u8"))
 KERNEL(k_pk_mad_i16, OP8_3("v_pk_mad_i16"))
 KERNEL(k_pk_min_u16, OP8("v_pk_min_u16"))
 KERNEL(k_lshl_or, OP8_3("v_lshl_or_b32"))
+KERNEL(k_pk_maximum3_f16, OP8_3("v_pk_maximum3_f16"))
+KERNEL(k_pk_max_f16, OP8("v_pk_max_f16"))
+KERNEL(k_pk_add_f16_clamp, OP8S("v_pk_add_f16", "clamp"))
+KERNEL(k_max_f32, OP8("v_max_f32"))
+KERNEL(k_add_f32, OP8("v_add_f32"))
+KERNEL(k_maximum3_f32, OP8_3("v_maximum3_f32"))
+KERNEL(k_max3_f32, OP8_3("v_max3_f32"))
+KERNEL(k_max3_i16, OP8_3("v_max3_i16"))
+KERNEL(k_pk_fma_f16, OP8_3("v_pk_fma_f16"))
 KERNEL(k_bfi, OP8_3("v_bfi_b32"))
 
 __global__ void k_lds_b128(uint32_t *out, int iters) {
@@ -70,7 +79,8 @@ int main() {
     K ks[] = {{"v_pk_add_i16 clamp", k_pk_add_i16_clamp}, {"v_pk_add_i16", k_pk_add_i16}, {"v_pk_max_i16", k_pk_max_i16},
               {"v_pk_sub_u16 clamp", k_pk_sub_u16_clamp}, {"v_pk_min_u16", k_pk_min_u16}, {"v_pk_mad_i16", k_pk_mad_i16}, {"v_add_u32", k_add_u32}, {"v_max_i32", k_max_i32},
               {"v_max3_i32", k_max3_i32}, {"v_add3_u32", k_add3_u32}, {"v_and_b32", k_and_b32}, {"v_perm_b32", k_perm_b32},
-              {"v_lshl_or_b32", k_lshl_or}, {"v_bfi_b32", k_bfi},
+              {"v_lshl_or_b32", k_lshl_or}, {"v_bfi_b32", k_bfi}, {"v_pk_maximum3_f16", k_pk_maximum3_f16}, {"v_pk_max_f16", k_pk_max_f16}, {"v_pk_add_f16 clamp", k_pk_add_f16_clamp},
+              {"v_max_f32", k_max_f32}, {"v_add_f32", k_add_f32}, {"v_maximum3_f32", k_maximum3_f32}, {"v_max3_f32", k_max3_f32}, {"v_max3_i16", k_max3_i16}, {"v_pk_fma_f16", k_pk_fma_f16},
               {"v_fma_f32", k_fma_f32}, {"v_pk_add_f16", k_pk_fma_f32_dummy}, {"v_mov_dpp row_shr", k_mov_dpp}, {"v_mov_dpp wave_shr", k_mov_dpp_wave},
               {"v_dot4_i32_i8", k_dot4_i32_i8}, {"v_sad_u8", k_sad_u8}};
     const int iters = 2000;
