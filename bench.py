@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--steps", type=int, default=960)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1]), 2: 3Di+AA")
@@ -142,12 +142,16 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     ready.wait()
     import torch
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()            # a generation-2 collection of the interpreter (torch is imported: ~50 ms) would stall every feeder thread at once
     t0 = time.perf_counter()
     go.wait()
     for th in ths:
         th.join()
     torch.cuda.synchronize()
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    gc.enable()
     # solo batch on an idle GPU for the roofline of the dominant kernel
     run(0, batches[-1], False)
     solo_ms, solo_cnt = kctx[0].kmer_stage_ms(), kctx[0].kmer_counts()
@@ -215,6 +219,9 @@ def kmer_cpu_baseline(args, synth, db):
 
 def main():
     args = parse()
+    # host feeder threads spend their time inside the library (ctypes releases the GIL); a thread returning from a call
+    # must not wait a whole default switch interval (5 ms) for the GIL while another one runs a few Python lines
+    sys.setswitchinterval(1e-4)
     import torch
     import torch.distributed as dist
     from foldseek_amd import api, synth
@@ -262,6 +269,7 @@ def main():
     go = threading.Barrier(nthreads + 1)
 
     G = max(1, args.group)
+    trace, t_go = [], [0.0]
 
     def steps(t, ids):
         """G queries: G gapless scans back to back, then ONE multi-query SW launch over all their hit lists"""
@@ -279,6 +287,12 @@ def main():
         if args.warmup < nthreads:
             step(t, 0)
         steps(t, list(range(min(G, nq))))
+        # one query of every 64-row length class: the first launch of a kernel instantiation (lazy code-object load,
+        # attribute set-up, scratch growth) must not land in the timed region
+        cls = {}
+        for i in range(nq):
+            cls.setdefault((len(q3[i]) + 63) // 64, i)
+        steps(t, sorted(cls.values()))
         ready.wait()
         go.wait()
         mine = list(range(args.warmup, nq))
@@ -288,7 +302,11 @@ def main():
                 h1, r1 = step(t, g[0])
                 hl, rs, km = [h1], [r1], [ctxs[t].kernel_ms(0)]
             else:
+                tg = time.perf_counter()
                 hl, rs, km = steps(t, g)
+                if os.environ.get("FS_BENCH_TRACE"):
+                    with lock:
+                        trace.append((t, tg - t_go[0], time.perf_counter() - tg))
             with lock:
                 kms.extend(km); sms.append(ctxs[t].kernel_ms(1) / len(g))
                 counts[0] += sum(len(h) for h in hl); counts[1] += sum(len(r) for r in rs)
@@ -300,7 +318,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()            # a generation-2 collection of the interpreter (torch is imported: ~50 ms) would stall every feeder thread at once
     t0 = time.perf_counter()
+    t_go[0] = t0
     go.wait()
     for th in ths:
         th.join()
@@ -308,6 +330,10 @@ def main():
     if world > 1:
         dist.barrier()
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    gc.enable()
+    if os.environ.get("FS_BENCH_TRACE"):
+        for rec in sorted(trace, key=lambda r: r[1]):
+            print("trace thread %d start %.2f ms dur %.2f ms" % (rec[0], rec[1] * 1e3, rec[2] * 1e3), file=sys.stderr)
     # dominant-kernel duration for the roofline: HIP events around the kernel on the library's stream, measured on an
     # otherwise idle GPU (in the timed region above three queries overlap, which stretches each kernel's wall time)
     solo_g, solo_s = [], []
@@ -321,6 +347,7 @@ def main():
     if rank == 0:
         residues = db.residues
         value = world * args.steps * residues / dt
+        VALU_PEAK = 1024 * 64 * (4.0 / 3.0) / 4.3 * 2.4
         kavg = float(np.mean(solo_g)) * 1e-3
         kreg = float(np.mean(kms)) * 1e-3
         cells_reg = float(np.mean([len(q3[i]) for i in range(args.warmup, nq)])) * residues
@@ -339,7 +366,7 @@ def main():
             "metric": "residues aligned/sec (prefilter+align)",
             "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i16", "data": "synthetic",
+            "dtype": "f16 (integer-exact, scaled 2^-11) gapless scan + i16 SW", "data": "synthetic",
             "config": {"workload": f"1 query/step vs {db.n}-structure synthetic 3Di DB (mean len {residues / db.n:.0f}), "
                                    f"gapless prefilter (all targets) + top-1000 + fwd/rev structure SW "
                                    f"(--alignment-type {args.alignment_type}) + host gates/backtrace; each host thread prefilters "
@@ -356,13 +383,14 @@ def main():
                          "frac": alg_bytes / kreg / 1e9 / 8000.0, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                          "kernel": "k_gapless", "kernel_ms": kreg * 1e3,
                          "note": "the scan is VALU/LDS bound (Lq cell updates per target byte), see valu below and DESIGN.md",
-                         # 1 packed VALU lane-op per DP cell; v_pk_* issue once per 4.2 cycles per SIMD (measured,
-                         # profiles/r01_valu_lds_issue_rate_ubench.txt): 1024 SIMDs x 64 cells / 4.2 cyc x 2.4 GHz
-                         "valu": {"achieved_gcups": cells_reg / kreg / 1e9, "peak_gcups": 1024 * 64 / 4.2 * 2.4,
-                                  "frac": cells_reg / kreg / 1e9 / (1024 * 64 / 4.2 * 2.4),
+                         # 0.75 packed VALU lane-ops per DP cell (2 x v_pk_add_f16 clamp + 1 x v_pk_maximum3_f16 per 4 cells); these
+                         # issue once per 4.3 cycles per SIMD (measured, profiles/r01_valu_lds_issue_rate_ubench.txt):
+                         # 1024 SIMDs x 64 lanes x 4/3 cells / 4.3 cyc x 2.4 GHz
+                         "valu": {"achieved_gcups": cells_reg / kreg / 1e9, "peak_gcups": VALU_PEAK,
+                                  "frac": cells_reg / kreg / 1e9 / VALU_PEAK,
                                   "note": "concurrent launches share the SIMDs; device-level rate = launches in flight x this"},
                          "solo": {"kernel_ms": kavg * 1e3, "achieved": alg_bytes / kavg / 1e9, "frac": alg_bytes / kavg / 1e9 / 8000.0,
-                                  "valu_achieved_gcups": cells / kavg / 1e9, "valu_frac": cells / kavg / 1e9 / (1024 * 64 / 4.2 * 2.4)},
+                                  "valu_achieved_gcups": cells / kavg / 1e9, "valu_frac": cells / kavg / 1e9 / VALU_PEAK},
                          "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s))},
             "db_broadcast_s": t_bcast,
         }

@@ -122,7 +122,9 @@ inline int ensurePinned(fsgpu_ctx *ctx, PinBuf &b, size_t bytes) {
 inline int ensure(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.cap >= bytes && b.p) return FSGPU_OK;
     if (b.p) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-    size_t want = std::max(bytes, (size_t) 256);
+    // grow geometrically: request sizes vary from call to call (hit counts, register classes, batch composition) and
+    // every hipFree/hipMalloc pair stalls the stream for milliseconds
+    size_t want = std::max(bytes + bytes / 2, (size_t) 4096);
     HIPCHK(hipMalloc(&b.p, want));
     b.cap = want;
     return FSGPU_OK;
