@@ -70,13 +70,26 @@ def make_queries(nq, seed=1, mean_len=350.0, lo=30, hi=2000):
     return q3, qa
 
 
+def sticky(rng, seq, stay):
+    """Markov 'stay' chain over an i.i.d. string: with probability `stay` a residue repeats its predecessor -- runs and
+    low-complexity stretches like real 3Di strings (helix = long V/L runs, strand = D runs)."""
+    keep = rng.random(len(seq)) < stay
+    keep[0] = False
+    idx = np.where(~keep, np.arange(len(seq)), 0)
+    np.maximum.accumulate(idx, out=idx)
+    return seq[idx]
+
+
 def make_db(n, queries=None, seed=20260923, homologs_per_query=50, mask_frac=0.01, mean_len=350.0, lo=30, hi=2000,
-            x_frac=0.002):
-    """Returns PaddedDB. `queries` = (q3, qa) lists from make_queries to plant homologs of."""
+            x_frac=0.002, stay=0.0):
+    """Returns PaddedDB. `queries` = (q3, qa) lists from make_queries to plant homologs of.
+    stay > 0: 3Di letters repeat their predecessor with that probability (runs / low complexity)."""
     rng = np.random.default_rng(seed)
     lens = _lengths(rng, n, mean_len, lo, hi)
     total = int(lens.sum())
     flat3 = rng.choice(20, size=total, p=BACK_3DI / BACK_3DI.sum()).astype(np.uint8)
+    if stay > 0:
+        flat3 = sticky(rng, flat3, stay)
     flata = rng.choice(20, size=total, p=BACK_AA / BACK_AA.sum()).astype(np.uint8)
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     seqs3 = [flat3[s:s + l] for s, l in zip(starts, lens)]

@@ -192,3 +192,33 @@ def test_masked_query_through_the_rescoring_path(world):
         b, _ = o.query(q, -1)
         assert status[k] == 0 and len(res[k]) == len(b) == 1 and (res[k] == b).all(), (k, res[k], b)
         assert res[k][0]["id"] == cands[k] and res[k][0]["score"] > 255
+
+
+def test_low_complexity_database():
+    """3Di strings with long runs (sticky Markov chain, like helices / strands): repeat masking, popular k-mers with long
+    index lists, many more double-diagonal candidates and natural databaseHits refills at small N"""
+    O = K.load_ora()
+    rs = np.random.default_rng(5)
+    q3, qa = synth.make_queries(4, seed=61)
+    q3 = [synth.sticky(rs, q, 0.6) for q in q3]
+    db = synth.make_db(2500, (q3, qa), seed=62, homologs_per_query=20, stay=0.6)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    o = K.OraKpf(O, ksub, pb, usub, targets, maxResListLen=300, maxDbMatches=60000)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=78)
+    off, seq, pos, msk = ctx.kmer_index_reference_order(db.data3di.size)
+    ooff, oseq, opos = o.index()
+    assert (off == ooff).all() and (seq == oseq).all() and (pos == opos).all()
+    assert (msk == 20).sum() > (db.data3di == 20).sum() + 1000          # repeat masking really happened
+    res, status, stats = run_gpu(dict(ctx=ctx, m8=m8, m2=m2), dict(maxResListLen=300, maxDbMatches=60000), q3, None)
+    for i, q in enumerate(q3):
+        b, st = o.query(q, -1)
+        assert status[i] == 0 and np.allclose(stats[i], st)
+        assert len(res[i]) == len(b) and (res[i] == b).all(), i
+    assert stats[:, 2].sum() > 0
+    o.close()
+    ctx.close()

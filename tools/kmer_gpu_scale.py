@@ -6,9 +6,13 @@ from foldseek_amd import api, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 THREADS = int(sys.argv[3]) if len(sys.argv) > 3 else (os.cpu_count() or 8)
+STAY = float(os.environ.get("FS_STAY", "0"))
 R = K.load_ref()
 q3, qa = synth.make_queries(NQ, seed=1)
-t = time.time(); db = synth.make_db(N, (q3, qa)); print("db %.1fs residues=%d" % (time.time() - t, db.residues), flush=True)
+if STAY > 0:
+    rs = np.random.default_rng(99)
+    q3 = [synth.sticky(rs, q, STAY) for q in q3]
+t = time.time(); db = synth.make_db(N, (q3, qa), stay=STAY); print("db %.1fs residues=%d" % (time.time() - t, db.residues), flush=True)
 ctx = api.Context(0); ctx.load_db(db)
 m8 = api.Matrix(0, 8.0, -0.2); m2 = api.Matrix(0, 2.0, -0.2)
 t = time.time(); ctx.kmer_index_build(m8, kmer_thr=78); print("gpu index build %.2fs entries=%d" % (time.time() - t, ctx.kmer_index_entries), flush=True)
