@@ -490,7 +490,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     RPCHK(hipMemsetAsync((uint32_t *) S.listSize.p + nLists, 0, sizeof(uint32_t), st));
     CHK(scanExclusive32to64(ctx, S.tmp, (const uint32_t *) S.listSize.p, (uint64_t *) S.listP.p, nLists + 1));
     hipLaunchKernelGGL(k_kmer_qbases, dim3(gridFor(nq, 64)), dim3(64), 0, st, (KmerQ *) S.qs.p, nq, (const uint64_t *) S.Kbase.p, (const uint64_t *) S.listP.p);
-    hipLaunchKernelGGL(k_kmer_chunks, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.Kbase.p, (const uint64_t *) S.listP.p, maxDbMatches, (KmerChunks *) S.chunks.p);
+    hipLaunchKernelGGL(k_kmer_chunks, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.Kbase.p, (const uint64_t *) S.listP.p, (const uint32_t *) S.listPos.p, maxDbMatches, (KmerChunks *) S.chunks.p);
     RPCHK(hipGetLastError());
     RPCHK(hipMemcpyAsync(&misc[1], (uint64_t *) S.listP.p + nLists, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     RPCHK(hipMemcpyAsync(S.hChunks.p, S.chunks.p, (size_t) nq * sizeof(KmerChunks), hipMemcpyDeviceToHost, st));
@@ -615,6 +615,10 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             for (int r = q + 1; r < nq; r++) { le = hq2[r].listBase; break; }
             stats[q * 4 + 0] = queries[q].L > 0 ? (double) (le - hq2[q].listBase) / (double) queries[q].L : 0.0;
             stats[q * 4 + 1] = (double) hck[q].total;
+            if (hck[q].aborted == 1) {      // match() left its loop at that list (QueryMatcher.cpp:330-332): the statistics stop there too
+                stats[q * 4 + 0] = (double) hck[q].abortKmers / (double) queries[q].L;
+                stats[q * 4 + 1] = (double) hck[q].start[hck[q].nChunks - 1];
+            }
             stats[q * 4 + 2] = hck[q].nChunks > 1 ? 1.0 : 0.0;
             stats[q * 4 + 3] = (double) pickBins(sp, n);
         }

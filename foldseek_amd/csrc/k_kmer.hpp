@@ -52,6 +52,7 @@ struct KmerChunks {                // per query
     uint32_t nChunks;              // >= 1
     uint32_t aborted;              // a single list >= maxDbMatches (QueryMatcher.cpp:330-332)
     uint64_t total;                // hits of the query
+    uint64_t abortKmers;           // aborted == 1: similar k-mers of the positions up to and including the aborting one
     uint64_t start[kMaxChunks + 1];// start[c] = first stream position of chunk c; start[nChunks] = total
 };
 
@@ -348,7 +349,7 @@ __global__ void k_kmer_qbases(KmerQ *qs, int nq, const uint64_t *Kbase, const ui
 
 // databaseHits refills: chunk c+1 starts at the first list l with (hits of chunk c so far) + size(l) >= maxDbMatches
 // (QueryMatcher.cpp:302-333).  One thread per query; every step is a binary search over the list prefix array.
-__global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, const uint64_t *listP, uint64_t maxDbMatches, KmerChunks *out) {
+__global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, const uint64_t *listP, const uint32_t *listPos, uint64_t maxDbMatches, KmerChunks *out) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint64_t lb = Kbase[qs[q].posBase], le = Kbase[qs[q].posBase + qs[q].nPos];
@@ -356,6 +357,7 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
     KmerChunks &c = out[q];
     c.total = listP[le] - base;
     c.aborted = 0;
+    c.abortKmers = 0;
     c.start[0] = 0;
     uint32_t nc = 1;
     uint64_t cur = lb, G = 0;
@@ -366,7 +368,7 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
         while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid + 1] >= want) hi = mid; else lo = mid + 1; }
         if (lo >= le) break;
         const uint64_t G2 = listP[lo] - base;
-        if (listP[lo + 1] - listP[lo] >= maxDbMatches) c.aborted = 1;
+        if (listP[lo + 1] - listP[lo] >= maxDbMatches) { c.aborted = 1; c.abortKmers = Kbase[listPos[lo] + 1] - lb; }
         if (nc >= (uint32_t) kMaxChunks) { c.aborted = 2; break; }
         c.start[nc++] = G2;
         if (c.aborted) break;

@@ -16,7 +16,7 @@ for rd in range(rounds):
     qa = [rng.integers(0, 21 if rng.random() < 0.3 else 20, size=L).astype(np.uint8) for L in lens]
     big = [q for q in zip(q3, qa) if len(q[0]) >= 30]
     db = synth.make_db(n, ([b[0] for b in big], [b[1] for b in big]) if big and n > 60 else None, seed=int(rng.integers(1 << 30)),
-                       homologs_per_query=int(rng.integers(1, 12)), mask_frac=float(rng.choice([0, 0.05])), mean_len=float(rng.choice([30, 150, 350])), lo=1, hi=1400)
+                       homologs_per_query=int(rng.integers(1, 12)), mask_frac=float(rng.choice([0, 0.05])), mean_len=float(rng.choice([30, 150, 350])), lo=1, hi=1400, stay=float(rng.choice([0.0, 0.0, 0.5, 0.8])))
     atype = int(rng.choice([0, 2])); cb = bool(rng.integers(0, 2)); max_res = int(rng.choice([1, 5, 50, 1000]))
     ctx = api.Context(0); ctx.load_db(db)
     par = api.default_params(); par.alignmentType = atype; par.compBiasCorrection = int(cb); par.maxResListLen = max_res

@@ -17,7 +17,7 @@ for rd in range(rounds):
     mean = float(rng.choice([40, 120, 350]))
     q3, qa = synth.make_queries(nq, seed=int(rng.integers(1 << 30)), mean_len=mean, lo=5, hi=int(mean * 4))
     db = synth.make_db(n, (q3, qa), seed=int(rng.integers(1 << 30)), homologs_per_query=int(rng.integers(0, min(40, n) + 1)) if n > 50 else 0,
-                       mask_frac=float(rng.choice([0.0, 0.02, 0.3])), mean_len=float(rng.choice([60, 200, 350])), lo=1, hi=1500)
+                       mask_frac=float(rng.choice([0.0, 0.02, 0.3])), mean_len=float(rng.choice([60, 200, 350])), lo=1, hi=1500, stay=float(rng.choice([0.0, 0.0, 0.5, 0.8])))
     targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
     thr = int(rng.choice([78, 78, 78, 60, 96, 110]))
     spaced = int(rng.integers(0, 2))
