@@ -4,6 +4,9 @@
 //   structurealign    <queryDB> <targetDB[_pad]> <prefDB> <outAlnDB>         F/src/strucclustutils/structurealign.cpp:141-481
 //   prefilter         <queryDB_ss> <targetDB_ss[_pad]> <outPrefDB>          M/src/prefiltering/Main.cpp -> Prefiltering.cpp:22-245,755-982
 //   makepaddedseqdb   <seqDB> <outPaddedDB>                                  M/src/util/makepaddedseqdb.cpp:14-154
+//   search            <queryDB> <targetDB[_pad]> <outAlnDB> [<outPrefDB>]   prefilter + structurealign of
+//                     F/data/structuresearch.sh:41-53,116-143 in ONE process: the target DB and (for the k-mer mode) its
+//                     index stay resident, no prefilter DB round trip; same result DBs
 // They read and write the same on-disk databases as the reference modules, so the shell workflows
 // (F/data/structuresearch.sh:41-53,116-143) can call them in place of the originals.  All DP work is done by the
 // device library (fsgpu_*), this file is DB plumbing + option parsing.
@@ -345,6 +348,161 @@ int fsmod_prefilter(int argc, const char **argv) {
     for (size_t id = 0; id < q.size(); id++) w.write(q.key(id), results[id].data(), results[id].size());   // empty entries too (Prefiltering.cpp:900)
     fsgpu_destroy(ctx0);
     if (!w.close(err)) return fail(err);
+    return EXIT_SUCCESS;
+}
+
+// prefilter (k-mer: --prefilter-mode 0, gapless: --prefilter-mode 1) + structurealign fused in one process
+int fsmod_search(int argc, const char **argv) {
+    Options o = parseArgs(argc, argv);
+    if (o.pos.size() != 3 && o.pos.size() != 4)
+        return fail("usage: search <queryDB> <targetDB> <outAlnDB> [<outPrefDB>] [--prefilter-mode 0|1] [-s S] [--max-seqs N] [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
+    std::string err;
+    DbReader qA, q3, tA, t3;
+    if (!qA.open(o.pos[0], err) || !q3.open(o.pos[0] + "_ss", err) || !tA.open(o.pos[1], err) || !t3.open(o.pos[1] + "_ss", err)) return fail(err);
+    if (qA.size() != q3.size()) return fail("query AA and 3Di databases differ in size");
+    const bool sameDB = o.pos[0] == o.pos[1];
+    const bool includeIdentical = o.geti("--add-self-matches", 0) != 0;
+    const int prefMode = o.geti("--prefilter-mode", 0);
+    if (prefMode != 0 && prefMode != 1) return fail("search: --prefilter-mode 0 (k-mer) or 1 (ungapped)");
+    fshost_params par;
+    fillParams(o, par);
+    par.prefCompBiasScale = (float) o.getd("--comp-bias-corr-scale", 0.15);    // StructureSearch.cpp:101
+    par.alnCompBiasScale = 0.5f;                                               // StructureSearch.cpp:107
+    const int kmerThr = o.has("--k-score") ? o.geti("--k-score", 0) : fshost_kmer_threshold((float) o.getd("-s", 9.5), 6);
+    const int spaced = o.geti("--spaced-kmer-mode", 1);
+    if (prefMode == 0 && (o.geti("-k", 0) != 0 && o.geti("-k", 6) != 6)) return fail("search: only -k 6 is implemented on the device path");
+    Matrix m3, mA;
+    m3.builtin(FSHOST_MAT_3DI, 2.1f, 0.0f);
+    mA.builtin(FSHOST_MAT_BLOSUM62, par.alignmentType == 2 ? 1.4f : 0.0f, 0.0f);
+    fshost_matrix *m8 = fshost_matrix_create(FSHOST_MAT_3DI, 8.0f, -0.2f), *m2 = fshost_matrix_create(FSHOST_MAT_3DI, 2.0f, -0.2f);
+    if (!m8 || !m2) return fail("matrix construction failed");
+    PaddedTarget pt;
+    if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
+    fsgpu_ctx *ctx0 = nullptr;
+    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
+    if (fsgpu_db_load(ctx0, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
+        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    const int maxRes = (int) std::min<uint64_t>((uint64_t) par.maxResListLen, std::max<uint64_t>(t3.size(), 1));
+    if (prefMode == 0) {
+        fsgpu_kmer_index_params ip;
+        ip.kmerSize = 6; ip.spaced = spaced; ip.kmerThr = kmerThr;
+        ip.maskLowerCase = o.geti("--mask-lower-case", 1); ip.maskNrepeats = o.geti("--mask-n-repeat", 6);
+        if (fsgpu_kmer_index_build(ctx0, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    }
+    fsgpu_kmer_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.maxResListLen = maxRes; sp.minDiagScoreThr = par.minDiagScoreThr;
+    DbWriter w, wp;
+    if (!w.open(o.pos[2], DBTYPE_ALIGNMENT_RES, err)) return fail(err);
+    const bool writePref = o.pos.size() == 4;
+    if (writePref && !wp.open(o.pos[3], DBTYPE_PREFILTER_RES, err)) return fail(err);
+    const int nthreads = std::max(1, std::min(o.geti("--threads", 3), 16));
+    const size_t batch = prefMode == 0 ? 32 : 16;
+    std::vector<std::string> results(q3.size()), prefs(writePref ? q3.size() : 0);
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    std::string firstErr;
+    auto work = [&](int tix) {
+        fsgpu_ctx *ctx = ctx0;
+        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data());
+        std::vector<std::vector<uint8_t>> cA(batch), c3(batch);
+        std::vector<std::vector<int16_t>> thr(batch);
+        std::vector<std::vector<int8_t>> prof(batch);
+        std::vector<fsgpu_kmer_query> kq(batch);
+        std::vector<fsgpu_kmer_hit> khits(batch * (size_t) maxRes);
+        std::vector<fsgpu_hit> ghits((size_t) maxRes);
+        std::vector<int32_t> nout(batch), status(batch);
+        std::vector<std::vector<uint32_t>> ids(batch);
+        std::vector<std::vector<fshost_result>> res(batch);
+        std::vector<const uint8_t *> pA(batch), p3(batch);
+        std::vector<const uint32_t *> pT(batch);
+        std::vector<fshost_result *> pR(batch);
+        std::vector<int> Ls(batch), ns(batch), nres(batch);
+        std::vector<int64_t> ident(batch);
+        std::vector<char> line(1024 + 2 * 65536 * 2);
+        char pl[128];
+        for (;;) {
+            const size_t b0 = next.fetch_add(batch);
+            if (b0 >= q3.size() || bad) break;
+            const size_t nb = std::min(batch, q3.size() - b0);
+            for (size_t k = 0; k < nb; k++) {
+                const size_t id = b0 + k;
+                const uint32_t L = q3.seqLen(id);
+                const int64_t aid = qA.idOf(q3.key(id));
+                if (aid < 0 || qA.seqLen((size_t) aid) != L) { if (!bad++) firstErr = "query AA / 3Di entries do not match"; break; }
+                cA[k].resize(L + 1); c3[k].resize(L + 1);
+                const char *sA = qA.data((size_t) aid), *s3 = q3.data(id);
+                for (uint32_t i = 0; i < L; i++) { cA[k][i] = mA.aa2num[(unsigned char) sA[i]]; c3[k][i] = m3.aa2num[(unsigned char) s3[i]]; }
+                ident[k] = (sameDB || includeIdentical) ? t3.idOf(q3.key(id)) : -1;
+                Ls[k] = (int) L; pA[k] = cA[k].data(); p3[k] = c3[k].data();
+                ids[k].clear();
+            }
+            if (bad) break;
+            // ---- prefilter ----
+            if (prefMode == 0) {
+                for (size_t k = 0; k < nb; k++) {
+                    thr[k].resize(Ls[k] + 1); prof[k].resize((size_t) Ls[k] * 21 + 1);
+                    fshost_kmer_query_prepare(m8, m2, c3[k].data(), Ls[k], par.compBiasCorrection, par.prefCompBiasScale, kmerThr, 6, spaced, thr[k].data(), prof[k].data());
+                    kq[k].seq = c3[k].data(); kq[k].kmerThr = thr[k].data(); kq[k].profile = prof[k].data(); kq[k].L = Ls[k]; kq[k].reserved = 0; kq[k].identity = ident[k];
+                }
+                if (fsgpu_kmer_search(ctx, &sp, kq.data(), (int) nb, khits.data(), nout.data(), status.data(), nullptr) != FSGPU_OK) { if (!bad++) firstErr = fsgpu_last_error(ctx); break; }
+                for (size_t k = 0; k < nb && !bad; k++) {
+                    if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(b0 + k)) + ": hit buffers of the reference would overflow"; break; }
+                    for (int h = 0; h < nout[k]; h++) {
+                        const fsgpu_kmer_hit &hit = khits[k * (size_t) maxRes + h];
+                        ids[k].push_back(hit.id);
+                        if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
+                    }
+                }
+            } else {
+                for (size_t k = 0; k < nb && !bad; k++) {
+                    if (Ls[k] == 0) continue;
+                    const int n = fshost_search_prefilter(s, c3[k].data(), Ls[k], ident[k], ghits.data());
+                    if (n < 0) { if (!bad++) firstErr = fshost_search_error(s); break; }
+                    for (int h = 0; h < n; h++) {
+                        ids[k].push_back(ghits[h].id);
+                        if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[ghits[h].id], ghits[h].score, 0));
+                    }
+                }
+            }
+            if (bad) break;
+            // ---- align: one multi-query launch for the batch (queries without hits keep an empty entry) ----
+            std::vector<size_t> live;
+            for (size_t k = 0; k < nb; k++) if (!ids[k].empty() && Ls[k] > 0) live.push_back(k);
+            if (live.empty()) continue;
+            std::vector<const uint8_t *> lA, l3; std::vector<const uint32_t *> lT; std::vector<fshost_result *> lR;
+            std::vector<int> lL, lN, lres(live.size()); std::vector<int64_t> lI;
+            for (size_t k : live) {
+                res[k].resize(ids[k].size() + 1);
+                lA.push_back(pA[k]); l3.push_back(p3[k]); lT.push_back(ids[k].data()); lR.push_back(res[k].data());
+                lL.push_back(Ls[k]); lN.push_back((int) ids[k].size()); lI.push_back(sameDB ? ident[k] : -1);
+            }
+            if (fshost_search_align_batch(s, (int) live.size(), lA.data(), l3.data(), lL.data(), lI.data(), lT.data(), lN.data(), lR.data(), lres.data()) != FSGPU_OK) {
+                if (!bad++) firstErr = fshost_search_error(s);
+                break;
+            }
+            for (size_t j = 0; j < live.size(); j++) {
+                std::string &out = results[b0 + live[j]];
+                for (int r = 0; r < lres[j]; r++)
+                    out.append(line.data(), fshost_format_result(line.data(), &res[live[j]][r], fshost_search_backtrace(s, &res[live[j]][r]), par.addBacktrace));
+            }
+        }
+        fshost_search_free(s);
+        if (tix > 0) fsgpu_destroy(ctx);
+    };
+    std::vector<std::thread> ths;
+    for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
+    work(0);
+    for (auto &th : ths) th.join();
+    fshost_matrix_free(m8); fshost_matrix_free(m2);
+    if (bad) { fsgpu_destroy(ctx0); return fail("search failed: " + firstErr); }
+    for (size_t id = 0; id < q3.size(); id++) {
+        w.write(q3.key(id), results[id].data(), results[id].size());
+        if (writePref) wp.write(q3.key(id), prefs[id].data(), prefs[id].size());
+    }
+    fsgpu_destroy(ctx0);
+    if (!w.close(err) || (writePref && !wp.close(err))) return fail(err);
     return EXIT_SUCCESS;
 }
 

@@ -167,6 +167,7 @@ size_t fshost_format_result(char *buf, const fshost_result *r, const char *backt
  * Return EXIT_SUCCESS or print a message to stderr and return EXIT_FAILURE. */
 int fsmod_ungappedprefilter(int argc, const char **argv);
 int fsmod_prefilter(int argc, const char **argv);
+int fsmod_search(int argc, const char **argv);   /* <queryDB> <targetDB> <outAlnDB> [<outPrefDB>]: prefilter + structurealign fused */
 int fsmod_structurealign(int argc, const char **argv);
 int fsmod_makepaddedseqdb(int argc, const char **argv);
 

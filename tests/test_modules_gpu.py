@@ -139,6 +139,20 @@ def test_prefilter_module_matches_oracle(tmp_path, padded):
     assert naln > 0
     s.close()
     ctx.close()
+    # fused module: prefilter + structurealign in one process must write the same two databases
+    for mode, ref_pref in ((0, out), (1, None)):
+        aln2, pref2 = str(tmp_path / f"aln_fused{mode}"), str(tmp_path / f"pref_fused{mode}")
+        subprocess.check_call([BIN, "search", qa_db, ta_db, aln2, pref2, "--prefilter-mode", str(mode), "--max-seqs", "120", "--alignment-type", "2",
+                               "-a", "--threads", "2", "-e", "10"])
+        if ref_pref is None:
+            ref_pref, ref_aln = str(tmp_path / "pref_u"), str(tmp_path / "aln_u")
+            subprocess.check_call([BIN, "ungappedprefilter", qa_db + "_ss", ta_db + "_ss", ref_pref, "--max-seqs", "120", "--threads", "2"])
+            subprocess.check_call([BIN, "structurealign", qa_db, ta_db, ref_pref, ref_aln, "--alignment-type", "2", "-a", "--threads", "2", "-e", "10"])
+        else:
+            ref_aln = aln
+        _, p_a = dbio.read_db(pref2); _, p_b = dbio.read_db(ref_pref)
+        _, a_a = dbio.read_db(aln2); _, a_b = dbio.read_db(ref_aln)
+        assert p_a == p_b and a_a == a_b, mode
     if not padded:
         # all-vs-all on the first 200 targets' worth of queries is too slow for the oracle; check identity handling on 3
         out2 = str(tmp_path / "pref_self")

@@ -26,6 +26,9 @@ run(["prefilter", qdb + "_ss", tdb + "_ss", pk, "--threads", "3"])
 run(["structurealign", qdb, tdb, pk, a1, "--alignment-type", "2", "-a", "--threads", "3"])
 run(["ungappedprefilter", qdb + "_ss", tdb + "_ss", pu, "--threads", "3"])
 run(["structurealign", qdb, tdb, pu, a2, "--alignment-type", "2", "-a", "--threads", "3"])
+af = os.path.join(tmp, "aln_fused")
+run(["search", qdb, tdb, af, "--prefilter-mode", "0", "--alignment-type", "2", "-a", "--threads", "3"])
+_, afd = dbio.read_db(af)
 _, dk = dbio.read_db(pk); _, du = dbio.read_db(pu); _, ak = dbio.read_db(a1); _, au = dbio.read_db(a2)
 print("entries", len(dk), len(du), len(ak), len(au), "bytes", sum(map(len, dk.values())), sum(map(len, du.values())), sum(map(len, ak.values())), sum(map(len, au.values())))
 # spot check 5 queries of each chain against the library
@@ -45,6 +48,8 @@ for i in (0, 1, 63, 500, NQ - 1):
     bad += du[int(qkeys[i])].decode() != "".join(api.format_prefilter_hit(int(h["id"]), int(h["score"]), 0) for h in hits)
     r, b = s.align(qa[i], q3[i], hits["id"], with_backtrace=True)
     bad += au[int(qkeys[i])].decode() != "".join(s.format_result(r[j:j + 1], b[j], True) for j in range(len(r)))
+print("fused search == prefilter + structurealign:", afd == ak)
+bad += afd != ak
 print("spot-check mismatches:", bad)
 subprocess.run(["rm", "-rf", tmp])
 assert bad == 0
