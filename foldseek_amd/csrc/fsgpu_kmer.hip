@@ -532,6 +532,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(syncStream(ctx));
         nCand = (uint32_t) misc[2];
     }
+    if (!nHits) { RPCHK(hipEventRecord(S.ev[3], st)); RPCHK(hipEventRecord(S.ev[4], st)); }   // keep every stage event recorded
     RPCHK(hipEventRecord(S.ev[5], st));
     if (nCand) {
         CHK(ensureK(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
@@ -598,6 +599,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         // [0] total, [1] count+scan, [2] lists+chunks, [3] emit, [4] sort, [5] dup flags+scan, [6] compact+score, [7] walk, [8] hist/cut/out
         for (int i = 0; i < 9; i++) ctx->kmerMs[i] = hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess ? (double) ms : -1.0;
         ctx->kmerMs[10] = nLists && hipEventElapsedTime(&ms, S.ev[10], S.ev[11]) == hipSuccess ? (double) ms : -1.0;
+        (void) hipGetLastError();   // an elapsed-time query must never leave a sticky error behind
         ctx->kmerCounts[0] = nLists; ctx->kmerCounts[1] = nHits; ctx->kmerCounts[2] = nCand; ctx->kmerCounts[3] = totalOut;
     }
     // ---- host tail ---------------------------------------------------------------------------------------------

@@ -222,3 +222,21 @@ def test_low_complexity_database():
     assert stats[:, 2].sum() > 0
     o.close()
     ctx.close()
+
+
+def test_no_index_hits_then_next_call():
+    """a query without any index hit (single tiny target) must not leave a sticky HIP error behind that the next library call
+    would trip over (found by tools/edge_probe.py: unrecorded stage events)"""
+    rng = np.random.default_rng(3)
+    lens = np.array([50], np.int32)
+    db = synth.PaddedDB(np.concatenate([rng.integers(0, 20, 50).astype(np.uint8), np.full(2, 20, np.uint8)]), None,
+                        np.array([0, 52], np.int64), lens)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    q = rng.integers(0, 20, 120).astype(np.uint8)
+    for _ in range(2):
+        ctx = api.Context(0)
+        ctx.load_db(db)
+        ctx.kmer_index_build(m8, kmer_thr=78)
+        res, status = ctx.kmer_search([api.kmer_query_prepare(m8, m2, q)], max_res=10)
+        assert status[0] == 0 and len(res[0]) == 0
+        ctx.close()
