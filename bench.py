@@ -268,7 +268,8 @@ def main():
     ready = threading.Barrier(nthreads + 1)
     go = threading.Barrier(nthreads + 1)
 
-    G = max(1, args.group)
+    # queries per multi-query SW launch; with few steps keep at least two groups per host thread so every thread has work
+    G = max(1, min(args.group, args.steps // (2 * nthreads))) if args.group > 0 else 1
     trace, t_go = [], [0.0]
 
     def steps(t, ids):
