@@ -9,6 +9,10 @@ constexpr int kAlphabet = 21;          // 20 states + X
 constexpr int kDeadCode = 21;          // extra profile row: "past the end of this target", never scores
 constexpr int kGaplessLanes = 8;       // lanes per target in the gapless scan (8 targets per wave64)
 constexpr int kStripeTargets = 8;      // targets interleaved per 128-byte line of the scan layout
+#ifndef FSGPU_GAPLESS_BLOCK
+#define FSGPU_GAPLESS_BLOCK 256
+#endif
+constexpr int kGaplessBlock = FSGPU_GAPLESS_BLOCK;   // threads per workgroup of the gapless scan (one LDS image each)
 constexpr int kGaplessMaxR = 32;       // register rows per strip per lane -> single tile covers 16*R <= 512 query rows
 constexpr int kSwMaxR = 8;             // register rows per lane in the SW wavefront -> 64*R <= 512 rows per tile
 constexpr uint32_t kFloor2 = 0x80008000u; // packed (INT16_MIN, INT16_MIN): the gapless recurrence's "zero"
@@ -16,12 +20,14 @@ constexpr uint32_t kFloor2 = 0x80008000u; // packed (INT16_MIN, INT16_MIN): the 
 // ------------------------------------------------------------------------------------------------------------
 // Gapless scan LDS image.  Lane g (0..7) of a target group owns query rows [g*2R, g*2R+2R); register r packs
 // (row g*2R + r) in the low half and (row g*2R + R + r) in the high half, so the diagonal hand-off is a whole-
-// register move.  One 256-byte LDS bank row holds, for one 4-register chunk k, two copies (A: groups 0,1,4,5;
-// B: groups 2,3,6,7) x 8 lanes x 16 B.  Row stride is a multiple of 256 B, hence the bank of an access depends
-// only on (copy, g): every ds_read_b128 is conflict free by construction.
+// register move.  One 256-byte LDS bank row holds, for one profile row and one 4-register chunk k, two copies
+// (A: groups 0,1,4,5; B: groups 2,3,6,7) x 8 lanes x 16 B.  The image is chunk-major: chunk k of profile row c sits
+// at k * gaplessChunkBytes() + c * 256, hence (1) the bank of an access depends only on (copy, g): every
+// ds_read_b128 is conflict free by construction, and (2) the byte address of a row is (c << 8) | laneOffset with
+// laneOffset < 256, which one v_perm_b32 assembles from the packed residue word.
 // ------------------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int gaplessRowBytes(int R) { return (R / 4) * 256; }
-__host__ __device__ constexpr int gaplessLdsBytes(int R) { return (kAlphabet + 1) * gaplessRowBytes(R); }
+__host__ __device__ constexpr int gaplessChunkBytes() { return (kAlphabet + 1) * 256; }
+__host__ __device__ constexpr int gaplessLdsBytes(int R) { return (R / 4) * gaplessChunkBytes(); }
 
 // ------------------------------------------------------------------------------------------------------------
 // SW wavefront LDS image: lane l owns query rows [l*R, l*R+R) of the current tile.  Registers are fetched in

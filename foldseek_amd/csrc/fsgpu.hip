@@ -243,17 +243,19 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
     static thread_local int perCUcached = 0;
     if (!attrSet) {
         HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, 512, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, kGaplessBlock, lds));
         attrSet = true;
     }
     int perCU = perCUcached;
-    // 2 workgroups (16 waves, <= 90 KB LDS) per CU already saturate VALU issue (profiles/r01_valu_lds_issue_rate_ubench.txt) and
-    // leave wave slots + LDS for the latency-bound SW wavefront kernel of another in-flight query to co-reside
+    // Workgroups of 4 waves, each with its own LDS image; 3 per CU (12 waves, <= 135 KB LDS): more does not issue faster
+    // (profiles/r01_m_gapless_ablation_ubench.txt, tools/bench_ab2.sh) and this leaves wave slots for the latency-bound SW
+    // wavefront kernels of other in-flight queries to co-reside.  FSGPU_GAPLESS_BLOCKS_PER_CU overrides.
+    constexpr int wavesPerBlock = kGaplessBlock / 64;
     perCU = std::max(1, std::min(perCU, ctx->gaplessBlocksPerCU));
     // one wave needs one stripe at a time: do not launch more waves than stripes
-    uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nStripes + 7) / 8);
+    uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nStripes + wavesPerBlock - 1) / wavesPerBlock);
     blocks = std::max(blocks, 1u);
-    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks), dim3(512), lds, ctx->stream, ga);
+    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks), dim3(kGaplessBlock), lds, ctx->stream, ga);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }

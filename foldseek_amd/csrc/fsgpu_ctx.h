@@ -51,7 +51,7 @@ struct DbStore {
 struct fsgpu_ctx {
     int device = 0;
     int numCU = 256;
-    int gaplessBlocksPerCU = 2;
+    int gaplessBlocksPerCU = 3;                 // gapless workgroups (kGaplessBlock threads) per CU, see launchGapless
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gapless start/stop, sw start/stop
     bool evValid[2] = {false, false};

@@ -13,8 +13,12 @@
 //     registers into the running maximum per instruction -> 3 VALU ops per 4 cells (the int16 formulation needs 4:
 //     there is no packed integer max3).  Exactness: a diagonal that ever exceeds 2048 already pins its target at the
 //     cap, below that all sums are exact, so the result equals the integer recurrence bit for bit (tests).
-//   * the 22 x (16R) int16 profile sits in LDS in a 2-copy, bank-row aligned image: all ds_read_b128 are
-//     conflict free (fs_kernels.h).  LDS bytes/cell = 2, VALU ops/cell = 1: the two CU resources are balanced.
+//   * the 22 x (16R) FP16 profile sits in LDS in a 2-copy, bank-row aligned image: all ds_read_b128 are
+//     conflict free (fs_kernels.h).  The image is chunk-major with a 256-byte row stride, so the row address of a
+//     target residue is (code << 8) | laneOffset: ONE v_perm_b32 straight from the packed residue word (the
+//     4-register chunks sit at immediate offsets k * 22 * 256).  LDS bytes/cell = 2.
+//   * per target column a lane issues 1.5 R DP ops + 3 others (row address, dpp, hand-off perm): measured
+//     tools/ubench/gapless_ablate.hip, profiles/r01_m_gapless_ablation_ubench.txt.
 //   * the target DB is pre-tiled in HBM as 8-target stripes interleaved at 16-byte granularity: one wave-level
 //     global load = one 128-byte line, every byte of the DB is read exactly once per query.
 //   * diagonal hand-off between lanes: v_mov_b32_dpp row_shr:1 + v_perm_b32 (no LDS round trip).
@@ -73,10 +77,11 @@ struct GaplessArgs {
 };
 
 template <int R, bool TILED>
-__global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
+__global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
     static_assert(R % 4 == 0 && R >= 4 && R <= kGaplessMaxR, "R must be a multiple of 4");
-    constexpr int ROWB = gaplessRowBytes(R);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CHB = gaplessChunkBytes();
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS: starts at LDS address 0
 
     // ---- build the LDS image from the int8 pssm (once per workgroup) ----
     {
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                 int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
                 v = f16ScaledBits(lo) | (f16ScaledBits(hi) << 16);
             }
-            *(uint32_t *) (smem + row * ROWB + k * 256 + copy * 128 + g * 16 + w * 4) = v;
+            *(uint32_t *) (smem + k * CHB + row * 256 + copy * 128 + g * 16 + w * 4) = v;
         }
     }
     __syncthreads();
@@ -103,10 +108,12 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
     const int lane = threadIdx.x & 63;
     const int j = lane >> 3;          // target slot inside the stripe
     const int g = lane & 7;           // lane inside the target group
-    const uint32_t laneOff = (uint32_t) (((j >> 1) & 1) * 128 + g * 16);
+    const uint32_t laneOff = (uint32_t) (((j >> 1) & 1) * 128 + g * 16);       // < 256: fits the low address byte
     // v_perm selector for the hand-off: lo half <- hi half of the previous lane's last register,
-    // hi half <- lo half of my own last register.  {S0 = prev (bytes 4..7), S1 = own (bytes 0..3)}
-    const uint32_t sel = 0x01000706u;
+    // hi half <- lo half of my own last register.  {S0 = prev (bytes 4..7), S1 = own (bytes 0..3)}.
+    // First lane of a target group (untiled): lo half <- constant zero (selector byte 0x0c), so the value the dpp
+    // move delivered from the neighbouring target is never looked at.
+    const uint32_t sel = (!TILED && g == 0) ? 0x01000c0cu : 0x01000706u;
 
     for (;;) {
         uint32_t w = 0;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
         uint32_t carryPrevChunk = 0;                      // border value of the column before this chunk
 
         uint32_t S[R];
-        uint32_t M = 0;
+        uint32_t M = 0, M2 = 0;                           // two running maxima: no dependent max3 chain
 #pragma unroll
         for (int r = 0; r < R; r++) S[r] = 0;
 
@@ -146,29 +153,32 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
             }
 #pragma unroll
             for (int b = 0; b < 16; b++) {
-                const uint32_t code = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-                const unsigned char *rowp = smem + code * ROWB + laneOff;
+                // LDS row address, bytes {0, 0, code, laneOff}: S0 = residue word (selector bytes 4..7), S1 = laneOff
+                const uint32_t addr = __builtin_amdgcn_perm(words[b >> 2], laneOff, 0x0c0c0000u | ((4u + (b & 3)) << 8));
+                const unsigned char __attribute__((address_space(3))) *rowp =
+                    (const unsigned char __attribute__((address_space(3))) *) (uintptr_t) addr;
                 uint32_t P[R];
 #pragma unroll
                 for (int k = 0; k < R / 4; k++) {
-                    const uint4 v = *(const uint4 *) (rowp + k * 256);
+                    const u32x4 v = *(const u32x4 __attribute__((address_space(3))) *) (rowp + k * CHB);
                     P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
                 }
                 // diagonal hand-off
-                uint32_t prev = __builtin_amdgcn_update_dpp(0u, S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+                uint32_t prev = __builtin_amdgcn_mov_dpp(S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, true);
                 if constexpr (TILED) {
                     // first lane: the diagonal enters from the previous row tile, column b - 1
                     const uint32_t fromTile = (b == 0) ? carryPrevChunk : ((b & 1) ? (bi[(b - 1) >> 1] & 0xffffu) : (bi[(b - 1) >> 1] >> 16));
                     prev = (g == 0) ? (fromTile << 16) : prev;
-                } else {
-                    prev = (g == 0) ? 0u : prev;
                 }
                 const uint32_t in = __builtin_amdgcn_perm(prev, S[R - 1], sel);
 #pragma unroll
                 for (int r = R - 1; r >= 1; r--) S[r] = pk_addc_f16(S[r - 1], P[r]);
                 S[0] = pk_addc_f16(in, P[0]);
 #pragma unroll
-                for (int r = 0; r < R; r += 2) M = pk_max3_f16(M, S[r], S[r + 1]);
+                for (int r = 0; r < R; r += 4) {
+                    M = pk_max3_f16(M, S[r], S[r + 1]);
+                    M2 = pk_max3_f16(M2, S[r + 2], S[r + 3]);
+                }
                 if constexpr (TILED) {
                     // last lane: its bottom row (high half of the last register) is the next tile's input
                     const uint32_t v = S[R - 1] >> 16;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
                     // Without an ordering point per column the compiler hoists the LDS profile reads of all 16 unrolled
                     // columns above the border bookkeeping: 256 VGPRs + 346 spilled (kernel 12x slower).  An empty asm that
                     // ties the border word to the running maximum pins each column's work in place: 92 VGPRs, no scratch.
-                    asm volatile("" : "+v"(bo[b >> 1]), "+v"(M));
+                    asm volatile("" : "+v"(bo[b >> 1]), "+v"(M), "+v"(M2));
                 }
             }
             if constexpr (TILED) {
@@ -188,6 +198,7 @@ __global__ __launch_bounds__(512) void k_gapless(GaplessArgs a) {
             }
         }
         // max over both strips and the 8 lanes of the group; non-negative FP16 values order like their bit patterns
+        M = pk_max3_f16(M, M2, M2);
         int m = max((int) (M & 0xffff), (int) (M >> 16));
         m = max(m, __shfl_xor(m, 1));
         m = max(m, __shfl_xor(m, 2));
