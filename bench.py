@@ -288,11 +288,12 @@ def main():
         if args.warmup < nthreads:
             step(t, 0)
         steps(t, list(range(min(G, nq))))
-        # one query of every 64-row length class: the first launch of a kernel instantiation (lazy code-object load,
-        # attribute set-up, scratch growth) must not land in the timed region
+        # one query of every 16-row length class (one gapless instantiation each; the SW classes are coarser): the first
+        # launch of a kernel instantiation (lazy code-object load, attribute set-up, scratch growth) must not land in
+        # the timed region
         cls = {}
         for i in range(nq):
-            cls.setdefault((len(q3[i]) + 63) // 64, i)
+            cls.setdefault((len(q3[i]) + 15) // 16, i)
         steps(t, sorted(cls.values()))
         ready.wait()
         go.wait()

@@ -27,7 +27,8 @@ constexpr uint32_t kFloor2 = 0x80008000u; // packed (INT16_MIN, INT16_MIN): the 
 // laneOffset < 256, which one v_perm_b32 assembles from the packed residue word.
 // ------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int gaplessChunkBytes() { return (kAlphabet + 1) * 256; }
-__host__ __device__ constexpr int gaplessLdsBytes(int R) { return (R / 4) * gaplessChunkBytes(); }
+__host__ __device__ constexpr int gaplessChunks(int R) { return (R + 3) / 4; }
+__host__ __device__ constexpr int gaplessLdsBytes(int R) { return gaplessChunks(R) * gaplessChunkBytes(); }
 
 // ------------------------------------------------------------------------------------------------------------
 // SW wavefront LDS image: lane l owns query rows [l*R, l*R+R) of the current tile.  Registers are fetched in

@@ -269,7 +269,7 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
     const int rows = (L + 15) / 16;                       // rows per strip per lane
     const int nTiles = (L + 16 * kGaplessMaxR - 1) / (16 * kGaplessMaxR);
-    const int R = nTiles > 1 ? kGaplessMaxR : std::max(4, ((rows + 3) / 4) * 4);
+    const int R = nTiles > 1 ? kGaplessMaxR : std::max(1, rows);
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = (uint32_t) ctx->db->n;
     const uint32_t nChunks = (n + kSelChunk - 1) / kSelChunk;
@@ -303,17 +303,19 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (nTiles == 1) {
         HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
-        switch (R) {
-            case 4: rc = launchGapless<4, false>(ctx, ga); break;
-            case 8: rc = launchGapless<8, false>(ctx, ga); break;
-            case 12: rc = launchGapless<12, false>(ctx, ga); break;
-            case 16: rc = launchGapless<16, false>(ctx, ga); break;
-            case 20: rc = launchGapless<20, false>(ctx, ga); break;
-            case 24: rc = launchGapless<24, false>(ctx, ga); break;
-            case 28: rc = launchGapless<28, false>(ctx, ga); break;
-            case 32: rc = launchGapless<32, false>(ctx, ga); break;
-            default: ctx->err = "internal: bad R"; return FSGPU_E_ARG;
-        }
+        // one instantiation per register count: a query of L residues runs with R = ceil(L / 16) (16-row granularity)
+        using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
+        static const LaunchFn table[kGaplessMaxR + 1] = {nullptr,
+            launchGapless<1, false>, launchGapless<2, false>, launchGapless<3, false>, launchGapless<4, false>,
+            launchGapless<5, false>, launchGapless<6, false>, launchGapless<7, false>, launchGapless<8, false>,
+            launchGapless<9, false>, launchGapless<10, false>, launchGapless<11, false>, launchGapless<12, false>,
+            launchGapless<13, false>, launchGapless<14, false>, launchGapless<15, false>, launchGapless<16, false>,
+            launchGapless<17, false>, launchGapless<18, false>, launchGapless<19, false>, launchGapless<20, false>,
+            launchGapless<21, false>, launchGapless<22, false>, launchGapless<23, false>, launchGapless<24, false>,
+            launchGapless<25, false>, launchGapless<26, false>, launchGapless<27, false>, launchGapless<28, false>,
+            launchGapless<29, false>, launchGapless<30, false>, launchGapless<31, false>, launchGapless<32, false>};
+        if (R < 1 || R > kGaplessMaxR) { ctx->err = "internal: bad R"; return FSGPU_E_ARG; }
+        rc = table[R](ctx, ga);
         if (rc != FSGPU_OK) return rc;
     } else {
         // query row tiles of 512 rows: tile t+1 continues every diagonal of tile t through the border arrays in HBM

@@ -78,29 +78,42 @@ struct GaplessArgs {
 
 template <int R, bool TILED>
 __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
-    static_assert(R % 4 == 0 && R >= 4 && R <= kGaplessMaxR, "R must be a multiple of 4");
+    static_assert(R >= 1 && R <= kGaplessMaxR, "1 <= R <= kGaplessMaxR");
     constexpr int CHB = gaplessChunkBytes();
+    constexpr int NCH = gaplessChunks(R);         // ds_read_b128 per column; the last one may carry unused registers
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS: starts at LDS address 0
 
     // ---- build the LDS image from the int8 pssm (once per workgroup) ----
+    // One item = (profile row, lane g, 4-register chunk k): 4 + 4 profile bytes -> one 16-byte slot, stored to both
+    // copies.  All byte loads of an item are independent and the item loop is unrolled, so the build costs a couple of
+    // global round trips instead of one per dword.
     {
         const int L = a.L;
-        constexpr int nDw = (kAlphabet + 1) * (R / 4) * 2 * 8 * 4;  // dwords incl. both copies
-        for (int idx = threadIdx.x; idx < nDw; idx += blockDim.x) {
-            int w = idx & 3, g = (idx >> 2) & 7, copy = (idx >> 5) & 1;
-            int k = (idx >> 6) % (R / 4), row = (idx >> 6) / (R / 4);
-            int r = 4 * k + w;
-            int qlo = a.tileBase + g * 2 * R + r, qhi = qlo + R;
-            uint32_t v;
-            if (row == kDeadCode) {
-                v = kDead2;
-            } else {
-                int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
-                int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
-                v = f16ScaledBits(lo) | (f16ScaledBits(hi) << 16);
+        constexpr int nItems = (kAlphabet + 1) * 8 * NCH;
+        constexpr int nIter = (nItems + kGaplessBlock - 1) / kGaplessBlock;
+#pragma unroll
+        for (int it = 0; it < nIter; it++) {
+            const int idx = it * kGaplessBlock + threadIdx.x;
+            if (idx < nItems) {
+                const int g = idx & 7, k = (idx >> 3) % NCH, row = (idx >> 3) / NCH;
+                uint32_t v[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const int r = 4 * k + w;
+                    const int qlo = a.tileBase + g * 2 * R + r, qhi = qlo + R;
+                    if (row == kDeadCode || r >= R) {
+                        v[w] = kDead2;             // r >= R: padding of the last chunk, never read into the recurrence
+                    } else {
+                        const int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
+                        const int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
+                        v[w] = f16ScaledBits(lo) | (f16ScaledBits(hi) << 16);
+                    }
+                }
+                unsigned char *dst = smem + k * CHB + row * 256 + g * 16;
+                *(u32x4 *) dst = (u32x4){v[0], v[1], v[2], v[3]};
+                *(u32x4 *) (dst + 128) = (u32x4){v[0], v[1], v[2], v[3]};
             }
-            *(uint32_t *) (smem + k * CHB + row * 256 + copy * 128 + g * 16 + w * 4) = v;
         }
     }
     __syncthreads();
@@ -157,9 +170,9 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
                 const uint32_t addr = __builtin_amdgcn_perm(words[b >> 2], laneOff, 0x0c0c0000u | ((4u + (b & 3)) << 8));
                 const unsigned char __attribute__((address_space(3))) *rowp =
                     (const unsigned char __attribute__((address_space(3))) *) (uintptr_t) addr;
-                uint32_t P[R];
+                uint32_t P[4 * NCH];
 #pragma unroll
-                for (int k = 0; k < R / 4; k++) {
+                for (int k = 0; k < NCH; k++) {
                     const u32x4 v = *(const u32x4 __attribute__((address_space(3))) *) (rowp + k * CHB);
                     P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
                 }
@@ -175,10 +188,13 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
                 for (int r = R - 1; r >= 1; r--) S[r] = pk_addc_f16(S[r - 1], P[r]);
                 S[0] = pk_addc_f16(in, P[0]);
 #pragma unroll
-                for (int r = 0; r < R; r += 4) {
+                for (int r = 0; r + 3 < R; r += 4) {
                     M = pk_max3_f16(M, S[r], S[r + 1]);
                     M2 = pk_max3_f16(M2, S[r + 2], S[r + 3]);
                 }
+                if constexpr (R % 4 == 1) M = pk_max3_f16(M, S[R - 1], S[R - 1]);
+                if constexpr (R % 4 == 2) M = pk_max3_f16(M, S[R - 2], S[R - 1]);
+                if constexpr (R % 4 == 3) { M = pk_max3_f16(M, S[R - 3], S[R - 2]); M2 = pk_max3_f16(M2, S[R - 1], S[R - 1]); }
                 if constexpr (TILED) {
                     // last lane: its bottom row (high half of the last register) is the next tile's input
                     const uint32_t v = S[R - 1] >> 16;

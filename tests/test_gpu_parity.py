@@ -45,6 +45,27 @@ def test_gapless_scores_and_hits(small_db, qi, comp_bias):
     assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
 
 
+def test_gapless_every_register_count():
+    """one query per 16-row register count R = 1..32 (L = 16R - 15 ... 16R) plus the length extremes of each class"""
+    rng = np.random.default_rng(4242)
+    lens = sorted(set([1, 2, 15, 16, 17] + [16 * r - int(rng.integers(0, 16)) for r in range(1, 33)] + [16 * r for r in (5, 11, 23, 31, 32)] + [16 * r + 1 for r in (5, 22, 31)]))
+    q3 = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    qa = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    db = synth.make_db(600, (q3, qa), seed=19, homologs_per_query=6, mask_frac=0.02)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m = api.Matrix(0, 2.0)
+    for qi, L in enumerate(lens):
+        pssm, cap = api.prefilter_profile(m, q3[qi], True, 0.15)
+        hits = ctx.gapless_scan(pssm, cap, min_score=20, max_res=100)
+        got = ctx.gapless_scores().astype(np.int32)
+        want = helpers.o_ungapped_scores(q3[qi], db, True)
+        assert (got == want).all(), (L, np.flatnonzero(got != want)[:10])
+        sel = helpers.o_prefilter_select(want, 20, -1, 100)
+        assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all(), L
+    ctx.close()
+
+
 def test_gapless_identity_and_truncation(small_db):
     ctx, db, q3, _ = small_db
     m = api.Matrix(0, 2.0)

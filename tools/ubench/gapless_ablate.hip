@@ -517,6 +517,107 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
 }
 
+
+// ---- candidate 5: stripe scheduling.  SCHED 0: static round robin (no atomics); SCHED 1: atomic ticket taken one
+//      stripe ahead, next stripe's metadata + first chunk loaded while the current stripe computes ----
+template <int R, int SCHED>
+__global__ __launch_bounds__(256) void k_v5(GaplessArgs a, const uint4 *) {
+    constexpr int CHB = (kAlphabet + 1) * 256;
+    constexpr int NCH = (R + 3) / 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const int L = a.L;
+        constexpr int nDw = (kAlphabet + 1) * NCH * 2 * 8 * 4;
+        for (int idx = threadIdx.x; idx < nDw; idx += blockDim.x) {
+            int w = idx & 3, g = (idx >> 2) & 7, copy = (idx >> 5) & 1;
+            int k = (idx >> 6) % NCH, row = (idx >> 6) / NCH;
+            int r = 4 * k + w;
+            int qlo = g * 2 * R + r, qhi = qlo + R;
+            uint32_t v;
+            if (row == kDeadCode || r >= R) v = kDead2;
+            else {
+                int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
+                int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
+                v = f16ScaledBits(lo) | (f16ScaledBits(hi) << 16);
+            }
+            *(uint32_t *) (smem + k * CHB + row * 256 + copy * 128 + g * 16 + w * 4) = v;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int j = lane >> 3, g = lane & 7;
+    const uint32_t laneOff = (uint32_t) (((j >> 1) & 1) * 128 + g * 16);
+    const uint32_t sel = (g == 0) ? 0x01000c0cu : 0x01000706u;
+    const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    auto ticket = [&]() -> uint32_t {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(a.queue, 1u);
+        return __builtin_amdgcn_readfirstlane(w);
+    };
+    uint32_t w = SCHED == 1 ? ticket() : waveId;       // SCHED 2: first stripe static, then tickets (offset by nWaves)
+    // metadata of the current stripe
+    uint32_t stripe = 0, len16 = 0; uint64_t soff = 0; uint4 first = make_uint4(0, 0, 0, 0);
+    auto fetchMeta = [&](uint32_t ww, uint32_t &st, uint32_t &ln, uint64_t &so, uint4 &f) {
+        if (ww < a.nStripes) {
+            st = a.order[ww]; ln = a.stripeLen[st]; so = a.stripeOff[st];
+            f = (a.scan + so + j)[0];
+        }
+    };
+    fetchMeta(w, stripe, len16, soff, first);
+    while (w < a.nStripes) {
+        // next stripe: ticket + metadata in flight while this one computes
+        uint32_t wN = SCHED == 0 ? w + nWaves : (SCHED == 1 ? ticket() : nWaves + ticket());
+        uint32_t stripeN = 0, len16N = 0; uint64_t soffN = 0; uint4 firstN = make_uint4(0, 0, 0, 0);
+        fetchMeta(wN, stripeN, len16N, soffN, firstN);
+        const uint4 *src = a.scan + soff + j;
+        uint32_t S[R];
+        uint32_t M = 0, M2 = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) S[r] = 0;
+        uint4 nxt = first;
+        for (uint32_t c = 0; c < len16; c++) {
+            const uint4 cur = nxt;
+            if (c + 1 < len16) nxt = src[(size_t) (c + 1) * 8];
+            const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t addr = __builtin_amdgcn_perm(words[b >> 2], laneOff, 0x0c0c0000u | ((4u + (b & 3)) << 8));
+                const unsigned char __attribute__((address_space(3))) *rowp = (const unsigned char __attribute__((address_space(3))) *) (uintptr_t) addr;
+                uint32_t P[4 * NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+                    const u32x4 v = *(const u32x4 __attribute__((address_space(3))) *) (rowp + k * CHB);
+                    P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
+                }
+                const uint32_t prev = __builtin_amdgcn_mov_dpp(S[R - 1], 0x111, 0xf, 0xf, true);
+                const uint32_t in = __builtin_amdgcn_perm(prev, S[R - 1], sel);
+#pragma unroll
+                for (int r = R - 1; r >= 1; r--) S[r] = pk_addc_f16(S[r - 1], P[r]);
+                S[0] = pk_addc_f16(in, P[0]);
+#pragma unroll
+                for (int r = 0; r + 3 < R; r += 4) {
+                    M = pk_max3_f16(M, S[r], S[r + 1]);
+                    M2 = pk_max3_f16(M2, S[r + 2], S[r + 3]);
+                }
+            }
+        }
+        M = pk_max3_f16(M, M2, M2);
+        int m = max((int) (M & 0xffff), (int) (M >> 16));
+        m = max(m, __shfl_xor(m, 1));
+        m = max(m, __shfl_xor(m, 2));
+        m = max(m, __shfl_xor(m, 4));
+        const uint32_t tid = stripe * kStripeTargets + j;
+        if (g == 0 && tid < a.nTargets) {
+            int sc = (int) (__half2float(__ushort_as_half((unsigned short) m)) * 2048.0f + 0.5f);
+            sc = sc < a.cap ? sc : a.cap;
+            a.scores[tid] = (uint8_t) sc;
+        }
+        w = wN; stripe = stripeN; len16 = len16N; soff = soffN; first = firstN;
+    }
+}
+
 template <typename K>
 static float runK2(K kern, int block, int lds, int blocks, GaplessArgs ga, const uint4 *s16, int reps) {
     hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -614,6 +715,9 @@ static void suite(int nStripes, int len16, int L) {
         const int lds16 = 22 * 2048;
         chk("v2 u16, tree, 512", runK2(k_v2<R, true, 512, 0>, 512, lds16, 512, ga, (const uint4 *) d16, 4));
         chk("v2 u16, interleave, 512", runK2(k_v2<R, true, 512, 1>, 512, lds16, 512, ga, (const uint4 *) d16, 4));
+        chk("v5 static round robin, 256 x3", runK2(k_v5<R, 0>, 256, lds, 768, ga, nullptr, 4));
+        chk("v5 ticket+meta prefetch, 256 x3", runK2(k_v5<R, 1>, 256, lds, 768, ga, nullptr, 4));
+        chk("v5 static first + prefetch, 256 x3", runK2(k_v5<R, 2>, 256, lds, 768, ga, nullptr, 4));
         chk("v4 perm-addr u8, 512 x2", runK2(k_v4<R, 512>, 512, lds, 512, ga, nullptr, 4));
         chk("v4 perm-addr u8, 512 x3", runK2(k_v4<R, 512>, 512, lds, 768, ga, nullptr, 4));
         chk("v4 perm-addr u8, 256 x3", runK2(k_v4<R, 256>, 256, lds, 768, ga, nullptr, 4));
@@ -634,9 +738,13 @@ static void suite(int nStripes, int len16, int L) {
     rep("6: 1024-thread WG x1/CU", runK(k_var<R, 0, 1024>, 1024, lds, 256, ga, 4));
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("device CUs %d clock %d MHz\n", p.multiProcessorCount, p.clockRate / 1000);
+    if (argc > 1) {     // fixed-cost probe: same stripe count, 1x / 2x / 4x columns -> the intercept is launch + LDS image build
+        for (int len16 : {6, 11, 22, 44, 88}) { printf("len16 = %d\n", len16); suite<24>(12288, len16, 380); }
+        return 0;
+    }
     suite<24>(12288, 22, 380);
     suite<16>(12288, 22, 250);
     suite<32>(12288, 22, 500);
