@@ -7,15 +7,20 @@
 //   search            <queryDB> <targetDB[_pad]> <outAlnDB> [<outPrefDB>]   prefilter + structurealign of
 //                     F/data/structuresearch.sh:41-53,116-143 in ONE process: the target DB and (for the k-mer mode) its
 //                     index stay resident, no prefilter DB round trip; same result DBs
+//   gpuserver         <targetDB_ss[_pad]>                                    M/src/util/gpuserver.cpp:24-101 (resident DB, shm protocol);
+//                     client side: ungappedprefilter --gpu-server 1           M/src/prefiltering/ungappedprefilter.cpp:71-122,208-257
 // They read and write the same on-disk databases as the reference modules, so the shell workflows
 // (F/data/structuresearch.sh:41-53,116-143) can call them in place of the originals.  All DP work is done by the
 // device library (fsgpu_*), this file is DB plumbing + option parsing.
 #include "hostlib.h"
 #include "mmseqs_db.h"
+#include "gpu_shm.h"
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +135,115 @@ void fillParams(const Options &o, fshost_params &p) {
     p.alnLenThr = o.geti("--min-aln-len", p.alnLenThr);
 }
 
+
+// ---- gpuserver protocol ------------------------------------------------------------------------------------------
+volatile sig_atomic_t gKeepRunning = 1;
+void onSignal(int) { gKeepRunning = 0; }
+void installSignalHandlers() {
+    struct sigaction act;
+    memset(&act, 0, sizeof(act));
+    act.sa_handler = onSignal;
+    sigaction(SIGINT, &act, nullptr);
+    sigaction(SIGTERM, &act, nullptr);
+}
+
+std::string shmNameFor(const Options &o, const std::string &db) {
+    auto it = o.kv.find("--shm-name");
+    if (it != o.kv.end()) return it->second;
+    // the reference hashes its own git version string into the name (GpuUtil.cpp:18-34): to pair with a reference
+    // binary pass that string with --gpu-server-version (or FSGPU_SERVER_VERSION); both of our sides default to the same
+    const char *ver = getenv("FSGPU_SERVER_VERSION");
+    auto iv = o.kv.find("--gpu-server-version");
+    std::string version = iv != o.kv.end() ? iv->second : (ver ? ver : "fsgpu-amd");
+    const char *dev = getenv("HIP_VISIBLE_DEVICES");
+    if (!dev) dev = getenv("CUDA_VISIBLE_DEVICES");
+    return gpuShmName(db, dev, version.c_str());
+}
+
+// client: the query loop of runFilterOnGpu in server mode (ungappedprefilter.cpp:171-327), one query in flight
+int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbReader &t, bool sameDB, const fshost_params &par, const Matrix &m3) {
+    const std::string name = shmNameFor(o, o.pos[1]);
+    const int waitTimeout = o.geti("--gpu-server-wait-timeout", 600);
+    const auto start = std::chrono::steady_clock::now();
+    bool printed = false;
+    while (!gpuShmExists(name)) {
+        if (waitTimeout == 0) return fail("gpuserver for database " + o.pos[1] + " not found.\nPlease start gpuserver with the same HIP_VISIBLE_DEVICES");
+        if (!printed) { fprintf(stderr, "Waiting for `gpuserver`\n"); printed = true; }
+        const auto elapsed = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - start).count();
+        if (waitTimeout > 0 && elapsed >= waitTimeout)
+            return fail("gpuserver for database " + o.pos[1] + " not found after " + std::to_string(elapsed) + " seconds.\nPlease start gpuserver with the same HIP_VISIBLE_DEVICES");
+        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+    }
+    std::string err;
+    GpuShm *shm = gpuShmOpen(name, err);
+    if (!shm) return fail(err);
+    installSignalHandlers();
+    DbWriter w;
+    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { gpuShmUnmap(shm); return fail(err); }
+    std::vector<uint8_t> codes;
+    std::vector<int8_t> pssm;
+    std::vector<GpuShmResult> results(shm->maxResListLen);
+    std::vector<fsgpu_hit> hits;
+    std::string out;
+    char line[128];
+    int rc = EXIT_SUCCESS;
+    for (size_t id = 0; id < q.size() && rc == EXIT_SUCCESS; id++) {
+        const uint32_t L = q.seqLen(id);
+        out.clear();
+        if (L > 0) {
+            if (L > shm->maxSeqLen) { rc = fail("query longer than the gpuserver's --max-seq-len"); break; }
+            codes.resize(L);
+            const char *sq = q.data(id);
+            for (uint32_t i = 0; i < L; i++) codes[i] = m3.aa2num[(unsigned char) sq[i]];
+            pssm.resize((size_t) m3.n * L);
+            int cap = 0;
+            if (prefilterProfile(m3, codes.data(), (int) L, par.compBiasCorrection != 0, par.prefCompBiasScale, pssm.data(), &cap) != FSGPU_OK) { rc = fail("bad query residue code"); break; }
+            unsigned int nres = 0;
+            for (bool claimed = false; !claimed;) {
+                if (shm->serverExit.load(std::memory_order_acquire)) { rc = fail("GPU server has unexpectedly shut down"); break; }
+                if (!gKeepRunning) { rc = EXIT_FAILURE; break; }
+                int expected = GpuShm::IDLE;
+                if (!shm->state.compare_exchange_strong(expected, GpuShm::RESERVED, std::memory_order_acq_rel)) { std::this_thread::yield(); continue; }
+                claimed = true;
+                memcpy(shm->query(), codes.data(), L);
+                memcpy(shm->profile(), pssm.data(), (size_t) m3.n * L);
+                shm->queryLen = L;
+                std::atomic_thread_fence(std::memory_order_release);
+                shm->state.store(GpuShm::READY, std::memory_order_release);
+                while (shm->state.load(std::memory_order_acquire) != GpuShm::DONE) {
+                    if (shm->serverExit.load(std::memory_order_acquire)) { rc = fail("GPU server has unexpectedly shut down"); break; }
+                    std::this_thread::yield();
+                }
+                if (rc != EXIT_SUCCESS) break;
+                std::atomic_thread_fence(std::memory_order_acquire);
+                nres = std::min(shm->resultLen, shm->maxResListLen);
+                memcpy(results.data(), shm->results(), nres * sizeof(GpuShmResult));
+                shm->state.store(GpuShm::IDLE, std::memory_order_release);
+            }
+            if (rc != EXIT_SUCCESS) break;
+            hits.clear();
+            const uint32_t qKey = q.key(id);
+            for (unsigned int i = 0; i < nres; i++) {
+                if (results[i].id >= t.size()) { rc = fail("gpuserver returned a target id outside the database (different DB?)"); break; }
+                const uint32_t tKey = t.key(results[i].id);
+                const bool isIdentity = qKey == tKey && sameDB;                          // includeIdentity: not a flag of this module
+                if (isIdentity || results[i].score > par.minDiagScoreThr) hits.push_back({tKey, results[i].score});
+            }
+            std::sort(hits.begin(), hits.end(), [](const fsgpu_hit &a, const fsgpu_hit &b) {   // hit_t::compareHitsByScoreAndId
+                if (a.score != b.score) return a.score > b.score;
+                return a.id < b.id;
+            });
+            const size_t n = std::min<size_t>(hits.size(), (size_t) par.maxResListLen);
+            for (size_t k = 0; k < n; k++) out.append(line, fshost_format_prefilter_hit(line, hits[k].id, hits[k].score, 0));
+        }
+        w.write(q.key(id), out.data(), out.size());
+    }
+    gpuShmUnmap(shm);
+    if (rc != EXIT_SUCCESS) return rc;
+    if (!w.close(err)) return fail(err);
+    return EXIT_SUCCESS;
+}
+
 } // namespace
 
 extern "C" {
@@ -190,6 +304,7 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
     par.prefCompBiasScale = (float) o.getd("--comp-bias-corr-scale", 0.15);
     Matrix m3;
     m3.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f);
+    if (o.geti("--gpu-server", 0) != 0) return ungappedPrefilterViaServer(o, q, t, sameDB, par, m3);
     PaddedTarget pt;
     if (!loadPadded(t, nullptr, m3, nullptr, pt, err)) return fail(err);
     fsgpu_ctx *ctx0 = nullptr;
@@ -605,6 +720,70 @@ int fsmod_structurealign(int argc, const char **argv) {
     fsgpu_destroy(ctx0);
     if (!w.close(err)) return fail(err);
     return EXIT_SUCCESS;
+}
+
+
+// gpuserver: load the target DB once, then answer gapless scans until SIGINT/SIGTERM (gpuserver.cpp:24-101).  The scan
+// is this library's (scores capped at 255 - bias like the CPU path, result order = score desc, id asc); the cap is
+// recovered from the profile the client sends (profile[a][i] - mat[a][q_i] = rounded composition bias of position i).
+int fsmod_gpuserver(int argc, const char **argv) {
+    Options o = parseArgs(argc, argv);
+    if (o.pos.size() != 1) return fail("usage: gpuserver <targetDB_ss[_pad]> [--max-seqs N] [--max-seq-len L] [--gpu-device D] [--gpu-server-version V | --shm-name NAME]");
+    std::string err;
+    DbReader t;
+    if (!t.open(o.pos[0], err)) return fail(err);
+    Matrix m3;
+    if (!m3.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f)) return fail("matrix construction failed");
+    PaddedTarget pt;
+    if (!loadPadded(t, nullptr, m3, nullptr, pt, err)) return fail(err);
+    fsgpu_ctx *ctx = nullptr;
+    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
+    if (fsgpu_db_load(ctx, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
+        return fail(std::string("GPU: ") + fsgpu_last_error(ctx));
+    const unsigned int maxSeqLen = (unsigned int) std::max(1, std::min(o.geti("--max-seq-len", 65535), (int) FSGPU_MAX_SEQ_LEN));
+    const unsigned int maxRes = (unsigned int) std::max(1, o.geti("--max-seqs", 1000));
+    installSignalHandlers();
+    const std::string name = shmNameFor(o, o.pos[0]);
+    GpuShm *shm = gpuShmCreate(name, maxSeqLen, maxRes, err);
+    if (!shm) { fsgpu_destroy(ctx); return fail(err); }
+    fprintf(stderr, "%s\n", name.c_str());
+    int matMin = 0;
+    for (int i = 0; i < m3.n * m3.n; i++) matMin = std::min(matMin, (int) m3.tiny[i]);
+    std::vector<fsgpu_hit> hits(maxRes);
+    int rc = EXIT_SUCCESS;
+    while (gKeepRunning) {
+        if (shm->state.load(std::memory_order_acquire) != GpuShm::READY) { std::this_thread::yield(); continue; }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const int L = (int) shm->queryLen;
+        int nout = 0;
+        if (L > 0 && (unsigned int) L <= maxSeqLen) {
+            const int8_t *qcodes = shm->query(), *prof = shm->profile();
+            int cbMin = 0;
+            for (int i = 0; i < L; i++) {
+                const int c = qcodes[i];
+                if (c < 0 || c >= m3.n) { cbMin = 0; nout = -1; break; }
+                cbMin = std::min(cbMin, (int) prof[i] - (int) m3.sub[c]);      // row a = 0: prof[0*L + i] - mat[0][q_i]
+            }
+            if (nout == 0) {
+                const int cap = 255 - (std::abs(matMin) + std::abs(cbMin));
+                if (fsgpu_gapless_scan(ctx, prof, L, cap, -1, -1, (int) maxRes, hits.data(), &nout) != FSGPU_OK) {
+                    fprintf(stderr, "gpuserver: %s\n", fsgpu_last_error(ctx));
+                    nout = 0; rc = EXIT_FAILURE; gKeepRunning = 0;
+                }
+            }
+            nout = std::max(nout, 0);
+        }
+        GpuShmResult *res = shm->results();
+        for (int k = 0; k < nout; k++) { res[k].id = hits[k].id; res[k].score = hits[k].score; res[k].qEndPos = 0; res[k].dbEndPos = 0; }
+        shm->resultLen = (unsigned int) nout;
+        std::atomic_thread_fence(std::memory_order_release);
+        shm->state.store(GpuShm::DONE, std::memory_order_release);
+    }
+    shm->serverExit.store(true, std::memory_order_release);
+    std::atomic_thread_fence(std::memory_order_release);
+    gpuShmDestroy(shm, name);
+    fsgpu_destroy(ctx);
+    return rc;
 }
 
 } // extern "C"

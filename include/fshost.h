@@ -170,6 +170,17 @@ int fsmod_prefilter(int argc, const char **argv);
 int fsmod_search(int argc, const char **argv);   /* <queryDB> <targetDB> <outAlnDB> [<outPrefDB>]: prefilter + structurealign fused */
 int fsmod_structurealign(int argc, const char **argv);
 int fsmod_makepaddedseqdb(int argc, const char **argv);
+/* gpuserver <targetDB_ss[_pad]>: keeps the target DB resident in HBM and serves gapless scans over the reference's
+ * shared-memory protocol until SIGINT/SIGTERM (M/src/util/gpuserver.cpp:24-101, M/src/commons/GpuUtil.h:9-49);
+ * `ungappedprefilter ... --gpu-server 1` is the client (M/src/prefiltering/ungappedprefilter.cpp:71-122,208-257). */
+int fsmod_gpuserver(int argc, const char **argv);
+/* protocol constants, exported so that tests (and a reference build) can check them:
+ * name of the block for a database (Util::hash of realpath + visible devices + version, GpuUtil.cpp:18-34),
+ * its size (GpuUtil.h:34-39) and the header layout: out = {sizeof, offsets of maxSeqLen, maxResListLen, state, serverExit,
+ * queryOffset, queryLen, resultsOffset, resultLen, profileOffset, sizeof(Marv::Result)} */
+int fshost_gpu_shm_name(const char *db, const char *visibleDevices, const char *version, char *out, size_t cap);
+size_t fshost_gpu_shm_bytes(unsigned int maxSeqLen, unsigned int maxResListLen);
+void fshost_gpu_shm_layout(unsigned int out[11]);
 
 #ifdef __cplusplus
 }

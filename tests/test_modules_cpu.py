@@ -87,3 +87,89 @@ def test_kmer_threshold_and_query_prepare():
     _, thr0, prof0 = api.kmer_query_prepare(m8, m2, q, comp_bias=False)
     assert (thr0 == 78).all() and (prof0 == us[q].astype(np.int8)).all()
     assert len(api.kmer_query_prepare(m8, m2, q[:7])[1]) == 0
+
+
+# ---- gpuserver protocol: constants against the reference's own header, failure modes without a GPU ----
+def _lib():
+    lib = C.CDLL(api.LIB_PATH)
+    lib.fshost_gpu_shm_bytes.restype = C.c_size_t
+    lib.fshost_gpu_shm_bytes.argtypes = [C.c_uint, C.c_uint]
+    lib.fshost_gpu_shm_name.restype = C.c_int
+    lib.fshost_gpu_shm_name.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    return lib
+
+
+def test_gpu_shm_layout_and_size():
+    """GPUSharedMemory (M/src/commons/GpuUtil.h:9-39) + Marv::Result: header offsets, block size"""
+    lib = _lib()
+    out = (C.c_uint * 11)()
+    lib.fshost_gpu_shm_layout(out)
+    assert list(out) == [36, 0, 4, 8, 12, 16, 20, 24, 28, 32, 16]
+    for (msl, mrl) in ((65535, 1000), (1, 1), (32000, 300)):
+        assert lib.fshost_gpu_shm_bytes(msl, mrl) == 36 + msl + 16 * mrl + 21 * msl
+    import oracle_lib
+    ref = oracle_lib.load_ref()
+    if ref is not None and hasattr(ref, "ref_gpu_shm_layout"):
+        want = (C.c_uint * 11)()
+        ref.ref_gpu_shm_layout(want)
+        assert list(out) == list(want)
+        ref.ref_gpu_shm_bytes.restype = C.c_size_t
+        ref.ref_gpu_shm_bytes.argtypes = [C.c_uint, C.c_uint]
+        assert ref.ref_gpu_shm_bytes(65535, 1000) == lib.fshost_gpu_shm_bytes(65535, 1000)
+        st = (C.c_int * 4)()
+        ref.ref_gpu_shm_states(st)
+        assert list(st) == [0, 1, 2, 3]             # IDLE, RESERVED, READY, DONE: the values the client/server code uses
+
+
+def test_gpu_shm_name(tmp_path):
+    """name = decimal Util::hash (h = 31 h + c over plain chars) of realpath(db minus .idx) + visible devices + version"""
+    lib = _lib()
+    db = tmp_path / "tdb_ss_pad"
+    db.write_bytes(b"x")
+    link = tmp_path / "link_ss_pad"
+    os.symlink(db, link)
+
+    buf = C.create_string_buffer(64)
+    for path, dev, ver in ((str(db), None, "abc123"), (str(link), b"0,1", "v\xc3\xa9rsion"), (str(db) + ".idx", b"3", "")):
+        n = lib.fshost_gpu_shm_name(path.encode(), dev, ver.encode("latin-1") if isinstance(ver, str) else ver, buf, 64)
+        assert n > 0
+        real = os.path.realpath(str(db))
+        s = real.encode() + (dev or b"") + ver.encode("latin-1")
+        h = 0
+        for ch in s:
+            c = ch - 256 if ch >= 128 else ch          # plain (signed) char, like the reference
+            h = (h * 31 + c) & 0xFFFFFFFFFFFFFFFF
+        assert buf.value.decode() == str(h)
+        import oracle_lib
+        ref = oracle_lib.load_ref()
+        if ref is not None and hasattr(ref, "ref_util_hash"):
+            ref.ref_util_hash.restype = C.c_size_t
+            ref.ref_util_hash.argtypes = [C.c_char_p, C.c_size_t]
+            assert str(ref.ref_util_hash(s, len(s))) == buf.value.decode()
+    assert lib.fshost_gpu_shm_name(str(db).encode(), None, b"v", buf, 2) < 0     # buffer too small
+
+
+def test_gpuserver_and_client_fail_loudly(tmp_path):
+    """no GPU here: the server must refuse to start (no CPU fallback); a client without a server must say so"""
+    import subprocess
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, 20, size=50).astype(np.uint8) for _ in range(6)]
+    src = str(tmp_path / "db_ss")
+    dbio.write_seq_db(src, seqs, list(range(6)))
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    assert _call("fsmod_gpuserver", []) != 0
+    assert _call("fsmod_gpuserver", [str(tmp_path / "missing")]) != 0
+    name = "fsgpu_test_nogpu_%d" % os.getpid()
+    srv = subprocess.Popen([exe, "gpuserver", src, "--shm-name", name], stderr=subprocess.PIPE, text=True)
+    try:
+        srv.wait(timeout=90)
+        assert srv.returncode != 0 and "GPU" in srv.stderr.read()          # no device: refuses, never serves from the CPU
+        assert not os.path.exists("/dev/shm/" + name)
+    except subprocess.TimeoutExpired:                                       # a GPU is present (test run on a GPU box): it serves
+        import signal
+        srv.send_signal(signal.SIGTERM)
+        srv.wait(timeout=60)
+        assert not os.path.exists("/dev/shm/" + name)
+    r = subprocess.run([exe, "ungappedprefilter", src, src, str(tmp_path / "out"), "--gpu-server", "1", "--gpu-server-wait-timeout", "0",
+                        "--shm-name", "fsgpu_test_absent_%d" % os.getpid()], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "gpuserver" in r.stderr and "not found" in r.stderr

@@ -165,3 +165,81 @@ def test_prefilter_module_matches_oracle(tmp_path, padded):
             assert d2[int(keys_t[tid])].decode() == exp
             assert exp.startswith("%d\t65535\t0\n" % keys_t[tid])
     o.close()
+
+
+# ---- gpuserver: resident DB + the reference's shared-memory protocol ----
+def _wait_for(path, proc, timeout=120.0):
+    import time
+    t0 = time.time()
+    while not (os.path.exists(path) and os.path.getsize(path) > 0):
+        assert proc.poll() is None, "gpuserver exited: " + (proc.stderr.read() if proc.stderr else "")
+        assert time.time() - t0 < timeout, "gpuserver did not come up"
+        time.sleep(0.05)
+
+
+def test_gpuserver_roundtrip_and_raw_protocol(tmp_path):
+    """(1) ungappedprefilter --gpu-server 1 through a resident gpuserver == the direct module, byte for byte;
+    (2) a client that knows nothing but the reference's byte layout (GpuUtil.h) and state machine gets the same hits;
+    (3) SIGTERM: the server flags serverExit and unlinks the block."""
+    import mmap, signal, struct, time
+    q3, qa = synth.make_queries(6, seed=77, mean_len=160, lo=40, hi=420)
+    db = synth.make_db(900, (q3, qa), seed=78, homologs_per_query=30, mean_len=170, lo=30, hi=700, mask_frac=0.02)
+    qkeys = [3 + 5 * i for i in range(len(q3))]
+    qdb = str(tmp_path / "query_ss")
+    dbio.write_seq_db(qdb, q3, qkeys)
+    tdb = str(tmp_path / "target_ss_pad")
+    dbio.write_padded_db(tdb, db, "3di")
+    direct, served = str(tmp_path / "direct"), str(tmp_path / "served")
+    subprocess.check_call([BIN, "ungappedprefilter", qdb, tdb, direct, "--max-seqs", "120"])
+    name = "fsgpu_test_%d" % os.getpid()
+    srv = subprocess.Popen([BIN, "gpuserver", tdb, "--max-seqs", "120", "--max-seq-len", "2000", "--shm-name", name], stderr=subprocess.PIPE, text=True)
+    try:
+        _wait_for("/dev/shm/" + name, srv)
+        subprocess.check_call([BIN, "ungappedprefilter", qdb, tdb, served, "--max-seqs", "120", "--gpu-server", "1", "--shm-name", name])
+        (t1, d1), (t2, d2) = dbio.read_db(direct), dbio.read_db(served)
+        assert t1 == t2 and sorted(d1) == sorted(d2) == sorted(qkeys)
+        for k in qkeys:
+            assert d1[k] == d2[k]
+        assert sum(len(v) for v in d1.values()) > 0
+        # raw client: header = {u32 maxSeqLen, u32 maxResListLen, i32 state, u8 serverExit (+3 pad), u32 queryOffset, queryLen,
+        # resultsOffset, resultLen, profileOffset}; states IDLE 0, RESERVED 1, READY 2, DONE 3
+        fd = os.open("/dev/shm/" + name, os.O_RDWR)
+        mm = mmap.mmap(fd, 0)
+        os.close(fd)
+        max_seq_len, max_res = struct.unpack_from("<II", mm, 0)
+        assert (max_seq_len, max_res) == (2000, 120) and len(mm) == 36 + 2000 + 16 * 120 + 21 * 2000
+        q_off, _, r_off, _, p_off = struct.unpack_from("<IIIII", mm, 16)
+        assert (q_off, r_off, p_off) == (36, 36 + 2000, 36 + 2000 + 16 * 120)
+        m = api.Matrix(0, 2.0)
+        ctx = api.Context(0)
+        ctx.load_db(db)
+        for qi in (0, 3):
+            L = len(q3[qi])
+            pssm, cap = api.prefilter_profile(m, q3[qi], True, 0.15)
+            assert struct.unpack_from("<i", mm, 8)[0] == 0
+            struct.pack_into("<i", mm, 8, 1)                                   # RESERVED
+            mm[q_off:q_off + L] = q3[qi].tobytes()
+            mm[p_off:p_off + 21 * L] = np.ascontiguousarray(pssm, dtype=np.int8).tobytes()
+            struct.pack_into("<I", mm, 20, L)
+            struct.pack_into("<i", mm, 8, 2)                                   # READY
+            t0 = time.time()
+            while struct.unpack_from("<i", mm, 8)[0] != 3:
+                assert time.time() - t0 < 60 and srv.poll() is None
+            n = struct.unpack_from("<I", mm, 28)[0]
+            res = np.frombuffer(mm[r_off:r_off + 16 * n], dtype=np.dtype([("id", "<u4"), ("score", "<i4"), ("qEnd", "<i4"), ("dbEnd", "<i4")]))
+            struct.pack_into("<i", mm, 8, 0)                                   # IDLE
+            want = helpers.o_ungapped_scores(q3[qi], db, True)
+            sel = helpers.o_prefilter_select(want, -1, -1, 120)               # server side: no threshold, top max-seqs
+            assert n == len(sel) == 120
+            assert (res["id"] == sel["key"]).all() and (res["score"] == sel["score"]).all()
+        ctx.close()
+        srv.send_signal(signal.SIGTERM)
+        srv.wait(timeout=60)
+        assert mm[12] == 1                                                     # serverExit
+        assert not os.path.exists("/dev/shm/" + name)
+        mm.close()
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+        if os.path.exists("/dev/shm/" + name):
+            os.remove("/dev/shm/" + name)
