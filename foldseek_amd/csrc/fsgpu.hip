@@ -156,6 +156,7 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
     }
     std::iota(ord.begin(), ord.end(), 0u);
     std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return sLen[a] > sLen[b]; });
+    ctx->db->hStripeLen = sLen;
 
     HIPCHK(hipMalloc((void **) &ctx->db->scan, std::max<uint64_t>(total, 1) * sizeof(uint4)));
     HIPCHK(hipMalloc((void **) &ctx->db->stripeOff, std::max<size_t>(nStripes, 1) * sizeof(uint64_t)));
@@ -233,6 +234,67 @@ int fsgpu_db_load(fsgpu_ctx *ctx, const uint8_t *data3di, const uint8_t *dataAA,
 
 } // extern "C"
 
+
+// ------------------------------------------------------------------------------------------------------------
+// gapless work list.  ov = warm-up chunks a column segment needs (= register count R of the query, 16 R >= Lq);
+// ov = 0: whole stripes only (row-tiled long queries).  A stripe longer than `cap` chunks is cut into K segments of
+// equal new length that each start ov chunks early; cap minimises max(cap, (work + warm-up work) / waves), the
+// completion time of a longest-first queue over equally fast waves.
+// ------------------------------------------------------------------------------------------------------------
+static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint64_t **items, uint32_t *nItems, bool *anySplit) {
+    DbStore &db = *ctx->db;
+    std::lock_guard<std::mutex> lock(db.itemMutex);
+    DbStore::ItemList &l = db.itemLists[ov];
+    if (!l.built) {
+        const std::vector<uint32_t> &len = db.hStripeLen;
+        const uint32_t nStripes = (uint32_t) len.size();
+        uint64_t total = 0;
+        uint32_t maxLen = 0;
+        for (uint32_t x : len) { total += x; maxLen = std::max(maxLen, x); }
+        const double waves = (double) ctx->numCU * 3 * (kGaplessBlock / 64);
+        uint32_t cap = maxLen;
+        if (ov > 0 && maxLen > 2u * ov && !getenv("FSGPU_GAPLESS_NOSPLIT")) {      // the variable exists for A/B measurements
+            // histogram of stripe lengths -> cost of every candidate cap
+            std::vector<uint32_t> hist(maxLen + 1, 0);
+            for (uint32_t x : len) hist[x]++;
+            double best = std::max((double) maxLen, (double) total / waves);
+            for (uint32_t c = 2u * ov; c < maxLen; c++) {
+                uint64_t extra = 0;
+                const uint32_t fresh = c - ov;
+                for (uint32_t x = c + 1; x <= maxLen; x++)
+                    if (hist[x]) extra += (uint64_t) hist[x] * ((x + fresh - 1) / fresh - 1) * ov;
+                const double t = std::max((double) c, (double) (total + extra) / waves);
+                if (t < best) { best = t; cap = c; }
+            }
+        }
+        std::vector<uint64_t> v;
+        v.reserve(nStripes + 64);
+        bool split = false;
+        for (uint32_t s = 0; s < nStripes; s++) {
+            const uint32_t L = len[s];
+            if (L == 0) continue;
+            if (L <= cap || ov == 0) { v.push_back(((uint64_t) s << 32) | L); continue; }
+            const uint32_t K = (L + (cap - ov) - 1) / (cap - ov), fresh = (L + K - 1) / K;
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t b = k * fresh, e = std::min(L, (k + 1) * fresh);
+                if (b >= e) break;
+                const uint32_t b0 = b > (uint32_t) ov ? b - ov : 0;
+                v.push_back(((uint64_t) s << 32) | (1ull << 31) | ((uint64_t) b0 << 16) | e);
+                split = true;
+            }
+        }
+        std::stable_sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) {
+            const uint32_t la = (uint32_t) (a & 0xffff) - (uint32_t) ((a >> 16) & 0x7fff), lb = (uint32_t) (b & 0xffff) - (uint32_t) ((b >> 16) & 0x7fff);
+            return la > lb;
+        });
+        HIPCHK(hipMalloc((void **) &l.items, std::max<size_t>(v.size(), 1) * sizeof(uint64_t)));
+        if (!v.empty()) HIPCHK(hipMemcpy(l.items, v.data(), v.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        l.n = (uint32_t) v.size(); l.split = split; l.built = true;
+    }
+    *items = l.items; *nItems = l.n; *anySplit = l.split;
+    return FSGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // gapless scan
 // ------------------------------------------------------------------------------------------------------------
@@ -253,7 +315,7 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
     constexpr int wavesPerBlock = kGaplessBlock / 64;
     perCU = std::max(1, std::min(perCU, ctx->gaplessBlocksPerCU));
     // one wave needs one stripe at a time: do not launch more waves than stripes
-    uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nStripes + wavesPerBlock - 1) / wavesPerBlock);
+    uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nItems + wavesPerBlock - 1) / wavesPerBlock);
     blocks = std::max(blocks, 1u);
     hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks), dim3(kGaplessBlock), lds, ctx->stream, ga);
     HIPCHK(hipGetLastError());
@@ -295,11 +357,14 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     memcpy(ctx->hPssm.p, pssm, (size_t) kAlphabet * L);
     HIPCHK(hipMemcpyAsync(ctx->pssm.p, ctx->hPssm.p, (size_t) kAlphabet * L, hipMemcpyHostToDevice, ctx->stream));
     GaplessArgs ga;
-    ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen; ga.order = ctx->db->order;
-    ga.nStripes = ctx->db->nStripes; ga.nTargets = n; ga.pssm = (const int8_t *) ctx->pssm.p; ga.L = L;
+    ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen;
+    bool anySplit = false;
+    if ((rc = gaplessItems(ctx, nTiles > 1 ? 0 : R, &ga.items, &ga.nItems, &anySplit)) != FSGPU_OK) return rc;
+    ga.nTargets = n; ga.pssm = (const int8_t *) ctx->pssm.p; ga.L = L;
     ga.cap = std::max(0, std::min(scoreCap, 255));
     ga.scores = (uint8_t *) ctx->scores.p; ga.queue = ctx->queue;
     ga.tileBase = 0; ga.firstTile = 1; ga.lastTile = 1; ga.borderIn = nullptr; ga.borderOut = nullptr; ga.scoreAcc = (int16_t *) ctx->scoreAcc.p;
+    if (anySplit) HIPCHK(hipMemsetAsync(ctx->scores.p, 0, n, ctx->stream));     // column segments combine by atomic max
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (nTiles == 1) {
         HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));

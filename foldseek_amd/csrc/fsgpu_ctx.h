@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -42,7 +43,14 @@ struct DbStore {
     uint64_t *dOffsets = nullptr;
     int32_t *dLengths = nullptr;
     std::vector<int32_t> hLengths;
+    // gapless work lists, one per overlap class (index = overlap in 16-column chunks, 0 = whole stripes): built on first
+    // use by gaplessItems() (fsgpu.hip), shared by all contexts of this DB
+    std::vector<uint32_t> hStripeLen;
+    struct ItemList { uint64_t *items = nullptr; uint32_t n = 0; bool split = false, built = false; };
+    ItemList itemLists[kGaplessMaxR + 1];
+    std::mutex itemMutex;
     ~DbStore() {
+        for (ItemList &l : itemLists) (void) hipFree(l.items);
         (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(order);
         (void) hipFree(aln3di); (void) hipFree(alnAA); (void) hipFree(raw3di); (void) hipFree(dOffsets); (void) hipFree(dLengths);
     }

@@ -22,7 +22,11 @@
 //   * the target DB is pre-tiled in HBM as 8-target stripes interleaved at 16-byte granularity: one wave-level
 //     global load = one 128-byte line, every byte of the DB is read exactly once per query.
 //   * diagonal hand-off between lanes: v_mov_b32_dpp row_shr:1 + v_perm_b32 (no LDS round trip).
-//   * waves pull stripes from an atomic queue ordered by descending length (LPT), so the tail is short.
+//   * waves pull work items from an atomic queue ordered by descending length (LPT).  An item is a stripe or, for
+//     stripes longer than the per-wave share of the launch, a column segment of it that starts ceil(Lq/16) chunks
+//     early: after that many warm-up columns every diagonal that reaches the segment's own columns has been followed from
+//     its row 0, warm-up cells only ever hold values <= the true ones, so max over segments == the stripe's maximum
+//     (combined with an atomic max on the score bytes).  Without it the longest stripe alone outlasts the average wave.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -60,8 +64,8 @@ struct GaplessArgs {
     const uint4 *scan;          // stripe-interleaved target residues (codes 0..20, 21 = past end)
     const uint64_t *stripeOff;  // [nStripes] offset in uint4 units
     const uint32_t *stripeLen;  // [nStripes] length in 16-column chunks
-    const uint32_t *order;      // [nStripes] stripe ids, longest first
-    uint32_t nStripes;
+    const uint64_t *items;      // [nItems] work items, longest first: stripe << 32 | split << 31 | firstChunk << 16 | endChunk
+    uint32_t nItems;
     uint32_t nTargets;
     const int8_t *pssm;         // [21][L] query profile (device copy)
     int L;
@@ -132,9 +136,11 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
         uint32_t w = 0;
         if (lane == 0) w = atomicAdd(a.queue, 1u);
         w = __builtin_amdgcn_readfirstlane(w);
-        if (w >= a.nStripes) break;
-        const uint32_t stripe = a.order[w];
-        const uint32_t len16 = a.stripeLen[stripe];
+        if (w >= a.nItems) break;
+        const uint64_t item = a.items[w];
+        const uint32_t stripe = (uint32_t) (item >> 32);
+        const bool split = (item >> 31) & 1;
+        const uint32_t cBegin = (uint32_t) (item >> 16) & 0x7fffu, cEnd = (uint32_t) item & 0xffffu;
         const uint64_t soff = a.stripeOff[stripe];
         const uint4 *src = a.scan + soff + j;
         // border arrays use the scan layout at 2 bytes per residue: 32 bytes per (chunk, target)
@@ -147,10 +153,10 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
 #pragma unroll
         for (int r = 0; r < R; r++) S[r] = 0;
 
-        uint4 nxt = src[0];
-        for (uint32_t c = 0; c < len16; c++) {
+        uint4 nxt = src[(size_t) cBegin * 8];
+        for (uint32_t c = cBegin; c < cEnd; c++) {
             const uint4 cur = nxt;
-            if (c + 1 < len16) nxt = src[(size_t) (c + 1) * 8];
+            if (c + 1 < cEnd) nxt = src[(size_t) (c + 1) * 8];
             const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
             uint32_t bi[8], bo[8];
             if constexpr (TILED) {
@@ -228,7 +234,20 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
             if (!TILED || a.lastTile) {
                 int sc = (int) (__half2float(__ushort_as_half((unsigned short) m)) * 2048.0f + 0.5f);
                 sc = sc < a.cap ? sc : a.cap;
-                a.scores[tid] = (uint8_t) sc;
+                if (!split) {
+                    a.scores[tid] = (uint8_t) sc;
+                } else {
+                    // column segment: byte-wise maximum into the (zeroed) score array
+                    uint32_t *word = (uint32_t *) (a.scores + (tid & ~3u));
+                    const int sh = (int) (tid & 3u) * 8;
+                    uint32_t old = *word;
+                    while ((int) ((old >> sh) & 0xffu) < sc) {
+                        const uint32_t want = (old & ~(0xffu << sh)) | ((uint32_t) sc << sh);
+                        const uint32_t seen = atomicCAS(word, old, want);
+                        if (seen == old) break;
+                        old = seen;
+                    }
+                }
             }
         }
     }

@@ -14,10 +14,11 @@
 #include "k_gapless.hpp"
 
 using namespace fs;
+struct AblArgs : GaplessArgs { const uint32_t *order; uint32_t nStripes; };   // variants: one whole stripe per queue entry
 static constexpr int oldRowBytes(int R) { return (R / 4) * 256; }   // row-major image of the first kernel version
 
 template <int R, int MODE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_var(GaplessArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_var(AblArgs a) {
     constexpr int ROWB = oldRowBytes(R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void k_var(GaplessArgs a) {
 // ---- candidate kernel: per-lane perm selector (no cndmask, no dpp old value), interleaved two-accumulator maximum,
 //      optional 16-bit pre-scaled row offsets (U16) so that the LDS address is one SDWA add ----
 template <int R, bool U16, int BLOCK, int ILV>
-__global__ __launch_bounds__(BLOCK) void k_v2(GaplessArgs a, const uint4 *scan16) {
+__global__ __launch_bounds__(BLOCK) void k_v2(AblArgs a, const uint4 *scan16) {
     constexpr int ROWB = U16 ? 2048 : oldRowBytes(R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void k_v2(GaplessArgs a, const uint4 *scan16
 
 // ---- candidate 3: v2 + explicit software prefetch of the next column's profile row (double-buffered P) ----
 template <int R, bool U16, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_v3(GaplessArgs a, const uint4 *scan16) {
+__global__ __launch_bounds__(BLOCK) void k_v3(AblArgs a, const uint4 *scan16) {
     constexpr int ROWB = U16 ? 2048 : oldRowBytes(R);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(BLOCK) void k_v3(GaplessArgs a, const uint4 *scan16
 // ---- candidate 4: u8 codes, LDS image chunk-major (chunk k at k*22*256, row stride 256 B) so that the row address
 //      (code << 8) | laneOff is ONE v_perm_b32; per-lane hand-off selector; two-accumulator maximum ----
 template <int R, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_v4(GaplessArgs a, const uint4 *) {
+__global__ __launch_bounds__(BLOCK) void k_v4(AblArgs a, const uint4 *) {
     constexpr int CHB = (kAlphabet + 1) * 256;       // bytes per 4-register chunk plane
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(BLOCK) void k_v4(GaplessArgs a, const uint4 *) {
 // ---- candidate 4: u8 codes, LDS image chunk-major (chunk k at k*22*256, row stride 256 B) so that the row address
 //      (code << 8) | laneOff is ONE v_perm_b32; per-lane hand-off selector; two-accumulator maximum ----
 template <int R, int BLOCK>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_v4w(GaplessArgs a, const uint4 *) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_v4w(AblArgs a, const uint4 *) {
     constexpr int CHB = (kAlphabet + 1) * 256;       // bytes per 4-register chunk plane
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // ---- candidate 5: stripe scheduling.  SCHED 0: static round robin (no atomics); SCHED 1: atomic ticket taken one
 //      stripe ahead, next stripe's metadata + first chunk loaded while the current stripe computes ----
 template <int R, int SCHED>
-__global__ __launch_bounds__(256) void k_v5(GaplessArgs a, const uint4 *) {
+__global__ __launch_bounds__(256) void k_v5(AblArgs a, const uint4 *) {
     constexpr int CHB = (kAlphabet + 1) * 256;
     constexpr int NCH = (R + 3) / 4;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void k_v5(GaplessArgs a, const uint4 *) {
 }
 
 template <typename K>
-static float runK2(K kern, int block, int lds, int blocks, GaplessArgs ga, const uint4 *s16, int reps) {
+static float runK2(K kern, int block, int lds, int blocks, AblArgs ga, const uint4 *s16, int reps) {
     hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
@@ -635,8 +636,8 @@ static float runK2(K kern, int block, int lds, int blocks, GaplessArgs ga, const
     return best;
 }
 
-template <typename K>
-static float runK(K kern, int block, int lds, int blocks, GaplessArgs ga, int reps) {
+template <typename K, typename A>
+static float runK(K kern, int block, int lds, int blocks, A ga, int reps) {
     hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
@@ -662,7 +663,7 @@ static void suite(int nStripes, int len16, int L) {
     for (int s = 0; s < nStripes; s++) { off[s] = (uint64_t) s * len16 * 8; len[s] = len16; ord[s] = s; }
     std::vector<int8_t> pssm(21 * L);
     for (auto &x : pssm) x = (int8_t) (rand() % 13 - 8);
-    GaplessArgs ga{};
+    AblArgs ga{};
     void *d;
     hipMalloc(&d, h.size()); hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice); ga.scan = (const uint4 *) d;
     hipMalloc(&d, 8 * nStripes); hipMemcpy(d, off.data(), 8 * nStripes, hipMemcpyHostToDevice); ga.stripeOff = (const uint64_t *) d;
@@ -671,6 +672,11 @@ static void suite(int nStripes, int len16, int L) {
     hipMalloc(&d, pssm.size()); hipMemcpy(d, pssm.data(), pssm.size(), hipMemcpyHostToDevice); ga.pssm = (const int8_t *) d;
     hipMalloc(&d, nStripes * 8); ga.scores = (uint8_t *) d;
     hipMalloc(&d, 4); ga.queue = (uint32_t *) d;
+    {
+        std::vector<uint64_t> items(nStripes);
+        for (int s2 = 0; s2 < nStripes; s2++) items[s2] = ((uint64_t) s2 << 32) | (uint32_t) len16;
+        hipMalloc(&d, 8 * nStripes); hipMemcpy(d, items.data(), 8 * nStripes, hipMemcpyHostToDevice); ga.items = (const uint64_t *) d; ga.nItems = nStripes;
+    }
     ga.nStripes = nStripes; ga.nTargets = nStripes * 8; ga.L = L; ga.cap = 255; ga.firstTile = ga.lastTile = 1;
     const int lds = gaplessLdsBytes(R);
     const double cells = (double) nStripes * 8 * len16 * 16 * (16.0 * R);
@@ -679,10 +685,10 @@ static void suite(int nStripes, int len16, int L) {
         // cycles per wave-column per SIMD: ms * 2.4e6 cycles * 1024 SIMDs / waveCols
         printf("R=%2d %-34s %7.3f ms  %6.2f Tcell/s  %6.1f cyc/wave-column/SIMD\n", R, name, ms, cells / ms * 1e-9, ms * 2.4e6 * 1024 / waveCols);
     };
-    runK(k_gapless<R, false>, kGaplessBlock, lds, 768, ga, 40);      // warm-up: let the clocks ramp before anything is timed
+    runK(k_gapless<R, false>, kGaplessBlock, lds, 768, (GaplessArgs) ga, 40);      // warm-up: let the clocks ramp before anything is timed
     for (int perCU = 2; perCU <= 4; perCU++) {
         char nm[64]; snprintf(nm, sizeof nm, "product kernel, %d WG/CU", perCU);
-        rep(nm, runK(k_gapless<R, false>, kGaplessBlock, lds, 256 * perCU, ga, 4));
+        rep(nm, runK(k_gapless<R, false>, kGaplessBlock, lds, 256 * perCU, (GaplessArgs) ga, 4));
     }
     rep("variant 0 (same code)", runK(k_var<R, 0, 512>, 512, lds, 512, ga, 4));
     rep("1: no LDS reads", runK(k_var<R, 1, 512>, 512, lds, 512, ga, 4));
@@ -698,7 +704,7 @@ static void suite(int nStripes, int len16, int L) {
             for (int b = 0; b < 16; b++) h16[u * 16 + b] = (uint16_t) (h[u * 16 + b] * 2048);
         void *d16; hipMalloc(&d16, h16.size() * 2); hipMemcpy(d16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice);
         std::vector<uint8_t> ref(nStripes * 8), got(nStripes * 8);
-        runK(k_gapless<R, false>, kGaplessBlock, lds, 768, ga, 2);
+        runK(k_gapless<R, false>, kGaplessBlock, lds, 768, (GaplessArgs) ga, 2);
         hipMemcpy(ref.data(), ga.scores, ref.size(), hipMemcpyDeviceToHost);
         auto chk = [&](const char *nm, float ms) {
             hipMemcpy(got.data(), ga.scores, got.size(), hipMemcpyDeviceToHost);
