@@ -95,11 +95,11 @@ uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx) { return ctx && ctx->db ? ctx->
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_db_scan_layout(const uint8_t *raw, const uint64_t *offsets, const int32_t *lengths,
                                                         uint32_t n, const uint64_t *stripeOff, const uint32_t *stripeLen,
-                                                        uint4 *out) {
+                                                        const uint32_t *stripeTargets, uint4 *out) {
     const uint32_t stripe = blockIdx.x;
     const uint32_t len16 = stripeLen[stripe];
     const int j = threadIdx.x & 7;
-    const uint32_t t = stripe * kStripeTargets + j;
+    const uint32_t t = stripeTargets[stripe * kStripeTargets + j];
     const bool live = t < n;
     const uint64_t off = live ? offsets[t] : 0;
     const int L = live ? lengths[t] : 0;
@@ -138,13 +138,23 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
     HIPCHK(hipMemcpy(ctx->db->hLengths.data(), dLen, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     const uint32_t nStripes = (uint32_t) ((n + kStripeTargets - 1) / kStripeTargets);
     std::vector<uint64_t> sOff(nStripes);
-    std::vector<uint32_t> sLen(nStripes), ord(nStripes);
+    std::vector<uint32_t> sLen(nStripes);
     uint64_t total = 0, residues = 0;
     int maxLen = 0;
+    // a stripe = 8 targets of similar length: group along the length-sorted order (identity for a padded DB, which
+    // makepaddedseqdb has already sorted; an ASCII DB arrives in arbitrary order)
+    std::vector<uint32_t> sTargets((size_t) nStripes * kStripeTargets, 0xffffffffu);
+    {
+        std::vector<uint32_t> byLen(n);
+        std::iota(byLen.begin(), byLen.end(), 0u);
+        const std::vector<int32_t> &hl = ctx->db->hLengths;
+        if (!std::is_sorted(hl.begin(), hl.end())) std::stable_sort(byLen.begin(), byLen.end(), [&](uint32_t a, uint32_t b) { return hl[a] < hl[b]; });
+        std::copy(byLen.begin(), byLen.end(), sTargets.begin());
+    }
     for (uint32_t s = 0; s < nStripes; s++) {
         int mx = 0;
-        for (uint64_t t = (uint64_t) s * 8; t < std::min<uint64_t>(n, (uint64_t) s * 8 + 8); t++) {
-            int L = ctx->db->hLengths[t];
+        for (uint64_t k = (uint64_t) s * 8; k < std::min<uint64_t>(n, (uint64_t) s * 8 + 8); k++) {
+            int L = ctx->db->hLengths[sTargets[k]];
             if (L < 0 || L > FSGPU_MAX_SEQ_LEN) { ctx->err = "target length out of range"; return FSGPU_E_ARG; }
             mx = std::max(mx, L);
             residues += (uint64_t) L;
@@ -154,27 +164,25 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
         sOff[s] = total;
         total += (uint64_t) sLen[s] * 8;
     }
-    std::iota(ord.begin(), ord.end(), 0u);
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return sLen[a] > sLen[b]; });
     ctx->db->hStripeLen = sLen;
 
     HIPCHK(hipMalloc((void **) &ctx->db->scan, std::max<uint64_t>(total, 1) * sizeof(uint4)));
     HIPCHK(hipMalloc((void **) &ctx->db->stripeOff, std::max<size_t>(nStripes, 1) * sizeof(uint64_t)));
     HIPCHK(hipMalloc((void **) &ctx->db->stripeLen, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void **) &ctx->db->order, std::max<size_t>(nStripes, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **) &ctx->db->stripeTargets, std::max<size_t>(sTargets.size(), 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void **) &ctx->db->aln3di, std::max<uint64_t>(bytes, 1)));
     HIPCHK(hipMalloc((void **) &ctx->db->dOffsets, (n + 1) * sizeof(uint64_t)));
     HIPCHK(hipMalloc((void **) &ctx->db->dLengths, std::max<uint64_t>(n, 1) * sizeof(int32_t)));
     if (nStripes) {
         HIPCHK(hipMemcpy(ctx->db->stripeOff, sOff.data(), nStripes * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->db->stripeLen, sLen.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->db->order, ord.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->db->stripeTargets, sTargets.data(), sTargets.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemcpy(ctx->db->dOffsets, dOff, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(ctx->db->dLengths, dLen, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
     if (nStripes) {
         hipLaunchKernelGGL(k_db_scan_layout, dim3(nStripes), dim3(256), 0, ctx->stream, dRaw3di, ctx->db->dOffsets, ctx->db->dLengths,
-                           (uint32_t) n, ctx->db->stripeOff, ctx->db->stripeLen, ctx->db->scan);
+                           (uint32_t) n, ctx->db->stripeOff, ctx->db->stripeLen, ctx->db->stripeTargets, ctx->db->scan);
         HIPCHK(hipGetLastError());
     }
     if (bytes) {
@@ -357,7 +365,7 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     memcpy(ctx->hPssm.p, pssm, (size_t) kAlphabet * L);
     HIPCHK(hipMemcpyAsync(ctx->pssm.p, ctx->hPssm.p, (size_t) kAlphabet * L, hipMemcpyHostToDevice, ctx->stream));
     GaplessArgs ga;
-    ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen;
+    ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen; ga.stripeTargets = ctx->db->stripeTargets;
     bool anySplit = false;
     if ((rc = gaplessItems(ctx, nTiles > 1 ? 0 : R, &ga.items, &ga.nItems, &anySplit)) != FSGPU_OK) return rc;
     ga.nTargets = n; ga.pssm = (const int8_t *) ctx->pssm.p; ga.L = L;

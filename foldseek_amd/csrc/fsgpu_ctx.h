@@ -35,7 +35,8 @@ struct DbStore {
     int maxLen = 0;
     uint4 *scan = nullptr;
     uint64_t *stripeOff = nullptr;
-    uint32_t *stripeLen = nullptr, *order = nullptr;
+    uint32_t *stripeLen = nullptr;
+    uint32_t *stripeTargets = nullptr;   // [nStripes][8] target id of every stripe slot (0xffffffff = empty), stripes follow the length order
     uint32_t nStripes = 0;
     uint64_t scanU4 = 0;          // size of `scan` in uint4 units
     uint8_t *aln3di = nullptr, *alnAA = nullptr;
@@ -51,7 +52,7 @@ struct DbStore {
     std::mutex itemMutex;
     ~DbStore() {
         for (ItemList &l : itemLists) (void) hipFree(l.items);
-        (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(order);
+        (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(stripeTargets);
         (void) hipFree(aln3di); (void) hipFree(alnAA); (void) hipFree(raw3di); (void) hipFree(dOffsets); (void) hipFree(dLengths);
     }
 };

@@ -19,7 +19,7 @@
 //     4-register chunks sit at immediate offsets k * 22 * 256).  LDS bytes/cell = 2.
 //   * per target column a lane issues 1.5 R DP ops + 3 others (row address, dpp, hand-off perm): measured
 //     tools/ubench/gapless_ablate.hip, profiles/r01_m_gapless_ablation_ubench.txt.
-//   * the target DB is pre-tiled in HBM as 8-target stripes interleaved at 16-byte granularity: one wave-level
+//   * the target DB is pre-tiled in HBM as 8-target stripes (targets grouped by length) interleaved at 16-byte granularity: one wave-level
 //     global load = one 128-byte line, every byte of the DB is read exactly once per query.
 //   * diagonal hand-off between lanes: v_mov_b32_dpp row_shr:1 + v_perm_b32 (no LDS round trip).
 //   * waves pull work items from an atomic queue ordered by descending length (LPT).  An item is a stripe or, for
@@ -64,6 +64,7 @@ struct GaplessArgs {
     const uint4 *scan;          // stripe-interleaved target residues (codes 0..20, 21 = past end)
     const uint64_t *stripeOff;  // [nStripes] offset in uint4 units
     const uint32_t *stripeLen;  // [nStripes] length in 16-column chunks
+    const uint32_t *stripeTargets; // [nStripes][8] target id per stripe slot, 0xffffffff = empty slot
     const uint64_t *items;      // [nItems] work items, longest first: stripe << 32 | split << 31 | firstChunk << 16 | endChunk
     uint32_t nItems;
     uint32_t nTargets;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
         m = max(m, __shfl_xor(m, 1));
         m = max(m, __shfl_xor(m, 2));
         m = max(m, __shfl_xor(m, 4));
-        const uint32_t tid = stripe * kStripeTargets + j;
+        const uint32_t tid = a.stripeTargets[stripe * kStripeTargets + j];
         if (g == 0 && tid < a.nTargets) {
             if constexpr (TILED) {
                 if (!a.firstTile) m = max(m, (int) a.scoreAcc[tid]);

@@ -66,6 +66,38 @@ def test_gapless_every_register_count():
     ctx.close()
 
 
+def test_gapless_unsorted_database():
+    """targets in arbitrary length order (an ASCII DB that never went through makepaddedseqdb): stripes are formed along
+    the length order through the slot -> target table, scores still land at the DB's own target ids"""
+    rng = np.random.default_rng(99)
+    q3, qa = synth.make_queries(3, seed=9, mean_len=200, lo=50, hi=400)
+    base = synth.make_db(1500, (q3, qa), seed=10, homologs_per_query=20, hi=1500, mask_frac=0.02)
+    perm = rng.permutation(base.n)
+    lens = base.lengths[perm].astype(np.int32)
+    offsets = np.zeros(base.n + 1, np.int64)
+    offsets[1:] = np.cumsum((lens + 3) // 4 * 4)
+    d3 = np.full(offsets[-1], 20, np.uint8)
+    da = np.full(offsets[-1], 20, np.uint8)
+    for new, old in enumerate(perm):
+        d3[offsets[new]:offsets[new] + lens[new]] = base.data3di[base.offsets[old]:base.offsets[old] + lens[new]]
+        da[offsets[new]:offsets[new] + lens[new]] = base.dataaa[base.offsets[old]:base.offsets[old] + lens[new]]
+    db = synth.PaddedDB(d3, da, offsets, lens)
+    assert not (np.diff(lens) >= 0).all()
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m = api.Matrix(0, 2.0)
+    for qi in range(3):
+        pssm, cap = api.prefilter_profile(m, q3[qi], True, 0.15)
+        hits = ctx.gapless_scan(pssm, cap, min_score=30, max_res=150)
+        got = ctx.gapless_scores().astype(np.int32)
+        want = helpers.o_ungapped_scores(q3[qi], db, True)
+        assert (got == want).all(), np.flatnonzero(got != want)[:10]
+        assert (got[np.argsort(perm)] == helpers.o_ungapped_scores(q3[qi], base, True)).all()      # same scores as the sorted DB
+        sel = helpers.o_prefilter_select(want, 30, -1, 150)
+        assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
+    ctx.close()
+
+
 def test_gapless_identity_and_truncation(small_db):
     ctx, db, q3, _ = small_db
     m = api.Matrix(0, 2.0)

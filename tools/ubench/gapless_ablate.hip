@@ -677,6 +677,11 @@ static void suite(int nStripes, int len16, int L) {
         for (int s2 = 0; s2 < nStripes; s2++) items[s2] = ((uint64_t) s2 << 32) | (uint32_t) len16;
         hipMalloc(&d, 8 * nStripes); hipMemcpy(d, items.data(), 8 * nStripes, hipMemcpyHostToDevice); ga.items = (const uint64_t *) d; ga.nItems = nStripes;
     }
+    {
+        std::vector<uint32_t> ident(nStripes * 8);
+        for (int t = 0; t < nStripes * 8; t++) ident[t] = t;
+        hipMalloc(&d, 4 * ident.size()); hipMemcpy(d, ident.data(), 4 * ident.size(), hipMemcpyHostToDevice); ga.stripeTargets = (const uint32_t *) d;
+    }
     ga.nStripes = nStripes; ga.nTargets = nStripes * 8; ga.L = L; ga.cap = 255; ga.firstTile = ga.lastTile = 1;
     const int lds = gaplessLdsBytes(R);
     const double cells = (double) nStripes * 8 * len16 * 16 * (16.0 * R);
