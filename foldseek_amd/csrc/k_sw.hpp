@@ -252,7 +252,11 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
             hOut = Hp[R - 1]; fsegOut = fseg; ffullOut = ffull;
             const uint32_t nb = A::max(best, cm);
             if (nb != best) {
-                const uint32_t m = A::gtMask(cm, best);
+                // some lane of the wave sees a new maximum (most steps of the first half of a target): one v_bfi_b32 per
+                // register.  The mask is made opaque so that the compiler keeps the bit-select form instead of
+                // re-deriving it as two half-word compares + selects + a byte permute per register.
+                uint32_t m = A::gtMask(cm, best);
+                asm volatile("" : "+v"(m));
                 const uint32_t cp = A::splat((uint32_t) col);
                 bestcol = (m & cp) | (~m & bestcol);
 #pragma unroll
