@@ -48,6 +48,21 @@ for i in (0, 1, 63, 500, NQ - 1):
     bad += du[int(qkeys[i])].decode() != "".join(api.format_prefilter_hit(int(h["id"]), int(h["score"]), 0) for h in hits)
     r, b = s.align(qa[i], q3[i], hits["id"], with_backtrace=True)
     bad += au[int(qkeys[i])].decode() != "".join(s.format_result(r[j:j + 1], b[j], True) for j in range(len(r)))
+# resident DB: gpuserver + ungappedprefilter --gpu-server 1 (one query in flight by protocol)
+import signal
+name = "fsgpu_soak_%d" % os.getpid()
+t = time.time()
+srv = subprocess.Popen([BIN, "gpuserver", tdb + "_ss", "--shm-name", name], stderr=subprocess.PIPE, text=True)
+while not (os.path.exists("/dev/shm/" + name) and os.path.getsize("/dev/shm/" + name) > 0):
+    assert srv.poll() is None
+    time.sleep(0.02)
+print("gpuserver up in %.2fs" % (time.time() - t), flush=True)
+ps = os.path.join(tmp, "pref_served")
+run(["ungappedprefilter", qdb + "_ss", tdb + "_ss", ps, "--gpu-server", "1", "--shm-name", name])
+srv.send_signal(signal.SIGTERM); srv.wait(timeout=60)
+_, dsv = dbio.read_db(ps)
+print("served ungappedprefilter == direct:", dsv == du)
+bad += dsv != du
 print("fused search == prefilter + structurealign:", afd == ak)
 bad += afd != ak
 print("spot-check mismatches:", bad)
