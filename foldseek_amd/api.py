@@ -67,6 +67,8 @@ def lib():
         "fsgpu_last_error": (C.c_char_p, [vp]),
         "fsgpu_clone": (i32, [vp, C.POINTER(vp)]),
         "fsgpu_device": (i32, [vp]),
+        "fsgpu_device_count": (i32, []),
+        "fsgpu_db_broadcast": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32)]),
         "fsgpu_stream": (vp, [vp]),
         "fsgpu_db_load": (i32, [vp, vp, vp, vp, vp, u64, u64]),
         "fsgpu_db_adopt_device": (i32, [vp, vp, vp, vp, vp, u64, u64]),
@@ -254,6 +256,16 @@ class Context:
     def clone(self):
         """second context (own stream + scratch) sharing this context's resident DB"""
         return Context(_clone_of=self)
+
+    def broadcast_db_to(self, others):
+        """replicate this context's resident DB into contexts created on other devices (fsgpu_db_broadcast); returns
+        True when RCCL carried the broadcast, False for peer copies"""
+        arr = (C.c_void_p * len(others))(*[o.h for o in others])
+        used = C.c_int(0)
+        self._chk(lib().fsgpu_db_broadcast(self.h, arr, len(others), C.byref(used)), "fsgpu_db_broadcast")
+        for o in others:
+            o._keep = self._keep
+        return bool(used.value)
 
     def _chk(self, rc, what):
         if rc != 0:

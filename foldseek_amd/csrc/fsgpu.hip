@@ -1,6 +1,7 @@
 // fsgpu.hip -- C ABI (include/fsgpu.h) over the gfx950 kernels.  Host side: HIP runtime only, no torch.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -84,6 +85,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
 
 const char *fsgpu_last_error(const fsgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
 int fsgpu_device(const fsgpu_ctx *ctx) { return ctx ? ctx->device : -1; }
+int fsgpu_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 void *fsgpu_stream(const fsgpu_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 uint64_t fsgpu_db_size(const fsgpu_ctx *ctx) { return ctx && ctx->db ? ctx->db->n : 0; }
 uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx) { return ctx && ctx->db ? ctx->db->residues : 0; }
@@ -242,6 +244,111 @@ int fsgpu_db_load(fsgpu_ctx *ctx, const uint8_t *data3di, const uint8_t *dataAA,
 
 } // extern "C"
 
+
+
+// ------------------------------------------------------------------------------------------------------------
+// One node, several GPUs, one process: replicate the resident database of `src` into contexts on other devices
+// with ONE broadcast per buffer (RCCL over xGMI, single-process communicator set; librccl is loaded on demand so
+// that single-GPU use has no dependency on it) or, when RCCL cannot be loaded, with peer copies.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    bool load() {
+        if (getenv("FSGPU_NO_RCCL")) return false;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll)) dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy)) dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart)) dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd)) dlsym(lib, "ncclGroupEnd");
+        Broadcast = (decltype(Broadcast)) dlsym(lib, "ncclBroadcast");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast;
+    }
+};
+} // namespace
+
+extern "C" int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *usedRccl) {
+    fsgpu_ctx *ctx = src;       // HIPCHK reports into the source context
+    if (usedRccl) *usedRccl = 0;
+    if (!src || (n > 0 && !dst) || n < 0) return FSGPU_E_ARG;
+    if (!src->db || src->db->n == 0) { src->err = "fsgpu_db_broadcast: no database loaded"; return FSGPU_E_NODB; }
+    if (n == 0) return FSGPU_OK;
+    bool distinct = true;
+    for (int i = 0; i < n; i++) {
+        if (!dst[i] || dst[i] == src) { src->err = "fsgpu_db_broadcast: bad destination context"; return FSGPU_E_ARG; }
+        distinct = distinct && dst[i]->device != src->device;      // a second copy on the same device is legal (tests), RCCL is not used for it
+    }
+    const DbStore &db = *src->db;
+    const uint64_t nT = db.n, bytes = db.bytes;
+    // the four inputs of buildDb as they live on the source device (the unmasked AA copy is a fixed point of k_db_unmask)
+    struct Buf { const void *srcp; size_t size; std::vector<void *> dstp; };
+    Buf bufs[4] = {{db.raw3di, (size_t) bytes, {}}, {db.hasAA ? db.alnAA : nullptr, db.hasAA ? (size_t) bytes : 0, {}},
+                   {db.dOffsets, (size_t) (nT + 1) * sizeof(uint64_t), {}}, {db.dLengths, (size_t) nT * sizeof(int32_t), {}}};
+    auto freeAll = [&]() {
+        for (Buf &b : bufs) for (size_t i = 0; i < b.dstp.size(); i++) if (b.dstp[i]) { (void) hipSetDevice(dst[i]->device); (void) hipFree(b.dstp[i]); }
+        (void) hipSetDevice(src->device);
+    };
+    for (Buf &b : bufs) {
+        b.dstp.assign(n, nullptr);
+        if (!b.size) continue;
+        for (int i = 0; i < n; i++) {
+            if (hipSetDevice(dst[i]->device) != hipSuccess || hipMalloc(&b.dstp[i], b.size) != hipSuccess) { freeAll(); src->err = "fsgpu_db_broadcast: out of device memory"; return FSGPU_E_NOMEM; }
+        }
+    }
+    HIPCHK(hipSetDevice(src->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    Rccl rccl;
+    bool done = false;
+    if (distinct && rccl.load()) {
+        std::vector<int> devs(n + 1);
+        devs[0] = src->device;
+        for (int i = 0; i < n; i++) devs[i + 1] = dst[i]->device;
+        std::vector<void *> comms(n + 1, nullptr);
+        if (rccl.CommInitAll(comms.data(), n + 1, devs.data()) == 0) {
+            bool ok = true;
+            for (Buf &b : bufs) {
+                if (!b.size) continue;
+                ok = ok && rccl.GroupStart() == 0;
+                for (int r = 0; r <= n && ok; r++) {
+                    fsgpu_ctx *c = r == 0 ? src : dst[r - 1];
+                    ok = hipSetDevice(c->device) == hipSuccess &&
+                         rccl.Broadcast(b.srcp, r == 0 ? const_cast<void *>(b.srcp) : b.dstp[r - 1], b.size, 1 /*ncclUint8*/, 0, comms[r], c->stream) == 0;
+                }
+                ok = (rccl.GroupEnd() == 0) && ok;
+            }
+            for (int r = 0; r <= n; r++) {
+                fsgpu_ctx *c = r == 0 ? src : dst[r - 1];
+                ok = hipSetDevice(c->device) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess && ok;
+            }
+            for (void *c : comms) if (c) rccl.CommDestroy(c);
+            done = ok;
+            if (usedRccl) *usedRccl = ok ? 1 : 0;
+        }
+    }
+    if (!done) {
+        for (Buf &b : bufs) {
+            if (!b.size) continue;
+            for (int i = 0; i < n; i++)
+                if (hipMemcpyPeer(b.dstp[i], dst[i]->device, b.srcp, src->device, b.size) != hipSuccess) { freeAll(); src->err = "fsgpu_db_broadcast: peer copy failed"; return FSGPU_E_HIP; }
+        }
+    }
+    int rc = FSGPU_OK;
+    for (int i = 0; i < n && rc == FSGPU_OK; i++) {
+        rc = fsgpu_db_adopt_device(dst[i], bufs[0].dstp[i], bufs[1].dstp[i], bufs[2].dstp[i], bufs[3].dstp[i], nT, bytes);
+        if (rc != FSGPU_OK) src->err = std::string("fsgpu_db_broadcast: ") + dst[i]->err;
+    }
+    freeAll();
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // gapless work list.  ov = warm-up chunks a column segment needs (= register count R of the query, 16 R >= Lq);

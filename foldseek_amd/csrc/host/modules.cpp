@@ -136,6 +136,55 @@ void fillParams(const Options &o, fshost_params &p) {
 }
 
 
+
+// ---- devices ------------------------------------------------------------------------------------------------------
+// --gpus N (or "all"): the target DB is loaded once on --gpu-device, replicated to N - 1 more devices with ONE broadcast
+// (fsgpu_db_broadcast: RCCL over xGMI, peer copies as fallback), and host threads -- `--threads` per GPU -- pull queries
+// from one shared counter: dynamic query sharding, no communication after the broadcast.
+struct DeviceSet {
+    std::vector<fsgpu_ctx *> root;            // one context per GPU, each owning that GPU's resident DB (+ k-mer index)
+    int perGpuThreads = 1;
+    int threads() const { return (int) root.size() * perGpuThreads; }
+    bool open(const Options &o, const PaddedTarget &pt, bool withAA, int defaultThreads, std::string &err) {
+        int count = 0;
+        const int first = o.geti("--gpu-device", 0);
+        auto it = o.kv.find("--gpus");
+        int want = 1;
+        fsgpu_ctx *c0 = nullptr;
+        if (fsgpu_create(first, &c0) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(nullptr); return false; }
+        root.push_back(c0);
+        if (it != o.kv.end()) {
+            count = fsgpu_device_count();
+            want = it->second == "all" ? count - first : atoi(it->second.c_str());
+            if (want < 1 || first + want > count) { err = "--gpus: " + it->second + " devices requested from device " + std::to_string(first) + ", " + std::to_string(count) + " visible"; return false; }
+        }
+        if (fsgpu_db_load(c0, pt.d3, withAA ? pt.dA : nullptr, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK) {
+            err = std::string("GPU: ") + fsgpu_last_error(c0); return false;
+        }
+        for (int d = 1; d < want; d++) {
+            fsgpu_ctx *c = nullptr;
+            if (fsgpu_create(first + d, &c) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(nullptr); return false; }
+            root.push_back(c);
+        }
+        if (want > 1) {
+            int usedRccl = 0;
+            if (fsgpu_db_broadcast(c0, root.data() + 1, want - 1, &usedRccl) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(c0); return false; }
+            fprintf(stderr, "target DB replicated to %d GPUs (%s)\n", want, usedRccl ? "RCCL broadcast" : "peer copies");
+        }
+        perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 16));
+        return true;
+    }
+    // worker tix runs on GPU tix % nGpus; the first worker of a GPU uses its root context, the others a clone
+    fsgpu_ctx *forThread(int tix, bool &owned) {
+        fsgpu_ctx *r = root[tix % root.size()];
+        owned = tix >= (int) root.size();
+        if (!owned) return r;
+        fsgpu_ctx *c = nullptr;
+        return fsgpu_clone(r, &c) == FSGPU_OK ? c : nullptr;
+    }
+    void close() { for (fsgpu_ctx *c : root) fsgpu_destroy(c); root.clear(); }
+};
+
 // ---- gpuserver protocol ------------------------------------------------------------------------------------------
 volatile sig_atomic_t gKeepRunning = 1;
 void onSignal(int) { gKeepRunning = 0; }
@@ -307,20 +356,19 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
     if (o.geti("--gpu-server", 0) != 0) return ungappedPrefilterViaServer(o, q, t, sameDB, par, m3);
     PaddedTarget pt;
     if (!loadPadded(t, nullptr, m3, nullptr, pt, err)) return fail(err);
-    fsgpu_ctx *ctx0 = nullptr;
-    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
-    if (fsgpu_db_load(ctx0, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
-        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    DeviceSet ds;
+    if (!ds.open(o, pt, false, 3, err)) { ds.close(); return fail(err); }
     DbWriter w;
-    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) return fail(err);
-    const int nthreads = std::max(1, std::min(o.geti("--threads", 3), 16));
+    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
+    const int nthreads = ds.threads();
     std::vector<std::string> results(q.size());
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     std::string firstErr;
     auto work = [&](int tix) {
-        fsgpu_ctx *ctx = ctx0;
-        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        bool owned = false;
+        fsgpu_ctx *ctx = ds.forThread(tix, owned);
+        if (!ctx) { bad++; return; }
         fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data());
         std::vector<fsgpu_hit> hits(par.maxResListLen);
         std::vector<uint8_t> codes;
@@ -340,15 +388,15 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
             for (int k = 0; k < n; k++) out.append(line, fshost_format_prefilter_hit(line, pt.keys[hits[k].id], hits[k].score, 0));
         }
         fshost_search_free(s);
-        if (tix > 0) fsgpu_destroy(ctx);
+        if (owned) fsgpu_destroy(ctx);
     };
     std::vector<std::thread> ths;
     for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
     work(0);
     for (auto &th : ths) th.join();
-    if (bad) { fsgpu_destroy(ctx0); return fail("ungappedprefilter failed: " + firstErr); }
+    ds.close();
+    if (bad) return fail("ungappedprefilter failed: " + firstErr);
     for (size_t id = 0; id < q.size(); id++) w.write(q.key(id), results[id].data(), results[id].size());   // empty entries too
-    fsgpu_destroy(ctx0);
     if (!w.close(err)) return fail(err);
     return EXIT_SUCCESS;
 }
@@ -392,28 +440,28 @@ int fsmod_prefilter(int argc, const char **argv) {
     if (!m8 || !m2 || !m3.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f)) return fail("matrix construction failed");
     PaddedTarget pt;
     if (!loadPadded(t, nullptr, m3, nullptr, pt, err)) return fail(err);
-    fsgpu_ctx *ctx0 = nullptr;
-    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
-    if (fsgpu_db_load(ctx0, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
-        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    DeviceSet ds;
+    if (!ds.open(o, pt, false, 2, err)) { ds.close(); return fail(err); }
     fsgpu_kmer_index_params ip;
     ip.kmerSize = kmerSize; ip.spaced = spaced; ip.kmerThr = kmerThr;
     ip.maskLowerCase = o.geti("--mask-lower-case", 1); ip.maskNrepeats = o.geti("--mask-n-repeat", 6);
-    if (fsgpu_kmer_index_build(ctx0, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    for (fsgpu_ctx *c : ds.root)      // every GPU builds its own index from its copy of the DB (0.1 - 0.6 s, cheaper than moving it)
+        if (fsgpu_kmer_index_build(c, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(c); ds.close(); return fail(err); }
     fsgpu_kmer_search_params sp;
     memset(&sp, 0, sizeof(sp));
     sp.maxResListLen = maxRes; sp.minDiagScoreThr = o.geti("--min-ungapped-score", 30);
     DbWriter w;
-    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) return fail(err);
-    const int nthreads = std::max(1, std::min(o.geti("--threads", 2), 16));
+    if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
+    const int nthreads = ds.threads();
     const size_t batch = 32;
     std::vector<std::string> results(q.size());
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0), unstable(0);
     std::string firstErr;
     auto work = [&](int tix) {
-        fsgpu_ctx *ctx = ctx0;
-        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        bool owned = false;
+        fsgpu_ctx *ctx = ds.forThread(tix, owned);
+        if (!ctx) { bad++; return; }
         std::vector<std::vector<uint8_t>> codes(batch);
         std::vector<std::vector<int16_t>> thr(batch);
         std::vector<std::vector<int8_t>> prof(batch);
@@ -451,17 +499,17 @@ int fsmod_prefilter(int argc, const char **argv) {
                 }
             }
         }
-        if (tix > 0) fsgpu_destroy(ctx);
+        if (owned) fsgpu_destroy(ctx);
     };
     std::vector<std::thread> ths;
     for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
     work(0);
     for (auto &th : ths) th.join();
     fshost_matrix_free(m8); fshost_matrix_free(m2);
-    if (bad) { fsgpu_destroy(ctx0); return fail("prefilter failed: " + firstErr); }
+    ds.close();
+    if (bad) return fail("prefilter failed: " + firstErr);
     if (unstable) fprintf(stderr, "prefilter: %d queries matched more than half of the diagonal buffer; equal scores at the --max-seqs cut are ordered deterministically there (the reference's order is unspecified)\n", (int) unstable);
     for (size_t id = 0; id < q.size(); id++) w.write(q.key(id), results[id].data(), results[id].size());   // empty entries too (Prefiltering.cpp:900)
-    fsgpu_destroy(ctx0);
     if (!w.close(err)) return fail(err);
     return EXIT_SUCCESS;
 }
@@ -493,33 +541,33 @@ int fsmod_search(int argc, const char **argv) {
     if (!m8 || !m2) return fail("matrix construction failed");
     PaddedTarget pt;
     if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
-    fsgpu_ctx *ctx0 = nullptr;
-    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
-    if (fsgpu_db_load(ctx0, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
-        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    DeviceSet ds;
+    if (!ds.open(o, pt, true, 3, err)) { ds.close(); return fail(err); }
     const int maxRes = (int) std::min<uint64_t>((uint64_t) par.maxResListLen, std::max<uint64_t>(t3.size(), 1));
     if (prefMode == 0) {
         fsgpu_kmer_index_params ip;
         ip.kmerSize = 6; ip.spaced = spaced; ip.kmerThr = kmerThr;
         ip.maskLowerCase = o.geti("--mask-lower-case", 1); ip.maskNrepeats = o.geti("--mask-n-repeat", 6);
-        if (fsgpu_kmer_index_build(ctx0, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+        for (fsgpu_ctx *c : ds.root)
+            if (fsgpu_kmer_index_build(c, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(c); ds.close(); return fail(err); }
     }
     fsgpu_kmer_search_params sp;
     memset(&sp, 0, sizeof(sp));
     sp.maxResListLen = maxRes; sp.minDiagScoreThr = par.minDiagScoreThr;
     DbWriter w, wp;
-    if (!w.open(o.pos[2], DBTYPE_ALIGNMENT_RES, err)) return fail(err);
+    if (!w.open(o.pos[2], DBTYPE_ALIGNMENT_RES, err)) { ds.close(); return fail(err); }
     const bool writePref = o.pos.size() == 4;
-    if (writePref && !wp.open(o.pos[3], DBTYPE_PREFILTER_RES, err)) return fail(err);
-    const int nthreads = std::max(1, std::min(o.geti("--threads", 3), 16));
+    if (writePref && !wp.open(o.pos[3], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
+    const int nthreads = ds.threads();
     const size_t batch = prefMode == 0 ? 32 : 16;
     std::vector<std::string> results(q3.size()), prefs(writePref ? q3.size() : 0);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     std::string firstErr;
     auto work = [&](int tix) {
-        fsgpu_ctx *ctx = ctx0;
-        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        bool owned = false;
+        fsgpu_ctx *ctx = ds.forThread(tix, owned);
+        if (!ctx) { bad++; return; }
         fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data());
         std::vector<std::vector<uint8_t>> cA(batch), c3(batch);
         std::vector<std::vector<int16_t>> thr(batch);
@@ -604,19 +652,19 @@ int fsmod_search(int argc, const char **argv) {
             }
         }
         fshost_search_free(s);
-        if (tix > 0) fsgpu_destroy(ctx);
+        if (owned) fsgpu_destroy(ctx);
     };
     std::vector<std::thread> ths;
     for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
     work(0);
     for (auto &th : ths) th.join();
     fshost_matrix_free(m8); fshost_matrix_free(m2);
-    if (bad) { fsgpu_destroy(ctx0); return fail("search failed: " + firstErr); }
+    ds.close();
+    if (bad) return fail("search failed: " + firstErr);
     for (size_t id = 0; id < q3.size(); id++) {
         w.write(q3.key(id), results[id].data(), results[id].size());
         if (writePref) wp.write(q3.key(id), prefs[id].data(), prefs[id].size());
     }
-    fsgpu_destroy(ctx0);
     if (!w.close(err) || (writePref && !wp.close(err))) return fail(err);
     return EXIT_SUCCESS;
 }
@@ -638,13 +686,11 @@ int fsmod_structurealign(int argc, const char **argv) {
     mA.builtin(FSHOST_MAT_BLOSUM62, par.alignmentType == 2 ? 1.4f : 0.0f, 0.0f);
     PaddedTarget pt;
     if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
-    fsgpu_ctx *ctx0 = nullptr;
-    if (fsgpu_create(o.geti("--gpu-device", 0), &ctx0) != FSGPU_OK) return fail(std::string("GPU: ") + fsgpu_last_error(nullptr));
-    if (fsgpu_db_load(ctx0, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data(), pt.lengths.size(), pt.bytes) != FSGPU_OK)
-        return fail(std::string("GPU: ") + fsgpu_last_error(ctx0));
+    DeviceSet ds;
+    if (!ds.open(o, pt, true, 3, err)) { ds.close(); return fail(err); }
     DbWriter w;
-    if (!w.open(o.pos[3], DBTYPE_ALIGNMENT_RES, err)) return fail(err);
-    const int nthreads = std::max(1, std::min(o.geti("--threads", 3), 16));
+    if (!w.open(o.pos[3], DBTYPE_ALIGNMENT_RES, err)) { ds.close(); return fail(err); }
+    const int nthreads = ds.threads();
     std::vector<std::string> results(pref.size());
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
@@ -653,8 +699,9 @@ int fsmod_structurealign(int argc, const char **argv) {
     // (fshost_search_align_batch), then gates / backtrace / formatting per query
     const size_t group = (size_t) std::max(1, std::min(o.geti("--align-batch", 8), 64));
     auto work = [&](int tix) {
-        fsgpu_ctx *ctx = ctx0;
-        if (tix > 0 && fsgpu_clone(ctx0, &ctx) != FSGPU_OK) { bad++; return; }
+        bool owned = false;
+        fsgpu_ctx *ctx = ds.forThread(tix, owned);
+        if (!ctx) { bad++; return; }
         fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data());
         std::vector<std::vector<uint8_t>> cA(group), c3(group);
         std::vector<std::vector<uint32_t>> ids(group);
@@ -709,15 +756,15 @@ int fsmod_structurealign(int argc, const char **argv) {
             }
         }
         fshost_search_free(s);
-        if (tix > 0) fsgpu_destroy(ctx);
+        if (owned) fsgpu_destroy(ctx);
     };
     std::vector<std::thread> ths;
     for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
     work(0);
     for (auto &th : ths) th.join();
-    if (bad) { fsgpu_destroy(ctx0); return fail("structurealign failed: " + firstErr); }
+    ds.close();
+    if (bad) return fail("structurealign failed: " + firstErr);
     for (size_t id = 0; id < pref.size(); id++) w.write(pref.key(id), results[id].data(), results[id].size());
-    fsgpu_destroy(ctx0);
     if (!w.close(err)) return fail(err);
     return EXIT_SUCCESS;
 }

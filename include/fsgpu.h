@@ -75,7 +75,14 @@ const char *fsgpu_last_error(const fsgpu_ctx *ctx); /* ctx may be NULL: returns 
  * `src` (reference counted): lets several host threads keep the device busy, the way the reference runs one aligner
  * object per OpenMP thread over one shared DBReader (F/src/strucclustutils/structurealign.cpp:284-321). */
 int fsgpu_clone(const fsgpu_ctx *src, fsgpu_ctx **out);
+/* One node, several GPUs, one process: replicates the resident database of `src` into the n contexts dst[] created on
+ * OTHER devices, one broadcast per buffer over RCCL (xGMI; librccl is loaded on demand) or peer copies when RCCL is
+ * not available (FSGPU_NO_RCCL=1 forces that).  *usedRccl (may be NULL) reports which.  Queries then shard over the
+ * devices with no further communication (the reference's multi-GPU path shards TARGETS per device and
+ * merges top-N lists, M/lib/libmarv/src/cudasw4.cuh:1477-1553 -- not needed when the DB fits every GPU's 288 GB). */
+int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *usedRccl);
 int fsgpu_device(const fsgpu_ctx *ctx);
+int fsgpu_device_count(void);      /* visible HIP devices, 0 when there is none */
 /* HIP stream all kernels of this context are launched on (a hipStream_t), for callers that time with events */
 void *fsgpu_stream(const fsgpu_ctx *ctx);
 

@@ -243,3 +243,49 @@ def test_gpuserver_roundtrip_and_raw_protocol(tmp_path):
             srv.kill()
         if os.path.exists("/dev/shm/" + name):
             os.remove("/dev/shm/" + name)
+
+
+def test_db_replication_and_gpus_option(tmp_path):
+    """fsgpu_db_broadcast: a context that received the DB through the replication path (peer copies here -- one GPU on
+    the box, so the second copy lives on the same device and RCCL is not involved) answers exactly like the source;
+    `--gpus 1` is the single-device path of the modules, asking for more devices than visible fails loudly."""
+    q3, qa = synth.make_queries(3, seed=91, mean_len=180, lo=60, hi=350)
+    db = synth.make_db(800, (q3, qa), seed=92, homologs_per_query=20, mask_frac=0.02)
+    src = api.Context(0)
+    src.load_db(db)
+    dst = api.Context(0)
+    os.environ["FSGPU_NO_RCCL"] = "1"
+    try:
+        assert src.broadcast_db_to([dst]) is False
+    finally:
+        del os.environ["FSGPU_NO_RCCL"]
+    assert dst.n == src.n and dst.residues == src.residues
+    par = api.default_params()
+    par.alignmentType = 2
+    sa, sb = api.Search(src, par), api.Search(dst, par)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    dst.kmer_index_build(m8, kmer_thr=api.kmer_threshold(9.5, 6))
+    src.kmer_index_build(m8, kmer_thr=api.kmer_threshold(9.5, 6))
+    for i in range(3):
+        ha, hb = sa.prefilter(q3[i]), sb.prefilter(q3[i])
+        assert (ha["id"] == hb["id"]).all() and (ha["score"] == hb["score"]).all() and len(ha) > 0
+        ra, rb = sa.align(qa[i], q3[i], ha["id"]), sb.align(qa[i], q3[i], hb["id"])
+        assert ra.tobytes() == rb.tobytes()
+        ka, _ = src.kmer_search([api.kmer_query_prepare(m8, m2, q3[i])], max_res=200)
+        kb, _ = dst.kmer_search([api.kmer_query_prepare(m8, m2, q3[i])], max_res=200)
+        assert ka[0].tobytes() == kb[0].tobytes()
+    sa.close(); sb.close(); dst.close(); src.close()
+    # module level
+    qdb, tdb = str(tmp_path / "q_ss"), str(tmp_path / "t_ss_pad")
+    dbio.write_seq_db(qdb, q3, [1, 2, 3])
+    dbio.write_padded_db(tdb, db, "3di")
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    subprocess.check_call([BIN, "ungappedprefilter", qdb, tdb, a, "--max-seqs", "100"])
+    subprocess.check_call([BIN, "ungappedprefilter", qdb, tdb, b, "--max-seqs", "100", "--gpus", "1", "--threads", "2"])
+    assert dbio.read_db(a) == dbio.read_db(b)
+    ngpu = api.lib().fsgpu_device_count()
+    r = subprocess.run([BIN, "ungappedprefilter", qdb, tdb, str(tmp_path / "c"), "--gpus", str(ngpu + 1)], capture_output=True, text=True)
+    assert r.returncode != 0 and "--gpus" in r.stderr
+    if ngpu > 1:       # more than one device on this box: the real thing, RCCL broadcast included
+        subprocess.check_call([BIN, "ungappedprefilter", qdb, tdb, str(tmp_path / "d"), "--max-seqs", "100", "--gpus", "all"])
+        assert dbio.read_db(a) == dbio.read_db(str(tmp_path / "d"))
