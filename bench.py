@@ -263,6 +263,12 @@ def main():
     from foldseek_amd import dist as fdist
     import threading
     nthreads = max(1, args.host_threads)
+    # host wait policy of the library (fsgpu_ctx.h::syncStream): a waiting feeder thread polls the stream for FSGPU_SPIN_US
+    # and then sleeps.  Polling all the way is 1.5 % faster but costs a core per thread; only do it when the cores this job
+    # may use (cgroup quota!) comfortably cover every rank's feeder threads.
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if "FSGPU_SPIN_US" not in os.environ:
+        os.environ["FSGPU_SPIN_US"] = "1000000" if usable_cores() >= 2 * local_world * nthreads else "40"
     nq = args.steps + args.warmup
     q3, qa = synth.make_queries(nq, seed=1000 + rank, lo=250, hi=450)        # per-rank queries around the mean length 350
     # ---- target DB: generated on rank 0, ONE broadcast (RCCL over xGMI), then resident in every GPU's HBM ----

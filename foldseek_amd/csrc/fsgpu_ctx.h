@@ -1,6 +1,8 @@
 // fsgpu_ctx.h -- private: the context / database structures shared by the translation units of libfsgpu.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -108,12 +110,21 @@ struct fsgpu_ctx {
 
 // Wait for the context stream by polling: hipStreamSynchronize from a non-main host thread falls back to a blocking
 // wait that costs ~0.2 ms per call on this stack, more than the kernels it waits for.
+// Wait for the context's stream.  Poll for a short while (a scan finishes in a few hundred microseconds and the caller
+// wants the result right away), then back off to short sleeps: a host thread that waits must not burn a core -- several
+// feeder threads per GPU times eight GPUs exceeds the CPU quota of a container long before it exceeds the GPUs.
+// FSGPU_SPIN_US overrides the polling window (microseconds, default 40; 0 = sleep immediately).
 inline int syncStream(fsgpu_ctx *ctx) {
-    for (unsigned spins = 0;; spins++) {
+    static const long spinUs = [] { const char *e = getenv("FSGPU_SPIN_US"); return e ? atol(e) : 40L; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned polls = 0;; polls++) {
         hipError_t e = hipStreamQuery(ctx->stream);
         if (e == hipSuccess) return FSGPU_OK;
         if (e != hipErrorNotReady) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
-        if (spins > 200000) { std::this_thread::yield(); }
+        if ((polls & 15) == 15 || spinUs == 0) {
+            const long us = (long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (us >= spinUs) std::this_thread::sleep_for(std::chrono::microseconds(us < 2000 ? 20 : 100));
+        }
     }
 }
 
