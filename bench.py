@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1]), 2: 3Di+AA")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
-    ap.add_argument("--group", type=int, default=16, help="queries a host thread prefilters back to back before ONE multi-query SW launch (0: one SW launch per query)")
+    ap.add_argument("--group", type=int, default=32, help="queries a host thread prefilters back to back before ONE multi-query SW launch (0: one SW launch per query)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
     ap.add_argument("--kmer-threads", type=int, default=3, help="host threads (context clones) of the k-mer section")

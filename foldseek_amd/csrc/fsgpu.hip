@@ -616,6 +616,28 @@ static int launchSwBlocksT(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStr
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
+// k_sw2: two targets per wave, one direction (image with the extra "past the end" row)
+template <int R, bool HAS_AA>
+static int launchSwBlocks2T(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
+    const int lds = (HAS_AA ? 2 : 1) * kSw2Rows * swRowDwords(R) * 4;
+    static thread_local bool attrSet = false;
+    if (!attrSet) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_sw2<R, HAS_AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL((k_sw2<R, HAS_AA>), dim3(nBlocks), dim3(256), lds, stream, sa);
+    HIPCHK(hipGetLastError());
+    return FSGPU_OK;
+}
+static int launchSwBlocks2(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks, hipStream_t stream) {
+#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocks2T<RR, true>(ctx, sa, nBlocks, stream) : launchSwBlocks2T<RR, false>(ctx, sa, nBlocks, stream);
+    switch (R) {
+        FS_SW_CASE(1) FS_SW_CASE(2) FS_SW_CASE(3) FS_SW_CASE(4) FS_SW_CASE(6) FS_SW_CASE(8)
+        default: ctx->err = "internal: bad SW R"; return FSGPU_E_ARG;
+    }
+#undef FS_SW_CASE
+}
+
 static int launchSwBlocks(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks, hipStream_t stream) {
 #define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocksT<RR, true>(ctx, sa, nBlocks, stream) : launchSwBlocksT<RR, false>(ctx, sa, nBlocks, stream);
     switch (R) {
@@ -782,9 +804,13 @@ int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_f
 // Several queries in one go: all single-tile queries (L <= 512) of one register class R share ONE launch -- workgroups
 // of 4 waves, each workgroup serving pairs of a single query and loading that query's LDS image -- so the device sees
 // tens of thousands of independent waves instead of ~1000 per launch and the long-target tail of one query overlaps
-// the bulk of the others.  Longer queries and int16-saturated pairs go through the single-query path.
-int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev) {
-    if (!ctx || nq < 0 || (nq > 0 && (!q || !fwd || !rev))) return FSGPU_E_ARG;
+// the bulk of the others.  One call runs ONE direction (dir 0: forward query, 1: reversed query) over the selected
+// pairs with k_sw2 (two targets per wave): structurealign looks at the reversed-query score only for pairs that pass
+// the forward gates, so the caller runs dir 0 over everything, gates, and runs dir 1 over the survivors.
+// Longer queries and int16-saturated pairs go through the single-query path (k_sw, both directions at once).
+int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, int dir,
+                       const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out) {
+    if (!ctx || nq < 0 || (nq > 0 && (!q || !out)) || (dir != 0 && dir != 1) || ((sel == nullptr) != (nsel == nullptr))) return FSGPU_E_ARG;
     if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
         ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
@@ -792,51 +818,57 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
     }
     if (ctx->sw.pending) { ctx->err = "previous SW batch not finished"; return FSGPU_E_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
-    std::vector<size_t> base(nq + 1, 0);
+    std::vector<size_t> base(nq + 1, 0), sbase(nq + 1, 0);     // offsets into out[] (all pairs) / into the launch (selected pairs)
     bool hasAA = false, anyAA = false, allAA = true;
     for (int i = 0; i < nq; i++) {
         if (!q[i].p3Di_fwd || !q[i].p3Di_rev || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN || q[i].n < 0 || (q[i].n > 0 && !q[i].targetIds) ||
             ((q[i].pAA_fwd == nullptr) != (q[i].pAA_rev == nullptr))) { ctx->err = "fsgpu_sw_multi: bad query"; return FSGPU_E_ARG; }
         anyAA = anyAA || q[i].pAA_fwd != nullptr; allAA = allAA && q[i].pAA_fwd != nullptr;
         base[i + 1] = base[i] + (size_t) q[i].n;
+        const int ns = sel ? nsel[i] : q[i].n;
+        if (ns < 0 || ns > q[i].n || (sel && ns > 0 && !sel[i])) { ctx->err = "fsgpu_sw_multi_dir: bad selection"; return FSGPU_E_ARG; }
+        sbase[i + 1] = sbase[i] + (size_t) ns;
         for (int k = 0; k < q[i].n; k++) if (q[i].targetIds[k] >= ctx->db->n) { ctx->err = "target id out of range"; return FSGPU_E_ARG; }
+        if (sel) for (int k = 0; k < ns; k++) if (sel[i][k] < 0 || sel[i][k] >= q[i].n) { ctx->err = "fsgpu_sw_multi_dir: selection index out of range"; return FSGPU_E_ARG; }
     }
     if (anyAA != allAA) { ctx->err = "fsgpu_sw_multi: either all or none of the queries carry AA profiles"; return FSGPU_E_ARG; }
     hasAA = anyAA;
     if (hasAA && !ctx->db->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
-    const size_t total = base[nq];
+    const size_t total = sbase[nq];
+    auto nSel = [&](int i) { return (int) (sbase[i + 1] - sbase[i]); };
+    auto selIdx = [&](int i, int k) { return sel ? sel[i][k] : k; };
     int rc;
-    std::vector<uint32_t> perm;
+    std::vector<uint32_t> perm;       // launch slot -> index into q[i].targetIds
     std::vector<uint64_t> lkey;
     // ---- launch groups by register class ----
     const int classes[6] = {1, 2, 3, 4, 6, 8};
     std::vector<int> cls(nq, -1);
-    for (int i = 0; i < nq; i++) if (q[i].L <= 64 * kSwMaxR && q[i].n > 0) cls[i] = swPickR(q[i].L);
+    for (int i = 0; i < nq; i++) if (q[i].L <= 64 * kSwMaxR && nSel(i) > 0) cls[i] = swPickR(q[i].L);
     size_t imgDwTotal = 0, nBlocks = 0;
-    for (int i = 0; i < nq; i++) if (cls[i] > 0) { imgDwTotal += (size_t) kAlphabet * swRowDwords(cls[i]) * (hasAA ? 2 : 1); nBlocks += ((size_t) q[i].n + 3) / 4; }
+    for (int i = 0; i < nq; i++) if (cls[i] > 0) { imgDwTotal += (size_t) kSw2Rows * swRowDwords(cls[i]) * (hasAA ? 2 : 1); nBlocks += ((size_t) nSel(i) + 7) / 8; }
     if (total) {
         if ((rc = ensure(ctx, ctx->tids, total * 4)) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->res0, total * 16)) != FSGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->res1, total * 16)) != FSGPU_OK) return rc;
         if ((rc = ensurePinned(ctx, ctx->hRes0, total * 16)) != FSGPU_OK) return rc;
-        if ((rc = ensurePinned(ctx, ctx->hRes1, total * 16)) != FSGPU_OK) return rc;
         if ((rc = ensurePinned(ctx, ctx->hTids, total * 4)) != FSGPU_OK) return rc;
-        // inside every query the pairs are issued longest target first (perm), and the workgroups of a launch are ordered
-        // by their longest target: the long wavefronts start early and the short ones fill the tail (LPT)
+        // inside every query the pairs are issued longest target first (perm) -- neighbours share a wave, so they should
+        // be of similar length --, and the workgroups of a launch are ordered by their longest target (LPT)
         perm.resize(total);
         for (int i = 0; i < nq; i++) {
-            uint32_t *p = perm.data() + base[i];
+            const int ns = nSel(i);
+            uint32_t *p = perm.data() + sbase[i];
             const uint32_t *ids = q[i].targetIds;
             const std::vector<int32_t> &len = ctx->db->hLengths;
-            lkey.resize(q[i].n);
-            for (int k = 0; k < q[i].n; k++) lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[k]]) << 32) | (uint32_t) k;
+            lkey.resize(ns);
+            for (int k = 0; k < ns; k++) { const int j = selIdx(i, k); lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[j]]) << 32) | (uint32_t) j; }
             std::sort(lkey.begin(), lkey.end());
-            uint32_t *dst = (uint32_t *) ctx->hTids.p + base[i];
-            for (int k = 0; k < q[i].n; k++) { p[k] = (uint32_t) lkey[k]; dst[k] = ids[p[k]]; }
+            uint32_t *dst = (uint32_t *) ctx->hTids.p + sbase[i];
+            for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; dst[k] = ids[p[k]]; }
         }
         HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->hTids.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (dir == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));     // a forward + reversed pass pair is timed as one
+    
     if (nBlocks) {
         if ((rc = ensurePinned(ctx, ctx->hImg, imgDwTotal * 4 + nBlocks * sizeof(SwBlockDesc) + 64)) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->img, imgDwTotal * 4 + nBlocks * sizeof(SwBlockDesc) + 64)) != FSGPU_OK) return rc;
@@ -849,7 +881,7 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
         for (int R : classes) {
             Group g{R, blkPos, 0};
             const int rowDw = swRowDwords(R);
-            const size_t tblDw = (size_t) kAlphabet * rowDw;
+            const size_t tblDw = (size_t) kSw2Rows * rowDw;
             for (int i = 0; i < nq; i++) {
                 if (cls[i] != R) continue;
                 const int L = q[i].L;
@@ -866,10 +898,14 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
                                 if (row < L) v = (uint32_t) (uint16_t) f[(size_t) a * L + row] | ((uint32_t) (uint16_t) r[(size_t) a * L + row] << 16);
                                 dst[(size_t) a * rowDw + swDwordIndex(R, lane, rr)] = v;
                             }
+                    // row 21: "past the end of this target" -- INT16_MIN in the 3Di table, 0 in the AA table (their sum must not wrap)
+                    const uint32_t dead = tbl == 0 ? 0x80008000u : 0u;
+                    for (int x = 0; x < rowDw; x++) dst[(size_t) kAlphabet * rowDw + x] = dead;
                 }
-                for (int p0 = 0; p0 < q[i].n; p0 += 4) {
+                const int ns = nSel(i);
+                for (int p0 = 0; p0 < ns; p0 += 8) {
                     SwBlockDesc &d = hb[blkPos++];
-                    d.imgOff = (uint32_t) imgPos; d.firstPair = (uint32_t) (base[i] + p0); d.nPairs = (uint16_t) std::min(4, q[i].n - p0);
+                    d.imgOff = (uint32_t) imgPos; d.firstPair = (uint32_t) (sbase[i] + p0); d.nPairs = (uint16_t) std::min(8, ns - p0);
                     d.rowsInTile = (uint16_t) L; d.segLen = (uint32_t) ((L + 15) / 16);
                     g.nblk++;
                 }
@@ -903,9 +939,10 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
             sa.go = (uint32_t) gapOpen | ((uint32_t) gapOpen << 16);
             sa.ge = (uint32_t) gapExtend | ((uint32_t) gapExtend << 16);
             sa.tileIn = 0; sa.tileOut = 0; sa.borderIn = nullptr; sa.borderOut = nullptr; sa.borderStride = 0; sa.keys = nullptr;
-            sa.res0 = (int32_t *) ctx->res0.p; sa.res1 = (int32_t *) ctx->res1.p;
+            sa.res0 = (int32_t *) ctx->res0.p; sa.res1 = nullptr;
             sa.blocks = (const SwBlockDesc *) ((const unsigned char *) ctx->img.p + descOff) + g.blk0;
-            rc = launchSwBlocks(ctx, g.R, hasAA, sa, (int) g.nblk, gs);
+            sa.dir = dir;
+            rc = launchSwBlocks2(ctx, g.R, hasAA, sa, (int) g.nblk, gs);
             if (rc != FSGPU_OK) return rc;
             if (gi > 0) { HIPCHK(hipEventRecord(ctx->swAuxEv[gi], gs)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[gi], 0)); }
             gi++;
@@ -915,33 +952,39 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen,
     ctx->evValid[1] = true;
     if (total) {
         HIPCHK(hipMemcpyAsync(ctx->hRes0.p, ctx->res0.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->hRes1.p, ctx->res1.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
         if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
-        const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hRes0.p, *r1 = (const fsgpu_swres *) ctx->hRes1.p;
+        const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hRes0.p;
         for (int i = 0; i < nq; i++)
-            for (int k = 0; k < q[i].n; k++) { fwd[base[i] + perm[base[i] + k]] = r0[base[i] + k]; rev[base[i] + perm[base[i] + k]] = r1[base[i] + k]; }
+            if (cls[i] > 0)
+                for (int k = 0; k < nSel(i); k++) out[base[i] + perm[sbase[i] + k]] = r0[sbase[i] + k];
     }
-    // long (row-tiled) queries and int16-saturated pairs: the single-query path
+    // long (row-tiled) queries and int16-saturated pairs: the single-query path (computes both directions, keeps `dir`)
+    std::vector<fsgpu_swres> f2, r2;
     for (int i = 0; i < nq; i++) {
-        if (q[i].n == 0) continue;
-        if (cls[i] < 0) {
-            rc = fsgpu_sw_batch(ctx, q[i].pAA_fwd, q[i].p3Di_fwd, q[i].pAA_rev, q[i].p3Di_rev, q[i].L, q[i].targetIds, q[i].n, gapOpen, gapExtend,
-                                fwd + base[i], rev + base[i]);
-            if (rc != FSGPU_OK) return rc;
-            continue;
-        }
+        const int ns = nSel(i);
+        if (ns == 0) continue;
         std::vector<uint32_t> ids;
         std::vector<int> where;
-        for (int k = 0; k < q[i].n; k++)
-            if (fwd[base[i] + k].score == 32767 || rev[base[i] + k].score == 32767) { ids.push_back(q[i].targetIds[k]); where.push_back(k); }
+        for (int k = 0; k < ns; k++) {
+            const int j = selIdx(i, k);
+            if (cls[i] < 0 || out[base[i] + j].score == 32767) { ids.push_back(q[i].targetIds[j]); where.push_back(j); }
+        }
         if (ids.empty()) continue;
-        std::vector<fsgpu_swres> f2(ids.size()), r2(ids.size());
+        f2.resize(ids.size()); r2.resize(ids.size());
         rc = fsgpu_sw_batch(ctx, q[i].pAA_fwd, q[i].p3Di_fwd, q[i].pAA_rev, q[i].p3Di_rev, q[i].L, ids.data(), (int) ids.size(), gapOpen, gapExtend,
                             f2.data(), r2.data());
         if (rc != FSGPU_OK) return rc;
-        for (size_t k = 0; k < ids.size(); k++) { fwd[base[i] + where[k]] = f2[k]; rev[base[i] + where[k]] = r2[k]; }
+        for (size_t k = 0; k < ids.size(); k++) out[base[i] + where[k]] = dir == 0 ? f2[k] : r2[k];
     }
     return FSGPU_OK;
+}
+
+// both directions of every pair: two fsgpu_sw_multi_dir passes (callers that gate between the passes save most of the second)
+int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev) {
+    if (!ctx || nq < 0 || (nq > 0 && (!q || !fwd || !rev))) return FSGPU_E_ARG;
+    int rc = fsgpu_sw_multi_dir(ctx, q, nq, gapOpen, gapExtend, 0, nullptr, nullptr, fwd);
+    if (rc != FSGPU_OK) return rc;
+    return fsgpu_sw_multi_dir(ctx, q, nq, gapOpen, gapExtend, 1, nullptr, nullptr, rev);
 }
 
 } // extern "C"

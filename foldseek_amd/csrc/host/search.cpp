@@ -167,6 +167,19 @@ int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, st
     return rc;
 }
 
+// the gates a pair passes BEFORE structurealign looks at its reversed-query score (structurealign.cpp:357-361 canBeCovered,
+// :50-58 coverage and e-value of the forward alignment): exactly the conditions gateAlign applies below, in the same order
+// and arithmetic, so that the reversed pass can be restricted to these pairs
+bool needsReversePass(const fshost_search *s, const AlignQuery &aq, uint32_t tid, const fsgpu_swres &f) {
+    const fshost_params &par = s->par;
+    const int L = aq.L, Lt = s->lengths[tid];
+    if (!canBeCovered(par.covThr, par.covMode, (float) L, (float) Lt)) return false;
+    const float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
+    if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) return false;
+    const double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, aq.lambda, aq.mu);
+    return !(evalue > par.evalThr);
+}
+
 // alignStructure gates + backtrace + checkCriteria + ordering for one query (structurealign.cpp:37-112,350-445)
 int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const uint32_t *targetIds, int n, const fsgpu_swres *fwd,
               const fsgpu_swres *rev, fshost_result *results, double &tBack) {
@@ -185,6 +198,7 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
         if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) { rejected++; continue; }
         double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, aq.lambda, aq.mu);
         if (evalue > par.evalThr) { rejected++; continue; }
+        s->stats[6] += 1.0;             // pairs whose reversed-query score is actually looked at
         const int32_t score = f.score - rev[k].score;
         evalue = s->evaluer.computeEvalueCorr(score, aq.lambda, aq.mu);
         if (evalue > par.evalThr) { rejected++; continue; }
@@ -288,10 +302,31 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
         dq[i].L = L[i]; dq[i].n = n[i]; dq[i].targetIds = targetIds[i];
         total += (size_t) n[i];
     }
-    s->fwd.resize(total); s->rev.resize(total);
+    s->fwd.resize(total); s->rev.assign(total, fsgpu_swres{0, 0, 0, 0});
     const double t1 = nowSec();
-    int rc = fsgpu_sw_multi(s->ctx, dq.data(), nq, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
+    // forward pass over every pair; the reversed-query pass only over the pairs whose forward score passes the gates
+    int rc = fsgpu_sw_multi_dir(s->ctx, dq.data(), nq, par.gapOpen, par.gapExtend, 0, nullptr, nullptr, s->fwd.data());
     if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    {
+        std::vector<std::vector<int32_t>> sel(nq);
+        std::vector<const int32_t *> selp(nq);
+        std::vector<int32_t> nsel(nq);
+        size_t b = 0, any = 0;
+        for (int i = 0; i < nq; i++) {
+            for (int k = 0; k < n[i]; k++) {
+                const uint32_t tid = targetIds[i][k];
+                if (tid >= s->keys.size()) { s->err = "target id out of range"; return FSGPU_E_ARG; }
+                if (needsReversePass(s, aq[i], tid, s->fwd[b + k])) sel[i].push_back(k);
+            }
+            selp[i] = sel[i].data(); nsel[i] = (int32_t) sel[i].size(); any += sel[i].size();
+            b += (size_t) n[i];
+        }
+        s->stats[7] = (double) any;
+        if (any) {
+            rc = fsgpu_sw_multi_dir(s->ctx, dq.data(), nq, par.gapOpen, par.gapExtend, 1, selp.data(), nsel.data(), s->rev.data());
+            if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+        }
+    }
     const double t2 = nowSec();
     double tBack = 0;
     s->cigars.clear();

@@ -81,6 +81,7 @@ struct SwArgs {
     int32_t *res1;                // packed only: reversed query
     // multi-query launches (single-tile queries of one R class): workgroup b serves blocks[b]; NULL = one query per launch
     const struct SwBlockDesc *blocks;
+    int dir;                      // k_sw2 only: 0 = forward-query halves of the image, 1 = reversed-query halves
 };
 
 // One workgroup of a multi-query launch: up to (blockDim.x / 64) consecutive pairs of one query.
@@ -311,6 +312,169 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
                 res[2] = (int32_t) (0xffffu - (uint32_t) ((key >> 16) & 0xffffu));
                 res[3] = A::packed ? 1 : 2;
             }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sw2 -- ONE direction of the structure SW for TWO targets per wave.
+// structurealign needs the reversed-query score only for pairs whose forward score passes the coverage and e-value
+// gates (structurealign.cpp:55-65); on real hit lists that is 3-15 % of the pairs.  So instead of packing (forward,
+// reversed) of one pair into the two int16 halves (k_sw), this kernel packs the SAME direction of two pairs of one
+// query: half the waves for the forward pass, and the reversed pass only over the survivors.  Recurrence, tie-breaks
+// and result format are k_sw's; per target column the profile rows of both targets are read from the (fwd | rev)
+// LDS image and the halves of the chosen direction are merged with one v_perm_b32 per register.  The shorter target
+// of a wave is continued with code 21, an extra image row of INT16_MIN (3Di table) / 0 (AA table): its H, E, F can then
+// only decay, never set a new maximum.  Single-tile queries in multi-query launches only; int16-saturated pairs are
+// re-run by the caller through k_sw's int32 instantiation like before.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kSw2Rows = kAlphabet + 1;
+
+template <int R, bool HAS_AA>
+__global__ __launch_bounds__(256) void k_sw2(SwArgs a) {
+    using A = Pk16;
+    constexpr int ROWB = swRowDwords(R) * 4;
+    constexpr int TBL = kSw2Rows * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SwBlockDesc bd = a.blocks[blockIdx.x];
+    const uint32_t *profSS = a.profSS + bd.imgOff;
+    const int rowsInTile = bd.rowsInTile, segLen = (int) bd.segLen, pairBase = (int) bd.firstPair, pairsHere = bd.nPairs;
+    {
+        const uint4 *s3 = (const uint4 *) profSS;
+        uint4 *d3 = (uint4 *) smem;
+        constexpr int n16 = (HAS_AA ? 2 : 1) * TBL / 16;
+        for (int i = threadIdx.x; i < n16; i += blockDim.x) d3[i] = s3[i];
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int waveInBlock = (int) (threadIdx.x >> 6);
+    if (2 * waveInBlock >= pairsHere) return;
+    const bool hasB = 2 * waveInBlock + 1 < pairsHere;
+    const int pairA = __builtin_amdgcn_readfirstlane(pairBase + 2 * waveInBlock);
+
+    const uint32_t tidA = __builtin_amdgcn_readfirstlane(a.targetIds[pairA]);
+    const uint32_t tidB = __builtin_amdgcn_readfirstlane(a.targetIds[pairA + (hasB ? 1 : 0)]);
+    const int LtA = __builtin_amdgcn_readfirstlane(a.lengths[tidA]);
+    const int LtB = hasB ? __builtin_amdgcn_readfirstlane(a.lengths[tidB]) : 0;
+    const uint64_t oA = a.offsets[tidA], oB = a.offsets[tidB];
+    const uint64_t offA = ((uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) (oA >> 32)) << 32) | (uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) oA);
+    const uint64_t offB = ((uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) (oB >> 32)) << 32) | (uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) oB);
+    const int Lt = LtA > LtB ? LtA : LtB;          // the caller orders pairs longest first: normally LtA
+    const int nLanes = (rowsInTile + R - 1) / R;
+    const int steps = Lt > 0 ? Lt + nLanes - 1 : 0;
+    const bool laneActive = lane < nLanes;
+    // merge selector: {S0 = target B's dword (bytes 4..7), S1 = target A's dword (bytes 0..3)} -> (A.dir, B.dir)
+    const uint32_t sel = a.dir ? 0x07060302u : 0x05040100u;
+
+    uint32_t segmask[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) segmask[r] = ((lane * R + r) % segLen == 0) ? 0u : 0xffffffffu;
+    uint32_t E[R], Hp[R], snap[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { E[r] = 0; Hp[r] = 0; snap[r] = 0; }
+    uint32_t best = 0, bestcol = 0;
+    uint32_t hOut = 0, fsegOut = 0, ffullOut = 0, hUpPrev = 0, tval = 0, tvalAA = 0;
+    uint32_t chunkCur = 0, chunkNxt = 0, chunkAACur = 0, chunkAANxt = 0;
+    constexpr uint32_t kDeadOff = (uint32_t) kAlphabet * (uint32_t) ROWB;
+
+    auto loadChunk = [&](int s0, uint32_t &vAA) -> uint32_t {
+        const int col = s0 + lane;
+        uint32_t v = kDeadOff | (kDeadOff << 16);
+        vAA = v;
+        if (col < LtA) {
+            v = (v & 0xffff0000u) | ((uint32_t) a.ss[offA + col] * (uint32_t) ROWB);
+            if constexpr (HAS_AA) vAA = (vAA & 0xffff0000u) | ((uint32_t) a.aa[offA + col] * (uint32_t) ROWB);
+        }
+        if (col < LtB) {
+            v = (v & 0xffffu) | (((uint32_t) a.ss[offB + col] * (uint32_t) ROWB) << 16);
+            if constexpr (HAS_AA) vAA = (vAA & 0xffffu) | (((uint32_t) a.aa[offB + col] * (uint32_t) ROWB) << 16);
+        }
+        return v;
+    };
+    chunkNxt = loadChunk(0, chunkAANxt);
+
+    for (int s = 0; s < steps; s++) {
+        if ((s & 63) == 0) {
+            chunkCur = chunkNxt; chunkAACur = chunkAANxt;
+            chunkNxt = loadChunk(s + 64, chunkAANxt);
+        }
+        uint32_t hUpNew = wave_shr1(hOut);
+        const uint32_t fsegIn = wave_shr1(fsegOut);
+        const uint32_t ffullIn = wave_shr1(ffullOut);
+        tval = wave_shr1(tval);
+        {
+            const uint32_t tv = __builtin_amdgcn_readlane(chunkCur, s & 63);
+            if (lane == 0) tval = tv;
+        }
+        if constexpr (HAS_AA) {
+            tvalAA = wave_shr1(tvalAA);
+            const uint32_t tv = __builtin_amdgcn_readlane(chunkAACur, s & 63);
+            if (lane == 0) tvalAA = tv;
+        }
+        const int col = s - lane;
+        if (laneActive && col >= 0 && col < Lt) {
+            uint32_t PA[R], PB[R];
+            swLoadRow<R>(smem + (tval & 0xffffu), lane, PA);
+            swLoadRow<R>(smem + (tval >> 16), lane, PB);
+            if constexpr (HAS_AA) {
+                uint32_t QA[R], QB[R];
+                swLoadRow<R>(smem + TBL + (tvalAA & 0xffffu), lane, QA);
+                swLoadRow<R>(smem + TBL + (tvalAA >> 16), lane, QB);
+#pragma unroll
+                for (int r = 0; r < R; r++) { PA[r] = A::add(QA[r], PA[r]); PB[r] = A::add(QB[r], PB[r]); }
+            }
+            uint32_t diag = hUpPrev, fseg = fsegIn, ffull = ffullIn, cm = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t sc = __builtin_amdgcn_perm(PB[r], PA[r], sel);
+                uint32_t h = A::adds(diag, sc);
+                h = A::max(h, E[r]);
+                fseg &= segmask[r];
+                h = A::max(h, fseg);
+                const uint32_t t = A::subus(h, a.go);
+                E[r] = A::max(A::subus(E[r], a.ge), t);
+                const uint32_t hf = A::max(h, ffull);
+                fseg = A::max(A::subus(fseg, a.ge), t);
+                ffull = A::max(A::subus(ffull, a.ge), t);
+                diag = Hp[r];
+                Hp[r] = hf;
+                cm = A::max(cm, hf);
+            }
+            hOut = Hp[R - 1]; fsegOut = fseg; ffullOut = ffull;
+            const uint32_t nb = A::max(best, cm);
+            if (nb != best) {
+                uint32_t m = A::gtMask(cm, best);
+                asm volatile("" : "+v"(m));
+                const uint32_t cp = A::splat((uint32_t) col);
+                bestcol = (m & cp) | (~m & bestcol);
+#pragma unroll
+                for (int r = 0; r < R; r++) snap[r] = (m & Hp[r]) | (~m & snap[r]);
+                best = nb;
+            }
+        }
+        hUpPrev = hUpNew;
+    }
+
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const uint32_t b = (best >> (16 * d)) & 0xffffu, c = (bestcol >> (16 * d)) & 0xffffu;
+        int row = 0;
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) {
+            const uint32_t v = (snap[r] >> (16 * d)) & 0xffffu;
+            if (v == b) row = r;
+        }
+        const uint32_t q = (uint32_t) (lane * R + row);
+        uint64_t key = ((uint64_t) b << 32) | ((uint64_t) (0xffffu - (c & 0xffffu)) << 16) | (uint64_t) (0xffffu - (q & 0xffffu));
+        key = waveMaxU64(key);
+        if (lane == 0 && (d == 0 || hasB)) {
+            int32_t *res = a.res0 + (size_t) (pairA + d) * 4;
+            res[0] = (int32_t) (key >> 32);
+            res[1] = (int32_t) (0xffffu - (uint32_t) (key & 0xffffu));
+            res[2] = (int32_t) (0xffffu - (uint32_t) ((key >> 16) & 0xffffu));
+            res[3] = 1;
         }
     }
 }

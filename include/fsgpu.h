@@ -142,6 +142,14 @@ typedef struct {
 } fsgpu_sw_query;
 int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *queries, int nq, int gapOpen, int gapExtend,
                    fsgpu_swres *fwd, fsgpu_swres *rev);
+/* ONE direction of the same (dir 0: forward-query profiles, 1: reversed-query profiles) for a selection of the pairs:
+ * sel[i][0..nsel[i]) are indices into q[i].targetIds (sel = nsel = NULL: every pair).  out has the layout of fwd[] above
+ * (all pairs of all queries, concatenated); only the selected entries are written.  structurealign looks at the
+ * reversed-query score only for pairs whose forward score passes the coverage and e-value gates
+ * (F/src/strucclustutils/structurealign.cpp:55-65): run dir 0 over everything, gate on the host, run dir 1 over the
+ * survivors.  Device side: two targets of one query share a wave (int16 halves), half the waves of fsgpu_sw_batch. */
+int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, int dir,
+                       const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out);
 int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
                     const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,
                     const uint32_t *targetIds, int n, int gapOpen, int gapExtend);
