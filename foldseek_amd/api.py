@@ -114,6 +114,7 @@ def lib():
         "fshost_search_align": (i32, [vp, vp, vp, i32, i64, vp, i32, vp]),
         "fshost_search_align_batch": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "fsgpu_sw_multi": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        "fsgpu_sw_multi_dir": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
         "fshost_search_stats": (None, [vp, vp]),
         "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -133,7 +134,8 @@ def lib():
 def exported_symbols():
     return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
-            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_launch", "fsgpu_sw_finish",
+            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_launch", "fsgpu_sw_finish",
+            "fsgpu_db_broadcast", "fsgpu_device_count",
             "fsgpu_last_kernel_ms", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
             "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts"]
 
@@ -380,6 +382,36 @@ class Context:
         s = np.zeros(self.n, np.uint8)
         self._chk(lib().fsgpu_gapless_scores(self.h, _ptr(s)), "fsgpu_gapless_scores")
         return s
+
+    def sw_multi_dir(self, queries, direction, selections=None, gap_open=10, gap_extend=1):
+        """queries: list of (pAAf|None, p3f, pAAr|None, p3r, L, target_ids); one direction of the structure SW for the
+        selected pairs (fsgpu_sw_multi_dir).  Returns one SWRES array per query (unselected entries stay zero)."""
+        class Q(C.Structure):
+            _fields_ = [("pAA_fwd", C.c_void_p), ("p3Di_fwd", C.c_void_p), ("pAA_rev", C.c_void_p), ("p3Di_rev", C.c_void_p),
+                        ("L", C.c_int32), ("n", C.c_int32), ("targetIds", C.c_void_p)]
+        nq = len(queries)
+        keep, arr = [], (Q * nq)()
+        for i, (paf, p3f, par_, p3r, L, ids) in enumerate(queries):
+            bufs = [None if x is None else np.ascontiguousarray(x, np.int16) for x in (paf, p3f, par_, p3r)]
+            ids = np.ascontiguousarray(ids, np.uint32)
+            keep.append((bufs, ids))
+            arr[i].pAA_fwd, arr[i].p3Di_fwd, arr[i].pAA_rev, arr[i].p3Di_rev = [None if b is None else b.ctypes.data for b in bufs]
+            arr[i].L, arr[i].n, arr[i].targetIds = int(L), len(ids), ids.ctypes.data
+        total = sum(len(k[1]) for k in keep)
+        out = np.zeros(max(1, total), SWRES_DT)
+        selp = nselp = None
+        if selections is not None:
+            sels = [np.ascontiguousarray(x, np.int32) for x in selections]
+            keep.append(sels)
+            selp = (C.c_void_p * nq)(*[x.ctypes.data for x in sels])
+            nselp = (C.c_int32 * nq)(*[len(x) for x in sels])
+        self._chk(lib().fsgpu_sw_multi_dir(self.h, C.cast(arr, C.c_void_p), nq, gap_open, gap_extend, direction,
+                                           None if selp is None else C.cast(selp, C.c_void_p), None if nselp is None else C.cast(nselp, C.c_void_p),
+                                           out.ctypes.data), "fsgpu_sw_multi_dir")
+        res, b = [], 0
+        for k in keep[:nq]:
+            res.append(out[b:b + len(k[1])].copy()); b += len(k[1])
+        return res
 
     def sw_batch(self, pAAf, p3f, pAAr, p3r, target_ids, gap_open=10, gap_extend=1):
         p3f = np.ascontiguousarray(p3f, np.int16)

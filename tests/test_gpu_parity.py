@@ -306,3 +306,50 @@ def test_align_batch_equals_per_query_align():
         assert total > 20
         s.close()
     ctx.close()
+
+
+def test_sw_multi_dir_two_targets_per_wave():
+    """fsgpu_sw_multi_dir (k_sw2: the same direction of two targets in one wave) against fsgpu_sw_batch (k_sw: both
+    directions of one target) and the oracle: every register class, odd pair counts, targets of very different length in
+    one wave, a one-pair list, with and without AA; a selection writes exactly the selected entries."""
+    rng = np.random.default_rng(2024)
+    lens = [20, 100, 130, 230, 350, 390, 512]
+    q3 = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    qa = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    db = synth.make_db(900, (q3, qa), seed=55, homologs_per_query=10, lo=1, hi=1800, mask_frac=0.02)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    for atype in (0, 2):
+        mA, m3 = api.Matrix(1, 1.4 if atype == 2 else 0.0), api.Matrix(0, 2.1)
+        queries, want_f, want_r = [], [], []
+        for i, L in enumerate(lens):
+            pAf, p3f, _, _ = api.align_profiles(mA, m3, qa[i], q3[i], True, 0.5)
+            pAr, p3r, _, _ = api.align_profiles(mA, m3, qa[i][::-1].copy(), q3[i][::-1].copy(), True, 0.5)
+            n = [1, 7, 64, 33, 120, 9, 250][i]
+            ids = rng.choice(db.n, size=n, replace=False).astype(np.uint32)
+            if i == 4:
+                ids[:4] = [0, db.n - 1, 1, db.n - 2]          # shortest and longest targets of the DB side by side
+            use_aa = atype == 2
+            queries.append((pAf if use_aa else None, p3f, pAr if use_aa else None, p3r, L, ids))
+            f, r = ctx.sw_batch(pAf if use_aa else None, p3f, pAr if use_aa else None, p3r, ids)
+            want_f.append(f); want_r.append(r)
+        for direction, want in ((0, want_f), (1, want_r)):
+            got = ctx.sw_multi_dir(queries, direction)
+            for i in range(len(lens)):
+                for fld in ("score", "qEnd", "dbEnd"):
+                    assert (got[i][fld] == want[i][fld]).all(), (atype, direction, lens[i], fld)
+        # oracle spot check of the forward pass
+        for i in (1, 4):
+            pA, p3 = helpers.o_align_profiles(qa[i], q3[i], atype)[:2]
+            for k in range(min(6, len(queries[i][5]))):
+                ta, t3 = helpers.target_seqs(db, int(queries[i][5][k]))
+                w = helpers.o_sw(pA, p3, lens[i], ta, t3)
+                assert (int(want_f[i][k]["score"]), int(want_f[i][k]["qEnd"]), int(want_f[i][k]["dbEnd"])) == (w["score"], w["qEnd"], w["dbEnd"])
+        # selections
+        sels = [np.array(sorted(rng.choice(len(q[5]), size=len(q[5]) // 3, replace=False)), np.int32) for q in queries]
+        got = ctx.sw_multi_dir(queries, 1, selections=sels)
+        for i in range(len(lens)):
+            mask = np.zeros(len(queries[i][5]), bool); mask[sels[i]] = True
+            assert (got[i]["score"][mask] == want_r[i]["score"][mask]).all() and (got[i]["dbEnd"][mask] == want_r[i]["dbEnd"][mask]).all()
+            assert (got[i]["score"][~mask] == 0).all() and (got[i]["word"][~mask] == 0).all()
+    ctx.close()

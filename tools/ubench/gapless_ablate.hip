@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 #include <vector>
 #include "k_gapless.hpp"
 
@@ -749,9 +751,83 @@ static void suite(int nStripes, int len16, int L) {
     rep("6: 1024-thread WG x1/CU", runK(k_var<R, 0, 1024>, 1024, lds, 256, ga, 4));
 }
 
+
+// ---- realistic length mix: gamma(2.2) lengths with mean 350 clipped to [30, 2000] (foldseek_amd/synth.py), length-sorted,
+//      stripes of 8, work items = whole stripes or column segments (cap / overlap like fsgpu.hip::gaplessItems) ----
+#include <random>
+#include <algorithm>
+template <int R>
+static void realMix(int nTargets, int L, int cap /* 0 = whole stripes */) {
+    std::mt19937_64 rng(7);
+    std::gamma_distribution<double> gd(2.2, 350.0 / 2.2);
+    std::vector<int> len(nTargets);
+    for (auto &x : len) x = std::min(2000, std::max(30, (int) std::lround(gd(rng))));
+    std::sort(len.begin(), len.end());
+    const int nStripes = (nTargets + 7) / 8;
+    std::vector<uint32_t> sLen(nStripes);
+    std::vector<uint64_t> sOff(nStripes);
+    uint64_t totalU4 = 0, residues = 0;
+    for (int s2 = 0; s2 < nStripes; s2++) {
+        int mx = 0;
+        for (int t = s2 * 8; t < std::min(nTargets, s2 * 8 + 8); t++) { mx = std::max(mx, len[t]); residues += len[t]; }
+        sLen[s2] = (mx + 15) / 16; sOff[s2] = totalU4; totalU4 += (uint64_t) sLen[s2] * 8;
+    }
+    std::vector<uint8_t> h(totalU4 * 16, 21);
+    for (int s2 = 0; s2 < nStripes; s2++)
+        for (int j = 0; j < 8; j++) {
+            const int t = s2 * 8 + j;
+            if (t >= nTargets) continue;
+            for (int c = 0; c < len[t]; c++) h[(sOff[s2] + (uint64_t) (c / 16) * 8 + j) * 16 + (c % 16)] = (uint8_t) (rng() % 20);
+        }
+    const int ov = R;
+    std::vector<uint64_t> items;
+    uint64_t units = 0;
+    for (int s2 = 0; s2 < nStripes; s2++) {
+        const uint32_t Ls = sLen[s2];
+        if (cap == 0 || (int) Ls <= cap) { items.push_back(((uint64_t) s2 << 32) | Ls); units += Ls; continue; }
+        const uint32_t K = (Ls + (cap - ov) - 1) / (cap - ov), fresh = (Ls + K - 1) / K;
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t b = k * fresh, e = std::min(Ls, (k + 1) * fresh);
+            if (b >= e) break;
+            const uint32_t b0 = b > (uint32_t) ov ? b - ov : 0;
+            items.push_back(((uint64_t) s2 << 32) | (1ull << 31) | ((uint64_t) b0 << 16) | e); units += e - b0;
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](uint64_t a, uint64_t b) {
+        return ((a & 0xffff) - ((a >> 16) & 0x7fff)) > ((b & 0xffff) - ((b >> 16) & 0x7fff)); });
+    std::vector<int8_t> pssm(21 * L);
+    for (auto &x : pssm) x = (int8_t) ((int) (rng() % 13) - 8);
+    std::vector<uint32_t> ident(nStripes * 8);
+    for (int t = 0; t < nStripes * 8; t++) ident[t] = t < nTargets ? t : 0xffffffffu;
+    GaplessArgs ga{};
+    void *d;
+    hipMalloc(&d, h.size()); hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice); ga.scan = (const uint4 *) d;
+    hipMalloc(&d, 8 * nStripes); hipMemcpy(d, sOff.data(), 8 * nStripes, hipMemcpyHostToDevice); ga.stripeOff = (const uint64_t *) d;
+    hipMalloc(&d, 4 * nStripes); hipMemcpy(d, sLen.data(), 4 * nStripes, hipMemcpyHostToDevice); ga.stripeLen = (const uint32_t *) d;
+    hipMalloc(&d, 4 * ident.size()); hipMemcpy(d, ident.data(), 4 * ident.size(), hipMemcpyHostToDevice); ga.stripeTargets = (const uint32_t *) d;
+    hipMalloc(&d, 8 * items.size()); hipMemcpy(d, items.data(), 8 * items.size(), hipMemcpyHostToDevice); ga.items = (const uint64_t *) d; ga.nItems = (uint32_t) items.size();
+    hipMalloc(&d, pssm.size()); hipMemcpy(d, pssm.data(), pssm.size(), hipMemcpyHostToDevice); ga.pssm = (const int8_t *) d;
+    hipMalloc(&d, nStripes * 8); hipMemset(d, 0, nStripes * 8); ga.scores = (uint8_t *) d;
+    hipMalloc(&d, 4); ga.queue = (uint32_t *) d;
+    ga.nTargets = nTargets; ga.L = L; ga.cap = 255; ga.firstTile = ga.lastTile = 1;
+    const int lds = gaplessLdsBytes(R);
+    runK(k_gapless<R, false>, kGaplessBlock, lds, 768, ga, 20);
+    for (int perCU : {2, 3, 4}) {
+        const float ms = runK(k_gapless<R, false>, kGaplessBlock, lds, 256 * perCU, ga, 6);
+        const double cellsReal = (double) residues * L, cellsDone = (double) units * 16 * 8 * (16.0 * R);
+        printf("real mix R=%2d L=%3d cap=%3d items %6zu units %7llu  %d WG/CU  %7.3f ms  %6.2f Tcell/s useful  %6.2f Tcell/s issued  %6.1f cyc/wave-column/SIMD\n",
+               R, L, cap, items.size(), (unsigned long long) units, perCU, ms, cellsReal / ms * 1e-9, cellsDone / ms * 1e-9, ms * 2.4e6 * 1024 / ((double) units * 16));
+    }
+}
+
 int main(int argc, char **argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("device CUs %d clock %d MHz\n", p.multiProcessorCount, p.clockRate / 1000);
+    if (argc > 1 && !strcmp(argv[1], "real")) {
+        realMix<21>(100000, 332, 0); realMix<21>(100000, 332, 91); realMix<21>(100000, 332, 64);
+        realMix<24>(100000, 380, 0); realMix<24>(100000, 380, 91);
+        return 0;
+    }
     if (argc > 1) {     // fixed-cost probe: same stripe count, 1x / 2x / 4x columns -> the intercept is launch + LDS image build
         for (int len16 : {6, 11, 22, 44, 88}) { printf("len16 = %d\n", len16); suite<24>(12288, len16, 380); }
         return 0;
