@@ -35,8 +35,8 @@ def parse():
     ap.add_argument("--group", type=int, default=32, help="queries a host thread prefilters back to back before ONE multi-query SW launch (0: one SW launch per query)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
-    ap.add_argument("--kmer-threads", type=int, default=3, help="host threads (context clones) of the k-mer section")
-    ap.add_argument("--kmer-queries", type=int, default=384, help="queries of the k-mer prefilter section (batches of 32)")
+    ap.add_argument("--kmer-threads", type=int, default=4, help="host threads (context clones) of the k-mer section")
+    ap.add_argument("--kmer-queries", type=int, default=768, help="queries of the k-mer prefilter section (batches of 32)")
     ap.add_argument("--kmer-cpu-queries", type=int, default=256, help="queries the reference k-mer prefilter is timed on")
     ap.add_argument("--cpu-sample-targets", type=int, default=100000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
