@@ -428,7 +428,7 @@ def main():
                          "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s))},
             "db_broadcast_s": t_bcast,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baselines are an N = 1 item (rank 0 has the host to itself)
             hits, _ = step(0, args.warmup)
             out["cpu_baseline"] = cpu_baseline(db, q3[args.warmup], qa[args.warmup], hits["id"], args.alignment_type, args.cpu_sample_targets,
                                                [q3[i] for i in range(args.warmup + 1, min(nq, args.warmup + max(1, args.cpu_sample_queries)))])
@@ -442,7 +442,7 @@ def main():
         kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist)
     if rank == 0:
         if kout is not None:
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:
                 kout["cpu_baseline"] = kmer_cpu_baseline(args, synth, db)
             out["kmer_prefilter"] = kout
         print(json.dumps(out))
