@@ -603,19 +603,6 @@ static int launchSw(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nPa
 #undef FS_SW_CASE
 }
 
-// multi-query launch: one workgroup (4 waves) per SwBlockDesc
-template <int R, bool HAS_AA>
-static int launchSwBlocksT(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
-    const int lds = (HAS_AA ? 2 : 1) * kAlphabet * swRowDwords(R) * 4;
-    static thread_local bool attrSet = false;
-    if (!attrSet) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_sw<R, HAS_AA, Pk16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attrSet = true;
-    }
-    hipLaunchKernelGGL((k_sw<R, HAS_AA, Pk16>), dim3(nBlocks), dim3(256), lds, stream, sa);
-    HIPCHK(hipGetLastError());
-    return FSGPU_OK;
-}
 // k_sw2: two targets per wave, one direction (image with the extra "past the end" row)
 template <int R, bool HAS_AA>
 static int launchSwBlocks2T(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
@@ -638,14 +625,6 @@ static int launchSwBlocks2(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, 
 #undef FS_SW_CASE
 }
 
-static int launchSwBlocks(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks, hipStream_t stream) {
-#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocksT<RR, true>(ctx, sa, nBlocks, stream) : launchSwBlocksT<RR, false>(ctx, sa, nBlocks, stream);
-    switch (R) {
-        FS_SW_CASE(1) FS_SW_CASE(2) FS_SW_CASE(3) FS_SW_CASE(4) FS_SW_CASE(6) FS_SW_CASE(8)
-        default: ctx->err = "internal: bad SW R"; return FSGPU_E_ARG;
-    }
-#undef FS_SW_CASE
-}
 
 // Builds the per-tile LDS images (host) and runs all row tiles of one pass.
 //   packed:  value = (fwd int16) | (rev int16) << 16;   int32: value = the selected direction's score

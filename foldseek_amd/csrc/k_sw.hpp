@@ -79,12 +79,12 @@ struct SwArgs {
     uint64_t *keys;               // [nPairs][2] running best across tiles (packed: fwd, rev; int32: slot 0)
     int32_t *res0;                // fsgpu_swres[nPairs] as int32 x4 (packed: forward; int32: the direction re-run)
     int32_t *res1;                // packed only: reversed query
-    // multi-query launches (single-tile queries of one R class): workgroup b serves blocks[b]; NULL = one query per launch
+    // k_sw2 (multi-query launches, single-tile queries of one R class): workgroup b serves blocks[b]
     const struct SwBlockDesc *blocks;
     int dir;                      // k_sw2 only: 0 = forward-query halves of the image, 1 = reversed-query halves
 };
 
-// One workgroup of a multi-query launch: up to (blockDim.x / 64) consecutive pairs of one query.
+// One workgroup of a multi-query launch (k_sw2): up to 2 * (blockDim.x / 64) consecutive pairs of one query.
 struct SwBlockDesc {
     uint32_t imgOff;              // dword offset of this query's LDS image inside SwArgs::profSS ([SS table][AA table])
     uint32_t firstPair;           // global pair index of wave 0 (targetIds / result arrays are concatenated over queries)
@@ -131,13 +131,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     constexpr int TBL = kAlphabet * ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t *profSS = a.profSS, *profAA = a.profAA;
-    int rowsInTile = a.rowsInTile, segLen = a.segLen, pairBase = -1, pairsHere = 0;
-    if (a.blocks) {               // multi-query launch: this workgroup's query
-        const SwBlockDesc bd = a.blocks[blockIdx.x];
-        profSS = a.profSS + bd.imgOff;
-        profAA = profSS + TBL / 4;
-        rowsInTile = bd.rowsInTile; segLen = (int) bd.segLen; pairBase = (int) bd.firstPair; pairsHere = bd.nPairs;
-    }
+    const int rowsInTile = a.rowsInTile, segLen = a.segLen;
     {
         const uint4 *s3 = (const uint4 *) profSS;
         uint4 *d3 = (uint4 *) smem;
@@ -155,8 +149,8 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     const int lane = threadIdx.x & 63;
     const int wavesPerBlock = blockDim.x >> 6;
     const int waveInBlock = (int) (threadIdx.x >> 6);
-    const int pair = __builtin_amdgcn_readfirstlane(pairBase >= 0 ? pairBase + waveInBlock : blockIdx.x * wavesPerBlock + waveInBlock);
-    if (pairBase >= 0 ? waveInBlock >= pairsHere : pair >= a.nPairs) return;
+    const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * wavesPerBlock + waveInBlock);
+    if (pair >= a.nPairs) return;
 
     // wave-uniform pair parameters -> SGPRs, scalar loop control
     const uint32_t tid = __builtin_amdgcn_readfirstlane(a.targetIds[pair]);
