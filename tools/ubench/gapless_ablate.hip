@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void k_v5(AblArgs a, const uint4 *) {
             int qlo = g * 2 * R + r, qhi = qlo + R;
             uint32_t v;
             if (row == kDeadCode || r >= R) v = kDead2;
+            else if (SCHED == 3) v = (uint32_t) ((qlo * 7 + row) & 7) * 0x00010001u;       // no global reads in the image build
             else {
                 int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
                 int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
@@ -731,6 +732,7 @@ static void suite(int nStripes, int len16, int L) {
         chk("v5 static round robin, 256 x3", runK2(k_v5<R, 0>, 256, lds, 768, ga, nullptr, 4));
         chk("v5 ticket+meta prefetch, 256 x3", runK2(k_v5<R, 1>, 256, lds, 768, ga, nullptr, 4));
         chk("v5 static first + prefetch, 256 x3", runK2(k_v5<R, 2>, 256, lds, 768, ga, nullptr, 4));
+        rep("v5 same, image build without loads", runK2(k_v5<R, 3>, 256, lds, 768, ga, nullptr, 4));
         chk("v4 perm-addr u8, 512 x2", runK2(k_v4<R, 512>, 512, lds, 512, ga, nullptr, 4));
         chk("v4 perm-addr u8, 512 x3", runK2(k_v4<R, 512>, 512, lds, 768, ga, nullptr, 4));
         chk("v4 perm-addr u8, 256 x3", runK2(k_v4<R, 256>, 256, lds, 768, ga, nullptr, 4));
