@@ -474,7 +474,7 @@ class Search:
         return res
 
     def align_batch(self, qAAs, q3dis, target_id_lists, identity=None, with_backtrace=False):
-        """several queries, one device call (fsgpu_sw_multi); returns a list of result arrays (and backtrace lists)"""
+        """several queries, one forward + one reversed device pass (fsgpu_sw_multi_dir); returns a list of result arrays (and backtrace lists)"""
         nq = len(q3dis)
         qa = [np.ascontiguousarray(x, np.uint8) for x in qAAs]
         q3 = [np.ascontiguousarray(x, np.uint8) for x in q3dis]

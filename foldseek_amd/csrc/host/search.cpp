@@ -280,7 +280,7 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
     return nres;
 }
 
-// The same for nq queries with ONE device call (fsgpu_sw_multi): results[q] must hold n[q] entries, nres[q] receives the
+// The same for nq queries with one forward and one reversed device pass (fsgpu_sw_multi_dir): results[q] must hold n[q] entries, nres[q] receives the
 // number of accepted alignments of query q.  Backtraces of all queries stay valid until the next align call.
 int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
                               const int64_t *identityId, const uint32_t *const *targetIds, const int *n,

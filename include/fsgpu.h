@@ -23,7 +23,10 @@
  *                                     M/src/prefiltering/Prefiltering.cpp:544-583,220-225, IndexBuilder.cpp:56-271
  *   fsgpu_kmer_search                 the per-query body of Prefiltering::runSplit = QueryMatcher::matchQuery
  *                                     M/src/prefiltering/Prefiltering.cpp:847-917, QueryMatcher.cpp:103-376
- *   fsgpu_sw_multi                    the same for a batch of queries in one device launch per register class
+ *   fsgpu_sw_multi / _multi_dir       the same for a batch of queries, one device launch per register class and direction
+ *                                     (forward over all pairs, reversed over the pairs alignStructure still needs:
+ *                                     F/src/strucclustutils/structurealign.cpp:50-65)
+ *   fsgpu_db_broadcast                replication of the resident DB over the GPUs of a node (RCCL), SURVEY 8e
  *   fshost_*                          host-side pieces of the same path that stay on the CPU, exported so the
  *                                     reference-side adapter and the tests can reach them.
  */
