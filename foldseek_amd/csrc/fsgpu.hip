@@ -416,12 +416,13 @@ static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint64_t **items, uint32_t
 template <int R, bool TILED>
 static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
     const int lds = gaplessLdsBytes(R);
-    static thread_local bool attrSet = false;
+    static thread_local uint64_t attrDevs = 0;       // devices on which this thread has set the attribute (it is per device)
     static thread_local int perCUcached = 0;
-    if (!attrSet) {
+    const uint64_t devBit = 1ull << (ctx->device & 63);
+    if (!(attrDevs & devBit)) {
         HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, kGaplessBlock, lds));
-        attrSet = true;
+        attrDevs |= devBit;
     }
     int perCU = perCUcached;
     // Workgroups of 4 waves, each with its own LDS image; 3 per CU (12 waves, <= 135 KB LDS): more does not issue faster
@@ -579,10 +580,11 @@ static int swPickR(int rows) {
 template <int R, bool HAS_AA, typename A>
 static int launchSwT(fsgpu_ctx *ctx, const SwArgs &sa, int nPairs) {
     const int lds = (HAS_AA ? 2 : 1) * kAlphabet * swRowDwords(R) * 4;
-    static thread_local bool attrSet = false;
-    if (!attrSet) {
+    static thread_local uint64_t attrDevs = 0;       // devices on which this thread has set the attribute (it is per device)
+    const uint64_t devBit = 1ull << (ctx->device & 63);
+    if (!(attrDevs & devBit)) {
         HIPCHK(hipFuncSetAttribute((const void *) k_sw<R, HAS_AA, A>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attrSet = true;
+        attrDevs |= devBit;
     }
     // small batches (one query) -> 4 waves per workgroup so that all CUs get work; big batches -> 8
     const int waves = nPairs <= 4096 ? 4 : 8;
@@ -607,10 +609,11 @@ static int launchSw(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nPa
 template <int R, bool HAS_AA>
 static int launchSwBlocks2T(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
     const int lds = (HAS_AA ? 2 : 1) * kSw2Rows * swRowDwords(R) * 4;
-    static thread_local bool attrSet = false;
-    if (!attrSet) {
+    static thread_local uint64_t attrDevs = 0;       // devices on which this thread has set the attribute (it is per device)
+    const uint64_t devBit = 1ull << (ctx->device & 63);
+    if (!(attrDevs & devBit)) {
         HIPCHK(hipFuncSetAttribute((const void *) k_sw2<R, HAS_AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attrSet = true;
+        attrDevs |= devBit;
     }
     hipLaunchKernelGGL((k_sw2<R, HAS_AA>), dim3(nBlocks), dim3(256), lds, stream, sa);
     HIPCHK(hipGetLastError());

@@ -162,7 +162,7 @@ def test_gpuserver_and_client_fail_loudly(tmp_path):
     name = "fsgpu_test_nogpu_%d" % os.getpid()
     srv = subprocess.Popen([exe, "gpuserver", src, "--shm-name", name], stderr=subprocess.PIPE, text=True)
     try:
-        srv.wait(timeout=90)
+        srv.wait(timeout=20)
         assert srv.returncode != 0 and "GPU" in srv.stderr.read()          # no device: refuses, never serves from the CPU
         assert not os.path.exists("/dev/shm/" + name)
     except subprocess.TimeoutExpired:                                       # a GPU is present (test run on a GPU box): it serves
