@@ -404,7 +404,7 @@ def main():
             "config": {"workload": f"1 query/step vs {db.n}-structure synthetic 3Di DB (mean len {residues / db.n:.0f}), "
                                    f"gapless prefilter (all targets) + top-1000 + fwd/rev structure SW "
                                    f"(--alignment-type {args.alignment_type}) + host gates/backtrace; each host thread prefilters "
-                                   f"{G} queries back to back, then aligns their hit lists with one multi-query SW launch",
+                                   f"{G} queries back to back, then aligns their hit lists with one multi-query SW launch per pass (forward over all pairs, reversed over the pairs that pass the forward gates)",
                        "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "max_seqs": 1000,
                        "queries_per_rank": args.steps, "host_threads_per_gpu": nthreads, "queries_per_sw_launch": G,
                        "parallelism": f"query-shard x{world}, DB replicated by one RCCL broadcast"},
