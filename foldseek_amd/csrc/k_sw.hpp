@@ -332,8 +332,10 @@ __global__ __launch_bounds__(256) void k_sw2(SwArgs a) {
     constexpr int TBL = kSw2Rows * ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SwBlockDesc bd = a.blocks[blockIdx.x];
-    const uint32_t *profSS = a.profSS + bd.imgOff;
-    const int rowsInTile = bd.rowsInTile, segLen = (int) bd.segLen, pairBase = (int) bd.firstPair, pairsHere = bd.nPairs;
+    // workgroup-uniform values -> SGPRs (scalar loop control, scalar address arithmetic)
+    const uint32_t *profSS = a.profSS + __builtin_amdgcn_readfirstlane(bd.imgOff);
+    const int rowsInTile = __builtin_amdgcn_readfirstlane((int) bd.rowsInTile), segLen = __builtin_amdgcn_readfirstlane((int) bd.segLen);
+    const int pairBase = __builtin_amdgcn_readfirstlane((int) bd.firstPair), pairsHere = __builtin_amdgcn_readfirstlane((int) bd.nPairs);
     {
         const uint4 *s3 = (const uint4 *) profSS;
         uint4 *d3 = (uint4 *) smem;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void k_sw2(SwArgs a) {
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
-    const int waveInBlock = (int) (threadIdx.x >> 6);
+    const int waveInBlock = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));     // wave-uniform: keep the pair bookkeeping scalar
     if (2 * waveInBlock >= pairsHere) return;
     const bool hasB = 2 * waveInBlock + 1 < pairsHere;
     const int pairA = __builtin_amdgcn_readfirstlane(pairBase + 2 * waveInBlock);
