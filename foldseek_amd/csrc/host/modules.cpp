@@ -697,7 +697,7 @@ int fsmod_structurealign(int argc, const char **argv) {
     std::string firstErr;
     // each host thread takes groups of prefilter entries: their hit lists go through ONE multi-query SW launch
     // (fshost_search_align_batch), then gates / backtrace / formatting per query
-    const size_t group = (size_t) std::max(1, std::min(o.geti("--align-batch", 8), 64));
+    const size_t group = (size_t) std::max(1, std::min(o.geti("--align-batch", 64), 64));
     auto work = [&](int tix) {
         bool owned = false;
         fsgpu_ctx *ctx = ds.forThread(tix, owned);

@@ -24,6 +24,13 @@ def run(args):
 pk, pu, a1, a2 = [os.path.join(tmp, x) for x in ("pref_k", "pref_u", "aln_k", "aln_u")]
 run(["prefilter", qdb + "_ss", tdb + "_ss", pk, "--threads", "3"])
 run(["structurealign", qdb, tdb, pk, a1, "--alignment-type", "2", "-a", "--threads", "3"])
+if os.environ.get("SOAK_ALIGN_BATCH_SWEEP"):
+    for ab in (8, 16, 32, 64):
+        for f in (a1 + "_ab", a1 + "_ab.index", a1 + "_ab.dbtype"):
+            if os.path.exists(f): os.remove(f)
+        print("--align-batch", ab, end="  ")
+        run(["structurealign", qdb, tdb, pk, a1 + "_ab", "--alignment-type", "2", "-a", "--threads", "3", "--align-batch", str(ab)])
+        assert dbio.read_db(a1 + "_ab") == dbio.read_db(a1)
 run(["ungappedprefilter", qdb + "_ss", tdb + "_ss", pu, "--threads", "3"])
 run(["structurealign", qdb, tdb, pu, a2, "--alignment-type", "2", "-a", "--threads", "3"])
 af = os.path.join(tmp, "aln_fused")
