@@ -447,7 +447,8 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
     const int rows = (L + 15) / 16;                       // rows per strip per lane
     const int nTiles = (L + 16 * kGaplessMaxR - 1) / (16 * kGaplessMaxR);
-    const int R = nTiles > 1 ? kGaplessMaxR : std::max(1, rows);
+    // row tiles of equal height: L = 513 runs as 2 x 272 rows (R = 17), not as 512 + 1 row at the full R = 32 cost each
+    const int R = nTiles > 1 ? ((L + nTiles - 1) / nTiles + 15) / 16 : std::max(1, rows);
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = (uint32_t) ctx->db->n;
     const uint32_t nChunks = (n + kSelChunk - 1) / kSelChunk;
@@ -499,14 +500,21 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
         rc = table[R](ctx, ga);
         if (rc != FSGPU_OK) return rc;
     } else {
-        // query row tiles of 512 rows: tile t+1 continues every diagonal of tile t through the border arrays in HBM
+        // query row tiles of 16 R <= 512 rows: tile t+1 continues every diagonal of tile t through the border arrays in HBM
+        using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
+        static const LaunchFn tiled[16] = {            // more than one tile means L > 512, so a tile has more than 256 rows: R = 17..32
+            launchGapless<17, true>, launchGapless<18, true>, launchGapless<19, true>, launchGapless<20, true>,
+            launchGapless<21, true>, launchGapless<22, true>, launchGapless<23, true>, launchGapless<24, true>,
+            launchGapless<25, true>, launchGapless<26, true>, launchGapless<27, true>, launchGapless<28, true>,
+            launchGapless<29, true>, launchGapless<30, true>, launchGapless<31, true>, launchGapless<32, true>};
+        if (R < 17 || R > kGaplessMaxR) { ctx->err = "internal: bad tiled R"; return FSGPU_E_ARG; }
         for (int t = 0; t < nTiles; t++) {
             HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
-            ga.tileBase = t * 16 * kGaplessMaxR;
+            ga.tileBase = t * 16 * R;
             ga.firstTile = t == 0; ga.lastTile = t == nTiles - 1;
             ga.borderIn = (const uint16_t *) ((t & 1) ? ctx->gBorder1.p : ctx->gBorder0.p);
             ga.borderOut = (uint16_t *) ((t & 1) ? ctx->gBorder0.p : ctx->gBorder1.p);
-            if ((rc = launchGapless<kGaplessMaxR, true>(ctx, ga)) != FSGPU_OK) return rc;
+            if ((rc = tiled[R - 17](ctx, ga)) != FSGPU_OK) return rc;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
