@@ -356,7 +356,7 @@ extern "C" int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *u
 // equal new length that each start ov chunks early; cap minimises max(cap, (work + warm-up work) / waves), the
 // completion time of a longest-first queue over equally fast waves.
 // ------------------------------------------------------------------------------------------------------------
-static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint64_t **items, uint32_t *nItems, bool *anySplit) {
+static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint4 **items, uint32_t *nItems, bool *anySplit) {
     DbStore &db = *ctx->db;
     std::lock_guard<std::mutex> lock(db.itemMutex);
     DbStore::ItemList &l = db.itemLists[ov];
@@ -402,8 +402,19 @@ static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint64_t **items, uint32_t
             const uint32_t la = (uint32_t) (a & 0xffff) - (uint32_t) ((a >> 16) & 0x7fff), lb = (uint32_t) (b & 0xffff) - (uint32_t) ((b >> 16) & 0x7fff);
             return la > lb;
         });
-        HIPCHK(hipMalloc((void **) &l.items, std::max<size_t>(v.size(), 1) * sizeof(uint64_t)));
-        if (!v.empty()) HIPCHK(hipMemcpy(l.items, v.data(), v.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        // device record: {stripe, range word, stripe offset in the scan layout (uint4 units) lo, hi}
+        std::vector<uint4> rec(v.size());
+        {
+            std::vector<uint64_t> sOff(nStripes);
+            uint64_t acc = 0;
+            for (uint32_t s = 0; s < nStripes; s++) { sOff[s] = acc; acc += (uint64_t) len[s] * 8; }
+            for (size_t i = 0; i < v.size(); i++) {
+                const uint32_t st = (uint32_t) (v[i] >> 32);
+                rec[i] = make_uint4(st, (uint32_t) v[i], (uint32_t) sOff[st], (uint32_t) (sOff[st] >> 32));
+            }
+        }
+        HIPCHK(hipMalloc((void **) &l.items, std::max<size_t>(rec.size(), 1) * sizeof(uint4)));
+        if (!rec.empty()) HIPCHK(hipMemcpy(l.items, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
         l.n = (uint32_t) v.size(); l.split = split; l.built = true;
     }
     *items = l.items; *nItems = l.n; *anySplit = l.split;

@@ -49,7 +49,7 @@ struct DbStore {
     // gapless work lists, one per overlap class (index = overlap in 16-column chunks, 0 = whole stripes): built on first
     // use by gaplessItems() (fsgpu.hip), shared by all contexts of this DB
     std::vector<uint32_t> hStripeLen;
-    struct ItemList { uint64_t *items = nullptr; uint32_t n = 0; bool split = false, built = false; };
+    struct ItemList { uint4 *items = nullptr; uint32_t n = 0; bool split = false, built = false; };
     ItemList itemLists[kGaplessMaxR + 1];
     std::mutex itemMutex;
     ~DbStore() {

@@ -65,7 +65,7 @@ struct GaplessArgs {
     const uint64_t *stripeOff;  // [nStripes] offset in uint4 units
     const uint32_t *stripeLen;  // [nStripes] length in 16-column chunks
     const uint32_t *stripeTargets; // [nStripes][8] target id per stripe slot, 0xffffffff = empty slot
-    const uint64_t *items;      // [nItems] work items, longest first: stripe << 32 | split << 31 | firstChunk << 16 | endChunk
+    const uint4 *items;         // [nItems] work items, longest first: {stripe, split << 31 | firstChunk << 16 | endChunk, stripe offset lo, hi}
     uint32_t nItems;
     uint32_t nTargets;
     const int8_t *pssm;         // [21][L] query profile (device copy)
@@ -133,16 +133,17 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
     // move delivered from the neighbouring target is never looked at.
     const uint32_t sel = (!TILED && g == 0) ? 0x01000c0cu : 0x01000706u;
 
-    for (;;) {
-        uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(a.queue, 1u);
-        w = __builtin_amdgcn_readfirstlane(w);
-        if (w >= a.nItems) break;
-        const uint64_t item = a.items[w];
-        const uint32_t stripe = (uint32_t) (item >> 32);
-        const bool split = (item >> 31) & 1;
-        const uint32_t cBegin = (uint32_t) (item >> 16) & 0x7fffu, cEnd = (uint32_t) item & 0xffffu;
-        const uint64_t soff = a.stripeOff[stripe];
+    // The first item of a wave is static (the nWaves longest items), the following ones come from the atomic queue: no
+    // ticket ramp at kernel start, and one 16-byte record per item keeps the dependent loads per stripe at two
+    // (record, first column chunk) -- what matters for short queries (tools/ubench/gapless_ablate.hip, "v6").
+    const uint32_t nWaves = gridDim.x * (kGaplessBlock / 64);
+    uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kGaplessBlock / 64) + (threadIdx.x >> 6));
+    for (; w < a.nItems;) {
+        const uint4 item = a.items[w];
+        const uint32_t stripe = item.x;
+        const bool split = (item.y >> 31) & 1;
+        const uint32_t cBegin = (item.y >> 16) & 0x7fffu, cEnd = item.y & 0xffffu;
+        const uint64_t soff = ((uint64_t) item.w << 32) | item.z;
         const uint4 *src = a.scan + soff + j;
         // border arrays use the scan layout at 2 bytes per residue: 32 bytes per (chunk, target)
         const uint4 *bin = TILED ? (const uint4 *) a.borderIn + (soff + j) * 2 : nullptr;
@@ -251,6 +252,9 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
                 }
             }
         }
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.queue, 1u);
+        w = nWaves + __builtin_amdgcn_readfirstlane(t);
     }
 }
 

@@ -622,6 +622,103 @@ __global__ __launch_bounds__(256) void k_v5(AblArgs a, const uint4 *) {
     }
 }
 
+// ---- candidate 6 (from 5): one 16-byte record per item {stripe, len16, soff}; SCHED 0: ticket at stripe end (2 dependent loads after it), SCHED 1: next ticket taken at stripe START, consumed at its end ----
+// candidate-5 text follows:  SCHED 0: static round robin (no atomics); SCHED 1: atomic ticket taken one
+//      stripe ahead, next stripe's metadata + first chunk loaded while the current stripe computes ----
+template <int R, int SCHED>
+__global__ __launch_bounds__(256) void k_v6(AblArgs a, const uint4 *scan16) {
+    constexpr int CHB = (kAlphabet + 1) * 256;
+    constexpr int NCH = (R + 3) / 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {
+        const int L = a.L;
+        constexpr int nDw = (kAlphabet + 1) * NCH * 2 * 8 * 4;
+        for (int idx = threadIdx.x; idx < nDw; idx += blockDim.x) {
+            int w = idx & 3, g = (idx >> 2) & 7, copy = (idx >> 5) & 1;
+            int k = (idx >> 6) % NCH, row = (idx >> 6) / NCH;
+            int r = 4 * k + w;
+            int qlo = g * 2 * R + r, qhi = qlo + R;
+            uint32_t v;
+            if (row == kDeadCode || r >= R) v = kDead2;
+            else if (SCHED == 3) v = (uint32_t) ((qlo * 7 + row) & 7) * 0x00010001u;       // no global reads in the image build
+            else {
+                int lo = qlo < L ? (int) a.pssm[row * L + qlo] : 0;
+                int hi = qhi < L ? (int) a.pssm[row * L + qhi] : 0;
+                v = f16ScaledBits(lo) | (f16ScaledBits(hi) << 16);
+            }
+            *(uint32_t *) (smem + k * CHB + row * 256 + copy * 128 + g * 16 + w * 4) = v;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int j = lane >> 3, g = lane & 7;
+    const uint32_t laneOff = (uint32_t) (((j >> 1) & 1) * 128 + g * 16);
+    const uint32_t sel = (g == 0) ? 0x01000c0cu : 0x01000706u;
+    const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    auto ticket = [&]() -> uint32_t {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(a.queue, 1u);
+        return __builtin_amdgcn_readfirstlane(w);
+    };
+    const uint4 *recs = (const uint4 *) scan16;         // {stripe, len16, soff lo, soff hi}
+    uint32_t w = waveId;                                 // first item static, then tickets offset by nWaves
+    while (w < a.nStripes) {
+        uint32_t wN = 0;
+        if (SCHED == 1) wN = nWaves + ticket();          // in flight while this stripe computes
+        const uint4 rec = recs[w];
+        const uint32_t stripe = rec.x, len16 = rec.y;
+        const uint64_t soff = ((uint64_t) rec.w << 32) | rec.z;
+        const uint4 first = (a.scan + soff + j)[0];
+        const uint4 *src = a.scan + soff + j;
+        uint32_t S[R];
+        uint32_t M = 0, M2 = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) S[r] = 0;
+        uint4 nxt = first;
+        for (uint32_t c = 0; c < len16; c++) {
+            const uint4 cur = nxt;
+            if (c + 1 < len16) nxt = src[(size_t) (c + 1) * 8];
+            const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t addr = __builtin_amdgcn_perm(words[b >> 2], laneOff, 0x0c0c0000u | ((4u + (b & 3)) << 8));
+                const unsigned char __attribute__((address_space(3))) *rowp = (const unsigned char __attribute__((address_space(3))) *) (uintptr_t) addr;
+                uint32_t P[4 * NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+                    const u32x4 v = *(const u32x4 __attribute__((address_space(3))) *) (rowp + k * CHB);
+                    P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
+                }
+                const uint32_t prev = __builtin_amdgcn_mov_dpp(S[R - 1], 0x111, 0xf, 0xf, true);
+                const uint32_t in = __builtin_amdgcn_perm(prev, S[R - 1], sel);
+#pragma unroll
+                for (int r = R - 1; r >= 1; r--) S[r] = pk_addc_f16(S[r - 1], P[r]);
+                S[0] = pk_addc_f16(in, P[0]);
+#pragma unroll
+                for (int r = 0; r + 3 < R; r += 4) {
+                    M = pk_max3_f16(M, S[r], S[r + 1]);
+                    M2 = pk_max3_f16(M2, S[r + 2], S[r + 3]);
+                }
+            }
+        }
+        M = pk_max3_f16(M, M2, M2);
+        int m = max((int) (M & 0xffff), (int) (M >> 16));
+        m = max(m, __shfl_xor(m, 1));
+        m = max(m, __shfl_xor(m, 2));
+        m = max(m, __shfl_xor(m, 4));
+        const uint32_t tid = stripe * kStripeTargets + j;
+        if (g == 0 && tid < a.nTargets) {
+            int sc = (int) (__half2float(__ushort_as_half((unsigned short) m)) * 2048.0f + 0.5f);
+            sc = sc < a.cap ? sc : a.cap;
+            a.scores[tid] = (uint8_t) sc;
+        }
+        if (SCHED == 0) wN = nWaves + ticket();
+        w = wN;
+    }
+}
+
 template <typename K>
 static float runK2(K kern, int block, int lds, int blocks, AblArgs ga, const uint4 *s16, int reps) {
     hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -676,9 +773,9 @@ static void suite(int nStripes, int len16, int L) {
     hipMalloc(&d, nStripes * 8); ga.scores = (uint8_t *) d;
     hipMalloc(&d, 4); ga.queue = (uint32_t *) d;
     {
-        std::vector<uint64_t> items(nStripes);
-        for (int s2 = 0; s2 < nStripes; s2++) items[s2] = ((uint64_t) s2 << 32) | (uint32_t) len16;
-        hipMalloc(&d, 8 * nStripes); hipMemcpy(d, items.data(), 8 * nStripes, hipMemcpyHostToDevice); ga.items = (const uint64_t *) d; ga.nItems = nStripes;
+        std::vector<uint4> items(nStripes);
+        for (int s2 = 0; s2 < nStripes; s2++) items[s2] = make_uint4((uint32_t) s2, (uint32_t) len16, (uint32_t) off[s2], (uint32_t) (off[s2] >> 32));
+        hipMalloc(&d, 16 * nStripes); hipMemcpy(d, items.data(), 16 * nStripes, hipMemcpyHostToDevice); ga.items = (const uint4 *) d; ga.nItems = nStripes;
     }
     {
         std::vector<uint32_t> ident(nStripes * 8);
@@ -733,6 +830,13 @@ static void suite(int nStripes, int len16, int L) {
         chk("v5 ticket+meta prefetch, 256 x3", runK2(k_v5<R, 1>, 256, lds, 768, ga, nullptr, 4));
         chk("v5 static first + prefetch, 256 x3", runK2(k_v5<R, 2>, 256, lds, 768, ga, nullptr, 4));
         rep("v5 same, image build without loads", runK2(k_v5<R, 3>, 256, lds, 768, ga, nullptr, 4));
+        {
+            std::vector<uint4> recs(nStripes);
+            for (int s2 = 0; s2 < nStripes; s2++) recs[s2] = make_uint4((uint32_t) s2, (uint32_t) len16, (uint32_t) off[s2], (uint32_t) (off[s2] >> 32));
+            void *dr; hipMalloc(&dr, 16 * nStripes); hipMemcpy(dr, recs.data(), 16 * nStripes, hipMemcpyHostToDevice);
+            chk("v6 16B records, ticket at end", runK2(k_v6<R, 0>, 256, lds, 768, ga, (const uint4 *) dr, 4));
+            chk("v6 16B records, ticket at start", runK2(k_v6<R, 1>, 256, lds, 768, ga, (const uint4 *) dr, 4));
+        }
         chk("v4 perm-addr u8, 512 x2", runK2(k_v4<R, 512>, 512, lds, 512, ga, nullptr, 4));
         chk("v4 perm-addr u8, 512 x3", runK2(k_v4<R, 512>, 512, lds, 768, ga, nullptr, 4));
         chk("v4 perm-addr u8, 256 x3", runK2(k_v4<R, 256>, 256, lds, 768, ga, nullptr, 4));
@@ -807,7 +911,11 @@ static void realMix(int nTargets, int L, int cap /* 0 = whole stripes */) {
     hipMalloc(&d, 8 * nStripes); hipMemcpy(d, sOff.data(), 8 * nStripes, hipMemcpyHostToDevice); ga.stripeOff = (const uint64_t *) d;
     hipMalloc(&d, 4 * nStripes); hipMemcpy(d, sLen.data(), 4 * nStripes, hipMemcpyHostToDevice); ga.stripeLen = (const uint32_t *) d;
     hipMalloc(&d, 4 * ident.size()); hipMemcpy(d, ident.data(), 4 * ident.size(), hipMemcpyHostToDevice); ga.stripeTargets = (const uint32_t *) d;
-    hipMalloc(&d, 8 * items.size()); hipMemcpy(d, items.data(), 8 * items.size(), hipMemcpyHostToDevice); ga.items = (const uint64_t *) d; ga.nItems = (uint32_t) items.size();
+    {
+        std::vector<uint4> recs(items.size());
+        for (size_t i = 0; i < items.size(); i++) { const uint32_t st = (uint32_t) (items[i] >> 32); recs[i] = make_uint4(st, (uint32_t) items[i], (uint32_t) sOff[st], (uint32_t) (sOff[st] >> 32)); }
+        hipMalloc(&d, 16 * recs.size()); hipMemcpy(d, recs.data(), 16 * recs.size(), hipMemcpyHostToDevice); ga.items = (const uint4 *) d; ga.nItems = (uint32_t) recs.size();
+    }
     hipMalloc(&d, pssm.size()); hipMemcpy(d, pssm.data(), pssm.size(), hipMemcpyHostToDevice); ga.pssm = (const int8_t *) d;
     hipMalloc(&d, nStripes * 8); hipMemset(d, 0, nStripes * 8); ga.scores = (uint8_t *) d;
     hipMalloc(&d, 4); ga.queue = (uint32_t *) d;
@@ -825,6 +933,7 @@ static void realMix(int nTargets, int L, int cap /* 0 = whole stripes */) {
 int main(int argc, char **argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("device CUs %d clock %d MHz\n", p.multiProcessorCount, p.clockRate / 1000);
+    if (argc > 1 && !strcmp(argv[1], "short")) { suite<8>(12288, 22, 125); suite<12>(12288, 22, 190); return 0; }
     if (argc > 1 && !strcmp(argv[1], "real")) {
         realMix<21>(100000, 332, 0); realMix<21>(100000, 332, 91); realMix<21>(100000, 332, 64);
         realMix<24>(100000, 380, 0); realMix<24>(100000, 380, 91);
