@@ -437,7 +437,7 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
     }
     int perCU = perCUcached;
     // Workgroups of 4 waves, each with its own LDS image; 3 per CU (12 waves, <= 135 KB LDS): more does not issue faster
-    // (profiles/r01_p_gapless_ablation_ubench.txt, tools/bench_ab2.sh) and this leaves wave slots for the latency-bound SW
+    // (profiles/r01_q_gapless_ablation_ubench.txt, tools/bench_ab2.sh) and this leaves wave slots for the latency-bound SW
     // wavefront kernels of other in-flight queries to co-reside.  FSGPU_GAPLESS_BLOCKS_PER_CU overrides.
     constexpr int wavesPerBlock = kGaplessBlock / 64;
     perCU = std::max(1, std::min(perCU, ctx->gaplessBlocksPerCU));

@@ -18,7 +18,7 @@
 //     target residue is (code << 8) | laneOffset: ONE v_perm_b32 straight from the packed residue word (the
 //     4-register chunks sit at immediate offsets k * 22 * 256).  LDS bytes/cell = 2.
 //   * per target column a lane issues 1.5 R DP ops + 3 others (row address, dpp, hand-off perm): measured
-//     tools/ubench/gapless_ablate.hip, profiles/r01_p_gapless_ablation_ubench.txt.
+//     tools/ubench/gapless_ablate.hip, profiles/r01_q_gapless_ablation_ubench.txt.
 //   * the target DB is pre-tiled in HBM as 8-target stripes (targets grouped by length) interleaved at 16-byte granularity: one wave-level
 //     global load = one 128-byte line, every byte of the DB is read exactly once per query.
 //   * diagonal hand-off between lanes: v_mov_b32_dpp row_shr:1 + v_perm_b32 (no LDS round trip).
