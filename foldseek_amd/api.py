@@ -68,6 +68,7 @@ def lib():
         "fsgpu_clone": (i32, [vp, C.POINTER(vp)]),
         "fsgpu_device": (i32, [vp]),
         "fsgpu_device_count": (i32, []),
+        "fsgpu_gapless_plan_items": (i64, [vp, C.c_uint32, i32, f64, vp, u64, vp]),
         "fsgpu_db_broadcast": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32)]),
         "fsgpu_stream": (vp, [vp]),
         "fsgpu_db_load": (i32, [vp, vp, vp, vp, vp, u64, u64]),
@@ -135,7 +136,7 @@ def exported_symbols():
     return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_launch", "fsgpu_sw_finish",
-            "fsgpu_db_broadcast", "fsgpu_device_count",
+            "fsgpu_db_broadcast", "fsgpu_device_count", "fsgpu_gapless_plan_items",
             "fsgpu_last_kernel_ms", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
             "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts"]
 

@@ -356,6 +356,62 @@ extern "C" int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *u
 // equal new length that each start ov chunks early; cap minimises max(cap, (work + warm-up work) / waves), the
 // completion time of a longest-first queue over equally fast waves.
 // ------------------------------------------------------------------------------------------------------------
+// pure planning step (host only, no device calls; exported as fsgpu_gapless_plan_items for the CPU tests)
+static void planGaplessItems(const std::vector<uint32_t> &len, int ov, double waves, bool allowSplit, std::vector<uint64_t> &v, bool &split, uint32_t &capOut) {
+    const uint32_t nStripes = (uint32_t) len.size();
+    uint64_t total = 0;
+    uint32_t maxLen = 0;
+    for (uint32_t x : len) { total += x; maxLen = std::max(maxLen, x); }
+    uint32_t cap = maxLen;
+    if (ov > 0 && maxLen > 2u * ov && allowSplit) {
+        // histogram of stripe lengths -> cost of every candidate cap
+        std::vector<uint32_t> hist(maxLen + 1, 0);
+        for (uint32_t x : len) hist[x]++;
+        double best = std::max((double) maxLen, (double) total / waves);
+        for (uint32_t c = 2u * ov; c < maxLen; c++) {
+            uint64_t extra = 0;
+            const uint32_t fresh = c - ov;
+            for (uint32_t x = c + 1; x <= maxLen; x++)
+                if (hist[x]) extra += (uint64_t) hist[x] * ((x + fresh - 1) / fresh - 1) * ov;
+            const double t = std::max((double) c, (double) (total + extra) / waves);
+            if (t < best) { best = t; cap = c; }
+        }
+    }
+    capOut = cap;
+    v.clear();
+    v.reserve(nStripes + 64);
+    split = false;
+    for (uint32_t s = 0; s < nStripes; s++) {
+        const uint32_t L = len[s];
+        if (L == 0) continue;
+        if (L <= cap || ov == 0) { v.push_back(((uint64_t) s << 32) | L); continue; }
+        const uint32_t K = (L + (cap - ov) - 1) / (cap - ov), fresh = (L + K - 1) / K;
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t b = k * fresh, e = std::min(L, (k + 1) * fresh);
+            if (b >= e) break;
+            const uint32_t b0 = b > (uint32_t) ov ? b - ov : 0;
+            v.push_back(((uint64_t) s << 32) | (1ull << 31) | ((uint64_t) b0 << 16) | e);
+            split = true;
+        }
+    }
+    std::stable_sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) {
+        const uint32_t la = (uint32_t) (a & 0xffff) - (uint32_t) ((a >> 16) & 0x7fff), lb = (uint32_t) (b & 0xffff) - (uint32_t) ((b >> 16) & 0x7fff);
+        return la > lb;
+    });
+}
+
+extern "C" int64_t fsgpu_gapless_plan_items(const uint32_t *stripeLen, uint32_t nStripes, int overlap, double waves, uint64_t *items, uint64_t capacity, uint32_t *cap) {
+    if ((!stripeLen && nStripes) || overlap < 0 || waves <= 0) return -1;
+    std::vector<uint32_t> len(stripeLen, stripeLen + nStripes);
+    std::vector<uint64_t> v;
+    bool split = false;
+    uint32_t c = 0;
+    planGaplessItems(len, overlap, waves, true, v, split, c);
+    if (cap) *cap = c;
+    if (items) for (size_t i = 0; i < v.size() && i < capacity; i++) items[i] = v[i];
+    return (int64_t) v.size();
+}
+
 static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint4 **items, uint32_t *nItems, bool *anySplit) {
     DbStore &db = *ctx->db;
     std::lock_guard<std::mutex> lock(db.itemMutex);
@@ -363,45 +419,10 @@ static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint4 **items, uint32_t *n
     if (!l.built) {
         const std::vector<uint32_t> &len = db.hStripeLen;
         const uint32_t nStripes = (uint32_t) len.size();
-        uint64_t total = 0;
-        uint32_t maxLen = 0;
-        for (uint32_t x : len) { total += x; maxLen = std::max(maxLen, x); }
-        const double waves = (double) ctx->numCU * 3 * (kGaplessBlock / 64);
-        uint32_t cap = maxLen;
-        if (ov > 0 && maxLen > 2u * ov && !getenv("FSGPU_GAPLESS_NOSPLIT")) {      // the variable exists for A/B measurements
-            // histogram of stripe lengths -> cost of every candidate cap
-            std::vector<uint32_t> hist(maxLen + 1, 0);
-            for (uint32_t x : len) hist[x]++;
-            double best = std::max((double) maxLen, (double) total / waves);
-            for (uint32_t c = 2u * ov; c < maxLen; c++) {
-                uint64_t extra = 0;
-                const uint32_t fresh = c - ov;
-                for (uint32_t x = c + 1; x <= maxLen; x++)
-                    if (hist[x]) extra += (uint64_t) hist[x] * ((x + fresh - 1) / fresh - 1) * ov;
-                const double t = std::max((double) c, (double) (total + extra) / waves);
-                if (t < best) { best = t; cap = c; }
-            }
-        }
         std::vector<uint64_t> v;
-        v.reserve(nStripes + 64);
         bool split = false;
-        for (uint32_t s = 0; s < nStripes; s++) {
-            const uint32_t L = len[s];
-            if (L == 0) continue;
-            if (L <= cap || ov == 0) { v.push_back(((uint64_t) s << 32) | L); continue; }
-            const uint32_t K = (L + (cap - ov) - 1) / (cap - ov), fresh = (L + K - 1) / K;
-            for (uint32_t k = 0; k < K; k++) {
-                const uint32_t b = k * fresh, e = std::min(L, (k + 1) * fresh);
-                if (b >= e) break;
-                const uint32_t b0 = b > (uint32_t) ov ? b - ov : 0;
-                v.push_back(((uint64_t) s << 32) | (1ull << 31) | ((uint64_t) b0 << 16) | e);
-                split = true;
-            }
-        }
-        std::stable_sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) {
-            const uint32_t la = (uint32_t) (a & 0xffff) - (uint32_t) ((a >> 16) & 0x7fff), lb = (uint32_t) (b & 0xffff) - (uint32_t) ((b >> 16) & 0x7fff);
-            return la > lb;
-        });
+        uint32_t cap = 0;
+        planGaplessItems(len, ov, (double) ctx->numCU * 3 * (kGaplessBlock / 64), !getenv("FSGPU_GAPLESS_NOSPLIT") /* A/B measurements */, v, split, cap);
         // device record: {stripe, range word, stripe offset in the scan layout (uint4 units) lo, hi}
         std::vector<uint4> rec(v.size());
         {

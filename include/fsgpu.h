@@ -117,6 +117,13 @@ int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, 
 int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out);
 /* Asynchronous halves of fsgpu_gapless_scan for callers that pipeline several queries / time the device part:
  * _launch enqueues profile upload + kernels on the context stream, _finish waits and post-processes. */
+/* Host-only planning step of the scan (no device call): the work list for stripes of stripeLen[] 16-column chunks when a
+ * column segment needs `overlap` warm-up chunks (= ceil(Lq / 16)) and `waves` waves pull from the queue.  items[i] =
+ * stripe << 32 | split << 31 | firstChunk << 16 | endChunk, longest first; *cap = the cut length chosen (minimises
+ * max(cut, (work + warm-up work) / waves)).  Returns the number of items (may exceed capacity; nothing beyond it is
+ * written).  Exported so that the policy can be tested without a GPU. */
+int64_t fsgpu_gapless_plan_items(const uint32_t *stripeLen, uint32_t nStripes, int overlap, double waves, uint64_t *items,
+                                 uint64_t capacity, uint32_t *cap);
 int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore,
                          int64_t identityId, int maxRes);
 int fsgpu_gapless_finish(fsgpu_ctx *ctx, fsgpu_hit *out, int *nout);

@@ -135,3 +135,64 @@ def test_no_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(api.FsgpuError):
         api.Context(0)
+
+
+def test_gapless_work_list_planner():
+    """fsgpu_gapless_plan_items (host only): column segments of long stripes.  Invariants: the segments of a stripe tile its
+    columns exactly once with their own ("fresh") parts, every later segment starts `overlap` chunks before its fresh part,
+    unsplit stripes appear whole, items are ordered longest first, no split without need, and the chosen cut is never worse
+    than not cutting under the planner's own cost model."""
+    import ctypes as C
+    L = api.lib()
+    rng = np.random.default_rng(12)
+
+    def plan(lens, ov, waves):
+        lens = np.ascontiguousarray(lens, np.uint32)
+        cap = C.c_uint32(0)
+        n = L.fsgpu_gapless_plan_items(lens.ctypes.data, len(lens), ov, float(waves), None, 0, C.byref(cap))
+        items = np.zeros(max(1, n), np.uint64)
+        assert L.fsgpu_gapless_plan_items(lens.ctypes.data, len(lens), ov, float(waves), items.ctypes.data, n, None) == n
+        return items[:n], int(cap.value)
+
+    for trial in range(40):
+        n = int(rng.integers(1, 3000))
+        lens = np.clip(np.rint(rng.gamma(2.2, 22.0 / 2.2, size=n)), 0 if trial % 5 == 0 else 1, 125).astype(np.uint32)
+        ov = int(rng.choice([0, 1, 7, 16, 22, 32]))
+        waves = float(rng.choice([8, 64, 3072, 4096]))
+        items, cap = plan(lens, ov, waves)
+        stripe = (items >> np.uint64(32)).astype(np.int64)
+        split = ((items >> np.uint64(31)) & np.uint64(1)).astype(bool)
+        b0 = ((items >> np.uint64(16)) & np.uint64(0x7fff)).astype(np.int64)
+        e = (items & np.uint64(0xffff)).astype(np.int64)
+        size = e - b0
+        assert (size > 0).all() and (np.diff(size) <= 0).all()                      # longest first
+        assert set(stripe.tolist()) == set(np.flatnonzero(lens > 0).tolist())      # empty stripes are dropped, nothing else
+        total_fresh = 0
+        for s_ in np.unique(stripe):
+            m = stripe == s_
+            Ls = int(lens[s_])
+            if not split[m].any():
+                assert m.sum() == 1 and b0[m][0] == 0 and e[m][0] == Ls and (Ls <= cap or ov == 0)
+                total_fresh += Ls
+                continue
+            assert split[m].all() and ov > 0 and Ls > cap
+            order = np.argsort(e[m])
+            ee, bb = e[m][order], b0[m][order]
+            fresh_begin = np.concatenate(([0], ee[:-1]))                          # a segment's own columns start where the previous one ended
+            assert ee[-1] == Ls and (np.diff(ee) > 0).all()
+            assert (bb == np.maximum(0, fresh_begin - ov)).all()                    # warm-up = overlap chunks (clipped at the stripe start)
+            assert (ee - bb <= cap + 1).all()                                        # no item longer than the cut (+ rounding of the equal split)
+            total_fresh += int((ee - fresh_begin).sum())
+        assert total_fresh == int(lens.sum())
+        if ov == 0 or lens.max(initial=0) <= 2 * ov:
+            assert not split.any() and cap == lens.max(initial=0)
+        # cost model: max(longest item, work / waves) must not be worse than the uncut list
+        cost = max(float(size.max(initial=0)), float(size.sum()) / waves)
+        uncut = max(float(lens.max(initial=0)), float(lens.sum()) / waves)
+        assert cost <= uncut + 1.0
+    # the bench DB shape: only the handful of longest stripes is cut, the extra work stays below 1 %
+    lens = np.sort(np.clip(np.rint(rng.gamma(2.2, 350.0 / 2.2, size=100000)), 30, 2000))[::-1]
+    s16 = ((lens.reshape(-1, 8).max(axis=1) + 15) // 16).astype(np.uint32)
+    items, cap = plan(s16, 21, 3072)
+    size = (items & np.uint64(0xffff)).astype(np.int64) - ((items >> np.uint64(16)) & np.uint64(0x7fff)).astype(np.int64)
+    assert 80 <= cap <= 100 and size.max() <= cap + 1 and size.sum() <= 1.01 * s16.sum() and len(items) < len(s16) + 64
