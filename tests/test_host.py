@@ -196,3 +196,14 @@ def test_gapless_work_list_planner():
     items, cap = plan(s16, 21, 3072)
     size = (items & np.uint64(0xffff)).astype(np.int64) - ((items >> np.uint64(16)) & np.uint64(0x7fff)).astype(np.int64)
     assert 80 <= cap <= 100 and size.max() <= cap + 1 and size.sum() <= 1.01 * s16.sum() and len(items) < len(s16) + 64
+
+
+def test_bench_usable_cores():
+    """bench.py sizes its CPU baselines and its host wait policy by the cores this process may really use"""
+    import importlib, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
