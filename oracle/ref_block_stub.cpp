@@ -24,6 +24,13 @@ void block_align_aa_trace_xdrop_posbias(BlockHandle, const struct PaddedBytes *,
 int8_t *aaprofile_pos_aa(struct AAProfile *) { die("aaprofile"); return NULL; }
 int16_t *aaprofile_aa_pos(struct AAProfile *) { die("aaprofile"); return NULL; }
 
+// --- used only by MMseqs' BlockAligner (the whole-binary build of oracle/build_ref_full.sh links it; the score-only
+//     x-drop aligner is reached by `mmseqs align --alignment-mode 4`-style paths, never by the foldseek modules tested here) ---
+BlockHandle block_new_aa_xdrop(uintptr_t, uintptr_t, uintptr_t) { return calloc(64, 1); }
+void block_free_aa_xdrop(BlockHandle b) { free(b); }
+void block_align_aa_xdrop_posbias(BlockHandle, const struct PaddedBytes *, const struct PosBias *, const struct PaddedBytes *, const struct PosBias *, const struct AAMatrix *, struct Gaps, struct SizeRange, int32_t) { die("block_align_aa_xdrop_posbias"); }
+struct AlignResult block_res_aa_xdrop(BlockHandle) { die("block_res_aa_xdrop"); struct AlignResult r = {0, 0, 0}; return r; }
+
 #ifndef FS_HAVE_BLOCK_ALIGNER
 void block_set_pos_bias(struct PosBias *, const int16_t *, uintptr_t) {}
 struct AlignResult block_res_aa_trace_xdrop(BlockHandle) { die("block_res_aa_trace_xdrop"); struct AlignResult r = {0, 0, 0}; return r; }
