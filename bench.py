@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- residues aligned / s of the hot path (prefilter + structurealign) on N MI355X of one node.
 
-Workload (BASELINE.json configs[1], the configuration that fits one GPU): 1 query per step against a 100k-structure
-synthetic 3Di(+AA) database (mean length 350) resident in HBM: exhaustive gapless prefilter over every target,
-top --max-seqs selection, 3Di Smith-Waterman (forward + reversed query) on the hits, host gates + backtrace.
-N > 1 (torchrun, one rank per GPU): rank 0 generates the padded DB, ONE RCCL broadcast puts it into every GPU's HBM,
-every rank then searches its own queries with no further communication (weak scaling, queries shard).
+Workload = BASELINE.json's metric configuration (configs[2], it fits one GPU): queries vs a 1M-structure synthetic
+3Di(+AA) database (mean length 350, 50 planted homologs for EVERY query) resident in HBM.
+One STEP = one batch of --group (32) queries through the whole path on one host feeder thread: exhaustive gapless
+prefilter over every target + top --max-seqs selection per query, then ONE multi-query structure Smith-Waterman launch
+per pass over the batch's hit lists (forward over all pairs, reversed query over the pairs that pass the forward
+gates), host gates, block-aligner backtrace of every accepted hit, result ordering.  --host-threads feeder threads
+(own HIP stream each, shared resident DB) run their steps concurrently, the way the reference's OpenMP threads do.
+--targets 100000 gives configs[1].
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, one rank per GPU; under torchrun it
+uses the ranks it is given): rank 0 generates the padded DB, ONE RCCL broadcast puts it into every GPU's HBM, every rank
+then searches its own queries with no further communication.  --scaling weak (default): every rank runs --steps
+steps of its own queries; --scaling strong: the SAME steps x group queries are split over the ranks.
 
 One JSON line on rank 0; see the prompt contract.  `roofline` is for the dominant kernel (gapless scan) from HIP
 events around that kernel on the library's stream; `cpu_baseline` times the reference's own AVX2 code (oracle/_ref,
@@ -24,23 +32,42 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=960)
-    ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--targets", type=int, default=100000)
-    ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1]), 2: 3Di+AA")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without a torchrun environment: bench.py launches them itself")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps per rank (weak) / in total (strong); a step = one batch of --group queries")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps per rank")
+    ap.add_argument("--targets", type=int, default=1000000)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--homologs", type=int, default=50, help="planted homologs per query (SURVEY.md 8d)")
+    ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1..2]), 2: 3Di+AA (configs[3])")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
-    ap.add_argument("--group", type=int, default=32, help="queries a host thread prefilters back to back before ONE multi-query SW launch (0: one SW launch per query)")
+    ap.add_argument("--group", type=int, default=32, help="queries per step: prefiltered back to back, then ONE multi-query SW launch per pass")
+    ap.add_argument("--dry-run", action="store_true", help="no device work: ranks, DB generation, broadcast and query sharding only (gloo on CPU when no GPU is visible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
     ap.add_argument("--kmer-threads", type=int, default=4, help="host threads (context clones) of the k-mer section")
-    ap.add_argument("--kmer-queries", type=int, default=768, help="queries of the k-mer prefilter section (batches of 32)")
-    ap.add_argument("--kmer-cpu-queries", type=int, default=256, help="queries the reference k-mer prefilter is timed on")
+    ap.add_argument("--kmer-queries", type=int, default=512, help="queries of the k-mer prefilter section (batches of 32)")
+    ap.add_argument("--kmer-cpu-queries", type=int, default=64, help="queries the reference k-mer prefilter is timed on")
     ap.add_argument("--cpu-sample-targets", type=int, default=100000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def relaunch_as_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script on this node (one per GPU) the way the
+    driver would (torch.distributed.run, rendezvous on 127.0.0.1) and pass its exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cores():
@@ -115,13 +142,14 @@ def cpu_baseline(db, q3, qa, hits_ids, atype, sample_targets, more_queries=()):
             "prefilter_s_sample": t_pref, "align_s": t_aln}
 
 
-def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdist):
+def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdist, q3, qa):
     """k-mer prefilter (Foldseek's default prefilter on CPUs) + structure SW on its hits, same resident DB.
     Every rank builds its own index from the broadcast DB (no collective) and searches its own queries."""
     import threading
     nqk = max(32, args.kmer_queries // 32 * 32)
-
-    q3, qa = synth.make_queries(nqk, seed=5000 + rank, lo=250, hi=450)
+    # this rank's own timed queries (their homologs are planted in the DB), repeated if the section asks for more
+    q3 = [q3[i % len(q3)] for i in range(nqk)]
+    qa = [qa[i % len(qa)] for i in range(nqk)]
     m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
     thr = api.kmer_threshold(9.5, 6)
     t0 = time.perf_counter()
@@ -193,11 +221,12 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     reg_ms = float(np.mean(stat["lists"]))
     reg_probes = float(np.mean([c[0] for c in stat["counts"]]))
     reg_alg = reg_probes * 8.0
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json")))
-        if args.targets == 100000:
-            traffic = tj["k_kmer_lists_bytes_per_probe"] * probes
+    traffic, traffic_src = None, None
+    try:   # HBM bytes per probe from a committed rocprofv3 --pmc pass of the same kernel on the same DB size
+        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json"))).get(str(args.targets))
+        if e:
+            traffic = e["k_kmer_lists_bytes_per_probe"] * probes
+            traffic_src = e["source"]
     except Exception:
         traffic = None
     out = {"workload": f"{nqk} queries in batches of 32 vs the same {db.n}-structure DB: k-mer prefilter (-s 9.5, k=6 spaced, "
@@ -213,7 +242,7 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
            # k_kmer_lists per-launch duration: HIP events on the library's stream, mean over the batches of the timed region
            # (the host threads overlap their batches); "solo" = the same launch alone on the device
            "roofline": {"bound": "hbm", "kernel": "k_kmer_lists", "kernel_ms": reg_ms, "achieved": reg_alg / (reg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": reg_alg / (reg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None if traffic is None else traffic * reg_probes / probes,
+                        "frac": reg_alg / (reg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None if traffic is None else traffic * reg_probes / probes, "traffic_source": traffic_src,
                         "algorithmic_bytes": reg_alg, "probes_per_launch": reg_probes, "probes_per_s": reg_probes / (reg_ms * 1e-3),
                         "solo": {"kernel_ms": solo_ms[10], "achieved": alg / lists_s / 1e9, "frac": alg / lists_s / 1e9 / 8000.0, "probes_per_launch": probes,
                                  "traffic": traffic},
@@ -230,7 +259,7 @@ def kmer_cpu_baseline(args, synth, db):
         return None
     threads = usable_cores()
     nq = args.kmer_cpu_queries
-    q3, _ = synth.make_queries(nq, seed=5000, lo=250, hi=450)
+    q3, _ = synth.make_queries(nq, seed=1000, lo=250, hi=450)       # the first queries of the timed set
     t0 = time.perf_counter()
     r = K.RefKpf(R, [db.seq(i, "3di", unmask=False) for i in range(db.n)], threads=threads)
     t_build = time.perf_counter() - t0
@@ -245,39 +274,83 @@ def kmer_cpu_baseline(args, synth, db):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_as_ranks(args))
     # host feeder threads spend their time inside the library (ctypes releases the GIL); a thread returning from a call
     # must not wait a whole default switch interval (5 ms) for the GIL while another one runs a few Python lines
     sys.setswitchinterval(1e-4)
     import torch
     import torch.distributed as dist
-    from foldseek_amd import api, synth
+    from foldseek_amd import synth
+    from foldseek_amd import dist as fdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not args.dry_run:
+        raise SystemExit("bench.py: no GPU visible (the hot path has no CPU fallback); --dry-run exercises the rank / broadcast / sharding plumbing only")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if have_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
 
-    from foldseek_amd import dist as fdist
     import threading
     nthreads = max(1, args.host_threads)
+    G = max(1, args.group)
+    # ---- queries: weak = every rank its own steps; strong = the same steps*G queries split contiguously over the ranks ----
+    per_rank_timed = args.steps * G if args.scaling == "weak" else None
+    n_timed_total = args.steps * G * (world if args.scaling == "weak" else 1)
+    n_warm = args.warmup * G
+    all_q3, all_qa = synth.make_queries(n_timed_total + world * n_warm, seed=1000, lo=250, hi=450)   # around the mean length 350; same on every rank
+    if args.scaling == "weak":
+        t_lo, t_hi = rank * per_rank_timed, (rank + 1) * per_rank_timed
+    else:
+        t_lo, t_hi = fdist.shard_range(n_timed_total, rank, world)
+    w_lo = n_timed_total + rank * n_warm
+    q3 = all_q3[w_lo:w_lo + n_warm] + all_q3[t_lo:t_hi]            # this rank: warm-up queries first, then its timed shard
+    qa = all_qa[w_lo:w_lo + n_warm] + all_qa[t_lo:t_hi]
+    nq = len(q3)
+    n_mine = t_hi - t_lo
+    # ---- target DB: generated on rank 0 (vectorised), ONE broadcast (RCCL over xGMI), then resident in every GPU's HBM ----
+    t_gen = time.perf_counter()
+    db = synth.make_db_fast(args.targets, (all_q3, all_qa), seed=20260923, homologs_per_query=args.homologs) if rank == 0 else None
+    t_gen = time.perf_counter() - t_gen
+    if have_gpu:
+        torch.cuda.synchronize()
+    tb = time.perf_counter()
+    tensors, db = fdist.broadcast_db(db, dev)
+    if have_gpu:
+        torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - tb if world > 1 else 0.0
+    if args.dry_run:
+        # everything up to here is the multi-rank plumbing; check what the other ranks received and stop
+        import zlib
+        digest = zlib.crc32(db.data3di.tobytes()[:1 << 20]) ^ zlib.crc32(np.ascontiguousarray(db.lengths).tobytes())
+        sizes = fdist.gather_objects((rank, n_mine, int(db.n), int(digest)))
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "residues aligned/sec (prefilter+align)", "value": 0.0, "unit": "residues/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": args.scaling,
+                              "backend": dist.get_backend() if world > 1 else "none", "db_broadcast_s": t_bcast, "db_generation_s": t_gen,
+                              "ranks": [{"rank": r, "timed_queries": m, "db_entries": n, "db_digest": d} for r, m, n, d in sizes],
+                              "config": {"workload": "dry run: no device work", "targets": int(db.n), "queries_per_step": G}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from foldseek_amd import api
     # host wait policy of the library (fsgpu_ctx.h::syncStream): a waiting feeder thread polls the stream for FSGPU_SPIN_US
     # and then sleeps.  Polling all the way is 1.5 % faster but costs a core per thread; only do it when the cores this job
     # may use (cgroup quota!) comfortably cover every rank's feeder threads.
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if "FSGPU_SPIN_US" not in os.environ:
         os.environ["FSGPU_SPIN_US"] = "1000000" if usable_cores() >= 2 * local_world * nthreads else "40"
-    nq = args.steps + args.warmup
-    q3, qa = synth.make_queries(nq, seed=1000 + rank, lo=250, hi=450)        # per-rank queries around the mean length 350
-    # ---- target DB: generated on rank 0, ONE broadcast (RCCL over xGMI), then resident in every GPU's HBM ----
-    db = synth.make_db(args.targets, synth.make_queries(8, seed=1000, lo=250, hi=450), seed=20260923, homologs_per_query=50) if rank == 0 else None
-    torch.cuda.synchronize()
-    tb = time.perf_counter()
-    tensors, db = fdist.broadcast_db(db, dev)
-    torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - tb if world > 1 else 0.0
     ctx0 = api.Context(local_rank)
     ctx0.adopt_device_db(tensors[0].data_ptr(), tensors[1].data_ptr(), tensors[2].data_ptr(), tensors[3].data_ptr(), db.n, db.data3di.size)
     ctx0._keep = (np.ascontiguousarray(db.data3di), np.ascontiguousarray(db.dataaa), np.ascontiguousarray(db.offsets, np.uint64),
@@ -290,22 +363,20 @@ def main():
     ctxs = [ctx0] + [ctx0.clone() for _ in range(nthreads - 1)]
     searches = [api.Search(c, par) for c in ctxs]
 
-    def step(t, i):
+    def step1(t, i):
         hits = searches[t].prefilter(q3[i])
         res = searches[t].align(qa[i], q3[i], hits["id"])
         return hits, res
 
     kms, sms, counts = [], [], [0, 0]
+    host = {"backtrace_s": 0.0, "rev_pairs": 0.0, "gates_s": 0.0, "profiles_s": 0.0, "sw_wait_s": 0.0}
     lock = threading.Lock()
     ready = threading.Barrier(nthreads + 1)
     go = threading.Barrier(nthreads + 1)
-
-    # queries per multi-query SW launch; with few steps keep at least two groups per host thread so every thread has work
-    G = max(1, min(args.group, args.steps // (2 * nthreads))) if args.group > 0 else 1
     trace, t_go = [], [0.0]
 
-    def steps(t, ids):
-        """G queries: G gapless scans back to back, then ONE multi-query SW launch over all their hit lists"""
+    def step(t, ids):
+        """one step: G gapless scans back to back, then ONE multi-query SW launch per pass over all their hit lists"""
         hl, km = [], []
         for i in ids:
             hl.append(searches[t].prefilter(q3[i]))
@@ -313,37 +384,36 @@ def main():
         rs = searches[t].align_batch([qa[i] for i in ids], [q3[i] for i in ids], [h["id"] for h in hl])
         return hl, rs, km
 
+    timed = list(range(n_warm, nq))
+    batches = [timed[k:k + G] for k in range(0, len(timed), G)]
+    warm = [list(range(k, min(k + G, n_warm))) for k in range(0, n_warm, G)]
+
     def worker(t):
-        # untimed warmup inside the worker: the first HIP calls of a host thread initialise per-thread state
-        for i in range(t, args.warmup, nthreads):
-            step(t, i)
-        if args.warmup < nthreads:
-            step(t, 0)
-        steps(t, list(range(min(G, nq))))
+        # untimed warm-up inside the worker: the first HIP calls of a host thread initialise per-thread state
+        for b in warm[t::nthreads]:
+            step(t, b)
+        if not warm[t::nthreads]:
+            step(t, list(range(min(G, nq))))
         # one query of every 16-row length class (one gapless instantiation each; the SW classes are coarser): the first
         # launch of a kernel instantiation (lazy code-object load, attribute set-up, scratch growth) must not land in
         # the timed region
         cls = {}
         for i in range(nq):
             cls.setdefault((len(q3[i]) + 15) // 16, i)
-        steps(t, sorted(cls.values()))
+        step(t, sorted(cls.values()))
         ready.wait()
         go.wait()
-        mine = list(range(args.warmup, nq))
-        groups = [mine[k:k + G] for k in range(0, len(mine), G)]
-        for g in groups[t::nthreads]:
-            if args.group == 0:                       # per-query path: fsgpu_sw_batch per query
-                h1, r1 = step(t, g[0])
-                hl, rs, km = [h1], [r1], [ctxs[t].kernel_ms(0)]
-            else:
-                tg = time.perf_counter()
-                hl, rs, km = steps(t, g)
-                if os.environ.get("FS_BENCH_TRACE"):
-                    with lock:
-                        trace.append((t, tg - t_go[0], time.perf_counter() - tg))
+        for b in batches[t::nthreads]:
+            tg = time.perf_counter()
+            hl, rs, km = step(t, b)
+            st = searches[t].stats()
             with lock:
-                kms.extend(km); sms.append(ctxs[t].kernel_ms(1) / len(g))
+                if os.environ.get("FS_BENCH_TRACE"):
+                    trace.append((t, tg - t_go[0], time.perf_counter() - tg))
+                kms.extend(km); sms.append(ctxs[t].kernel_ms(1) / len(b))
                 counts[0] += sum(len(h) for h in hl); counts[1] += sum(len(r) for r in rs)
+                host["profiles_s"] += st[2]; host["sw_wait_s"] += st[3]; host["gates_s"] += st[4]; host["backtrace_s"] += st[5]
+                host["rev_pairs"] += st[7]
 
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
     for th in ths:
@@ -368,53 +438,65 @@ def main():
     if os.environ.get("FS_BENCH_TRACE"):
         for rec in sorted(trace, key=lambda r: r[1]):
             print("trace thread %d start %.2f ms dur %.2f ms" % (rec[0], rec[1] * 1e3, rec[2] * 1e3), file=sys.stderr)
-    # dominant-kernel duration for the roofline: HIP events around the kernel on the library's stream, measured on an
-    # otherwise idle GPU (in the timed region above three queries overlap, which stretches each kernel's wall time)
+    # dominant-kernel duration on an otherwise idle GPU (in the timed region the feeder threads' launches overlap, which
+    # stretches each kernel's wall time)
     solo_g, solo_s = [], []
-    for i in range(args.warmup, min(nq, args.warmup + 8)):
-        step(0, i)
+    for i in range(n_warm, min(nq, n_warm + 8)):
+        step1(0, i)
         solo_g.append(ctxs[0].kernel_ms(0)); solo_s.append(ctxs[0].kernel_ms(1))
-    nh, nr = counts
+    tot = fdist.gather_objects((counts[0], counts[1], n_mine, host))
     ctx = ctx0
-    search = searches[0]
 
     if rank == 0:
         residues = db.residues
-        value = world * args.steps * residues / dt
+        nq_total = sum(x[2] for x in tot)
+        nh, nr = sum(x[0] for x in tot), sum(x[1] for x in tot)
+        value = nq_total * residues / dt
         VALU_PEAK = 1024 * 64 * (4.0 / 3.0) / 4.3 * 2.4
         kavg = float(np.mean(solo_g)) * 1e-3
         kreg = float(np.mean(kms)) * 1e-3
-        cells_reg = float(np.mean([len(q3[i]) for i in range(args.warmup, nq)])) * residues
-        solo_lq = float(np.mean([len(q3[i]) for i in range(args.warmup, min(nq, args.warmup + 8))]))
+        lq_timed = [len(q3[i]) for i in timed]
+        cells_reg = float(np.mean(lq_timed)) * residues
+        solo_lq = float(np.mean([len(q3[i]) for i in range(n_warm, min(nq, n_warm + 8))]))
         alg_bytes = residues + db.n                       # every target residue read once (1 B) + 1 score byte written
-        mean_lq = float(np.mean([len(q3[i]) for i in range(args.warmup, nq)]))
+        mean_lq = float(np.mean(lq_timed))
         cells = solo_lq * residues
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same DB)
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from a committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of the same kernel on the same DB size
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if args.targets == 100000:
-                traffic = tj["fetch_correction"] * tj["fetch_size_kb"] * 1024 + tj["write_size_kb"] * 1024
+            e = tj.get(str(args.targets))
+            if e:
+                traffic = e["fetch_correction"] * e["fetch_size_kb"] * 1024 + e["write_size_kb"] * 1024
+                traffic_src = e["source"]
         except Exception:
             traffic = None
+        mine = tot[0][3]
         out = {
             "metric": "residues aligned/sec (prefilter+align)",
             "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16 (integer-exact, scaled 2^-11) gapless scan + i16 SW", "data": "synthetic",
-            "config": {"workload": f"1 query/step vs {db.n}-structure synthetic 3Di DB (mean len {residues / db.n:.0f}), "
-                                   f"gapless prefilter (all targets) + top-1000 + fwd/rev structure SW "
-                                   f"(--alignment-type {args.alignment_type}) + host gates/backtrace; each host thread prefilters "
-                                   f"{G} queries back to back, then aligns their hit lists with one multi-query SW launch per pass (forward over all pairs, reversed over the pairs that pass the forward gates)",
-                       "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "max_seqs": 1000,
-                       "queries_per_rank": args.steps, "host_threads_per_gpu": nthreads, "queries_per_sw_launch": G,
-                       "parallelism": f"query-shard x{world}, DB replicated by one RCCL broadcast"},
-            "queries_per_s": world * args.steps / dt,
-            "hits_per_query": nh / args.steps, "alignments_per_query": nr / args.steps,
+            "config": {"workload": f"1 step = {G} queries vs {db.n}-structure synthetic 3Di DB (mean len {residues / db.n:.0f}, {args.homologs} planted homologs per query): "
+                                   f"gapless prefilter (all targets) + top-1000 per query, then one multi-query fwd/rev structure SW launch per pass "
+                                   f"(--alignment-type {args.alignment_type}; forward over all pairs, reversed over the pairs that pass the forward gates) "
+                                   f"+ host gates + block-aligner backtrace of every accepted hit; {nthreads} host feeder threads per GPU run their steps concurrently",
+                       "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "max_seqs": 1000, "homologs_per_query": args.homologs,
+                       "queries_per_step": G, "queries_total": nq_total, "host_threads_per_gpu": nthreads,
+                       "parallelism": f"query-shard x{world} ({args.scaling}), DB replicated by one RCCL broadcast"},
+            "queries_per_s": nq_total / dt, "ms_per_query": 1e3 * dt / (nq_total / world),
+            "hits_per_query": nh / nq_total, "alignments_per_query": nr / nq_total,
+            # rank 0's host-side accounting of the align leg (sums over its feeder threads, per query)
+            "align_leg": {"reverse_pass_fraction": mine["rev_pairs"] / max(1, tot[0][0]),
+                          "host_backtrace_ms_per_query": 1e3 * mine["backtrace_s"] / max(1, n_mine),
+                          "host_gates_ms_per_query": 1e3 * mine["gates_s"] / max(1, n_mine),
+                          "host_profiles_ms_per_query": 1e3 * mine["profiles_s"] / max(1, n_mine),
+                          "sw_call_wall_ms_per_query": 1e3 * mine["sw_wait_s"] / max(1, n_mine),
+                          "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s))},
             # per-launch duration of the dominant kernel from HIP events on the library's stream, averaged over the launches
-            # of the TIMED region (three host threads overlap their launches there, which stretches each one); the same
+            # of the TIMED region (the host threads overlap their launches there, which stretches each one); the same
             # kernel alone on the device is reported under "solo"
             "roofline": {"bound": "hbm", "achieved": alg_bytes / kreg / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_bytes / kreg / 1e9 / 8000.0, "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                         "frac": alg_bytes / kreg / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
                          "kernel": "k_gapless", "kernel_ms": kreg * 1e3,
                          "note": "the scan is VALU/LDS bound (Lq cell updates per target byte), see valu below and DESIGN.md",
                          # 0.75 packed VALU lane-ops per DP cell (2 x v_pk_add_f16 clamp + 1 x v_pk_maximum3_f16 per 4 cells); these
@@ -422,16 +504,17 @@ def main():
                          # 1024 SIMDs x 64 lanes x 4/3 cells / 4.3 cyc x 2.4 GHz
                          "valu": {"achieved_gcups": cells_reg / kreg / 1e9, "peak_gcups": VALU_PEAK,
                                   "frac": cells_reg / kreg / 1e9 / VALU_PEAK,
-                                  "note": "concurrent launches share the SIMDs; device-level rate = launches in flight x this"},
+                                  "device_level_gcups": nq_total / world * cells_reg / dt / 1e9,
+                                  "device_level_frac": nq_total / world * cells_reg / dt / 1e9 / VALU_PEAK,
+                                  "note": "concurrent launches share the SIMDs; device_level = cells of all timed queries of one rank / wall time"},
                          "solo": {"kernel_ms": kavg * 1e3, "achieved": alg_bytes / kavg / 1e9, "frac": alg_bytes / kavg / 1e9 / 8000.0,
-                                  "valu_achieved_gcups": cells / kavg / 1e9, "valu_frac": cells / kavg / 1e9 / VALU_PEAK},
-                         "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s))},
-            "db_broadcast_s": t_bcast,
+                                  "valu_achieved_gcups": cells / kavg / 1e9, "valu_frac": cells / kavg / 1e9 / VALU_PEAK}},
+            "db_broadcast_s": t_bcast, "db_generation_s": t_gen,
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU baselines are an N = 1 item (rank 0 has the host to itself)
-            hits, _ = step(0, args.warmup)
-            out["cpu_baseline"] = cpu_baseline(db, q3[args.warmup], qa[args.warmup], hits["id"], args.alignment_type, args.cpu_sample_targets,
-                                               [q3[i] for i in range(args.warmup + 1, min(nq, args.warmup + max(1, args.cpu_sample_queries)))])
+            hits, _ = step1(0, n_warm)
+            out["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], args.alignment_type, args.cpu_sample_targets,
+                                               [q3[i] for i in range(n_warm + 1, min(nq, n_warm + max(1, args.cpu_sample_queries)))])
     for x in searches[1:]:
         x.close()
     for c in ctxs[1:]:
@@ -439,7 +522,7 @@ def main():
     searches, ctxs = searches[:1], ctxs[:1]
     kout = None
     if not args.no_kmer:
-        kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist)
+        kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist, [q3[i] for i in timed], [qa[i] for i in timed])
     if rank == 0:
         if kout is not None:
             if not args.no_cpu_baseline and world == 1:

@@ -37,27 +37,148 @@ struct Options {
     std::vector<std::string> pos;
     std::map<std::string, std::string> kv;
     bool has(const std::string &k) const { return kv.count(k) != 0; }
-    int geti(const std::string &k, int d) const { auto it = kv.find(k); return it == kv.end() ? d : atoi(it->second.c_str()); }
-    double getd(const std::string &k, double d) const { auto it = kv.find(k); return it == kv.end() ? d : atof(it->second.c_str()); }
+    // MultiParam values ("aa:10,nucl:10", "seq:80,prof:80") carry the amino-acid / sequence component first
+    static std::string first(const std::string &v) {
+        const size_t c = v.find(':');
+        if (c == std::string::npos) return v;
+        const size_t e = v.find(',', c);
+        return v.substr(c + 1, e == std::string::npos ? std::string::npos : e - c - 1);
+    }
+    std::string gets(const std::string &k, const std::string &d) const { auto it = kv.find(k); return it == kv.end() ? d : first(it->second); }
+    int geti(const std::string &k, int d) const { auto it = kv.find(k); return it == kv.end() ? d : atoi(first(it->second).c_str()); }
+    double getd(const std::string &k, double d) const { auto it = kv.find(k); return it == kv.end() ? d : atof(first(it->second).c_str()); }
 };
 
-// flags of the reference modules that take no value (M/src/commons/Parameters.cpp); everything else is "--flag value"
-const char *kBoolFlags[] = {"-a", "--add-backtrace", "-h", "--help", nullptr};
+// ---- option tables -----------------------------------------------------------------------------------------------
+// The workflows hand every module its complete parameter string (Parameters::createParameterString, e.g.
+// F/src/workflow/StructureSearch.cpp:95-121), so a drop-in has to know every flag of the module it replaces
+// (M/src/commons/Parameters.cpp:415-447,508-524,913-921,1638-1640; F/src/commons/LocalParameters.cpp:161-167) and say
+// what it does with it:
+//   USE     implemented, the value is honoured
+//   IGNORE  has no effect on this path in the reference either (profile pseudo counts, nucleotide-only options, I/O
+//           tuning) -- accepted with any value
+//   ONLY    changes results in the reference; this implementation covers the listed values only and REFUSES anything
+//           else (EXIT_FAILURE, like the reference's "Error in argument"), never silently computes something different
+// Unknown flags are refused with the reference's message (Parameters.cpp:2087).
+enum FlagSupport { USE, IGNORE, ONLY };
+struct FlagSpec {
+    const char *name;
+    bool isBool;            // typeid(bool): the value is optional, a bare flag toggles the default (Parameters.cpp:2052-2062)
+    FlagSupport support;
+    const char *only;       // ONLY: '|'-separated accepted values (first MultiParam component); bool defaults for isBool
+};
 
-Options parseArgs(int argc, const char **argv) {
-    Options o;
-    for (int i = 0; i < argc; i++) {
-        std::string a = argv[i];
-        if (a.size() > 1 && a[0] == '-' && !(a.size() > 1 && isdigit((unsigned char) a[1]))) {
-            bool isBool = false;
-            for (int k = 0; kBoolFlags[k]; k++) isBool = isBool || a == kBoolFlags[k];
-            if (isBool) { o.kv[a] = "1"; continue; }
-            if (i + 1 < argc) { o.kv[a] = argv[++i]; } else { o.kv[a] = "1"; }
-        } else {
-            o.pos.push_back(a);
-        }
+// flags every module shares (Parameters.cpp COMMAND_COMMON) + the device selection flags of this implementation
+const FlagSpec kCommonFlags[] = {
+    {"--threads", false, USE, nullptr}, {"-v", false, IGNORE, nullptr}, {"--compressed", false, ONLY, "0"},
+    {"--db-load-mode", false, IGNORE, nullptr}, {"--sub-mat", false, ONLY, "3di.out"},
+    {"--gpus", false, USE, nullptr}, {"--gpu-device", false, USE, nullptr}, {"--gpu", false, IGNORE, nullptr},
+    {nullptr, false, USE, nullptr}};
+
+const FlagSpec kPrefilterFlags[] = {           // Parameters::prefilter (Parameters.cpp:350-395)
+    {"--seed-sub-mat", false, ONLY, "3di.out"}, {"-s", false, USE, nullptr}, {"-k", false, ONLY, "0|6"},
+    {"--target-search-mode", false, ONLY, "0"}, {"--k-score", false, USE, nullptr}, {"--alph-size", false, ONLY, "21"},
+    {"--max-seq-len", false, USE, nullptr}, {"--max-seqs", false, USE, nullptr}, {"--split", false, ONLY, "0|1"},
+    {"--split-mode", false, IGNORE, nullptr}, {"--split-memory-limit", false, IGNORE, nullptr},
+    {"--disk-space-limit", false, IGNORE, nullptr}, {"-c", false, USE, nullptr}, {"--cov-mode", false, USE, nullptr},
+    {"--comp-bias-corr", false, USE, nullptr}, {"--comp-bias-corr-scale", false, USE, nullptr},
+    {"--diag-score", true, ONLY, "1"}, {"--exact-kmer-matching", false, ONLY, "0"}, {"--mask", false, ONLY, "0"},
+    {"--mask-prob", false, IGNORE, nullptr}, {"--mask-lower-case", false, USE, nullptr}, {"--mask-n-repeat", false, USE, nullptr},
+    {"--min-ungapped-score", false, USE, nullptr}, {"--add-self-matches", true, USE, "0"}, {"--spaced-kmer-mode", false, USE, nullptr},
+    {"--spaced-kmer-pattern", false, ONLY, ""}, {"--local-tmp", false, IGNORE, nullptr}, {"--pca", false, IGNORE, nullptr},
+    {"--pcb", false, IGNORE, nullptr}, {"--taxon-list", false, ONLY, ""}, {"-e", false, IGNORE, nullptr},
+    {nullptr, false, USE, nullptr}};
+
+const FlagSpec kUngappedFlags[] = {            // Parameters::ungappedprefilter (Parameters.cpp:508-524)
+    {"-c", false, IGNORE, nullptr}, {"-e", false, IGNORE, nullptr}, {"--cov-mode", false, IGNORE, nullptr},   // read in prefilter-mode 2 only
+    {"--comp-bias-corr", false, USE, nullptr}, {"--comp-bias-corr-scale", false, USE, nullptr},
+    {"--min-ungapped-score", false, USE, nullptr}, {"--max-seqs", false, USE, nullptr}, {"--taxon-list", false, ONLY, ""},
+    {"--gpu-server", false, USE, nullptr}, {"--gpu-server-wait-timeout", false, USE, nullptr},
+    {"--prefilter-mode", false, ONLY, "0|1"},  // 2 = ungapped + gapped (Marv GAPLESS_SMITH_WATERMAN) is not on this path
+    {"--shm-name", false, USE, nullptr}, {"--gpu-server-version", false, USE, nullptr},
+    {nullptr, false, USE, nullptr}};
+
+const FlagSpec kAlignFlags[] = {               // LocalParameters::structurealign = structurealign + Parameters::align
+    {"--tmscore-threshold", false, ONLY, "0|0.0|0.000"}, {"--tmscore-threshold-mode", false, IGNORE, nullptr},
+    {"--lddt-threshold", false, ONLY, "0|0.0|0.000"}, {"--sort-by-structure-bits", false, USE, nullptr},
+    {"--alignment-type", false, ONLY, "0|2"}, {"--exact-tmscore", false, IGNORE, nullptr},
+    {"-a", true, USE, "0"}, {"--add-backtrace", true, USE, "0"}, {"--alignment-mode", false, ONLY, "0|3"},
+    {"--alignment-output-mode", false, ONLY, "0"}, {"--wrapped-scoring", true, ONLY, "0"}, {"-e", false, USE, nullptr},
+    {"--min-seq-id", false, USE, nullptr}, {"--min-aln-len", false, USE, nullptr}, {"--seq-id-mode", false, USE, nullptr},
+    {"--alt-ali", false, ONLY, "0"}, {"-c", false, USE, nullptr}, {"--cov-mode", false, USE, nullptr},
+    {"--max-seq-len", false, USE, nullptr}, {"--comp-bias-corr", false, USE, nullptr}, {"--comp-bias-corr-scale", false, USE, nullptr},
+    {"--max-rejected", false, USE, nullptr}, {"--max-accept", false, USE, nullptr}, {"--add-self-matches", true, USE, "0"},
+    {"--pca", false, IGNORE, nullptr}, {"--pcb", false, IGNORE, nullptr}, {"--score-bias", false, ONLY, "0|0.0|0.000"},
+    {"--realign", true, ONLY, "0"}, {"--realign-score-bias", false, IGNORE, nullptr}, {"--realign-max-seqs", false, IGNORE, nullptr},
+    {"--corr-score-weight", false, IGNORE, nullptr}, {"--gap-open", false, USE, nullptr}, {"--gap-extend", false, USE, nullptr},
+    {"--zdrop", false, IGNORE, nullptr}, {"--align-batch", false, USE, nullptr},
+    {nullptr, false, USE, nullptr}};
+
+const FlagSpec kSearchFlags[] = {              // the fused module: prefilter / ungappedprefilter + structurealign
+    {"--prefilter-mode", false, ONLY, "0|1"}, {nullptr, false, USE, nullptr}};
+
+const FlagSpec kPaddedFlags[] = {              // Parameters::makepaddedseqdb (Parameters.cpp:913-921)
+    {"--score-bias", false, IGNORE, nullptr}, {"--mask", false, ONLY, "0"}, {"--mask-prob", false, IGNORE, nullptr},
+    {"--mask-lower-case", false, IGNORE, nullptr}, {"--mask-n-repeat", false, IGNORE, nullptr}, {"--write-lookup", false, USE, nullptr},
+    {nullptr, false, USE, nullptr}};
+
+const FlagSpec kServerFlags[] = {              // Parameters::gpuserver (Parameters.cpp:1638-1640)
+    {"--max-seqs", false, USE, nullptr}, {"--prefilter-mode", false, ONLY, "0|1"}, {"--max-seq-len", false, USE, nullptr},
+    {"--shm-name", false, USE, nullptr}, {"--gpu-server-version", false, USE, nullptr},
+    {nullptr, false, USE, nullptr}};
+
+const FlagSpec *findFlag(const std::string &a, std::initializer_list<const FlagSpec *> tables) {
+    for (const FlagSpec *t : tables)
+        for (; t->name; t++)
+            if (a == t->name) return t;
+    return nullptr;
+}
+
+bool valueAllowed(const std::string &v, const char *only) {
+    std::string rest = only;
+    for (;;) {
+        const size_t bar = rest.find('|');
+        const std::string one = rest.substr(0, bar);
+        if (v == one) return true;
+        // a matrix may be given as a path: compare the file name
+        if (!one.empty() && v.size() > one.size() && v.compare(v.size() - one.size(), one.size(), one) == 0 && v[v.size() - one.size() - 1] == '/') return true;
+        if (bar == std::string::npos) return false;
+        rest = rest.substr(bar + 1);
     }
-    return o;
+}
+
+// Parses the argument vector against the module's tables.  On failure `err` holds the message (reference wording for
+// unknown flags and malformed booleans) and the caller returns EXIT_FAILURE.
+bool parseArgs(int argc, const char **argv, const char *module, std::initializer_list<const FlagSpec *> tables, Options &o, std::string &err) {
+    for (int i = 0; i < argc; i++) {
+        const std::string a = argv[i];
+        const bool isFlag = a.size() > 1 && a[0] == '-' && !isdigit((unsigned char) a[1]) && a[1] != '.';
+        if (!isFlag) { o.pos.push_back(a); continue; }
+        const FlagSpec *f = findFlag(a, tables);
+        if (!f) { err = "Unrecognized parameter \"" + a + "\""; return false; }
+        std::string v;
+        if (f->isBool) {
+            if (i + 1 == argc || argv[i + 1][0] == '-') {
+                // a bare bool flag toggles the module default (all defaults here are false except --diag-score)
+                v = (a == "--diag-score") ? "0" : "1";
+            } else {
+                const std::string b = argv[++i];
+                if (b == "true" || b == "TRUE" || b == "1") v = "1";
+                else if (b == "false" || b == "FALSE" || b == "0") v = "0";
+                else { err = "Invalid boolean string " + b; return false; }
+            }
+        } else {
+            if (i + 1 >= argc) { err = "Missing argument " + a; return false; }
+            v = argv[++i];
+        }
+        if (f->support == ONLY && !valueAllowed(Options::first(v), f->only)) {
+            err = std::string(module) + ": " + a + " " + v + " is not implemented on the device path (supported: " +
+                  (f->only[0] ? f->only : "unset") + ")";
+            return false;
+        }
+        o.kv[a] = v;
+    }
+    return true;
 }
 
 int fail(const std::string &msg) {
@@ -79,41 +200,53 @@ bool loadPadded(const DbReader &r3, const DbReader *rA, const Matrix &m3, const 
     const size_t n = r3.size();
     t.offsets.resize(n + 1); t.lengths.resize(n); t.keys.resize(n);
     const bool padded = (r3.extended() & DBTYPE_EXTENDED_GPU) != 0;
+    const bool paddedAA = rA && (rA->extended() & DBTYPE_EXTENDED_GPU) != 0;
     if (rA && rA->size() != n) { err = "AA and 3Di target databases differ in size"; return false; }
     if (padded) {
-        for (size_t i = 0; i < n; i++) {
-            t.offsets[i] = r3.offset(i); t.lengths[i] = (int32_t) r3.seqLen(i); t.keys[i] = r3.key(i);
-            if (rA && (rA->offset(i) != r3.offset(i) || rA->seqLen(i) != r3.seqLen(i))) { err = "padded AA and 3Di databases are not aligned"; return false; }
-        }
+        for (size_t i = 0; i < n; i++) { t.offsets[i] = r3.offset(i); t.lengths[i] = (int32_t) r3.seqLen(i); t.keys[i] = r3.key(i); }
         t.offsets[n] = r3.dataSize();
         t.d3 = (const uint8_t *) r3.dataBase();
-        t.dA = rA ? (const uint8_t *) rA->dataBase() : nullptr;
         t.bytes = r3.dataSize();
+    } else {
+        // ASCII database: encode in index order (lower case = soft-masked -> code + 32), pad each entry to a multiple of 4
+        uint64_t off = 0;
+        for (size_t i = 0; i < n; i++) {
+            t.offsets[i] = off; t.lengths[i] = (int32_t) r3.seqLen(i); t.keys[i] = r3.key(i);
+            off += ((uint64_t) t.lengths[i] + 3) / 4 * 4;
+        }
+        t.offsets[n] = off; t.bytes = off;
+        t.own3di.assign(off, 20);
+        for (size_t i = 0; i < n; i++) {
+            const char *s = r3.data(i);
+            for (int k = 0; k < t.lengths[i]; k++) {
+                uint8_t c = m3.aa2num[(unsigned char) s[k]];
+                t.own3di[t.offsets[i] + k] = (uint8_t) (islower((unsigned char) s[k]) ? c + 32 : c);
+            }
+        }
+        t.d3 = t.own3di.data();
+    }
+    if (!rA) return true;
+    if (paddedAA) {
+        // both halves padded by base:makepaddedseqdb: same order, same offsets
+        if (!padded) { err = "padded AA database with an unpadded 3Di database"; return false; }
+        for (size_t i = 0; i < n; i++)
+            if (rA->offset(i) != r3.offset(i) || rA->seqLen(i) != r3.seqLen(i)) { err = "padded AA and 3Di databases are not aligned"; return false; }
+        t.dA = (const uint8_t *) rA->dataBase();
         return true;
     }
-    // ASCII database: encode in index order (lower case = soft-masked -> code + 32), pad each entry to a multiple of 4
-    uint64_t off = 0;
+    // ASCII AA database.  For a padded target this is what Foldseek's makepaddedseqdb workflow leaves behind
+    // (F/data/makepaddeddb.sh:18-40): only <db>_ss is re-encoded, <db> is the source AA data file linked under the new
+    // name with an index whose keys were renamed to the padded ids (renamedbkeys).  The device wants the AA codes at the
+    // 3Di offsets, so they are encoded here, entry by entry, matched by KEY.
+    t.ownAA.assign(t.bytes, 20);
     for (size_t i = 0; i < n; i++) {
-        t.offsets[i] = off; t.lengths[i] = (int32_t) r3.seqLen(i); t.keys[i] = r3.key(i);
-        off += ((uint64_t) t.lengths[i] + 3) / 4 * 4;
-        if (rA && rA->seqLen(i) != r3.seqLen(i)) { err = "AA and 3Di entries differ in length"; return false; }
+        const int64_t ia = rA->idOf(t.keys[i]);
+        if (ia < 0) { err = "AA target database has no entry with key " + std::to_string(t.keys[i]); return false; }
+        if ((int32_t) rA->seqLen((size_t) ia) != t.lengths[i]) { err = "AA and 3Di entries of key " + std::to_string(t.keys[i]) + " differ in length"; return false; }
+        const char *a = rA->data((size_t) ia);
+        for (int k = 0; k < t.lengths[i]; k++) t.ownAA[t.offsets[i] + k] = mA->aa2num[(unsigned char) a[k]];
     }
-    t.offsets[n] = off; t.bytes = off;
-    t.own3di.assign(off, 20);
-    if (rA) t.ownAA.assign(off, 20);
-    for (size_t i = 0; i < n; i++) {
-        const char *s = r3.data(i);
-        for (int k = 0; k < t.lengths[i]; k++) {
-            uint8_t c = m3.aa2num[(unsigned char) s[k]];
-            t.own3di[t.offsets[i] + k] = (uint8_t) (islower((unsigned char) s[k]) ? c + 32 : c);
-        }
-        if (rA) {
-            const char *a = rA->data(i);
-            for (int k = 0; k < t.lengths[i]; k++) t.ownAA[t.offsets[i] + k] = mA->aa2num[(unsigned char) a[k]];
-        }
-    }
-    t.d3 = t.own3di.data();
-    t.dA = rA ? t.ownAA.data() : nullptr;
+    t.dA = t.ownAA.data();
     return true;
 }
 
@@ -128,14 +261,40 @@ void fillParams(const Options &o, fshost_params &p) {
     p.evalThr = o.getd("-e", p.evalThr);
     p.covThr = (float) o.getd("-c", p.covThr);
     p.covMode = o.geti("--cov-mode", p.covMode);
-    p.addBacktrace = (o.has("-a") || o.has("--add-backtrace")) ? 1 : 0;
+    p.addBacktrace = (o.geti("-a", 0) || o.geti("--add-backtrace", 0)) ? 1 : 0;
     p.maxAccept = o.geti("--max-accept", p.maxAccept);
     p.maxRejected = o.geti("--max-rejected", p.maxRejected);
     p.seqIdThr = (float) o.getd("--min-seq-id", p.seqIdThr);
     p.alnLenThr = o.geti("--min-aln-len", p.alnLenThr);
+    p.seqIdMode = o.geti("--seq-id-mode", p.seqIdMode);
 }
 
+// Sequence::mapSequence cuts entries at --max-seq-len (M/src/commons/Sequence.cpp:289-300); truncation is not implemented
+// here, so a database with longer entries than the limit is refused instead of being searched differently.
+bool checkMaxSeqLen(const Options &o, const DbReader &r, const std::string &what, std::string &err) {
+    const long maxLen = std::min<long>(o.geti("--max-seq-len", FSGPU_MAX_SEQ_LEN), FSGPU_MAX_SEQ_LEN);
+    for (size_t i = 0; i < r.size(); i++)
+        if ((long) r.seqLen(i) > maxLen) {
+            err = what + " entry " + std::to_string(r.key(i)) + " has " + std::to_string(r.seqLen(i)) + " residues: longer than --max-seq-len " +
+                  std::to_string(maxLen) + " (truncation is not implemented on the device path)";
+            return false;
+        }
+    return true;
+}
 
+// --sort-by-structure-bits 1 (default of the workflow) rescales scores by TM-score x LDDT and needs both C-alpha DBs
+// (structurealign.cpp:182-197): without them the reference warns and turns it off -- so do we; WITH them the rescoring
+// would run, which this path does not implement: refuse.
+bool resolveStructureBits(const Options &o, const std::string &qdb, const std::string &tdb, std::string &err) {
+    if (o.geti("--sort-by-structure-bits", 1) == 0) return true;
+    auto exists = [](const std::string &p) { FILE *f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; };
+    if (exists(qdb + "_ca.dbtype") && exists(tdb + "_ca.dbtype")) {
+        err = "structurealign: --sort-by-structure-bits 1 with C-alpha databases (TM-score / LDDT rescoring) is not implemented on the device path; pass --sort-by-structure-bits 0";
+        return false;
+    }
+    fprintf(stderr, "Cannot find %s C-alpha or %s C-alpha database\nDisabling --sort-by-structure-bits\n", qdb.c_str(), tdb.c_str());
+    return true;
+}
 
 // ---- devices ------------------------------------------------------------------------------------------------------
 // --gpus N (or "all"): the target DB is loaded once on --gpu-device, replicated to N - 1 more devices with ONE broadcast
@@ -293,16 +452,51 @@ int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbRead
     return EXIT_SUCCESS;
 }
 
+// Util::parseFastaHeader (M/src/commons/Util.cpp:147-229): the accession of a header line -- the field between the
+// database prefix ("sp|", "gi|x|y|" ...) and the next '|' or blank, else the first word
+std::string fastaHeaderName(const char *headerPtr) {
+    size_t len = 0;
+    while (headerPtr[len] != '\0' && !isspace((unsigned char) headerPtr[len])) len++;
+    const std::string header(headerPtr, len);
+    if (header.empty()) return "";
+    size_t offset = header.compare(0, 10, "consensus_") == 0 ? 10 : 0;
+    static const struct { const char *prefix; unsigned int length, bar; } dbs[] = {
+        {"cl|", 3, 1}, {"sp|", 3, 1}, {"tr|", 3, 1}, {"gb|", 3, 1}, {"ref|", 4, 1}, {"pdb|", 4, 1}, {"bbs|", 4, 1}, {"lcl|", 4, 1},
+        {"pir||", 5, 1}, {"prf||", 5, 1}, {"gnl|", 4, 2}, {"pat|", 4, 2}, {"gi|", 3, 3}};
+    for (const auto &d : dbs) {
+        if (header.compare(offset, d.length, d.prefix) != 0) continue;
+        size_t start = offset + d.length;
+        for (unsigned int j = 0; j + 1 < d.bar; j++) {
+            const size_t end = header.find('|', start);
+            if (end == std::string::npos) return "";
+            start = end + 1;
+        }
+        size_t end = header.find('|', start);
+        if (end == std::string::npos) end = header.find_first_of(" \n", start);
+        return header.substr(start, end == std::string::npos ? std::string::npos : end - start);
+    }
+    const size_t end = header.find_first_of(" \n", offset);
+    return header.substr(offset, end == std::string::npos ? std::string::npos : end - offset);
+}
+
 } // namespace
 
 extern "C" {
 
 int fsmod_makepaddedseqdb(int argc, const char **argv) {
-    Options o = parseArgs(argc, argv);
-    if (o.pos.size() != 2) return fail("usage: makepaddedseqdb <sequenceDB> <outPaddedDB>");
-    DbReader r;
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "makepaddedseqdb", {kPaddedFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
+    if (o.pos.size() != 2) return fail("usage: makepaddedseqdb <sequenceDB> <outPaddedDB> [--write-lookup 0|1]");
+    DbReader r, rh;
     std::string err;
     if (!r.open(o.pos[0], err)) return fail(err);
+    // header DB <in>_h (par.hdr1): the reference opens it unconditionally (makepaddedseqdb.cpp:22-23); databases written by
+    // test harnesses may lack it, then names in the lookup fall back to the key
+    std::string herr;
+    const bool haveHeaders = rh.open(o.pos[0] + "_h", herr);
     Matrix m;
     if (!m.builtin(FSHOST_MAT_3DI, 2.0f, 0.0f)) return fail("matrix construction failed");
     const size_t n = r.size();
@@ -311,13 +505,17 @@ int fsmod_makepaddedseqdb(int argc, const char **argv) {
     for (size_t i = 0; i < n; i++) ord[i] = i;
     std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return r.seqLen(a) > r.seqLen(b); });
     std::reverse(ord.begin(), ord.end());
+    const bool writeLookup = o.geti("--write-lookup", 1) != 0;
     FILE *fd = fopen(o.pos[1].c_str(), "wb");
     FILE *fi = fopen((o.pos[1] + ".index").c_str(), "wb");
-    FILE *fl = fopen((o.pos[1] + ".lookup").c_str(), "wb");
-    if (!fd || !fi || !fl) return fail("cannot create " + o.pos[1]);
-    uint64_t off = 0;
+    FILE *fl = writeLookup ? fopen((o.pos[1] + ".lookup").c_str(), "wb") : nullptr;
+    FILE *fh = haveHeaders ? fopen((o.pos[1] + "_h").c_str(), "wb") : nullptr;
+    FILE *fhi = haveHeaders ? fopen((o.pos[1] + "_h.index").c_str(), "wb") : nullptr;
+    if (!fd || !fi || (writeLookup && !fl) || (haveHeaders && (!fh || !fhi))) return fail("cannot create " + o.pos[1]);
+    bool ioOk = true;
+    uint64_t off = 0, hoff = 0;
     std::string out;
-    for (size_t k = 0; k < n; k++) {
+    for (size_t k = 0; k < n && ioOk; k++) {
         const size_t id = ord[k];
         const char *s = r.data(id);
         const uint32_t L = r.seqLen(id);
@@ -327,22 +525,46 @@ int fsmod_makepaddedseqdb(int argc, const char **argv) {
             out.push_back((char) (islower((unsigned char) s[i]) ? c + 32 : c));
         }
         out.append((L % 4 == 0) ? 0 : 4 - L % 4, (char) 20);
-        fwrite(out.data(), 1, out.size(), fd);
-        fprintf(fi, "%zu\t%llu\t%u\n", k, (unsigned long long) off, L + 2);
-        fprintf(fl, "%zu\t%u\t%u\n", k, r.key(id), r.key(id));   // new key -> original key (name column unknown here)
+        ioOk = ioOk && fwrite(out.data(), 1, out.size(), fd) == out.size();
+        ioOk = ioOk && fprintf(fi, "%zu\t%llu\t%u\n", k, (unsigned long long) off, L + 2) > 0;
         off += out.size();
+        std::string name = std::to_string(r.key(id));
+        if (haveHeaders) {
+            const int64_t hid = rh.idOf(r.key(id));
+            if (hid < 0) return fail("Invalid header key " + std::to_string(r.key(id)) + ".");
+            const char *h = rh.data((size_t) hid);
+            const uint32_t hl = rh.entryLen((size_t) hid);
+            ioOk = ioOk && fwrite(h, 1, hl, fh) == hl;                       // entry incl. its terminator, verbatim
+            ioOk = ioOk && fprintf(fhi, "%zu\t%llu\t%u\n", k, (unsigned long long) hoff, hl) > 0;
+            hoff += hl;
+            name = fastaHeaderName(h);
+        }
+        // lookup: new key, entry name parsed from the header, ORIGINAL key in the file-number column (makepaddedseqdb.cpp:121-138)
+        if (fl) ioOk = ioOk && fprintf(fl, "%zu\t%s\t%u\n", k, name.c_str(), r.key(id)) > 0;
     }
-    fclose(fd); fclose(fi); fclose(fl);
-    FILE *ft = fopen((o.pos[1] + ".dbtype").c_str(), "wb");
-    if (!ft) return fail("cannot create dbtype");
-    int32_t t = (int32_t) ((uint32_t) r.dbtype() | ((uint32_t) (r.extended() | DBTYPE_EXTENDED_GPU) << 16));
-    fwrite(&t, 4, 1, ft);
-    fclose(ft);
+    ioOk = (fclose(fd) == 0) && ioOk;
+    ioOk = (fclose(fi) == 0) && ioOk;
+    if (fl) ioOk = (fclose(fl) == 0) && ioOk;
+    if (fh) ioOk = (fclose(fh) == 0) && ioOk;
+    if (fhi) ioOk = (fclose(fhi) == 0) && ioOk;
+    auto writeType = [&](const std::string &path, int32_t t) {
+        FILE *ft = fopen(path.c_str(), "wb");
+        if (!ft) return false;
+        const bool ok = fwrite(&t, 4, 1, ft) == 1;
+        return (fclose(ft) == 0) && ok;
+    };
+    ioOk = writeType(o.pos[1] + ".dbtype", (int32_t) ((uint32_t) r.dbtype() | ((uint32_t) (r.extended() | DBTYPE_EXTENDED_GPU) << 16))) && ioOk;
+    if (haveHeaders) ioOk = writeType(o.pos[1] + "_h.dbtype", 12 /* DBTYPE_GENERIC_DB */) && ioOk;
+    if (!ioOk) return fail("write error on " + o.pos[1]);
     return EXIT_SUCCESS;
 }
 
 int fsmod_ungappedprefilter(int argc, const char **argv) {
-    Options o = parseArgs(argc, argv);
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "ungappedprefilter", {kUngappedFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
     if (o.pos.size() != 3) return fail("usage: ungappedprefilter <queryDB_ss> <targetDB_ss> <outPrefDB> [--max-seqs N] [--min-ungapped-score S] [--comp-bias-corr 0|1] [--threads T]");
     std::string err;
     DbReader q, t;
@@ -412,7 +634,11 @@ static bool canBeCovered(float covThr, int covMode, float q, float t) {
 }
 
 int fsmod_prefilter(int argc, const char **argv) {
-    Options o = parseArgs(argc, argv);
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "prefilter", {kPrefilterFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
     if (o.pos.size() != 3) return fail("usage: prefilter <queryDB_ss> <targetDB_ss> <outPrefDB> [-s S] [-k 6] [--k-score T] [--max-seqs N] [--min-ungapped-score S] "
                                        "[--comp-bias-corr 0|1] [--comp-bias-corr-scale F] [--mask-lower-case 0|1] [--mask-n-repeat N] [--spaced-kmer-mode 0|1] "
                                        "[--add-self-matches 0|1] [-c F --cov-mode M] [--threads T]");
@@ -421,6 +647,7 @@ int fsmod_prefilter(int argc, const char **argv) {
     if (!q.open(o.pos[0], err) || !t.open(o.pos[1], err)) return fail(err);
     const bool sameDB = o.pos[0] == o.pos[1];
     const bool includeIdentical = o.geti("--add-self-matches", 0) != 0;
+    if (!checkMaxSeqLen(o, q, "query", err) || !checkMaxSeqLen(o, t, "target", err)) return fail(err);
     // defaults as Foldseek sets them for its prefilter call (F/src/workflow/StructureSearch.cpp:101, F/src/commons/LocalParameters.cpp:382-412)
     const int kmerSize = o.geti("-k", 0) == 0 ? 6 : o.geti("-k", 6);     // k = 0: auto -> 6 below 3.35e9 residues (IndexTable.h:456-458)
     if (kmerSize != 6) return fail("prefilter: only -k 6 is implemented on the device path");
@@ -428,7 +655,8 @@ int fsmod_prefilter(int argc, const char **argv) {
     if (o.geti("--diag-score", 1) != 1 || o.geti("--exact-kmer-matching", 0) != 0 || o.geti("--mask", 0) != 0)
         return fail("prefilter: --diag-score 0, --exact-kmer-matching 1 and --mask 1 are not implemented on the device path");
     const float sens = (float) o.getd("-s", 9.5);
-    const int kmerThr = o.has("--k-score") ? o.geti("--k-score", 0) : fshost_kmer_threshold(sens, kmerSize);
+    // --k-score INT_MAX (the default the workflow passes) = derive the threshold from -s (Prefiltering.cpp:1036-1096)
+    const int kmerThr = o.geti("--k-score", INT_MAX) != INT_MAX ? o.geti("--k-score", 0) : fshost_kmer_threshold(sens, kmerSize);
     const int spaced = o.geti("--spaced-kmer-mode", 1);
     const int maxRes = (int) std::min<uint64_t>((uint64_t) o.geti("--max-seqs", 1000), std::max<uint64_t>(t.size(), 1));
     const int compBias = o.geti("--comp-bias-corr", 1);
@@ -516,7 +744,11 @@ int fsmod_prefilter(int argc, const char **argv) {
 
 // prefilter (k-mer: --prefilter-mode 0, gapless: --prefilter-mode 1) + structurealign fused in one process
 int fsmod_search(int argc, const char **argv) {
-    Options o = parseArgs(argc, argv);
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "search", {kSearchFlags, kPrefilterFlags, kAlignFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
     if (o.pos.size() != 3 && o.pos.size() != 4)
         return fail("usage: search <queryDB> <targetDB> <outAlnDB> [<outPrefDB>] [--prefilter-mode 0|1] [-s S] [--max-seqs N] [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
@@ -531,7 +763,9 @@ int fsmod_search(int argc, const char **argv) {
     fillParams(o, par);
     par.prefCompBiasScale = (float) o.getd("--comp-bias-corr-scale", 0.15);    // StructureSearch.cpp:101
     par.alnCompBiasScale = 0.5f;                                               // StructureSearch.cpp:107
-    const int kmerThr = o.has("--k-score") ? o.geti("--k-score", 0) : fshost_kmer_threshold((float) o.getd("-s", 9.5), 6);
+    const int kmerThr = o.geti("--k-score", INT_MAX) != INT_MAX ? o.geti("--k-score", 0) : fshost_kmer_threshold((float) o.getd("-s", 9.5), 6);
+    if (!resolveStructureBits(o, o.pos[0], o.pos[1], err)) return fail(err);
+    if (!checkMaxSeqLen(o, q3, "query", err) || !checkMaxSeqLen(o, t3, "target", err)) return fail(err);
     const int spaced = o.geti("--spaced-kmer-mode", 1);
     if (prefMode == 0 && (o.geti("-k", 0) != 0 && o.geti("-k", 6) != 6)) return fail("search: only -k 6 is implemented on the device path");
     Matrix m3, mA;
@@ -614,6 +848,8 @@ int fsmod_search(int argc, const char **argv) {
                     if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(b0 + k)) + ": hit buffers of the reference would overflow"; break; }
                     for (int h = 0; h < nout[k]; h++) {
                         const fsgpu_kmer_hit &hit = khits[k * (size_t) maxRes + h];
+                        if (par.covThr > 0.0 && (par.covMode == 0 || par.covMode == 2 || par.covMode == 5) &&
+                            !canBeCovered(par.covThr, par.covMode, (float) Ls[k], (float) pt.lengths[hit.id])) continue;   // Prefiltering.cpp:880-887
                         ids[k].push_back(hit.id);
                         if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
                     }
@@ -639,7 +875,9 @@ int fsmod_search(int argc, const char **argv) {
             for (size_t k : live) {
                 res[k].resize(ids[k].size() + 1);
                 lA.push_back(pA[k]); l3.push_back(p3[k]); lT.push_back(ids[k].data()); lR.push_back(res[k].data());
-                lL.push_back(Ls[k]); lN.push_back((int) ids[k].size()); lI.push_back(sameDB ? ident[k] : -1);
+                lL.push_back(Ls[k]); lN.push_back((int) ids[k].size());
+                // structurealign compares the query's and the target's INDEX in their readers (structurealign.cpp:359)
+                lI.push_back((sameDB || includeIdentical) ? (int64_t) (b0 + k) : -1);
             }
             if (fshost_search_align_batch(s, (int) live.size(), lA.data(), l3.data(), lL.data(), lI.data(), lT.data(), lN.data(), lR.data(), lres.data()) != FSGPU_OK) {
                 if (!bad++) firstErr = fshost_search_error(s);
@@ -670,7 +908,11 @@ int fsmod_search(int argc, const char **argv) {
 }
 
 int fsmod_structurealign(int argc, const char **argv) {
-    Options o = parseArgs(argc, argv);
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "structurealign", {kAlignFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
     if (o.pos.size() != 4) return fail("usage: structurealign <queryDB> <targetDB> <prefDB> <outAlnDB> [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
     DbReader qA, q3, tA, t3, pref;
@@ -678,9 +920,12 @@ int fsmod_structurealign(int argc, const char **argv) {
         !pref.open(o.pos[2], err))
         return fail(err);
     const bool sameDB = o.pos[0] == o.pos[1];
+    const bool includeIdentical = o.geti("--add-self-matches", 0) != 0;
     fshost_params par;
     fillParams(o, par);
     par.alnCompBiasScale = (float) o.getd("--comp-bias-corr-scale", 0.5);
+    if (!resolveStructureBits(o, o.pos[0], o.pos[1], err)) return fail(err);
+    if (!checkMaxSeqLen(o, q3, "query", err) || !checkMaxSeqLen(o, t3, "target", err)) return fail(err);
     Matrix m3, mA;
     m3.builtin(FSHOST_MAT_3DI, 2.1f, 0.0f);
     mA.builtin(FSHOST_MAT_BLOSUM62, par.alignmentType == 2 ? 1.4f : 0.0f, 0.0f);
@@ -740,7 +985,8 @@ int fsmod_structurealign(int argc, const char **argv) {
                 if (bad) break;
                 res[m].resize(ids[m].size() + 1);
                 entry[m] = id; pA[m] = cA[m].data(); p3[m] = c3[m].data(); pT[m] = ids[m].data(); pR[m] = res[m].data();
-                Ls[m] = (int) L; ns[m] = (int) ids[m].size(); ident[m] = sameDB ? t3.idOf(queryKey) : -1;
+                Ls[m] = (int) L; ns[m] = (int) ids[m].size();
+                ident[m] = (sameDB || includeIdentical) ? qid : -1;      // queryId == targetId, reader indices (structurealign.cpp:359)
                 m++;
             }
             if (bad) break;
@@ -774,7 +1020,11 @@ int fsmod_structurealign(int argc, const char **argv) {
 // is this library's (scores capped at 255 - bias like the CPU path, result order = score desc, id asc); the cap is
 // recovered from the profile the client sends (profile[a][i] - mat[a][q_i] = rounded composition bias of position i).
 int fsmod_gpuserver(int argc, const char **argv) {
-    Options o = parseArgs(argc, argv);
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "gpuserver", {kServerFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
     if (o.pos.size() != 1) return fail("usage: gpuserver <targetDB_ss[_pad]> [--max-seqs N] [--max-seq-len L] [--gpu-device D] [--gpu-server-version V | --shm-name NAME]");
     std::string err;
     DbReader t;

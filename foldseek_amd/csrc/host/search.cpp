@@ -59,6 +59,8 @@ void fshost_params_default(fshost_params *p) {
     p->maxRejected = INT_MAX;
     p->seqIdThr = 0.0f;
     p->alnLenThr = 0;
+    p->seqIdMode = 0;
+    p->altAlignment = 0;
 }
 
 fshost_search *fshost_search_create(fsgpu_ctx *ctx, const fshost_params *p, const uint32_t *keys, const char *nnPath,
@@ -229,7 +231,9 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
         unsigned int alnLength = std::max(abs(f.qEnd - qStart), abs(f.dbEnd - dbStart)) + 1;   // Matcher::computeAlnLength
         if (bo.backtrace.size() > 0) {
             alnLength = bo.backtrace.size();
-            seqId = static_cast<float>(bo.identicalAA) / static_cast<float>(alnLength);          // SEQ_ID_ALN_LEN
+            // Util::computeSeqId (M/src/commons/Util.cpp:597-607)
+            const int den = par.seqIdMode == 1 ? std::min(L, Lt) : par.seqIdMode == 2 ? std::max(L, Lt) : (int) alnLength;
+            seqId = static_cast<float>(bo.identicalAA) / static_cast<float>(den);
         }
         r.dbKey = s->keys[tid]; r.score = score; r.qcov = qCov; r.dbcov = tCov; r.seqId = seqId; r.eval = evalue;
         r.alnLength = alnLength; r.qStartPos = qStart; r.qEndPos = f.qEnd; r.qLen = L; r.dbStartPos = dbStart; r.dbEndPos = f.dbEnd;

@@ -139,3 +139,93 @@ def make_db(n, queries=None, seed=20260923, homologs_per_query=50, mask_frac=0.0
             mm = m & inside
             d3[seg] = np.where(mm, d3[seg] + 32, d3[seg])
     return PaddedDB(d3, da, offsets, lens)
+
+
+# ---- vectorised generator for the full-size bench databases (1M targets: 350 M residues in a few seconds) ---------
+def _draw(rng, n, back):
+    """n i.i.d. letters from `back` through a 16-bit inverse-CDF table (one integer draw + one gather per letter)"""
+    cdf = np.cumsum(back / back.sum())
+    lut = np.minimum(np.searchsorted(cdf, (np.arange(65536) + 0.5) / 65536.0), len(back) - 1).astype(np.uint8)
+    out = np.empty(n, np.uint8)
+    step = 1 << 26
+    for a in range(0, n, step):                       # chunked: the uint16 temporaries stay small
+        m = min(step, n - a)
+        out[a:a + m] = lut[rng.integers(0, 65536, size=m, dtype=np.uint16)]
+    return out
+
+
+def _homologs(rng, q3, qa, H, lo, hi, indel_rate=0.05):
+    """H mutated copies of one query at once: substitution rate 20 % ... 60 % (drawn from the backgrounds), deletions
+    (indel_rate / 2 per residue) and insertions (indel_rate / 6 per residue, geometric length, mean 3); same model as
+    _mutate.  Returns (flat 3Di, flat AA, lengths)."""
+    L = len(q3)
+    rate = (0.2 + 0.4 * np.arange(H) / max(1, H - 1))[:, None]
+    keep = rng.random((H, L)) >= indel_rate / 2
+    s3 = np.where(rng.random((H, L)) < rate, _draw(rng, H * L, BACK_3DI).reshape(H, L), q3[None, :])
+    sa = np.where(rng.random((H, L)) < rate, _draw(rng, H * L, BACK_AA).reshape(H, L), qa[None, :])
+    lens = keep.sum(1)
+    f3, fa = s3[keep], sa[keep]                        # row-major concatenation of the kept residues
+    ins = rng.random(len(f3)) < indel_rate / 6
+    cnt = np.ones(len(f3), np.int64)
+    cnt[ins] += rng.geometric(1 / 3.0, size=int(ins.sum()))
+    row = np.repeat(np.arange(H), lens)
+    lens = np.bincount(row, weights=cnt, minlength=H).astype(np.int64)
+    first = np.zeros(int(cnt.sum()), bool)
+    first[np.concatenate([[0], np.cumsum(cnt)[:-1]])] = True
+    f3, fa = np.repeat(f3, cnt), np.repeat(fa, cnt)
+    nc = int((~first).sum())
+    f3[~first] = _draw(rng, nc, BACK_3DI)              # the extra copies become the inserted letters
+    fa[~first] = _draw(rng, nc, BACK_AA)
+    # cut to [.., hi] and drop copies shorter than lo
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    out3, outa, outl = [], [], []
+    for h in range(H):
+        l = int(min(lens[h], hi))
+        if l < lo:
+            continue
+        out3.append(f3[starts[h]:starts[h] + l]); outa.append(fa[starts[h]:starts[h] + l]); outl.append(l)
+    return out3, outa, outl
+
+
+def make_db_fast(n, queries=None, seed=20260923, homologs_per_query=50, mask_frac=0.01, mean_len=350.0, lo=30, hi=2000,
+                 x_frac=0.002):
+    """Same distributional model as make_db without per-entry Python work: lengths are drawn first and
+    sorted, the padded buffers are filled with i.i.d. letters in one go, the planted homologs (homologs_per_query for
+    EVERY query given) overwrite their slots.  Not bit-compatible with make_db (different draw order)."""
+    rng = np.random.default_rng(seed)
+    h3, ha, hl = [], [], []
+    if queries is not None and homologs_per_query > 0:
+        for q3, qa in zip(*queries):
+            a, b, c = _homologs(rng, q3, qa, homologs_per_query, lo, hi)
+            h3 += a; ha += b; hl += c
+        if len(hl) > n:
+            h3, ha, hl = h3[:n], ha[:n], hl[:n]
+    nbg = n - len(hl)
+    lens = np.concatenate([_lengths(rng, nbg, mean_len, lo, hi), np.array(hl, np.int32)]).astype(np.int32)
+    order = np.argsort(lens, kind="stable")
+    lens = lens[order]
+    padded = (lens.astype(np.int64) + 3) // 4 * 4
+    offsets = np.zeros(n + 1, np.int64)
+    offsets[1:] = np.cumsum(padded)
+    total = int(offsets[-1])
+    d3, da = _draw(rng, total, BACK_3DI), _draw(rng, total, BACK_AA)
+    slot = np.empty(n, np.int64)
+    slot[order] = np.arange(n)                          # old entry number -> position in the length order
+    for k in range(len(hl)):
+        o = offsets[slot[nbg + k]]
+        d3[o:o + hl[k]] = h3[k]; da[o:o + hl[k]] = ha[k]
+    if x_frac > 0:
+        xs = rng.integers(0, total, size=int(total * x_frac))
+        d3[xs] = 20
+    if mask_frac > 0:
+        st = rng.integers(0, total, size=max(1, int(total * mask_frac / 8)))
+        idx = np.minimum(st[:, None] + np.arange(8)[None, :], total - 1).ravel()
+        e = np.searchsorted(offsets, idx, side="right") - 1
+        idx = np.unique(idx[(idx - offsets[e]) < lens[e]])
+        idx = idx[d3[idx] < 32]
+        d3[idx] += 32
+    for k in range(1, 4):                               # padding bytes (<= 3 per entry) are code 20 in both buffers
+        p = offsets[:-1] + lens + (k - 1)
+        p = p[p < offsets[1:]]
+        d3[p] = 20; da[p] = 20
+    return PaddedDB(d3, da, offsets, lens)

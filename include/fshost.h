@@ -94,6 +94,8 @@ typedef struct {
     int maxAccept, maxRejected; /* INT_MAX */
     float seqIdThr;           /* --min-seq-id 0 */
     int alnLenThr;            /* --min-aln-len 0 */
+    int seqIdMode;            /* --seq-id-mode 0: identities / alignment length, 1: / shorter, 2: / longer sequence (Util::computeSeqId) */
+    int altAlignment;         /* --alt-ali 0: up to this many alternative alignments per accepted hit (structurealign.cpp:115-138,415-429) */
 } fshost_params;
 
 void fshost_params_default(fshost_params *p);

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""tests/golden/make_scop_golden.py -- generator of tests/golden/scop_v1 (TEST INFRASTRUCTURE).
+
+Runs the WHOLE reference binary (oracle/_ref_full/bin/foldseek, built from a patched out-of-tree copy of
+/root/reference by oracle/build_ref_full.sh) on the reference's own example structures (F/example: 25 SCOP domains +
+1tim/8tim) and freezes
+
+  * the databases the reference's `createdb` and `makepaddedseqdb` WRITE (db, db_ss, db_h, db_pad*, with .index /
+    .dbtype / .lookup) -- the modules under test read these, never a DB written by this repository's own dbio.py;
+  * the result DBs of the reference's `prefilter` (k-mer), `ungappedprefilter` (CPU) and `structurealign` run
+    all-vs-all with the parameter strings F/data/structuresearch.sh passes (captured with `easy-search -v 3`), plus
+    the variants listed in RUNS below.
+
+Only runs where /root/reference and the built binary exist (this container); the frozen files travel to the GPU box.
+`--sort-by-structure-bits 0`: TM-score/LDDT rescoring needs the _ca DB and is out of scope.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+FS = os.path.join(ROOT, "oracle", "_ref_full", "bin", "foldseek")
+EXAMPLE = "/root/reference/example"
+OUT = os.path.join(HERE, "scop_v1")
+
+SUBMAT = "aa:3di.out,nucl:3di.out"
+# F/data/structuresearch.sh:41-53 ${PREFILTER_PAR} as easy-search composes it (v 3 log of the reference binary)
+PREFILTER_PAR = ["--sub-mat", SUBMAT, "--seed-sub-mat", SUBMAT, "-s", "9.5", "-k", "6", "--target-search-mode", "0",
+                 "--k-score", "seq:2147483647,prof:2147483647", "--alph-size", "aa:21,nucl:5", "--max-seq-len", "65535",
+                 "--max-seqs", "1000", "--split", "0", "--split-mode", "2", "--split-memory-limit", "0", "-c", "0",
+                 "--cov-mode", "0", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "0.15", "--diag-score", "1",
+                 "--exact-kmer-matching", "0", "--mask", "0", "--mask-prob", "0.999995", "--mask-lower-case", "1",
+                 "--mask-n-repeat", "6", "--min-ungapped-score", "30", "--add-self-matches", "0", "--spaced-kmer-mode", "1",
+                 "--db-load-mode", "0", "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800",
+                 "--threads", "1", "--compressed", "0", "-v", "1"]
+UNGAPPED_PAR = ["--sub-mat", SUBMAT, "-c", "0", "-e", "1.79769e+308", "--cov-mode", "0", "--comp-bias-corr", "1",
+                "--comp-bias-corr-scale", "0.15", "--min-ungapped-score", "30", "--max-seqs", "1000", "--db-load-mode", "0",
+                "--gpu", "0", "--gpu-server", "0", "--gpu-server-wait-timeout", "600", "--prefilter-mode", "1",
+                "--threads", "1", "--compressed", "0", "-v", "1"]
+
+
+def align_par(atype, a, extra=()):
+    # F/data/structuresearch.sh:116-143 ${ALIGNMENT_PAR}; --sort-by-structure-bits 0 (no _ca rescoring, see docstring)
+    return ["--tmscore-threshold", "0", "--tmscore-threshold-mode", "0", "--lddt-threshold", "0", "--sort-by-structure-bits", "0",
+            "--alignment-type", str(atype), "--exact-tmscore", "0", "--sub-mat", SUBMAT, "-a", str(a), "--alignment-mode", "3",
+            "--alignment-output-mode", "0", "--wrapped-scoring", "0", "-e", "10", "--min-seq-id", "0", "--min-aln-len", "0",
+            "--seq-id-mode", "0", "--alt-ali", "0", "-c", "0", "--cov-mode", "0", "--max-seq-len", "65535", "--comp-bias-corr", "1",
+            "--comp-bias-corr-scale", "0.5", "--max-rejected", "2147483647", "--max-accept", "2147483647", "--add-self-matches", "0",
+            "--db-load-mode", "0", "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800",
+            "--score-bias", "0", "--realign", "0", "--realign-score-bias", "-0.2", "--realign-max-seqs", "2147483647",
+            "--corr-score-weight", "0", "--gap-open", "aa:10,nucl:10", "--gap-extend", "aa:1,nucl:1", "--zdrop", "40",
+            "--threads", "1", "--compressed", "0", "-v", "1"] + list(extra)
+
+
+def override(par, **kw):
+    """replace the value of given flags in a parameter list (flag names with '-' written as '_' and a leading 'p_')"""
+    par = list(par)
+    for k, v in kw.items():
+        flag = k
+        i = par.index(flag)
+        par[i + 1] = str(v)
+    return par
+
+
+# name -> (module, positional args (relative to the work dir), parameter list)
+RUNS = {
+    # ---- prefilters ----
+    "pref_kmer": ("prefilter", ["db_ss", "db_ss"], PREFILTER_PAR),
+    "pref_kmer_s75": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"-s": "7.5"})),
+    "pref_kmer_max5_self": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"--max-seqs": "5", "--add-self-matches": "1"})),
+    "pref_kmer_pad": ("prefilter", ["db_ss", "db_pad_ss"], PREFILTER_PAR),
+    "pref_ung": ("ungappedprefilter", ["db_ss", "db_ss"], UNGAPPED_PAR),
+    "pref_ung_pad": ("ungappedprefilter", ["db_ss", "db_pad_ss"], UNGAPPED_PAR),
+    "pref_ung_max7": ("ungappedprefilter", ["db_ss", "db_ss"], override(UNGAPPED_PAR, **{"--max-seqs": "7", "--min-ungapped-score": "40"})),
+    "pref_ung_nocb": ("ungappedprefilter", ["db_ss", "db_ss"], override(UNGAPPED_PAR, **{"--comp-bias-corr": "0"})),
+    # ---- structurealign (3Di+AA and 3Di only), on the prefilter results above ----
+    "aln_t2_a": ("structurealign", ["db", "db", "pref_kmer"], align_par(2, 1)),
+    "aln_t0_a": ("structurealign", ["db", "db", "pref_kmer"], align_par(0, 1)),
+    "aln_t2": ("structurealign", ["db", "db", "pref_kmer"], align_par(2, 0)),
+    "aln_t2_a_ung": ("structurealign", ["db", "db", "pref_ung"], align_par(2, 1)),
+    "aln_t2_a_pad": ("structurealign", ["db", "db_pad", "pref_ung_pad"], align_par(2, 1)),
+    "aln_t0_a_pad": ("structurealign", ["db", "db_pad", "pref_kmer_pad"], align_par(0, 1)),
+    "aln_t2_a_e001_c08": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"-e": "0.001", "-c": "0.8"})),
+    "aln_t2_a_cov2": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"-c": "0.9", "--cov-mode": "2"})),
+    "aln_t2_a_maxacc": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--max-accept": "3", "--max-rejected": "2"})),
+    "aln_t2_a_altali": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--alt-ali": "2"})),
+    "aln_t2_a_nocb": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--comp-bias-corr": "0"})),
+}
+
+
+def run(cmd, cwd):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise SystemExit(f"FAILED: {' '.join(cmd)}")
+    return r.stdout
+
+
+def main():
+    if not os.path.exists(FS):
+        raise SystemExit("build the reference first: bash oracle/build_ref_full.sh cpu")
+    work = os.path.join(ROOT, "oracle", "_ref_full", "scop_work")
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(work)
+    run([FS, "createdb", EXAMPLE, "db", "--threads", "1", "-v", "1"], work)
+    for f in os.listdir(work):          # no C-alpha DB: TM/LDDT rescoring is out of scope and turns itself off without it
+        if f.startswith("db_ca"):
+            os.remove(os.path.join(work, f))
+    run([FS, "makepaddedseqdb", "db", "db_pad", "--threads", "1", "-v", "1"], work)
+    manifest = {"reference": "steineggerlab/foldseek tree at /root/reference, binary from oracle/build_ref_full.sh cpu",
+                "links": {}, "runs": {}}
+    for name, (module, pos, par) in RUNS.items():
+        cmd = [FS, module] + pos + [name] + par
+        run(cmd, work)
+        manifest["runs"][name] = {"module": module, "positional": pos, "parameters": par}
+    shutil.rmtree(OUT, ignore_errors=True)
+    os.makedirs(OUT)
+    for f in sorted(os.listdir(work)):
+        p = os.path.join(work, f)
+        if os.path.islink(p):            # makepaddedseqdb links the AA / header data files to the source DB's
+            manifest["links"][f] = os.path.basename(os.readlink(p))
+            continue
+        if os.path.isdir(p) or f.endswith(".source") or "_tmp" in f:
+            continue
+        shutil.copy(p, os.path.join(OUT, f))
+    json.dump(manifest, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    n = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"{len(os.listdir(OUT))} files, {n} bytes -> {OUT}")
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,7 @@ what is under test is foldseek_amd/dist.py."""
 import os
 import sys
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -60,3 +61,27 @@ def test_broadcast_and_query_sharding_world2():
     for qi, keys, scores in flat:
         sel = helpers.o_prefilter_select(helpers.o_ungapped_scores(q3[qi], db, True), 30, -1, 10)
         assert keys == sel["key"].tolist() and scores == sel["score"].tolist()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_gpus2_dry_run_starts_two_ranks(scaling):
+    """`python bench.py --gpus 2` (no torchrun around it) must come up with two ranks through the BENCH code path: the
+    self-launch, process-group init (gloo here, nccl on GPUs), vectorised DB generation on rank 0, one broadcast, query
+    sharding.  --dry-run stops before the first device call."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--targets", "2500", "--steps", "3",
+                        "--warmup", "1", "--group", "4", "--scaling", scaling], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scaling"] == scaling and out["backend"] == "gloo"
+    ranks = out["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1]
+    assert ranks[0]["db_digest"] == ranks[1]["db_digest"] and ranks[0]["db_entries"] == ranks[1]["db_entries"] == 2500
+    timed = [x["timed_queries"] for x in ranks]
+    assert timed == ([12, 12] if scaling == "weak" else [6, 6])     # weak: steps x group per rank; strong: the same 12 split

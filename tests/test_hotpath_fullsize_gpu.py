@@ -1,0 +1,135 @@
+"""Gapless prefilter + structure SW at the size of BASELINE.json configs[1] (100k targets, 35 M residues) and -- scores
+only -- configs[2] (1M targets): the device path against the COMPILED REFERENCE (oracle/_ref/libfsref.so travels to the
+GPU box as a built file) and, where the reference would take too long, against size-independent properties.
+
+What only shows up at this size: the column-segment work items and the atomic work queue of the scan (k_gapless.hpp), the
+byte-wise atomicCAS max over a stripe's segments, 8-target stripes of up to 2000 columns, multi-query SW launches with
+tens of thousands of waves, several register classes in one launch.
+"""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib
+from foldseek_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+N = 100000
+
+
+def _queries():
+    q3, qa = synth.make_queries(6, seed=77, lo=120, hi=480)
+    q3[3] = np.concatenate([q3[3], q3[4], q3[5]])[:777]            # row-tiled query (> 512 rows)
+    qa[3] = np.concatenate([qa[3], qa[4], qa[5]])[:777]
+    return q3[:4], qa[:4]
+
+
+@pytest.fixture(scope="module")
+def world():
+    q3, qa = _queries()
+    db = synth.make_db_fast(N, (q3, qa), seed=4711, homologs_per_query=50)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    ref = oracle_lib.load_ref()
+    return dict(db=db, q3=q3, qa=qa, ctx=ctx, ref=ref)
+
+
+def _ref_scores(ref, db, q, threads=16):
+    scores = np.zeros(db.n, np.int32)
+    ref.ref_ungapped(q, len(q), 1, 0.15, db.data3di, np.ascontiguousarray(db.offsets[:-1]), np.ascontiguousarray(db.lengths), db.n, threads, scores)
+    return scores
+
+
+def test_gapless_scores_and_hit_lists_equal_reference_at_100k(world):
+    """every one of the 100k per-target scores + the selected hit list, four query lengths (R classes 8..30 and a row-tiled one)"""
+    ref, db = world["ref"], world["db"]
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    s = api.Search(world["ctx"])
+    for qi, q in enumerate(world["q3"]):
+        hits = s.prefilter(q, identity=(12345 if qi == 1 else -1))
+        got = world["ctx"].gapless_scores().astype(np.int32)
+        want = _ref_scores(ref, db, q)
+        bad = np.flatnonzero(got != want)
+        assert len(bad) == 0, (qi, len(q), bad[:10], got[bad[:10]], want[bad[:10]])
+        sel = helpers.o_prefilter_select(want, 30, 12345 if qi == 1 else -1, 1000)
+        assert len(hits) == len(sel) == 1000
+        assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
+    s.close()
+
+
+@pytest.mark.parametrize("atype", [0, 2])
+def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, atype):
+    """prefilter hit lists (1000 targets each, 50 planted homologs among them) through the batch path (k_sw2 forward over all
+    pairs, reversed over the gate survivors, host gates, block-aligner backtrace): forward score / end positions of EVERY pair
+    and the complete accepted records (scores, e-value bits, start/end, CIGAR, order) against the reference's alignStructure"""
+    ref, db, q3, qa = world["ref"], world["db"], world["q3"], world["qa"]
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    par = api.default_params()
+    par.alignmentType = atype
+    par.addBacktrace = 1
+    s = api.Search(world["ctx"], par)
+    hit_lists = [s.prefilter(q)["id"] for q in q3]
+    res, bts = s.align_batch(qa, q3, hit_lists, with_backtrace=True)
+    t3 = np.where(db.data3di >= 32, db.data3di - 32, db.data3di).astype(np.uint8)
+    accepted = 0
+    for qi in range(len(q3)):
+        h = np.ascontiguousarray(hit_lists[qi].astype(np.int64))
+        n = len(h)
+        aln = np.zeros(n, oracle_lib.REFALN_DT)
+        cig = np.zeros(1 << 22, np.uint8)
+        ref.ref_structure_align(qa[qi], q3[qi], len(q3[qi]), atype, 1, 0.5, 10, 1, db.dataaa, t3,
+                                np.ascontiguousarray(db.offsets[:-1][h]), np.ascontiguousarray(db.lengths[h]), n,
+                                db.residues, 10.0, 1, 16, None, None, aln.ctypes.data, cig.ctypes.data, cig.size)
+        cigs = cig.tobytes().split(b"\0")[0].decode().split("\n")
+        ok = np.flatnonzero(aln["status"] == 0)
+        # reference records in structurealign's output order (Matcher::compareHits: e-value asc, score desc, dbLen asc, key asc)
+        want = sorted(ok, key=lambda k: (aln["evalue"][k], -int(aln["score"][k]), int(db.lengths[h[k]]), int(h[k])))
+        got = res[qi]
+        assert len(got) == len(want), (qi, len(got), len(want))
+        for r, k, bt in zip(got, want, bts[qi]):
+            a = aln[k]
+            assert (r["dbKey"], r["score"], r["qStartPos"], r["qEndPos"], r["dbStartPos"], r["dbEndPos"]) == \
+                   (h[k], a["score"], a["qStart"], a["qEnd"], a["dbStart"], a["dbEnd"]), (qi, k)
+            assert r["eval"] == a["evalue"] and r["alnLength"] == a["alnLen"] and abs(r["seqId"] - a["seqId"]) == 0
+            assert bt == cigs[k], (qi, k)
+        accepted += len(want)
+    assert accepted >= 150            # the planted homologs are found and aligned, not just random pairs
+    s.close()
+
+
+def test_gapless_properties_at_1M_targets():
+    """configs[2] size (1M targets, 350 M residues).  The reference needs ~0.3 s per query here even on 16 cores, so: a
+    3000-target sample spread over the whole length range is checked against it, the full score vector through properties
+    (every score in [0, cap], planted homologs score above the random background, hit list = exact top-1000 of the vector
+    in (score desc, id asc) order, a second run is identical: the atomic queue order must not leak into results)."""
+    q3, qa = synth.make_queries(3, seed=99, lo=250, hi=450)
+    db = synth.make_db_fast(1000000, (q3, qa), seed=31337, homologs_per_query=50)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    ref = oracle_lib.load_ref()
+    s = api.Search(ctx)
+    sub, pb = helpers.o_submat("MAT3DI", 2.0)
+    for q in q3:
+        hits = s.prefilter(q)
+        got = ctx.gapless_scores().astype(np.int32)
+        hits2 = s.prefilter(q)
+        assert (ctx.gapless_scores().astype(np.int32) == got).all() and (hits2 == hits).all()
+        sel = helpers.o_prefilter_select(got, 30, -1, 1000)
+        assert (hits["id"] == sel["key"]).all() and (hits["score"] == sel["score"]).all()
+        assert got.min() >= 0 and got.max() <= 255
+        assert (np.sort(got)[-40:] > np.percentile(got, 99.9)).all()
+        if ref is not None:
+            idx = np.linspace(0, db.n - 1, 3000).astype(np.int64)
+            want = np.zeros(len(idx), np.int32)
+            ref.ref_ungapped(q, len(q), 1, 0.15, db.data3di, np.ascontiguousarray(db.offsets[:-1][idx]), np.ascontiguousarray(db.lengths[idx]),
+                             len(idx), 16, want)
+            assert (got[idx] == want).all()
+            top = np.ascontiguousarray(hits["id"][:300].astype(np.int64))
+            want = np.zeros(len(top), np.int32)
+            ref.ref_ungapped(q, len(q), 1, 0.15, db.data3di, np.ascontiguousarray(db.offsets[:-1][top]), np.ascontiguousarray(db.lengths[top]),
+                             len(top), 16, want)
+            assert (hits["score"][:300] == want).all()
+    s.close()
+    ctx.close()

@@ -1,0 +1,110 @@
+"""Drop-in tests on REAL data and REFERENCE-WRITTEN databases (tests/golden/scop_v1, generator make_scop_golden.py):
+
+the reference's own `createdb` / `makepaddedseqdb` wrote the sequence DBs from F/example (25 SCOP domains + 1tim/8tim),
+its `prefilter` / `ungappedprefilter` / `structurealign` wrote the result DBs -- here `fsgpu-modules` runs with the SAME
+positional arguments and the SAME complete parameter strings (what F/data/structuresearch.sh hands the modules) on those
+DBs and every entry of every result DB must be byte-identical.  Nothing in these tests is written by foldseek_amd/dbio.py.
+"""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "foldseek_amd", "bin", "fsgpu-modules")
+GOLD = os.path.join(ROOT, "tests", "golden", "scop_v1")
+MANIFEST = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
+
+# runs whose parameters ask for something the device path refuses (with a message) instead of computing it
+NOT_IMPLEMENTED = {"aln_t2_a_altali": "--alt-ali 2 is not implemented"}
+
+
+def read_db(path):
+    """(dbtype int32, {key: entry bytes without the terminator}) straight from the files, no project code involved"""
+    t = int.from_bytes(open(path + ".dbtype", "rb").read(4), "little", signed=True)
+    data = open(path, "rb").read()
+    out = {}
+    for line in open(path + ".index"):
+        k, off, ln = line.split()
+        out[int(k)] = data[int(off):int(off) + int(ln) - 1]
+    return t, out
+
+
+@pytest.fixture()
+def scop(tmp_path):
+    """a private copy of the frozen reference DBs with the links makepaddedseqdb makes (AA / header data -> source DB)"""
+    work = tmp_path / "scop"
+    shutil.copytree(GOLD, work)
+    for link, target in MANIFEST["links"].items():
+        os.symlink(str(work / target), str(work / link))
+    return work
+
+
+def test_makepaddedseqdb_equals_reference_written_db(scop):
+    """host-only module: base:makepaddedseqdb of the reference on db_ss (+ headers) == ours, all seven files byte for byte
+    (M/src/util/makepaddedseqdb.cpp:14-154; the workflow links <db>_h next to the 3Di DB first, F/data/makepaddeddb.sh:10-19)"""
+    for ext in ("", ".index", ".dbtype"):
+        shutil.copy(scop / ("db_h" + ext), scop / ("db_ss_h" + ext))
+    subprocess.check_call([BIN, "makepaddedseqdb", str(scop / "db_ss"), str(scop / "mine_ss"), "--threads", "1", "-v", "1"])
+    for ext in ("", ".index", ".lookup", ".dbtype", "_h", "_h.index", "_h.dbtype"):
+        assert open(scop / ("mine_ss" + ext), "rb").read() == open(scop / ("db_pad_ss" + ext), "rb").read(), ext
+
+
+@pytest.mark.parametrize("module,args,needle", [
+    ("prefilter", ["--no-such-flag", "1"], 'Unrecognized parameter "--no-such-flag"'),
+    ("prefilter", ["--mask", "1"], "--mask 1 is not implemented"),
+    ("prefilter", ["-k", "7"], "-k 7 is not implemented"),
+    ("prefilter", ["--sub-mat", "aa:blosum62.out,nucl:nucleotide.out"], "--sub-mat"),
+    ("prefilter", ["--exact-kmer-matching", "1"], "not implemented"),
+    ("ungappedprefilter", ["--prefilter-mode", "2"], "not implemented"),
+    ("ungappedprefilter", ["--max-seqs"], "Missing argument --max-seqs"),
+    ("structurealign", ["--alignment-type", "1"], "--alignment-type 1 is not implemented"),
+    ("structurealign", ["--tmscore-threshold", "0.5"], "not implemented"),
+    ("structurealign", ["--realign", "1"], "not implemented"),
+    ("structurealign", ["-a", "maybe"], "Invalid boolean string maybe"),
+    ("structurealign", ["--compressed", "1"], "--compressed 1 is not implemented"),
+])
+def test_modules_refuse_what_they_do_not_implement(scop, module, args, needle):
+    """a drop-in must not swallow flags: unknown ones get the reference's message (Parameters.cpp:2087), known ones whose
+    value selects an unimplemented feature are refused -- before any device is touched, so this runs without a GPU"""
+    pos = [str(scop / "db_ss"), str(scop / "db_ss"), str(scop / "out")] if module != "structurealign" else \
+          [str(scop / "db"), str(scop / "db"), str(scop / "pref_kmer"), str(scop / "out")]
+    r = subprocess.run([BIN, module] + pos + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1
+    assert needle in r.stderr
+    assert not os.path.exists(scop / "out.index")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(MANIFEST["runs"]))
+def test_module_equals_reference_result_db(scop, name):
+    run = MANIFEST["runs"][name]
+    out = str(scop / ("mine_" + name))
+    cmd = [BIN, run["module"]] + [str(scop / p) for p in run["positional"]] + [out] + run["parameters"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if name in NOT_IMPLEMENTED:
+        assert r.returncode == 1 and NOT_IMPLEMENTED[name] in r.stderr
+        return
+    assert r.returncode == 0, r.stderr
+    want_t, want = read_db(str(scop / name))
+    got_t, got = read_db(out)
+    assert got_t == want_t
+    assert sorted(got) == sorted(want)
+    for k in sorted(want):
+        assert got[k] == want[k], f"{name}: entry {k}\nwant {want[k][:300]!r}\ngot  {got[k][:300]!r}"
+    assert sum(len(v) for v in want.values()) > 0
+
+
+@pytest.mark.gpu
+def test_fused_search_equals_reference_two_step(scop):
+    """`search` (prefilter + structurealign in one process) on the reference-written DBs == the reference's two modules"""
+    for mode, pref, aln in ((0, "pref_kmer", "aln_t2_a"), (1, "pref_ung", "aln_t2_a_ung")):
+        out, outp = str(scop / f"mine_search{mode}"), str(scop / f"mine_search{mode}_pref")
+        cmd = [BIN, "search", str(scop / "db"), str(scop / "db"), out, outp, "--prefilter-mode", str(mode), "-a", "1",
+               "--alignment-type", "2", "--sort-by-structure-bits", "0", "--threads", "2", "-s", "9.5", "--max-seqs", "1000", "-e", "10"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        assert read_db(outp) == read_db(str(scop / pref))
+        assert read_db(out) == read_db(str(scop / aln))
