@@ -384,7 +384,9 @@ size_t fshost_format_result(char *buf, const fshost_result *r, const char *backt
     *p++ = '\t';
     // Util::fastSeqIdToBuffer (Util.cpp:251-279)
     if (r->seqId == 1.0) {
-        memcpy(p, "1.000", 5); p += 5;
+        // the reference prints "1.00": fastSeqIdToBuffer writes "1.000\0" but, unlike the Itoa routines, returns the address
+        // OF the terminator, so resultToBuffer's `*(tmpBuff-1) = '\t'` lands on the last zero (Util.cpp:252-263, Matcher.cpp:288-289)
+        memcpy(p, "1.00", 4); p += 4;
     } else {
         *p++ = '0'; *p++ = '.';
         if (r->seqId < 0.10) *p++ = '0';

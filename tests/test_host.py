@@ -123,7 +123,7 @@ def test_formats():
     assert buf.raw[:n].decode() == "12\t345\t0.056\t1.234E-07\t0\t99\t100\t3\t104\t120\t3M2I1M2D1M\n"
     r["seqId"] = 1.0
     n = api.lib().fshost_format_result(buf, C.c_void_p(r.ctypes.data), None, 0)
-    assert buf.raw[:n].decode().split("\t")[2] == "1.000"
+    assert buf.raw[:n].decode().split("\t")[2] == "1.00"      # the reference's own off-by-one (Util.cpp:252-263 + Matcher.cpp:289), pinned by tests/golden/scop_v1
     r["seqId"] = 0.5
     n = api.lib().fshost_format_result(buf, C.c_void_p(r.ctypes.data), None, 0)
     assert buf.raw[:n].decode().split("\t")[2] == "0.500"
