@@ -351,6 +351,9 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if "FSGPU_SPIN_US" not in os.environ:
         os.environ["FSGPU_SPIN_US"] = "1000000" if usable_cores() >= 2 * local_world * nthreads else "40"
+    # host pool for the per-hit backtraces: the cores this rank may use beyond its feeder threads (cgroup quota / local ranks)
+    if "FSGPU_HOST_WORKERS" not in os.environ:
+        api.set_host_workers(max(0, min(8, usable_cores() // local_world - nthreads)))
     ctx0 = api.Context(local_rank)
     ctx0.adopt_device_db(tensors[0].data_ptr(), tensors[1].data_ptr(), tensors[2].data_ptr(), tensors[3].data_ptr(), db.n, db.data3di.size)
     ctx0._keep = (np.ascontiguousarray(db.data3di), np.ascontiguousarray(db.dataaa), np.ascontiguousarray(db.offsets, np.uint64),
@@ -481,7 +484,7 @@ def main():
                                    f"(--alignment-type {args.alignment_type}; forward over all pairs, reversed over the pairs that pass the forward gates) "
                                    f"+ host gates + block-aligner backtrace of every accepted hit; {nthreads} host feeder threads per GPU run their steps concurrently",
                        "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "max_seqs": 1000, "homologs_per_query": args.homologs,
-                       "queries_per_step": G, "queries_total": nq_total, "host_threads_per_gpu": nthreads,
+                       "queries_per_step": G, "queries_total": nq_total, "host_threads_per_gpu": nthreads, "host_backtrace_workers_per_gpu": api.host_workers(),
                        "parallelism": f"query-shard x{world} ({args.scaling}), DB replicated by one RCCL broadcast"},
             "queries_per_s": nq_total / dt, "ms_per_query": 1e3 * dt / (nq_total / world),
             "hits_per_query": nh / nq_total, "alignments_per_query": nr / nq_total,

@@ -536,6 +536,15 @@ def block_backtrace(mAA, m3Di, qAA, q3Di, cbAA, cbSS, tAA, t3Di, q_end, db_end, 
     return bool(ok), qs.value, ds.value, ident.value, buf.value.decode()
 
 
+def set_host_workers(n):
+    """size of the process-wide host pool that computes the per-hit backtraces (0: the calling threads do it themselves)"""
+    lib().fshost_set_host_workers(int(n))
+
+
+def host_workers():
+    return int(lib().fshost_host_workers())
+
+
 def default_params():
     p = Params()
     lib().fshost_params_default(C.byref(p))

@@ -156,6 +156,7 @@ bool parseArgs(int argc, const char **argv, const char *module, std::initializer
         if (!isFlag) { o.pos.push_back(a); continue; }
         const FlagSpec *f = findFlag(a, tables);
         if (!f) { err = "Unrecognized parameter \"" + a + "\""; return false; }
+        if (o.kv.count(a)) { err = "Duplicate parameter " + a; return false; }        // Parameters.cpp:1895-1899
         std::string v;
         if (f->isBool) {
             if (i + 1 == argc || argv[i + 1][0] == '-') {

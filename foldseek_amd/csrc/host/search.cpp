@@ -7,11 +7,17 @@
 #include "hostlib.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 using namespace fsh;
 
@@ -39,6 +45,84 @@ struct fshost_search {
     double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 static inline double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- host worker pool ------------------------------------------------------------------------------------------------
+// The block-aligner backtrace of an accepted hit costs ~20 us on a host core; with 50 accepted hits per query that is
+// 1 ms per query -- more than the device needs for prefilter + SW of a query against 100k targets.  The reference spreads
+// this over its OpenMP threads (one query per thread, structurealign.cpp:318); here the feeder thread that owns a batch
+// hands the backtraces of ALL its queries to a process-wide pool and works on them itself until they are done.
+// Size: fshost_set_host_workers(n) / FSGPU_HOST_WORKERS, default min(6, usable cores - 1) where "usable" honours the
+// cgroup CPU quota (a container that shows 256 CPUs may own the time of 16).
+namespace {
+
+int usableCores() {
+    int n = (int) std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, atoll(q) / period));
+        fclose(f);
+    }
+    return std::max(1, n);
+}
+
+class HostPool {
+public:
+    static HostPool &get() { static HostPool *p = new HostPool(); return *p; }      // leaked on purpose: workers may outlive static destructors
+    // runs fn(0..n-1); the caller takes part and returns when all indices are done
+    void parallelFor(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        Job job; job.n = n; job.fn = &fn;
+        if (n > 1 && workers() > 0) {
+            { std::lock_guard<std::mutex> g(m_); jobs_.push_back(&job); }
+            cv_.notify_all();
+        }
+        for (;;) { const int i = job.next.fetch_add(1); if (i >= n) break; fn(i); job.done.fetch_add(1); }
+        if (n > 1 && workers() > 0) {
+            { std::lock_guard<std::mutex> g(m_); jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job)); }
+            while (job.done.load(std::memory_order_acquire) < n || job.inside.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        }
+    }
+    void resize(int n) {
+        std::lock_guard<std::mutex> g(m_);
+        want_ = std::max(0, std::min(n, 64));
+        while ((int) threads_.size() < want_) { const int id = (int) threads_.size(); threads_.emplace_back([this, id] { loop(id); }); threads_.back().detach(); }
+        cv_.notify_all();
+    }
+    int workers() const { return want_; }
+private:
+    struct Job { int n = 0; const std::function<void(int)> *fn = nullptr; std::atomic<int> next{0}, done{0}, inside{0}; };
+    HostPool() {
+        const char *e = getenv("FSGPU_HOST_WORKERS");
+        resize(e ? atoi(e) : std::min(6, usableCores() - 1));
+    }
+    void loop(int id) {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            Job *job = nullptr;
+            if (id < want_) for (Job *j : jobs_) if (j->next.load(std::memory_order_relaxed) < j->n) { job = j; break; }
+            if (!job) { cv_.wait(lk); continue; }
+            job->inside.fetch_add(1);          // under the lock: the owner cannot retire the job before it sees us
+            lk.unlock();
+            for (;;) { const int i = job->next.fetch_add(1); if (i >= job->n) break; (*job->fn)(i); job->done.fetch_add(1, std::memory_order_release); }
+            job->inside.fetch_sub(1, std::memory_order_release);
+            lk.lock();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<Job *> jobs_;
+    std::vector<std::thread> threads_;
+    int want_ = 0;
+};
+
+} // namespace
+
+extern "C" {
+void fshost_set_host_workers(int n) { HostPool::get().resize(n); }
+int fshost_host_workers(void) { return HostPool::get().workers(); }
+int fshost_usable_cores(void) { return usableCores(); }
+}
 
 extern "C" {
 
@@ -182,47 +266,79 @@ bool needsReversePass(const fshost_search *s, const AlignQuery &aq, uint32_t tid
     return !(evalue > par.evalThr);
 }
 
-// alignStructure gates + backtrace + checkCriteria + ordering for one query (structurealign.cpp:37-112,350-445)
+// start position + backtrace of one pair on the host (alignStartPosBacktraceBlock); safe to call from any thread
+void pairBacktrace(const fshost_search *s, const AlignQuery &aq, uint32_t tid, const fsgpu_swres &f, BlockAlnOut &bo) {
+    static thread_local std::vector<uint8_t> tAA, t3Di;
+    const fshost_params &par = s->par;
+    const int Lt = s->lengths[tid];
+    tAA.resize(Lt); t3Di.resize(Lt);
+    for (int i = 0; i < Lt; i++) {          // padded-DB codes: +32 = soft-masked, same letter for the aligner
+        uint8_t c = s->data3di[s->offsets[tid] + i];
+        c = c >= 32 ? c - 32 : c;
+        t3Di[i] = c > 20 ? 20 : c;
+        uint8_t a = s->dataAA ? s->dataAA[s->offsets[tid] + i] : 20;
+        a = a >= 32 ? a - 32 : a;
+        tAA[i] = a > 20 ? 20 : a;
+    }
+    blockBacktrace(s->matAA, s->mat3Di, aq.qAA, aq.q3di, aq.cbAA.data(), aq.cbSS.data(), aq.L, tAA.data(), t3Di.data(), Lt, f.qEnd, f.dbEnd,
+                   f.score, par.gapOpen, par.gapExtend, bo);
+}
+
+// the gates of alignStructure that come BEFORE the backtrace (structurealign.cpp:357-361 canBeCovered, :50-58 coverage and
+// e-value of the forward alignment, :68-73 e-value of fwd - rev); fills score / evalue of the pair when it passes
+bool passesScoreGates(const fshost_search *s, const AlignQuery &aq, uint32_t tid, const fsgpu_swres &f, const fsgpu_swres &r,
+                      int32_t &score, double &evalue, bool *lookedAtRev) {
+    const fshost_params &par = s->par;
+    const int L = aq.L, Lt = s->lengths[tid];
+    if (!canBeCovered(par.covThr, par.covMode, (float) L, (float) Lt)) return false;
+    const float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
+    if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) return false;
+    evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, aq.lambda, aq.mu);
+    if (evalue > par.evalThr) return false;
+    if (lookedAtRev) *lookedAtRev = true;
+    score = f.score - r.score;
+    evalue = s->evaluer.computeEvalueCorr(score, aq.lambda, aq.mu);
+    return !(evalue > par.evalThr);
+}
+
+// alignStructure gates + backtrace + checkCriteria + ordering for one query (structurealign.cpp:37-112,350-445).
+// pre / preIdx: backtraces computed ahead by the worker pool (preIdx[k] = index into pre, -1 = none); without them the
+// backtrace of a pair is computed here, when the loop reaches it (the --max-accept / --max-rejected path).
 int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const uint32_t *targetIds, int n, const fsgpu_swres *fwd,
-              const fsgpu_swres *rev, fshost_result *results, double &tBack) {
+              const fsgpu_swres *rev, fshost_result *results, double &tBack, const BlockAlnOut *pre, const int *preIdx) {
     const fshost_params &par = s->par;
     const int L = aq.L;
     int passedNum = 0, rejected = 0, nres = 0;
+    BlockAlnOut local;
     for (int k = 0; k < n && passedNum < par.maxAccept && rejected < par.maxRejected; k++) {
         const uint32_t tid = targetIds[k];
         const bool isIdentity = ((int64_t) tid == identityId);
         if (tid >= s->keys.size()) { s->err = "target id out of range"; return FSGPU_E_ARG; }
         const int Lt = s->lengths[tid];
-        if (!canBeCovered(par.covThr, par.covMode, (float) L, (float) Lt)) { rejected++; continue; }
         // ---- alignStructure ----
         const fsgpu_swres &f = fwd[k];
-        float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
-        if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) { rejected++; continue; }
-        double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, aq.lambda, aq.mu);
-        if (evalue > par.evalThr) { rejected++; continue; }
-        s->stats[6] += 1.0;             // pairs whose reversed-query score is actually looked at
-        const int32_t score = f.score - rev[k].score;
-        evalue = s->evaluer.computeEvalueCorr(score, aq.lambda, aq.mu);
-        if (evalue > par.evalThr) { rejected++; continue; }
+        int32_t score = 0;
+        double evalue = 0;
+        bool looked = false;
+        const bool pass = passesScoreGates(s, aq, tid, f, rev[k], score, evalue, &looked);
+        if (looked) s->stats[6] += 1.0;             // pairs whose reversed-query score is actually looked at
+        if (!pass) { rejected++; continue; }
         // start position + backtrace on the host (block aligner), only for hits that survived both gates
-        s->tAA.resize(Lt); s->t3Di.resize(Lt);
-        for (int i = 0; i < Lt; i++) {          // padded-DB codes: +32 = soft-masked, same letter for the aligner
-            uint8_t c = s->data3di[s->offsets[tid] + i];
-            c = c >= 32 ? c - 32 : c;
-            s->t3Di[i] = c > 20 ? 20 : c;
-            uint8_t a = s->dataAA ? s->dataAA[s->offsets[tid] + i] : 20;
-            a = a >= 32 ? a - 32 : a;
-            s->tAA[i] = a > 20 ? 20 : a;
+        const BlockAlnOut *bop;
+        if (pre && preIdx && preIdx[k] >= 0) {
+            bop = &pre[preIdx[k]];
+        } else {
+            const double tb0 = nowSec();
+            pairBacktrace(s, aq, tid, f, local);
+            tBack += nowSec() - tb0;
+            bop = &local;
         }
-        BlockAlnOut bo;
-        const double tb0 = nowSec();
-        blockBacktrace(s->matAA, s->mat3Di, aq.qAA, aq.q3di, aq.cbAA.data(), aq.cbSS.data(), L, s->tAA.data(), s->t3Di.data(), Lt, f.qEnd, f.dbEnd,
-                       f.score, par.gapOpen, par.gapExtend, bo);
-        tBack += nowSec() - tb0;
+        const BlockAlnOut &bo = *bop;
         fshost_result r;
         memset(&r, 0, sizeof(r));
         int qStart = -1, dbStart = -1;
         float seqId = 0.0f;
+        float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
         if (bo.ok) {
             qStart = bo.qStart; dbStart = bo.dbStart;
             qCov = computeCov(qStart, f.qEnd, L);
@@ -257,6 +373,44 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
     return nres;
 }
 
+// Backtraces of every pair of the given queries that passes the score gates, computed by the host pool (the calling
+// thread takes part).  Only when the accept / reject limits cannot cut a query short (their defaults): otherwise gateAlign
+// computes them one by one, like the reference, and stops where the reference stops.
+struct PreBacktrace {
+    std::vector<BlockAlnOut> outs;
+    std::vector<std::vector<int>> idx;       // [query][pair] -> outs index or -1
+    double seconds = 0;                       // wall time of the parallel section
+};
+void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> &aq, const uint32_t *const *targetIds, const int *n,
+                          const fsgpu_swres *fwd, const fsgpu_swres *rev, PreBacktrace &pb) {
+    const int nq = (int) aq.size();
+    pb.idx.assign(nq, {});
+    if (s->par.maxAccept != INT_MAX || s->par.maxRejected != INT_MAX) return;
+    struct Task { int q, k; size_t base; };
+    std::vector<Task> tasks;
+    size_t base = 0;
+    for (int i = 0; i < nq; i++) {
+        pb.idx[i].assign(n[i], -1);
+        for (int k = 0; k < n[i]; k++) {
+            const uint32_t tid = targetIds[i][k];
+            if (tid >= s->keys.size()) continue;
+            int32_t score; double evalue;
+            if (passesScoreGates(s, aq[i], tid, fwd[base + k], rev[base + k], score, evalue, nullptr)) {
+                pb.idx[i][k] = (int) tasks.size();
+                tasks.push_back({i, k, base});
+            }
+        }
+        base += (size_t) n[i];
+    }
+    pb.outs.resize(tasks.size());
+    const double t0 = nowSec();
+    HostPool::get().parallelFor((int) tasks.size(), [&](int t) {
+        const Task &tk = tasks[t];
+        pairBacktrace(s, aq[tk.q], targetIds[tk.q][tk.k], fwd[tk.base + tk.k], pb.outs[t]);
+    });
+    pb.seconds = nowSec() - t0;
+}
+
 } // namespace
 
 extern "C" {
@@ -279,7 +433,15 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
     const double t2 = nowSec();
     double tBack = 0;
     s->cigars.clear();
-    const int nres = gateAlign(s, aq, identityId, targetIds, n, s->fwd.data(), s->rev.data(), results, tBack);
+    PreBacktrace pb;
+    {
+        std::vector<AlignQuery> one(1);
+        one[0] = std::move(aq);
+        precomputeBacktraces(s, one, &targetIds, &n, s->fwd.data(), s->rev.data(), pb);
+        aq = std::move(one[0]);
+    }
+    tBack += pb.seconds;
+    const int nres = gateAlign(s, aq, identityId, targetIds, n, s->fwd.data(), s->rev.data(), results, tBack, pb.outs.data(), pb.idx[0].empty() ? nullptr : pb.idx[0].data());
     s->stats[2] = t1 - t0; s->stats[3] = t2 - t1; s->stats[5] = tBack; s->stats[4] = nowSec() - t2 - tBack;
     return nres;
 }
@@ -334,9 +496,13 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
     const double t2 = nowSec();
     double tBack = 0;
     s->cigars.clear();
+    PreBacktrace pb;
+    precomputeBacktraces(s, aq, targetIds, n, s->fwd.data(), s->rev.data(), pb);
+    tBack += pb.seconds;
     size_t base = 0;
     for (int i = 0; i < nq; i++) {
-        nres[i] = gateAlign(s, aq[i], identityId ? identityId[i] : -1, targetIds[i], n[i], s->fwd.data() + base, s->rev.data() + base, results[i], tBack);
+        nres[i] = gateAlign(s, aq[i], identityId ? identityId[i] : -1, targetIds[i], n[i], s->fwd.data() + base, s->rev.data() + base, results[i], tBack,
+                            pb.outs.data(), pb.idx[i].empty() ? nullptr : pb.idx[i].data());
         if (nres[i] < 0) return nres[i];
         base += (size_t) n[i];
     }

@@ -143,6 +143,12 @@ const char *fshost_search_backtrace(const fshost_search *s, const fshost_result 
  * [1] fsgpu_gapless_scan incl. wait, [2] align profiles + e-value net, [3] fsgpu_sw_batch incl. wait, [4] gates,
  * [5] block-aligner backtrace; [6..7] reserved. */
 void fshost_search_stats(const fshost_search *s, double *out8);
+/* Host worker pool for the per-hit backtraces (block aligner, ~20 us each): a feeder thread hands the accepted pairs of its
+ * batch to the pool and takes part itself.  n = 0: the calling threads do everything themselves.  Default:
+ * FSGPU_HOST_WORKERS or min(6, usable cores - 1), "usable" = hardware threads capped by the cgroup CPU quota. */
+void fshost_set_host_workers(int n);
+int fshost_host_workers(void);
+int fshost_usable_cores(void);
 /* Raw per-pair device results of the last fshost_search_align (n entries each), for tests. */
 void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev);
 

@@ -99,6 +99,28 @@ def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, a
     s.close()
 
 
+def test_backtrace_pool_does_not_change_results(world):
+    """the accepted hits' backtraces run on a host worker pool (search.cpp HostPool); any pool size gives the same records"""
+    db, q3, qa = world["db"], world["q3"], world["qa"]
+    par = api.default_params()
+    par.addBacktrace = 1
+    s = api.Search(world["ctx"], par)
+    hit_lists = [s.prefilter(q)["id"] for q in q3]
+    before = api.host_workers()
+    outs = []
+    for w in (0, 1, 7):
+        api.set_host_workers(w)
+        assert api.host_workers() == w
+        res, bts = s.align_batch(qa, q3, hit_lists, with_backtrace=True)
+        outs.append(([r.tobytes() for r in res], bts))
+        one, bt1 = s.align(qa[0], q3[0], hit_lists[0], with_backtrace=True)
+        assert one.tobytes() == res[0].tobytes() and bt1 == bts[0]
+    api.set_host_workers(before)
+    assert outs[0] == outs[1] == outs[2]
+    assert sum(len(b) for b in outs[0][1]) >= 150
+    s.close()
+
+
 def test_gapless_properties_at_1M_targets():
     """configs[2] size (1M targets, 350 M residues).  The reference needs ~0.3 s per query here even on 16 cores, so: a
     3000-target sample spread over the whole length range is checked against it, the full score vector through properties

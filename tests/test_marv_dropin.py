@@ -27,11 +27,12 @@ def _env():
     return env
 
 
-def _gpu_par(extra=()):
+def _gpu_par(server=0):
     par = list(MANIFEST["runs"]["pref_ung_pad"]["parameters"])
     par[par.index("--gpu") + 1] = "1"
+    par[par.index("--gpu-server") + 1] = str(server)
     par[par.index("--prefilter-mode") + 1] = "0"           # what the search workflow passes with --gpu 1
-    return par + list(extra)
+    return par
 
 
 def test_reference_ungappedprefilter_gpu_path_through_our_marv(scop):
@@ -48,7 +49,7 @@ def test_reference_gpuserver_and_client_through_our_marv(scop):
     try:
         out = str(scop / "mine_srv")
         r = subprocess.run([FS_GPU, "ungappedprefilter", str(scop / "db_ss"), str(scop / "db_pad_ss"), out] +
-                           _gpu_par(["--gpu-server", "1"]), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
+                           _gpu_par(server=1), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stdout[-3000:]
         assert read_db(out) == read_db(str(scop / "pref_ung_pad"))
     finally:
