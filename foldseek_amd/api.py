@@ -464,7 +464,7 @@ class Search:
         qa = np.ascontiguousarray(qAA, np.uint8)
         q3 = np.ascontiguousarray(q3di, np.uint8)
         t = np.ascontiguousarray(target_ids, np.uint32)
-        res = np.zeros(max(1, len(t)), RESULT_DT)
+        res = np.zeros(max(1, len(t) * (1 + max(0, self.par.altAlignment))), RESULT_DT)
         n = lib().fshost_search_align(self.h, _ptr(qa), _ptr(q3), len(q3), identity, _ptr(t), len(t), _ptr(res))
         if n < 0:
             raise FsgpuError(f"align rc={n}: {lib().fshost_search_error(self.h).decode()}")
@@ -480,7 +480,7 @@ class Search:
         qa = [np.ascontiguousarray(x, np.uint8) for x in qAAs]
         q3 = [np.ascontiguousarray(x, np.uint8) for x in q3dis]
         ts = [np.ascontiguousarray(x, np.uint32) for x in target_id_lists]
-        res = [np.zeros(max(1, len(t)), RESULT_DT) for t in ts]
+        res = [np.zeros(max(1, len(t) * (1 + max(0, self.par.altAlignment))), RESULT_DT) for t in ts]
         P = C.c_void_p * max(nq, 1)
         pa, p3, pt, pr = P(*[x.ctypes.data for x in qa]), P(*[x.ctypes.data for x in q3]), P(*[x.ctypes.data for x in ts]), P(*[x.ctypes.data for x in res])
         Ls = np.array([len(x) for x in q3], np.int32)

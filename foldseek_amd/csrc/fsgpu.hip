@@ -70,7 +70,8 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     ctx->kidx.reset();
     if (ctx->kmer) fsgpu_kmer_free_scratch(ctx->kmer);
     DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
-                      &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys};
+                      &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys,
+                      &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     hipFree(ctx->dMeta); hipFree(ctx->queue);
     hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId.p); hipHostFree(ctx->hOutScore.p);
@@ -571,6 +572,7 @@ int fsgpu_gapless_finish(fsgpu_ctx *ctx, fsgpu_hit *out, int *nout) {
     if (!ctx || !out || !nout) return FSGPU_E_ARG;
     if (!ctx->gaplessPending) { ctx->err = "no gapless scan in flight"; return FSGPU_E_ARG; }
     ctx->gaplessPending = false;
+    HIPCHK(hipSetDevice(ctx->device));
     { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; }
     const uint32_t m = std::min<uint32_t>(ctx->hMeta->nOut, (uint32_t) ctx->pendingMaxRes);
     for (uint32_t i = 0; i < m; i++) { out[i].id = ((const uint32_t *) ctx->hOutId.p)[i]; out[i].score = ((const int32_t *) ctx->hOutScore.p)[i]; }
@@ -713,7 +715,11 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
     }
     for (int t = 0; t < nTiles; t++) {
         SwArgs sa;
-        sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
+        if (ctx->sw.explicitTargets) {
+            sa.aa = (const uint8_t *) ctx->ovAA.p; sa.ss = (const uint8_t *) ctx->ovSS.p; sa.offsets = (const uint64_t *) ctx->ovOff.p; sa.lengths = (const int32_t *) ctx->ovLen.p;
+        } else {
+            sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
+        }
         sa.targetIds = dTids; sa.nPairs = nPairs;
         sa.profSS = (const uint32_t *) ctx->img.p + imgDw * t;
         sa.profAA = hasAA ? sa.profSS + tblDw : nullptr;
@@ -737,29 +743,73 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
 
 extern "C" {
 
+static int swLaunchImpl(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev,
+                        const int16_t *p3Di_rev, int L, const uint32_t *targetIds, int n, int gapOpen, int gapExtend, bool explicitTargets);
+
 int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev,
                     const int16_t *p3Di_rev, int L, const uint32_t *targetIds, int n, int gapOpen, int gapExtend) {
+    return swLaunchImpl(ctx, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, targetIds, n, gapOpen, gapExtend, false);
+}
+
+// Explicit target sequences (structurealign --alt-ali re-aligns a target whose previous alignment range was overwritten with X,
+// F/src/strucclustutils/structurealign.cpp:115-138): the sequences are staged in per-context device buffers and the same
+// kernels run on them with ids 0..n-1.
+int fsgpu_sw_batch_seqs(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev, const int16_t *p3Di_rev,
+                        int L, const uint8_t *tAA, const uint8_t *t3Di, const uint64_t *offsets, const int32_t *lengths, int n,
+                        int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev) {
+    if (!ctx || !t3Di || !offsets || !lengths || n < 0 || !fwd || !rev || (pAA_fwd && !tAA)) { if (ctx) ctx->err = "fsgpu_sw_batch_seqs: bad argument"; return FSGPU_E_ARG; }
+    if (ctx->sw.pending) { ctx->err = "previous SW batch not finished"; return FSGPU_E_ARG; }
+    if (n == 0) return FSGPU_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t bytes = offsets[n];
+    int rc;
+    if ((rc = ensure(ctx, ctx->ovSS, bytes + 16)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ovAA, bytes + 16)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ovOff, (size_t) (n + 1) * 8)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ovLen, (size_t) n * 4)) != FSGPU_OK) return rc;
+    ctx->sw.ovLengths.assign(lengths, lengths + n);
+    for (int i = 0; i < n; i++)
+        if (lengths[i] <= 0 || lengths[i] > FSGPU_MAX_SEQ_LEN || offsets[i] + (uint64_t) lengths[i] > bytes) { ctx->err = "fsgpu_sw_batch_seqs: bad target layout"; return FSGPU_E_ARG; }
+    // pageable sources: synchronous copies (this path serves a handful of pairs per query)
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(ctx->ovSS.p, t3Di, bytes, hipMemcpyHostToDevice));
+    if (tAA) HIPCHK(hipMemcpy(ctx->ovAA.p, tAA, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->ovOff.p, offsets, (size_t) (n + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->ovLen.p, lengths, (size_t) n * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> ids(n);
+    for (int i = 0; i < n; i++) ids[i] = (uint32_t) i;
+    rc = swLaunchImpl(ctx, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, ids.data(), n, gapOpen, gapExtend, true);
+    if (rc != FSGPU_OK) { ctx->sw.explicitTargets = false; return rc; }
+    rc = fsgpu_sw_finish(ctx, fwd, rev);
+    ctx->sw.explicitTargets = false;
+    return rc;
+}
+
+static int swLaunchImpl(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev,
+                        const int16_t *p3Di_rev, int L, const uint32_t *targetIds, int n, int gapOpen, int gapExtend, bool explicitTargets) {
     if (!ctx) return FSGPU_E_ARG;
     if (!p3Di_fwd || !p3Di_rev || L <= 0 || L > FSGPU_MAX_SEQ_LEN || n < 0 || (n > 0 && !targetIds) || ((pAA_fwd == nullptr) != (pAA_rev == nullptr))) {
         ctx->err = "fsgpu_sw_launch: bad argument"; return FSGPU_E_ARG;
     }
     if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
-    if (pAA_fwd && !ctx->db->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
+    if (pAA_fwd && !explicitTargets && !ctx->db->hasAA) { ctx->err = "AA profiles given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
     if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
         ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
         return FSGPU_E_UNSUPPORTED;
     }
     if (ctx->sw.pending) { ctx->err = "previous SW batch not finished"; return FSGPU_E_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->sw.explicitTargets = explicitTargets;
+    const std::vector<int32_t> &hLen = explicitTargets ? ctx->sw.ovLengths : ctx->db->hLengths;
+    const uint64_t nTargets = explicitTargets ? ctx->sw.ovLengths.size() : ctx->db->n;
     ctx->sw.n = n; ctx->sw.L = L; ctx->sw.go = gapOpen; ctx->sw.ge = gapExtend; ctx->sw.hasAA = pAA_fwd != nullptr;
     ctx->sw.pAAf = pAA_fwd; ctx->sw.p3f = p3Di_fwd; ctx->sw.pAAr = pAA_rev; ctx->sw.p3r = p3Di_rev;
     ctx->sw.tids.assign(targetIds, targetIds + n);
-    ctx->sw.pending = true;
-    if (n == 0) return FSGPU_OK;
+    if (n == 0) { ctx->sw.pending = true; return FSGPU_OK; }
     int maxLt = 1;
     for (int i = 0; i < n; i++) {
-        if (targetIds[i] >= ctx->db->n) { ctx->sw.pending = false; ctx->err = "target id out of range"; return FSGPU_E_ARG; }
-        maxLt = std::max(maxLt, ctx->db->hLengths[targetIds[i]]);
+        if (targetIds[i] >= nTargets) { ctx->err = "target id out of range"; return FSGPU_E_ARG; }
+        maxLt = std::max(maxLt, hLen[targetIds[i]]);
     }
     int rc;
     if ((rc = ensure(ctx, ctx->tids, (size_t) n * 4)) != FSGPU_OK) return rc;
@@ -773,11 +823,12 @@ int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     rc = runSwPass(ctx, true, pAA_fwd, p3Di_fwd, pAA_rev, p3Di_rev, L, (const uint32_t *) ctx->tids.p, n, maxLt, gapOpen, gapExtend,
                    (int32_t *) ctx->res0.p, (int32_t *) ctx->res1.p);
-    if (rc != FSGPU_OK) { ctx->sw.pending = false; return rc; }
+    if (rc != FSGPU_OK) return rc;
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->evValid[1] = true;
     HIPCHK(hipMemcpyAsync(ctx->hRes0.p, ctx->res0.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->hRes1.p, ctx->res1.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sw.pending = true;          // only now: an error above leaves the context free for the next launch
     return FSGPU_OK;
 }
 
@@ -785,6 +836,7 @@ int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev) {
     if (!ctx || !fwd || !rev) return FSGPU_E_ARG;
     if (!ctx->sw.pending) { ctx->err = "no SW batch in flight"; return FSGPU_E_ARG; }
     ctx->sw.pending = false;
+    HIPCHK(hipSetDevice(ctx->device));        // the int32 re-run below launches kernels: the calling thread may have another device current
     const int n = ctx->sw.n;
     if (n == 0) return FSGPU_OK;
     { int rc = syncStream(ctx); if (rc != FSGPU_OK) return rc; }
@@ -799,11 +851,12 @@ int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev) {
         for (int i = 0; i < n; i++)
             if (res[i].score == 32767) {
                 ids.push_back(ctx->sw.tids[i]); where.push_back(i);
-                maxLt = std::max(maxLt, ctx->db->hLengths[ctx->sw.tids[i]]);
+                maxLt = std::max(maxLt, (ctx->sw.explicitTargets ? ctx->sw.ovLengths : ctx->db->hLengths)[ctx->sw.tids[i]]);
             }
         if (ids.empty()) continue;
         const int m = (int) ids.size();
-        HIPCHK(hipMemcpy(ctx->tids.p, ids.data(), (size_t) m * 4, hipMemcpyHostToDevice));
+        memcpy(ctx->hTids.p, ids.data(), (size_t) m * 4);         // pinned staging (sized for n >= m at launch), ordered on the context stream
+        HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->hTids.p, (size_t) m * 4, hipMemcpyHostToDevice, ctx->stream));
         const int16_t *pA = dir == 0 ? ctx->sw.pAAf : ctx->sw.pAAr;
         const int16_t *p3 = dir == 0 ? ctx->sw.p3f : ctx->sw.p3r;
         int rc = runSwPass(ctx, false, pA, p3, nullptr, nullptr, ctx->sw.L, (const uint32_t *) ctx->tids.p, m, maxLt, ctx->sw.go, ctx->sw.ge,

@@ -89,6 +89,7 @@ struct fsgpu_ctx {
     hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
     hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf img, tids, res0, res1, border0, border1, keys;
+    DevBuf ovAA, ovSS, ovOff, ovLen;               // explicit target sequences of fsgpu_sw_batch_seqs (instead of database entries)
     PinBuf hRes0, hRes1;                           // pinned result staging
     struct {
         bool pending = false;
@@ -96,6 +97,8 @@ struct fsgpu_ctx {
         bool hasAA = false;
         std::vector<uint32_t> tids;
         const int16_t *pAAf = nullptr, *p3f = nullptr, *pAAr = nullptr, *p3r = nullptr;
+        bool explicitTargets = false;              // the batch runs on ovAA/ovSS/ovOff/ovLen, ids = 0..n-1
+        std::vector<int32_t> ovLengths;            // host copy of their lengths
     } sw;
 };
 

@@ -105,7 +105,7 @@ const FlagSpec kAlignFlags[] = {               // LocalParameters::structurealig
     {"-a", true, USE, "0"}, {"--add-backtrace", true, USE, "0"}, {"--alignment-mode", false, ONLY, "0|3"},
     {"--alignment-output-mode", false, ONLY, "0"}, {"--wrapped-scoring", true, ONLY, "0"}, {"-e", false, USE, nullptr},
     {"--min-seq-id", false, USE, nullptr}, {"--min-aln-len", false, USE, nullptr}, {"--seq-id-mode", false, USE, nullptr},
-    {"--alt-ali", false, ONLY, "0"}, {"-c", false, USE, nullptr}, {"--cov-mode", false, USE, nullptr},
+    {"--alt-ali", false, USE, nullptr}, {"-c", false, USE, nullptr}, {"--cov-mode", false, USE, nullptr},
     {"--max-seq-len", false, USE, nullptr}, {"--comp-bias-corr", false, USE, nullptr}, {"--comp-bias-corr-scale", false, USE, nullptr},
     {"--max-rejected", false, USE, nullptr}, {"--max-accept", false, USE, nullptr}, {"--add-self-matches", true, USE, "0"},
     {"--pca", false, IGNORE, nullptr}, {"--pcb", false, IGNORE, nullptr}, {"--score-bias", false, ONLY, "0|0.0|0.000"},
@@ -268,6 +268,7 @@ void fillParams(const Options &o, fshost_params &p) {
     p.seqIdThr = (float) o.getd("--min-seq-id", p.seqIdThr);
     p.alnLenThr = o.geti("--min-aln-len", p.alnLenThr);
     p.seqIdMode = o.geti("--seq-id-mode", p.seqIdMode);
+    p.altAlignment = std::max(0, o.geti("--alt-ali", p.altAlignment));
 }
 
 // Sequence::mapSequence cuts entries at --max-seq-len (M/src/commons/Sequence.cpp:289-300); truncation is not implemented
@@ -874,7 +875,7 @@ int fsmod_search(int argc, const char **argv) {
             std::vector<const uint8_t *> lA, l3; std::vector<const uint32_t *> lT; std::vector<fshost_result *> lR;
             std::vector<int> lL, lN, lres(live.size()); std::vector<int64_t> lI;
             for (size_t k : live) {
-                res[k].resize(ids[k].size() + 1);
+                res[k].resize(ids[k].size() * (size_t) (1 + par.altAlignment) + 1);
                 lA.push_back(pA[k]); l3.push_back(p3[k]); lT.push_back(ids[k].data()); lR.push_back(res[k].data());
                 lL.push_back(Ls[k]); lN.push_back((int) ids[k].size());
                 // structurealign compares the query's and the target's INDEX in their readers (structurealign.cpp:359)
@@ -984,7 +985,7 @@ int fsmod_structurealign(int argc, const char **argv) {
                     if (*data == '\n') data++;
                 }
                 if (bad) break;
-                res[m].resize(ids[m].size() + 1);
+                res[m].resize(ids[m].size() * (size_t) (1 + par.altAlignment) + 1);
                 entry[m] = id; pA[m] = cA[m].data(); p3[m] = c3[m].data(); pT[m] = ids[m].data(); pR[m] = res[m].data();
                 Ls[m] = (int) L; ns[m] = (int) ids[m].size();
                 ident[m] = (sameDB || includeIdentical) ? qid : -1;      // queryId == targetId, reader indices (structurealign.cpp:359)

@@ -301,6 +301,74 @@ bool passesScoreGates(const fshost_search *s, const AlignQuery &aq, uint32_t tid
     return !(evalue > par.evalThr);
 }
 
+// --alt-ali (structurealign.cpp:115-138, 415-429): after an accepted hit, up to altAlignment more alignments of the SAME
+// target, each on the target with the previous alignment's range [dbStartPos, dbEndPos) overwritten by X in both alphabets
+// (cumulative), through the whole of alignStructure again (forward SW, coverage + e-value gates, reversed SW, e-value of the
+// difference, block backtrace) and checkCriteria with isIdentity = false.  The masked sequence exists only here, so the
+// pair goes to the device as an explicit sequence (fsgpu_sw_batch_seqs).  first = the accepted result; appends to results.
+int alternativeAlignments(fshost_search *s, const AlignQuery &aq, uint32_t tid, const fshost_result &first, fshost_result *results, int &nres, int resCap) {
+    const fshost_params &par = s->par;
+    const bool useAA = par.alignmentType == 2;
+    const int L = aq.L, Lt = s->lengths[tid];
+    std::vector<uint8_t> tAA(Lt), t3Di(Lt);
+    for (int i = 0; i < Lt; i++) {
+        uint8_t c = s->data3di[s->offsets[tid] + i];
+        c = c >= 32 ? c - 32 : c;
+        t3Di[i] = c > 20 ? 20 : c;
+        uint8_t a = s->dataAA ? s->dataAA[s->offsets[tid] + i] : 20;
+        a = a >= 32 ? a - 32 : a;
+        tAA[i] = a > 20 ? 20 : a;
+    }
+    fshost_result prev = first;
+    const uint64_t offs[2] = {0, (uint64_t) Lt};
+    const int32_t lens[1] = {Lt};
+    for (int alt = 0; alt < par.altAlignment && nres < resCap; alt++) {
+        // a failed block alignment leaves dbStartPos = -1: the reference's loop then starts one byte BEFORE the sequence
+        // buffer; the in-range part of that is [0, dbEndPos)
+        for (int pos = std::max(prev.dbStartPos, 0); pos < prev.dbEndPos && pos < Lt; ++pos) { tAA[pos] = 20; t3Di[pos] = 20; }
+        fsgpu_swres f, r;
+        int rc = fsgpu_sw_batch_seqs(s->ctx, useAA ? aq.pAAf.data() : nullptr, aq.p3f.data(), useAA ? aq.pAAr.data() : nullptr, aq.p3r.data(), L,
+                                     tAA.data(), t3Di.data(), offs, lens, 1, par.gapOpen, par.gapExtend, &f, &r);
+        if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+        // ---- alignStructure on the masked target ----
+        float qCov = computeCov(0, f.qEnd, L), tCov = computeCov(0, f.dbEnd, Lt);
+        if (!hasCoverage(par.covThr, par.covMode, qCov, tCov)) break;
+        double evalue = s->evaluer.computeEvalueCorr((double) (uint32_t) f.score, aq.lambda, aq.mu);
+        if (evalue > par.evalThr) break;
+        const int32_t score = f.score - r.score;
+        evalue = s->evaluer.computeEvalueCorr(score, aq.lambda, aq.mu);
+        if (evalue > par.evalThr) break;
+        BlockAlnOut bo;
+        blockBacktrace(s->matAA, s->mat3Di, aq.qAA, aq.q3di, aq.cbAA.data(), aq.cbSS.data(), L, tAA.data(), t3Di.data(), Lt, f.qEnd, f.dbEnd,
+                       f.score, par.gapOpen, par.gapExtend, bo);
+        fshost_result a;
+        memset(&a, 0, sizeof(a));
+        int qStart = -1, dbStart = -1;
+        float seqId = 0.0f;
+        if (bo.ok) {
+            qStart = bo.qStart; dbStart = bo.dbStart;
+            qCov = computeCov(qStart, f.qEnd, L);
+            tCov = computeCov(dbStart, f.dbEnd, Lt);
+        }
+        unsigned int alnLength = std::max(abs(f.qEnd - qStart), abs(f.dbEnd - dbStart)) + 1;
+        if (bo.backtrace.size() > 0) {
+            alnLength = bo.backtrace.size();
+            const int den = par.seqIdMode == 1 ? std::min(L, Lt) : par.seqIdMode == 2 ? std::max(L, Lt) : (int) alnLength;
+            seqId = static_cast<float>(bo.identicalAA) / static_cast<float>(den);
+        }
+        a.dbKey = s->keys[tid]; a.score = score; a.qcov = qCov; a.dbcov = tCov; a.seqId = seqId; a.eval = evalue;
+        a.alnLength = alnLength; a.qStartPos = qStart; a.qEndPos = f.qEnd; a.qLen = L; a.dbStartPos = dbStart; a.dbEndPos = f.dbEnd;
+        a.dbLen = Lt; a.backtraceOff = (uint32_t) s->cigars.size(); a.backtraceLen = (uint32_t) bo.backtrace.size();
+        // Alignment::checkCriteria(altRes, false, ...)
+        if (!((a.eval <= par.evalThr) && (a.seqId >= par.seqIdThr) && hasCoverage(par.covThr, par.covMode, a.qcov, a.dbcov) && (int) a.alnLength >= par.alnLenThr)) break;
+        s->cigars.append(bo.backtrace);
+        s->cigars.push_back('\0');
+        results[nres++] = a;
+        prev = a;
+    }
+    return FSGPU_OK;
+}
+
 // alignStructure gates + backtrace + checkCriteria + ordering for one query (structurealign.cpp:37-112,350-445).
 // pre / preIdx: backtraces computed ahead by the worker pool (preIdx[k] = index into pre, -1 = none); without them the
 // backtrace of a pair is computed here, when the loop reaches it (the --max-accept / --max-rejected path).
@@ -308,6 +376,7 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
               const fsgpu_swres *rev, fshost_result *results, double &tBack, const BlockAlnOut *pre, const int *preIdx) {
     const fshost_params &par = s->par;
     const int L = aq.L;
+    const int resCap = n * (1 + std::max(0, par.altAlignment));
     int passedNum = 0, rejected = 0, nres = 0;
     BlockAlnOut local;
     for (int k = 0; k < n && passedNum < par.maxAccept && rejected < par.maxRejected; k++) {
@@ -363,6 +432,10 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
             s->cigars.append(bo.backtrace);
             s->cigars.push_back('\0');
             results[nres++] = r;
+            if (par.altAlignment > 0) {
+                const int rc = alternativeAlignments(s, aq, tid, r, results, nres, resCap);
+                if (rc != FSGPU_OK) return rc;
+            }
             passedNum++;
             rejected = 0;
         } else {

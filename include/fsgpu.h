@@ -140,6 +140,13 @@ int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_f
                    const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,
                    const uint32_t *targetIds, int n, int gapOpen, int gapExtend,
                    fsgpu_swres *fwd, fsgpu_swres *rev);
+/* The same for n EXPLICIT target sequences instead of database entries: tAA / t3Di hold unmasked codes 0..20, entry k at
+ * offsets[k] with lengths[k] residues (offsets[n] = total bytes).  structurealign --alt-ali re-aligns a target whose
+ * previous alignment range was overwritten with X (F/src/strucclustutils/structurealign.cpp:115-138, 415-429); that
+ * sequence exists nowhere in the database.  tAA may be NULL when pAA_* are. */
+int fsgpu_sw_batch_seqs(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev,
+                        const int16_t *p3Di_rev, int L, const uint8_t *tAA, const uint8_t *t3Di, const uint64_t *offsets,
+                        const int32_t *lengths, int n, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev);
 /* Several queries per call (what a host thread of structurealign would do one after the other, structurealign.cpp:322-452):
  * same semantics per query as fsgpu_sw_batch; results are concatenated in query order (sum of n entries).  All queries of
  * at most 512 residues that share a register class run in ONE launch, which fills the device where a single query's
@@ -160,6 +167,8 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *queries, int nq, int ga
  * survivors.  Device side: two targets of one query share a wave (int16 halves), half the waves of fsgpu_sw_batch. */
 int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, int dir,
                        const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out);
+/* Asynchronous halves of fsgpu_sw_batch.  The four profile arrays and targetIds are BORROWED until fsgpu_sw_finish returns
+ * (the int32 re-run of saturated pairs reads the profiles again); after a failed _launch nothing is pending. */
 int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
                     const int16_t *pAA_rev, const int16_t *p3Di_rev, int L,
                     const uint32_t *targetIds, int n, int gapOpen, int gapExtend);

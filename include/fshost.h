@@ -129,11 +129,11 @@ const char *fshost_search_error(const fshost_search *s);
 
 /* Prefilter one query: fills hits (capacity maxResListLen) sorted like the reference; returns count or < 0. */
 int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_t identityId, fsgpu_hit *hits);
-/* Align one query against a hit list (target indices); results (capacity n) sorted like structurealign writes them.
+/* Align one query against a hit list (target indices); results (capacity n * (1 + altAlignment)) sorted like structurealign writes them.
  * Returns number of accepted alignments or < 0. */
 int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,
                         const uint32_t *targetIds, int n, fshost_result *results);
-/* The same for nq queries with one forward and one reversed device pass (fsgpu_sw_multi_dir): results[q] has room for n[q] entries, nres[q] receives
+/* The same for nq queries with one forward and one reversed device pass (fsgpu_sw_multi_dir): results[q] has room for n[q] * (1 + altAlignment) entries, nres[q] receives
  * the number of accepted alignments of query q; identityId may be NULL.  Returns 0 or < 0. */
 int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
                               const int64_t *identityId, const uint32_t *const *targetIds, const int *n,

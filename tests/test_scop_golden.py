@@ -18,7 +18,7 @@ GOLD = os.path.join(ROOT, "tests", "golden", "scop_v1")
 MANIFEST = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
 
 # runs whose parameters ask for something the device path refuses (with a message) instead of computing it
-NOT_IMPLEMENTED = {"aln_t2_a_altali": "--alt-ali 2 is not implemented"}
+NOT_IMPLEMENTED = {}
 
 
 def read_db(path):
