@@ -24,7 +24,7 @@ class Params(C.Structure):
                 ("prefCompBiasScale", C.c_float), ("alignmentType", C.c_int), ("alnCompBiasScale", C.c_float),
                 ("gapOpen", C.c_int), ("gapExtend", C.c_int), ("evalThr", C.c_double), ("covThr", C.c_float),
                 ("covMode", C.c_int), ("addBacktrace", C.c_int), ("maxAccept", C.c_int), ("maxRejected", C.c_int),
-                ("seqIdThr", C.c_float), ("alnLenThr", C.c_int), ("seqIdMode", C.c_int), ("altAlignment", C.c_int)]
+                ("seqIdThr", C.c_float), ("alnLenThr", C.c_int), ("seqIdMode", C.c_int), ("altAlignment", C.c_int), ("skipUndefinedDiagonals", C.c_int)]
 
 
 class KmerIndexParams(C.Structure):

@@ -100,7 +100,7 @@ const FlagSpec kUngappedFlags[] = {            // Parameters::ungappedprefilter 
 
 const FlagSpec kAlignFlags[] = {               // LocalParameters::structurealign = structurealign + Parameters::align
     {"--tmscore-threshold", false, ONLY, "0|0.0|0.000"}, {"--tmscore-threshold-mode", false, IGNORE, nullptr},
-    {"--lddt-threshold", false, ONLY, "0|0.0|0.000"}, {"--sort-by-structure-bits", false, USE, nullptr},
+    {"--lddt-threshold", false, ONLY, "0|0.0|0.000"},
     {"--alignment-type", false, ONLY, "0|2"}, {"--exact-tmscore", false, IGNORE, nullptr},
     {"-a", true, USE, "0"}, {"--add-backtrace", true, USE, "0"}, {"--alignment-mode", false, ONLY, "0|3"},
     {"--alignment-output-mode", false, ONLY, "0"}, {"--wrapped-scoring", true, ONLY, "0"}, {"-e", false, USE, nullptr},
@@ -111,8 +111,12 @@ const FlagSpec kAlignFlags[] = {               // LocalParameters::structurealig
     {"--pca", false, IGNORE, nullptr}, {"--pcb", false, IGNORE, nullptr}, {"--score-bias", false, ONLY, "0|0.0|0.000"},
     {"--realign", true, ONLY, "0"}, {"--realign-score-bias", false, IGNORE, nullptr}, {"--realign-max-seqs", false, IGNORE, nullptr},
     {"--corr-score-weight", false, IGNORE, nullptr}, {"--gap-open", false, USE, nullptr}, {"--gap-extend", false, USE, nullptr},
-    {"--zdrop", false, IGNORE, nullptr}, {"--align-batch", false, USE, nullptr},
+    {"--zdrop", false, IGNORE, nullptr},
     {nullptr, false, USE, nullptr}};
+const FlagSpec kStructAlignOnlyFlags[] = {     // structurealign, not structurerescorediagonal (LocalParameters.cpp:154-167)
+    {"--sort-by-structure-bits", false, USE, nullptr}, {"--align-batch", false, USE, nullptr}, {nullptr, false, USE, nullptr}};
+const FlagSpec kRescoreOnlyFlags[] = {         // ours: what to do with pairs whose reference result is undefined (see fsgpu.h)
+    {"--undefined-diagonals", false, ONLY, "fail|skip"}, {nullptr, false, USE, nullptr}};
 
 const FlagSpec kSearchFlags[] = {              // the fused module: prefilter / ungappedprefilter + structurealign
     {"--prefilter-mode", false, ONLY, "0|1"}, {nullptr, false, USE, nullptr}};
@@ -749,7 +753,7 @@ int fsmod_search(int argc, const char **argv) {
     Options o;
     {
         std::string perr;
-        if (!parseArgs(argc, argv, "search", {kSearchFlags, kPrefilterFlags, kAlignFlags, kCommonFlags}, o, perr)) return fail(perr);
+        if (!parseArgs(argc, argv, "search", {kSearchFlags, kPrefilterFlags, kAlignFlags, kStructAlignOnlyFlags, kCommonFlags}, o, perr)) return fail(perr);
     }
     if (o.pos.size() != 3 && o.pos.size() != 4)
         return fail("usage: search <queryDB> <targetDB> <outAlnDB> [<outPrefDB>] [--prefilter-mode 0|1] [-s S] [--max-seqs N] [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
@@ -913,7 +917,7 @@ int fsmod_structurealign(int argc, const char **argv) {
     Options o;
     {
         std::string perr;
-        if (!parseArgs(argc, argv, "structurealign", {kAlignFlags, kCommonFlags}, o, perr)) return fail(perr);
+        if (!parseArgs(argc, argv, "structurealign", {kAlignFlags, kStructAlignOnlyFlags, kCommonFlags}, o, perr)) return fail(perr);
     }
     if (o.pos.size() != 4) return fail("usage: structurealign <queryDB> <targetDB> <prefDB> <outAlnDB> [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
@@ -1012,6 +1016,124 @@ int fsmod_structurealign(int argc, const char **argv) {
     for (auto &th : ths) th.join();
     ds.close();
     if (bad) return fail("structurealign failed: " + firstErr);
+    for (size_t id = 0; id < pref.size(); id++) w.write(pref.key(id), results[id].data(), results[id].size());
+    if (!w.close(err)) return fail(err);
+    return EXIT_SUCCESS;
+}
+
+
+// structurerescorediagonal (a.k.a. structureungappedalign): rescoring of kmermatcher / prefilter hits along their diagonal
+int fsmod_structurerescorediagonal(int argc, const char **argv) {
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "structurerescorediagonal", {kAlignFlags, kRescoreOnlyFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
+    if (o.pos.size() != 4) return fail("usage: structurerescorediagonal <queryDB> <targetDB> <prefDB> <outAlnDB> [-e E] [-c C --cov-mode M] [--alignment-type 0|2] [-a] [--threads T] ...");
+    if (o.geti("--alt-ali", 0) != 0) return fail("structurerescorediagonal: --alt-ali is not read by this module");
+    std::string err;
+    DbReader qA, q3, tA, t3, pref;
+    if (!qA.open(o.pos[0], err) || !q3.open(o.pos[0] + "_ss", err) || !tA.open(o.pos[1], err) || !t3.open(o.pos[1] + "_ss", err) ||
+        !pref.open(o.pos[2], err))
+        return fail(err);
+    const bool sameDB = o.pos[0] == o.pos[1];
+    const bool includeIdentical = o.geti("--add-self-matches", 0) != 0;
+    fshost_params par;
+    fillParams(o, par);
+    par.skipUndefinedDiagonals = o.gets("--undefined-diagonals", "fail") == "skip";
+    if (!checkMaxSeqLen(o, q3, "query", err) || !checkMaxSeqLen(o, t3, "target", err)) return fail(err);
+    Matrix m3, mA;
+    m3.builtin(FSHOST_MAT_3DI, 2.1f, 0.0f);
+    mA.builtin(FSHOST_MAT_BLOSUM62, par.alignmentType == 2 ? 1.4f : 0.0f, 0.0f);
+    PaddedTarget pt;
+    if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
+    DeviceSet ds;
+    if (!ds.open(o, pt, true, 2, err)) { ds.close(); return fail(err); }
+    DbWriter w;
+    if (!w.open(o.pos[3], DBTYPE_ALIGNMENT_RES, err)) { ds.close(); return fail(err); }
+    const int nthreads = ds.threads();
+    std::vector<std::string> results(pref.size());
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    std::string firstErr;
+    const size_t group = 2048;       // prefilter entries per device call: a handful of pairs each
+    auto work = [&](int tix) {
+        bool owned = false;
+        fsgpu_ctx *ctx = ds.forThread(tix, owned);
+        if (!ctx) { bad++; return; }
+        fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, pt.dA, pt.offsets.data(), pt.lengths.data());
+        std::vector<std::vector<uint8_t>> cA(group), c3(group);
+        std::vector<std::vector<uint32_t>> ids(group);
+        std::vector<std::vector<int16_t>> diags(group);
+        std::vector<std::vector<fshost_result>> res(group);
+        std::vector<size_t> entry(group);
+        std::vector<const uint8_t *> pA(group), p3(group);
+        std::vector<const uint32_t *> pT(group);
+        std::vector<const int16_t *> pD(group);
+        std::vector<fshost_result *> pR(group);
+        std::vector<int> Ls(group), ns(group), nres(group);
+        std::vector<int64_t> ident(group);
+        std::vector<char> line(1024 + 2 * 65536 * 2);
+        for (;;) {
+            const size_t b0 = next.fetch_add(group);
+            if (b0 >= pref.size() || bad) break;
+            size_t m = 0;
+            for (size_t id = b0; id < std::min(pref.size(), b0 + group) && !bad; id++) {
+                const uint32_t queryKey = pref.key(id);
+                const char *data = pref.data(id);
+                if (*data == '\0') continue;
+                const int64_t qid = q3.idOf(queryKey);
+                if (qid < 0 || qA.idOf(queryKey) < 0) { if (!bad++) firstErr = "query key missing in query database"; break; }
+                const uint32_t L = q3.seqLen((size_t) qid);
+                cA[m].resize(L); c3[m].resize(L);
+                const char *sA = qA.data((size_t) qA.idOf(queryKey)), *s3 = q3.data((size_t) qid);
+                for (uint32_t i = 0; i < L; i++) { cA[m][i] = mA.aa2num[(unsigned char) sA[i]]; c3[m][i] = m3.aa2num[(unsigned char) s3[i]]; }
+                ids[m].clear(); diags[m].clear();
+                while (*data != '\0') {          // QueryMatcher::parsePrefilterHit: exactly three columns
+                    char *e1, *e2, *e3;
+                    const uint32_t dbKey = (uint32_t) strtoul(data, &e1, 10);
+                    (void) strtol(e1, &e2, 10);
+                    const long dg = strtol(e2, &e3, 10);
+                    if (e1 == data || e2 == e1 || e3 == e2) { if (!bad++) firstErr = "Invalid prefilter input"; break; }
+                    const int64_t tid = t3.idOf(dbKey);
+                    if (tid < 0) { if (!bad++) firstErr = "target key missing in target database"; break; }
+                    ids[m].push_back((uint32_t) tid);
+                    diags[m].push_back((int16_t) dg);
+                    while (*data != '\n' && *data != '\0') data++;
+                    if (*data == '\n') data++;
+                }
+                if (bad) break;
+                if (L == 0 || ids[m].empty()) continue;
+                res[m].resize(ids[m].size() + 1);
+                entry[m] = id; pA[m] = cA[m].data(); p3[m] = c3[m].data(); pT[m] = ids[m].data(); pD[m] = diags[m].data(); pR[m] = res[m].data();
+                Ls[m] = (int) L; ns[m] = (int) ids[m].size();
+                ident[m] = (sameDB || includeIdentical) ? qid : -1;      // queryId == targetId (structurerescorediagonal.cpp:310)
+                m++;
+            }
+            if (bad) break;
+            if (m == 0) continue;
+            if (fshost_search_rescore_diagonal_batch(s, (int) m, pA.data(), p3.data(), Ls.data(), ident.data(), pT.data(), pD.data(), ns.data(), pR.data(), nres.data()) != FSGPU_OK) {
+                if (!bad++) firstErr = fshost_search_error(s);
+                break;
+            }
+            for (size_t k = 0; k < m; k++) {
+                std::string &out = results[entry[k]];
+                for (int r = 0; r < nres[k]; r++) {
+                    const size_t need = 1024 + (size_t) res[k][r].backtraceLen + 64;
+                    if (line.size() < need) line.resize(need);
+                    out.append(line.data(), fshost_format_result(line.data(), &res[k][r], fshost_search_backtrace(s, &res[k][r]), par.addBacktrace));
+                }
+            }
+        }
+        fshost_search_free(s);
+        if (owned) fsgpu_destroy(ctx);
+    };
+    std::vector<std::thread> ths;
+    for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
+    work(0);
+    for (auto &th : ths) th.join();
+    ds.close();
+    if (bad) return fail("structurerescorediagonal failed: " + firstErr);
     for (size_t id = 0; id < pref.size(); id++) w.write(pref.key(id), results[id].data(), results[id].size());
     if (!w.close(err)) return fail(err);
     return EXIT_SUCCESS;

@@ -145,6 +145,7 @@ void fshost_params_default(fshost_params *p) {
     p->alnLenThr = 0;
     p->seqIdMode = 0;
     p->altAlignment = 0;
+    p->skipUndefinedDiagonals = 0;
 }
 
 fshost_search *fshost_search_create(fsgpu_ctx *ctx, const fshost_params *p, const uint32_t *keys, const char *nnPath,
@@ -580,6 +581,96 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
         base += (size_t) n[i];
     }
     s->stats[2] = t1 - t0; s->stats[3] = t2 - t1; s->stats[5] = tBack; s->stats[4] = nowSec() - t2 - tBack;
+    return FSGPU_OK;
+}
+
+// structurerescorediagonal's per-query body (F/src/strucclustutils/structurerescorediagonal.cpp:50-156, 300-370) for nq queries:
+// the Kadane scans run on the device (fsgpu_diag_rescore), here are the module's gates in the module's order.
+// diagonals[q][k] is the prefilter line's third column (a short, as parsePrefilterHit reads it).
+int fshost_search_rescore_diagonal_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
+                                         const int64_t *identityId, const uint32_t *const *targetIds, const int16_t *const *diagonals,
+                                         const int *n, fshost_result *const *results, int *nres) {
+    if (!s || !s->ctx || nq < 0 || (nq > 0 && (!qAA || !q3di || !L || !targetIds || !diagonals || !n || !results || !nres))) return FSGPU_E_ARG;
+    const fshost_params &par = s->par;
+    std::vector<uint8_t> catA, cat3;
+    std::vector<uint64_t> qOff(nq + 1, 0);
+    std::vector<int32_t> qLen(nq);
+    std::vector<fsgpu_diag_pair> pairs;
+    std::vector<size_t> base(nq + 1, 0);
+    for (int i = 0; i < nq; i++) {
+        if (!qAA[i] || !q3di[i] || L[i] <= 0 || n[i] < 0) return FSGPU_E_ARG;
+        qLen[i] = L[i];
+        qOff[i + 1] = qOff[i] + (uint64_t) ((L[i] + 3) / 4 * 4);
+        catA.resize(qOff[i + 1], 20); cat3.resize(qOff[i + 1], 20);
+        memcpy(catA.data() + qOff[i], qAA[i], L[i]); memcpy(cat3.data() + qOff[i], q3di[i], L[i]);
+        for (int k = 0; k < n[i]; k++) {
+            if (targetIds[i][k] >= s->keys.size()) { s->err = "target id out of range"; return FSGPU_E_ARG; }
+            pairs.push_back({(uint32_t) i, targetIds[i][k], (int32_t) diagonals[i][k]});
+        }
+        base[i + 1] = pairs.size();
+    }
+    std::vector<fsgpu_diag_res> dr(pairs.size());
+    const double t1 = nowSec();
+    if (!pairs.empty()) {
+        const int rc = fsgpu_diag_rescore(s->ctx, catA.data(), cat3.data(), qOff.data(), qLen.data(), nq, s->mat3Di.sub.data(), s->matAA.sub.data(),
+                                          pairs.data(), (int64_t) pairs.size(), dr.data());
+        if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    }
+    const double t2 = nowSec();
+    s->cigars.clear();
+    for (int i = 0; i < nq; i++) {
+        double lambda = 0, mu = 0;
+        s->evaluer.predictMuLambda(q3di[i], L[i], s->mat3Di.n, &lambda, &mu);
+        const int Lq = L[i];
+        int passedNum = 0, rejected = 0, cnt = 0;
+        for (int k = 0; k < n[i] && passedNum < par.maxAccept && rejected < par.maxRejected; k++) {
+            const uint32_t tid = targetIds[i][k];
+            const bool isIdentity = identityId && ((int64_t) tid == identityId[i]);
+            const int Lt = s->lengths[tid];
+            if (!canBeCovered(par.covThr, par.covMode, (float) Lq, (float) Lt)) { rejected++; continue; }
+            const fsgpu_diag_res &d = dr[base[i] + k];
+            if (d.status == FSGPU_DIAG_UNDEFINED || d.status == FSGPU_DIAG_NO_OVERLAP) {
+                if (par.skipUndefinedDiagonals) continue;
+                s->err = "structurerescorediagonal: query " + std::to_string(i) + " target key " + std::to_string(s->keys[tid]) + " diagonal " + std::to_string(diagonals[i][k]) +
+                         (d.status == FSGPU_DIAG_UNDEFINED ? ": negative diagonal with a target longer than the query -- the reference's reverse pass reads past the query here "
+                                                             "(structurerescorediagonal.cpp:96-99), its result is undefined"
+                                                           : ": diagonal outside the sequences (the reference indexes position -1 here)");
+                return FSGPU_E_UNSUPPORTED;
+            }
+            const int diagonal = diagonals[i][k];
+            const int dist = abs(diagonal);
+            const int32_t score = d.score - d.revScore;
+            const double evalue = s->evaluer.computeEvalueCorr(score, lambda, mu);
+            int qStart, qEnd, dbStart, dbEnd;
+            if (diagonal >= 0) { qStart = d.startPos + dist; qEnd = d.endPos + dist; dbStart = d.startPos; dbEnd = d.endPos; }
+            else { qStart = d.startPos; qEnd = d.endPos; dbStart = d.startPos + dist; dbEnd = d.endPos + dist; }
+            const unsigned int alnLength = std::max(abs(qEnd - qStart), abs(dbEnd - dbStart)) + 1;
+            const float queryCov = computeCov(qStart, qEnd, Lq), targetCov = computeCov(dbStart, dbEnd, Lt);
+            if (!hasCoverage(par.covThr, par.covMode, queryCov, targetCov)) { rejected++; continue; }
+            if (evalue > par.evalThr) { rejected++; continue; }
+            const int den = par.seqIdMode == 1 ? std::min(Lq, Lt) : par.seqIdMode == 2 ? std::max(Lq, Lt) : (int) alnLength;
+            fshost_result r;
+            memset(&r, 0, sizeof(r));
+            r.dbKey = s->keys[tid]; r.score = score; r.qcov = queryCov; r.dbcov = targetCov;
+            r.seqId = static_cast<float>(d.identicalAA) / static_cast<float>(den);
+            r.eval = evalue; r.alnLength = alnLength; r.qStartPos = qStart; r.qEndPos = qEnd; r.qLen = Lq;
+            r.dbStartPos = dbStart; r.dbEndPos = dbEnd; r.dbLen = Lt;
+            r.backtraceOff = (uint32_t) s->cigars.size(); r.backtraceLen = par.addBacktrace ? alnLength : 0;
+            const bool ok = (r.eval <= par.evalThr) && (r.seqId >= par.seqIdThr) && hasCoverage(par.covThr, par.covMode, r.qcov, r.dbcov) && (int) r.alnLength >= par.alnLenThr;
+            if (isIdentity || ok) {
+                if (par.addBacktrace) s->cigars.append(alnLength, 'M');
+                s->cigars.push_back('\0');
+                results[i][cnt++] = r;
+                passedNum++;
+                rejected = 0;
+            } else {
+                rejected++;
+            }
+        }
+        if (cnt > 1) std::sort(results[i], results[i] + cnt, compareHits);
+        nres[i] = cnt;
+    }
+    s->stats[3] = t2 - t1; s->stats[4] = nowSec() - t2;
     return FSGPU_OK;
 }
 

@@ -174,6 +174,36 @@ int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_
                     const uint32_t *targetIds, int n, int gapOpen, int gapExtend);
 int fsgpu_sw_finish(fsgpu_ctx *ctx, fsgpu_swres *fwd, fsgpu_swres *rev);
 
+/* ---- single-diagonal rescoring: Foldseek's structurerescorediagonal (F/src/strucclustutils/structurerescorediagonal.cpp:23-102) ----
+ * For every (query, target, diagonal) triple -- what linclust's kmermatcher hands on, prefilter-format lines
+ * "targetKey score diagonal" -- the best ungapped run of sub3Di[q][t] + subAA[q][t] along that one diagonal for the forward
+ * and for the reversed query.  Targets are entries of the resident database (AA half required), queries are given
+ * explicitly: codes 0..20, query k at qOffsets[k] with qLengths[k] residues (qOffsets[nq] = bytes).  mat3Di / matAA: the
+ * bit-scaled int16 matrices [21*21] (SubstitutionMatrix(3di.out, 2.1, 0) and (blosum62.out, 1.4 or 0.0, 0)). */
+typedef struct {
+    uint32_t query;         /* index into the query batch */
+    uint32_t target;        /* index in the loaded DB */
+    int32_t diagonal;       /* i - j as the prefilter prints it (int16 range) */
+} fsgpu_diag_pair;
+enum {
+    FSGPU_DIAG_OK = 0,
+    FSGPU_DIAG_NO_OVERLAP = 1,   /* |diagonal| beyond the sequence: the reference keeps LocalAlignment's defaults (-1, -1, 0) */
+    FSGPU_DIAG_UNDEFINED = 2,    /* negative diagonal with a target longer than the query: the reference's reverse pass reads
+                                    past the query (structurerescorediagonal.cpp:96-99); forward fields are valid, revScore is not */
+    FSGPU_DIAG_BAD_ID = 3
+};
+typedef struct {
+    int32_t score;          /* forward run */
+    int32_t startPos, endPos;   /* along the diagonal, like DistanceCalculator::LocalAlignment */
+    int32_t revScore;       /* reversed-query run (module score = score - revScore) */
+    int32_t diagonalLen;
+    int32_t identicalAA;    /* equal amino acids inside [startPos, endPos] */
+    int32_t status;         /* FSGPU_DIAG_* */
+    int32_t reserved;
+} fsgpu_diag_res;
+int fsgpu_diag_rescore(fsgpu_ctx *ctx, const uint8_t *qAA, const uint8_t *q3Di, const uint64_t *qOffsets, const int32_t *qLengths,
+                       int nq, const int16_t *mat3Di, const int16_t *matAA, const fsgpu_diag_pair *pairs, int64_t n, fsgpu_diag_res *out);
+
 /* ---- prefilter: k-mer matching with double-diagonal hits + ungapped diagonal scoring ------------------------- */
 /* Index parameters == the subset of Prefiltering's members that shape IndexTable / SequenceLookup.  Sequence-
  * sequence searches with k = 6 only (what setupSplit picks below 3.35e9 residues, IndexTable.h:456-458). */

@@ -96,6 +96,7 @@ typedef struct {
     int alnLenThr;            /* --min-aln-len 0 */
     int seqIdMode;            /* --seq-id-mode 0: identities / alignment length, 1: / shorter, 2: / longer sequence (Util::computeSeqId) */
     int altAlignment;         /* --alt-ali 0: up to this many alternative alignments per accepted hit (structurealign.cpp:115-138,415-429) */
+    int skipUndefinedDiagonals; /* structurerescorediagonal: 0 = fail on a pair whose reference result is undefined (FSGPU_DIAG_UNDEFINED / NO_OVERLAP), 1 = drop it */
 } fshost_params;
 
 void fshost_params_default(fshost_params *p);
@@ -138,6 +139,12 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
 int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
                               const int64_t *identityId, const uint32_t *const *targetIds, const int *n,
                               fshost_result *const *results, int *nres);
+/* structurerescorediagonal for nq queries (F/src/strucclustutils/structurerescorediagonal.cpp:50-156,300-370): targetIds / diagonals
+ * are the first and third column of the prefilter lines in their order; results[q] has room for n[q] entries; gates, e-value,
+ * seq. id, ordering and (with addBacktrace) the all-match backtrace as the module writes them. */
+int fshost_search_rescore_diagonal_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
+                                         const int64_t *identityId, const uint32_t *const *targetIds, const int16_t *const *diagonals,
+                                         const int *n, fshost_result *const *results, int *nres);
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r);
 /* Host wall time (seconds) spent in the stages of the last prefilter/align calls: [0] prefilter profile build,
  * [1] fsgpu_gapless_scan incl. wait, [2] align profiles + e-value net, [3] fsgpu_sw_batch incl. wait, [4] gates,
@@ -178,6 +185,8 @@ int fsmod_prefilter(int argc, const char **argv);
 int fsmod_search(int argc, const char **argv);   /* <queryDB> <targetDB> <outAlnDB> [<outPrefDB>]: prefilter + structurealign fused */
 int fsmod_structurealign(int argc, const char **argv);
 int fsmod_makepaddedseqdb(int argc, const char **argv);
+/* structurerescorediagonal <queryDB> <targetDB> <prefDB> <outAlnDB>   F/src/strucclustutils/structurerescorediagonal.cpp:159-393 */
+int fsmod_structurerescorediagonal(int argc, const char **argv);
 /* gpuserver <targetDB_ss[_pad]>: keeps the target DB resident in HBM and serves gapless scans over the reference's
  * shared-memory protocol until SIGINT/SIGTERM (M/src/util/gpuserver.cpp:24-101, M/src/commons/GpuUtil.h:9-49);
  * `ungappedprefilter ... --gpu-server 1` is the client (M/src/prefiltering/ungappedprefilter.cpp:71-122,208-257). */

@@ -91,6 +91,60 @@ RUNS = {
 }
 
 
+def rescore_par(atype, a, e, c, extra=()):
+    # F/data/structurecluster.sh via easy-cluster -v 3: ${STRUCTURERESCOREDIAGONAL_PAR}
+    return ["--exact-tmscore", "0", "--tmscore-threshold", "0", "--tmscore-threshold-mode", "0", "--lddt-threshold", "0",
+            "--alignment-type", str(atype), "--sub-mat", SUBMAT, "-a", str(a), "--alignment-mode", "3", "--alignment-output-mode", "0",
+            "--wrapped-scoring", "0", "-e", str(e), "--min-seq-id", "0", "--min-aln-len", "0", "--seq-id-mode", "0", "--alt-ali", "0",
+            "-c", str(c), "--cov-mode", "0", "--max-seq-len", "65535", "--comp-bias-corr", "0", "--comp-bias-corr-scale", "1",
+            "--max-rejected", "2147483647", "--max-accept", "2147483647", "--add-self-matches", "1", "--db-load-mode", "0",
+            "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800", "--score-bias", "0", "--realign", "0",
+            "--realign-score-bias", "-0.2", "--realign-max-seqs", "2147483647", "--corr-score-weight", "0", "--gap-open", "aa:10,nucl:10",
+            "--gap-extend", "aa:1,nucl:1", "--zdrop", "40", "--threads", "1", "--compressed", "0", "-v", "1"] + list(extra)
+
+
+RESCORE_RUNS = {
+    # structurerescorediagonal on the k-mer prefilter's (target, diagonal) lists restricted to the pairs whose reference result
+    # is DEFINED (pref_kmer_defined, written by write_defined_pref below: diagonal >= 0, or < 0 with a target not longer than
+    # the query -- see foldseek_amd/csrc/fsgpu_diag.hip); the first line is the parameter set of the cluster workflow
+    "resc_t2_clu": ("structurerescorediagonal", ["db", "db", "pref_kmer_defined"], rescore_par(2, 0, "0.01", "0.8")),
+    "resc_t2_a": ("structurerescorediagonal", ["db", "db", "pref_kmer_defined"], rescore_par(2, 1, "10", "0")),
+    "resc_t0_a_sid1": ("structurerescorediagonal", ["db", "db", "pref_kmer_defined"], override(rescore_par(0, 1, "1000", "0.3"), **{"--seq-id-mode": "1", "--cov-mode": "2"})),
+}
+
+
+def read_db(path):
+    data = open(path, "rb").read()
+    out = {}
+    for line in open(path + ".index"):
+        k, off, ln = line.split()
+        out[int(k)] = data[int(off):int(off) + int(ln) - 1]
+    return out
+
+
+def write_defined_pref(work):
+    """pref_kmer restricted to pairs with a defined reference result; an INPUT of the reference run, same on-disk format"""
+    lens = {int(l.split()[0]): int(l.split()[2]) - 2 for l in open(os.path.join(work, "db_ss.index"))}
+    pref = read_db(os.path.join(work, "pref_kmer"))
+    blob, index, off, kept, dropped = b"", [], 0, 0, 0
+    for q in sorted(pref):
+        lines = []
+        for ln in pref[q].decode().splitlines():
+            t, _, d = ln.split("\t")
+            d, lq, lt = int(d), lens[q], lens[int(t)]
+            ok = (d >= 0 and d < lq) or (d < 0 and -d < lt and lt <= lq)
+            kept += ok; dropped += not ok
+            if ok:
+                lines.append(ln)
+        body = ("\n".join(lines) + "\n" if lines else "").encode() + b"\0"
+        index.append(f"{q}\t{off}\t{len(body)}\n")
+        blob += body; off += len(body)
+    open(os.path.join(work, "pref_kmer_defined"), "wb").write(blob)
+    open(os.path.join(work, "pref_kmer_defined.index"), "w").write("".join(index))
+    shutil.copy(os.path.join(work, "pref_kmer.dbtype"), os.path.join(work, "pref_kmer_defined.dbtype"))
+    return kept, dropped
+
+
 def run(cmd, cwd):
     r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -115,6 +169,11 @@ def main():
     for name, (module, pos, par) in RUNS.items():
         cmd = [FS, module] + pos + [name] + par
         run(cmd, work)
+        manifest["runs"][name] = {"module": module, "positional": pos, "parameters": par}
+    kept, dropped = write_defined_pref(work)
+    manifest["pref_kmer_defined"] = {"pairs_kept": kept, "pairs_with_undefined_reference_result_dropped": dropped}
+    for name, (module, pos, par) in RESCORE_RUNS.items():
+        run([FS, module] + pos + [name] + par, work)
         manifest["runs"][name] = {"module": module, "positional": pos, "parameters": par}
     shutil.rmtree(OUT, ignore_errors=True)
     os.makedirs(OUT)

@@ -108,3 +108,19 @@ def test_fused_search_equals_reference_two_step(scop):
         assert r.returncode == 0, r.stderr
         assert read_db(outp) == read_db(str(scop / pref))
         assert read_db(out) == read_db(str(scop / aln))
+
+
+@pytest.mark.gpu
+def test_rescorediagonal_undefined_pairs_are_refused_or_skipped(scop):
+    """pref_kmer holds 297 (query, target, diagonal) lines whose reference result is undefined (negative diagonal, target longer
+    than the query: the reference's reverse pass reads past the query, structurerescorediagonal.cpp:96-99).  Default: the module
+    says so and fails; --undefined-diagonals skip drops exactly those lines == the reference run on the defined lines."""
+    run = MANIFEST["runs"]["resc_t2_a"]
+    pos = [str(scop / "db"), str(scop / "db"), str(scop / "pref_kmer")]
+    r = subprocess.run([BIN, "structurerescorediagonal"] + pos + [str(scop / "mine_u1")] + run["parameters"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "undefined" in r.stderr and "structurerescorediagonal.cpp:96-99" in r.stderr
+    out = str(scop / "mine_u2")
+    r = subprocess.run([BIN, "structurerescorediagonal"] + pos + [out] + run["parameters"] + ["--undefined-diagonals", "skip"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    assert read_db(out) == read_db(str(scop / "resc_t2_a"))
