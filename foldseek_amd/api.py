@@ -123,6 +123,16 @@ def lib():
                                          C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
         "fshost_format_prefilter_hit": (C.c_size_t, [C.c_char_p, C.c_uint32, i32, i32]),
         "fshost_format_result": (C.c_size_t, [C.c_char_p, vp, C.c_char_p, i32]),
+        "fsgpu_gapless_scan_multi": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        "fsgpu_gapless_last_batch": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "fsgpu_gapless_scores_multi": (i32, [vp, i32, vp]),
+        "fsgpu_sw_batch_seqs": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+        "fsgpu_diag_rescore": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]),
+        "fshost_search_prefilter_batch": (i32, [vp, i32, vp, vp, vp, vp, vp]),
+        "fshost_search_rescore_diagonal_batch": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "fshost_set_host_workers": (None, [i32]),
+        "fshost_host_workers": (i32, []),
+        "fshost_usable_cores": (i32, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -379,6 +389,16 @@ class Context:
         """ms of the last k-mer batch: device total, count, lists, emit, sort, dupflags, score, walk, select; [9] host tail; [10] k_kmer_lists kernel alone"""
         return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(11)]
 
+    def gapless_scores_multi(self, query_index):
+        out = np.zeros(self.n, np.uint8)
+        self._chk(lib().fsgpu_gapless_scores_multi(self.h, int(query_index), _ptr(out)), "gapless_scores_multi")
+        return out
+
+    def gapless_last_batch(self):
+        a, b = C.c_int(0), C.c_int(0)
+        lib().fsgpu_gapless_last_batch(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def gapless_scores(self):
         s = np.zeros(self.n, np.uint8)
         self._chk(lib().fsgpu_gapless_scores(self.h, _ptr(s)), "fsgpu_gapless_scores")
@@ -459,6 +479,22 @@ class Search:
         if n < 0:
             raise FsgpuError(f"prefilter rc={n}: {lib().fshost_search_error(self.h).decode()}")
         return hits[:n]
+
+    def prefilter_batch(self, q3dis, identity=None):
+        """several queries, as few scan launches as their lengths allow (fsgpu_gapless_scan_multi); list of hit arrays"""
+        nq = len(q3dis)
+        q3 = [np.ascontiguousarray(x, np.uint8) for x in q3dis]
+        P = C.c_void_p * max(nq, 1)
+        p3 = P(*[x.ctypes.data for x in q3])
+        Ls = np.array([len(x) for x in q3], np.int32)
+        ident = None if identity is None else np.ascontiguousarray(identity, np.int64)
+        K = self.par.maxResListLen
+        hits = np.zeros(max(1, nq * K), HIT_DT)
+        nh = np.zeros(max(nq, 1), np.int32)
+        rc = lib().fshost_search_prefilter_batch(self.h, nq, C.cast(p3, C.c_void_p), _ptr(Ls), _ptr(ident), _ptr(hits), _ptr(nh))
+        if rc != 0:
+            raise FsgpuError(f"prefilter_batch rc={rc}: {lib().fshost_search_error(self.h).decode()}")
+        return [hits[i * K:i * K + nh[i]].copy() for i in range(nq)]
 
     def align(self, qAA, q3di, target_ids, identity=-1, with_backtrace=False):
         qa = np.ascontiguousarray(qAA, np.uint8)

@@ -71,12 +71,15 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (ctx->kmer) fsgpu_kmer_free_scratch(ctx->kmer);
     DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
                       &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys,
-                      &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen};
+                      &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen,
+                      &ctx->mqPssm, &ctx->mqScores, &ctx->mqQueues, &ctx->mqRec, &ctx->mqHist, &ctx->mqBaseGt, &ctx->mqBaseTie, &ctx->mqMeta,
+                      &ctx->mqOutId, &ctx->mqOutScore, &ctx->mqIdent};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     hipFree(ctx->dMeta); hipFree(ctx->queue);
     hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId.p); hipHostFree(ctx->hOutScore.p);
     hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p);
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
+    hipHostFree(ctx->hMqPssm.p); hipHostFree(ctx->hMqRec.p); hipHostFree(ctx->hMqMeta.p); hipHostFree(ctx->hMqOutId.p); hipHostFree(ctx->hMqOutScore.p); hipHostFree(ctx->hMqIdent.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamDestroy(ctx->swAux[i]);
     for (int i = 0; i < 7; i++) if (ctx->swAuxEv[i]) (void) hipEventDestroy(ctx->swAuxEv[i]);
@@ -436,7 +439,10 @@ static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint4 **items, uint32_t *n
             }
         }
         HIPCHK(hipMalloc((void **) &l.items, std::max<size_t>(rec.size(), 1) * sizeof(uint4)));
-        if (!rec.empty()) HIPCHK(hipMemcpy(l.items, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        if (!rec.empty()) {
+            const hipError_t ce = hipMemcpy(l.items, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice);
+            if (ce != hipSuccess) { (void) hipFree(l.items); l.items = nullptr; ctx->err = std::string("hipMemcpy(work items): ") + hipGetErrorString(ce); return FSGPU_E_HIP; }
+        }
         l.n = (uint32_t) v.size(); l.split = split; l.built = true;
     }
     *items = l.items; *nItems = l.n; *anySplit = l.split;
@@ -447,7 +453,8 @@ static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint4 **items, uint32_t *n
 // gapless scan
 // ------------------------------------------------------------------------------------------------------------
 template <int R, bool TILED>
-static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
+static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &gaIn) {
+    GaplessArgs ga = gaIn;
     const int lds = gaplessLdsBytes(R);
     static thread_local uint64_t attrDevs = 0;       // devices on which this thread has set the attribute (it is per device)
     static thread_local int perCUcached = 0;
@@ -466,7 +473,10 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &ga) {
     // one wave needs one stripe at a time: do not launch more waves than stripes
     uint32_t blocks = (uint32_t) std::min<uint64_t>((uint64_t) ctx->numCU * perCU, ((uint64_t) ga.nItems + wavesPerBlock - 1) / wavesPerBlock);
     blocks = std::max(blocks, 1u);
-    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks), dim3(kGaplessBlock), lds, ctx->stream, ga);
+    // multi-query launch: ga.blocksPerQuery carries the number of queries on entry; every query gets `blocks` workgroups
+    const uint32_t nQueries = ga.queries ? std::max(1u, ga.blocksPerQuery) : 1u;
+    ga.blocksPerQuery = blocks;
+    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks * nQueries), dim3(kGaplessBlock), lds, ctx->stream, ga);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
@@ -507,6 +517,7 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     memcpy(ctx->hPssm.p, pssm, (size_t) kAlphabet * L);
     HIPCHK(hipMemcpyAsync(ctx->pssm.p, ctx->hPssm.p, (size_t) kAlphabet * L, hipMemcpyHostToDevice, ctx->stream));
     GaplessArgs ga;
+    ga.queries = nullptr; ga.blocksPerQuery = 0;
     ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen; ga.stripeTargets = ctx->db->stripeTargets;
     bool anySplit = false;
     if ((rc = gaplessItems(ctx, nTiles > 1 ? 0 : R, &ga.items, &ga.nItems, &anySplit)) != FSGPU_OK) return rc;
@@ -552,12 +563,12 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     }
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(k_sel_hist, dim3(nChunks), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->scores.p, n, minScore,
-                       identityId, (uint32_t *) ctx->chunkHist.p);
+                       identityId, (uint32_t *) ctx->chunkHist.p, (const int64_t *) nullptr, (uint64_t) 0);
     hipLaunchKernelGGL(k_sel_threshold, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *) ctx->chunkHist.p, nChunks, K, ctx->dMeta,
                        (uint32_t *) ctx->baseGt.p, (uint32_t *) ctx->baseTie.p);
     hipLaunchKernelGGL(k_sel_emit, dim3(nChunks), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->scores.p, n, minScore,
                        identityId, (const SelMeta *) ctx->dMeta, (const uint32_t *) ctx->baseGt.p, (const uint32_t *) ctx->baseTie.p,
-                       (uint32_t *) ctx->outId.p, (int32_t *) ctx->outScore.p);
+                       (uint32_t *) ctx->outId.p, (int32_t *) ctx->outScore.p, (const int64_t *) nullptr, (uint64_t) 0, K);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->hMeta, ctx->dMeta, sizeof(SelMeta), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->hOutId.p, ctx->outId.p, (size_t) K * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -590,6 +601,166 @@ int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, 
     int rc = fsgpu_gapless_launch(ctx, pssm, L, scoreCap, minScore, identityId, maxRes);
     if (rc != FSGPU_OK) return rc;
     return fsgpu_gapless_finish(ctx, out, nout);
+}
+
+// Several queries, one resident-DB pass each, in as few launches as their lengths allow: queries of one register class
+// (R = ceil(L / 16)) share ONE launch of k_gapless (GaplessQuery records; workgroups of query q + 1 move in as those of
+// query q drain), the three selection passes run once for the whole batch (blockIdx.y = query).  Results are those of nq
+// fsgpu_gapless_scan calls.  Queries longer than 512 residues (row tiles) go through the single-query path.
+int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int nq, int minScore, int maxRes, fsgpu_hit *out, int *nout) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (nq < 0 || maxRes <= 0 || (nq > 0 && (!q || !out || !nout))) { ctx->err = "fsgpu_gapless_scan_multi: bad argument"; return FSGPU_E_ARG; }
+    if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
+    for (int i = 0; i < nq; i++)
+        if (!q[i].pssm || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN) { ctx->err = "fsgpu_gapless_scan_multi: bad query"; return FSGPU_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->mqLaunches = 0; ctx->mqQueries = 0;
+    ctx->mqSlot.assign(nq, -1);
+    // ---- device batch: the single-tile queries, grouped by register class ----
+    std::vector<int> batch, longQ;
+    for (int i = 0; i < nq; i++) (q[i].L <= 16 * kGaplessMaxR ? batch : longQ).push_back(i);
+    std::stable_sort(batch.begin(), batch.end(), [&](int x, int y) { return (q[x].L + 15) / 16 > (q[y].L + 15) / 16; });   // long queries first
+    const int nb = (int) batch.size();
+    const uint32_t n = (uint32_t) ctx->db->n;
+    const uint32_t nChunks = (n + kSelChunk - 1) / kSelChunk;
+    const uint32_t K = (uint32_t) std::min<uint64_t>((uint64_t) maxRes, ctx->db->n);
+    const uint64_t scoreStride = ((uint64_t) n + 255) / 256 * 256;
+    if (nb > 0) {
+        int rc;
+        std::vector<size_t> pOff(nb + 1, 0);
+        for (int k = 0; k < nb; k++) pOff[k + 1] = pOff[k] + ((size_t) kAlphabet * q[batch[k]].L + 63) / 64 * 64;
+        if ((rc = ensure(ctx, ctx->mqPssm, pOff[nb])) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqScores, scoreStride * nb)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqQueues, (size_t) nb * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqRec, (size_t) nb * sizeof(GaplessQuery))) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqHist, (size_t) nb * nChunks * 256 * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqBaseGt, (size_t) nb * nChunks * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqBaseTie, (size_t) nb * nChunks * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqMeta, (size_t) nb * sizeof(SelMeta))) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqOutId, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqOutScore, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqIdent, (size_t) nb * 8)) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqPssm, pOff[nb])) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqRec, (size_t) nb * sizeof(GaplessQuery))) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqMeta, (size_t) nb * sizeof(SelMeta))) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqOutId, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqOutScore, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqIdent, (size_t) nb * 8)) != FSGPU_OK) return rc;
+        ctx->mqScoreStride = scoreStride;
+        GaplessQuery *rec = (GaplessQuery *) ctx->hMqRec.p;
+        int64_t *ident = (int64_t *) ctx->hMqIdent.p;
+        for (int k = 0; k < nb; k++) {
+            const fsgpu_gapless_query &qq = q[batch[k]];
+            memcpy((char *) ctx->hMqPssm.p + pOff[k], qq.pssm, (size_t) kAlphabet * qq.L);
+            rec[k].pssm = (const int8_t *) ctx->mqPssm.p + pOff[k];
+            rec[k].scores = (uint8_t *) ctx->mqScores.p + scoreStride * k;
+            rec[k].queue = (uint32_t *) ctx->mqQueues.p + k;
+            rec[k].L = qq.L;
+            rec[k].cap = std::max(0, std::min(qq.scoreCap, 255));
+            ident[k] = qq.identityId;
+            ctx->mqSlot[batch[k]] = k;
+        }
+        // one scan batch at a time per database: scans of different host threads would only stretch each other (each launch
+        // already fills the device), while the SW / selection kernels of the other threads co-run in the slots the scan leaves
+        static const bool exclusive = [] { const char *e = getenv("FSGPU_SCAN_EXCLUSIVE"); return !e || atoi(e) != 0; }();
+        std::unique_lock<std::mutex> scanLock(ctx->db->scanMutex, std::defer_lock);
+        if (exclusive) scanLock.lock();
+        HIPCHK(hipMemcpyAsync(ctx->mqPssm.p, ctx->hMqPssm.p, pOff[nb], hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->mqRec.p, ctx->hMqRec.p, (size_t) nb * sizeof(GaplessQuery), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->mqIdent.p, ctx->hMqIdent.p, (size_t) nb * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->mqQueues.p, 0, (size_t) nb * 4, ctx->stream));
+        using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
+        static const LaunchFn table[kGaplessMaxR + 1] = {nullptr,
+            launchGapless<1, false>, launchGapless<2, false>, launchGapless<3, false>, launchGapless<4, false>,
+            launchGapless<5, false>, launchGapless<6, false>, launchGapless<7, false>, launchGapless<8, false>,
+            launchGapless<9, false>, launchGapless<10, false>, launchGapless<11, false>, launchGapless<12, false>,
+            launchGapless<13, false>, launchGapless<14, false>, launchGapless<15, false>, launchGapless<16, false>,
+            launchGapless<17, false>, launchGapless<18, false>, launchGapless<19, false>, launchGapless<20, false>,
+            launchGapless<21, false>, launchGapless<22, false>, launchGapless<23, false>, launchGapless<24, false>,
+            launchGapless<25, false>, launchGapless<26, false>, launchGapless<27, false>, launchGapless<28, false>,
+            launchGapless<29, false>, launchGapless<30, false>, launchGapless<31, false>, launchGapless<32, false>};
+        struct Group { int R, k0, k1; const uint4 *items; uint32_t nItems; };
+        std::vector<Group> groups;
+        bool anySplitAtAll = false;
+        for (int k0 = 0; k0 < nb;) {
+            const int R = std::max(1, (q[batch[k0]].L + 15) / 16);
+            int k1 = k0;
+            while (k1 < nb && std::max(1, (q[batch[k1]].L + 15) / 16) == R) k1++;
+            Group g{R, k0, k1, nullptr, 0};
+            bool split = false;
+            if ((rc = gaplessItems(ctx, R, &g.items, &g.nItems, &split)) != FSGPU_OK) return rc;
+            anySplitAtAll = anySplitAtAll || split;
+            groups.push_back(g);
+            k0 = k1;
+        }
+        // column segments combine by atomic max into zeroed score bytes: clear all slices BEFORE the first launch (a memset
+        // between launches would wipe what earlier groups stored)
+        if (anySplitAtAll) HIPCHK(hipMemsetAsync(ctx->mqScores.p, 0, scoreStride * nb, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+        for (const Group &g : groups) {
+            GaplessArgs ga;
+            ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen; ga.stripeTargets = ctx->db->stripeTargets;
+            ga.items = g.items; ga.nItems = g.nItems;
+            ga.queries = (const GaplessQuery *) ctx->mqRec.p + g.k0;
+            ga.blocksPerQuery = (uint32_t) (g.k1 - g.k0);         // number of queries on entry, see launchGapless
+            ga.nTargets = n; ga.pssm = nullptr; ga.L = 0; ga.cap = 0; ga.scores = nullptr; ga.queue = nullptr;
+            ga.tileBase = 0; ga.firstTile = 1; ga.lastTile = 1; ga.borderIn = nullptr; ga.borderOut = nullptr; ga.scoreAcc = nullptr;
+            if ((rc = table[g.R](ctx, ga)) != FSGPU_OK) return rc;
+            ctx->mqLaunches++;
+        }
+        HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+        ctx->evValid[0] = true;
+        ctx->mqQueries = nb;
+        hipLaunchKernelGGL(k_sel_hist, dim3(nChunks, nb), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->mqScores.p, n, minScore,
+                           (int64_t) -1, (uint32_t *) ctx->mqHist.p, (const int64_t *) ctx->mqIdent.p, scoreStride);
+        hipLaunchKernelGGL(k_sel_threshold, dim3(nb), dim3(256), 0, ctx->stream, (const uint32_t *) ctx->mqHist.p, nChunks, K, (SelMeta *) ctx->mqMeta.p,
+                           (uint32_t *) ctx->mqBaseGt.p, (uint32_t *) ctx->mqBaseTie.p);
+        hipLaunchKernelGGL(k_sel_emit, dim3(nChunks, nb), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->mqScores.p, n, minScore,
+                           (int64_t) -1, (const SelMeta *) ctx->mqMeta.p, (const uint32_t *) ctx->mqBaseGt.p, (const uint32_t *) ctx->mqBaseTie.p,
+                           (uint32_t *) ctx->mqOutId.p, (int32_t *) ctx->mqOutScore.p, (const int64_t *) ctx->mqIdent.p, scoreStride, K);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->hMqMeta.p, ctx->mqMeta.p, (size_t) nb * sizeof(SelMeta), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->hMqOutId.p, ctx->mqOutId.p, (size_t) nb * K * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->hMqOutScore.p, ctx->mqOutScore.p, (size_t) nb * K * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
+        if (exclusive) scanLock.unlock();
+        const SelMeta *meta = (const SelMeta *) ctx->hMqMeta.p;
+        for (int k = 0; k < nb; k++) {
+            const int qi = batch[k];
+            fsgpu_hit *o = out + (size_t) qi * maxRes;
+            const uint32_t m = std::min<uint32_t>(meta[k].nOut, K);
+            const uint32_t *ids = (const uint32_t *) ctx->hMqOutId.p + (size_t) k * K;
+            const int32_t *sc = (const int32_t *) ctx->hMqOutScore.p + (size_t) k * K;
+            for (uint32_t i = 0; i < m; i++) { o[i].id = ids[i]; o[i].score = sc[i]; }
+            std::sort(o, o + m, [](const fsgpu_hit &a, const fsgpu_hit &b) {      // hit_t::compareHitsByScoreAndId
+                if (a.score != b.score) return a.score > b.score;
+                return a.id < b.id;
+            });
+            nout[qi] = (int) m;
+        }
+    }
+    for (int qi : longQ) {
+        const int rc = fsgpu_gapless_scan(ctx, q[qi].pssm, q[qi].L, q[qi].scoreCap, minScore, q[qi].identityId, maxRes, out + (size_t) qi * maxRes, &nout[qi]);
+        if (rc != FSGPU_OK) return rc;
+    }
+    return FSGPU_OK;
+}
+
+int fsgpu_gapless_scores_multi(fsgpu_ctx *ctx, int queryIndex, uint8_t *scores_out) {
+    if (!ctx || !scores_out) return FSGPU_E_ARG;
+    if (!ctx->db || queryIndex < 0 || queryIndex >= (int) ctx->mqSlot.size() || ctx->mqSlot[queryIndex] < 0) { ctx->err = "no batched scan results for this query"; return FSGPU_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(scores_out, (const uint8_t *) ctx->mqScores.p + ctx->mqScoreStride * (uint64_t) ctx->mqSlot[queryIndex], ctx->db->n, hipMemcpyDeviceToHost));
+    return FSGPU_OK;
+}
+
+int fsgpu_gapless_last_batch(const fsgpu_ctx *ctx, int *launches, int *queries) {
+    if (!ctx) return FSGPU_E_ARG;
+    if (launches) *launches = ctx->mqLaunches;
+    if (queries) *queries = ctx->mqQueries;
+    return FSGPU_OK;
 }
 
 int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out) {

@@ -52,6 +52,7 @@ struct DbStore {
     struct ItemList { uint4 *items = nullptr; uint32_t n = 0; bool split = false, built = false; };
     ItemList itemLists[kGaplessMaxR + 1];
     std::mutex itemMutex;
+    std::mutex scanMutex;        // multi-query scans of the contexts sharing this DB run one after the other (fsgpu_gapless_scan_multi)
     ~DbStore() {
         for (ItemList &l : itemLists) (void) hipFree(l.items);
         (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(stripeTargets);
@@ -84,6 +85,12 @@ struct fsgpu_ctx {
     PinBuf hOutId, hOutScore;            // pinned
     int pendingMaxRes = 0;
     bool gaplessPending = false;
+    // multi-query scan (fsgpu_gapless_scan_multi): per-batch arrays, query-major
+    DevBuf mqPssm, mqScores, mqQueues, mqRec, mqHist, mqBaseGt, mqBaseTie, mqMeta, mqOutId, mqOutScore, mqIdent;
+    PinBuf hMqPssm, hMqRec, hMqMeta, hMqOutId, hMqOutScore, hMqIdent;
+    int mqLaunches = 0, mqQueries = 0;          // scan kernel launches / queries of the last batch
+    uint64_t mqScoreStride = 0;
+    std::vector<int> mqSlot;                    // query index of the last call -> slice of mqScores (-1: went through the single-query path)
 
     // sw scratch
     hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails

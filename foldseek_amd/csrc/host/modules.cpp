@@ -598,22 +598,39 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
         fsgpu_ctx *ctx = ds.forThread(tix, owned);
         if (!ctx) { bad++; return; }
         fshost_search *s = fshost_search_create(ctx, &par, pt.keys.data(), nullptr, pt.d3, nullptr, pt.offsets.data(), pt.lengths.data());
-        std::vector<fsgpu_hit> hits(par.maxResListLen);
-        std::vector<uint8_t> codes;
+        // batches of queries: one multi-query scan per batch (queries of equal ceil(L / 16) share a launch)
+        const size_t batch = 32;
+        std::vector<fsgpu_hit> hits(batch * (size_t) par.maxResListLen);
+        std::vector<std::vector<uint8_t>> codes(batch);
+        std::vector<const uint8_t *> pq(batch);
+        std::vector<int> Ls(batch), nh(batch);
+        std::vector<int64_t> ident(batch);
+        std::vector<size_t> qid(batch);
         char line[128];
         for (;;) {
-            const size_t id = next++;
-            if (id >= q.size() || bad) break;
-            const uint32_t L = q.seqLen(id);
-            if (L == 0) continue;
-            codes.resize(L);
-            const char *sq = q.data(id);
-            for (uint32_t i = 0; i < L; i++) codes[i] = m3.aa2num[(unsigned char) sq[i]];
-            const int64_t identity = sameDB ? t.idOf(q.key(id)) : -1;
-            const int n = fshost_search_prefilter(s, codes.data(), (int) L, identity, hits.data());
-            if (n < 0) { if (!bad++) firstErr = fshost_search_error(s); break; }
-            std::string &out = results[id];
-            for (int k = 0; k < n; k++) out.append(line, fshost_format_prefilter_hit(line, pt.keys[hits[k].id], hits[k].score, 0));
+            const size_t b0 = next.fetch_add(batch);
+            if (b0 >= q.size() || bad) break;
+            size_t m = 0;
+            for (size_t id = b0; id < std::min(q.size(), b0 + batch); id++) {
+                const uint32_t L = q.seqLen(id);
+                if (L == 0) continue;
+                codes[m].resize(L);
+                const char *sq = q.data(id);
+                for (uint32_t i = 0; i < L; i++) codes[m][i] = m3.aa2num[(unsigned char) sq[i]];
+                pq[m] = codes[m].data(); Ls[m] = (int) L; qid[m] = id;
+                ident[m] = sameDB ? t.idOf(q.key(id)) : -1;
+                m++;
+            }
+            if (m == 0) continue;
+            if (fshost_search_prefilter_batch(s, (int) m, pq.data(), Ls.data(), ident.data(), hits.data(), nh.data()) != FSGPU_OK) {
+                if (!bad++) firstErr = fshost_search_error(s);
+                break;
+            }
+            for (size_t k = 0; k < m; k++) {
+                std::string &out = results[qid[k]];
+                const fsgpu_hit *h = hits.data() + k * (size_t) par.maxResListLen;
+                for (int i = 0; i < nh[k]; i++) out.append(line, fshost_format_prefilter_hit(line, pt.keys[h[i].id], h[i].score, 0));
+            }
         }
         fshost_search_free(s);
         if (owned) fsgpu_destroy(ctx);
@@ -861,13 +878,20 @@ int fsmod_search(int argc, const char **argv) {
                     }
                 }
             } else {
-                for (size_t k = 0; k < nb && !bad; k++) {
-                    if (Ls[k] == 0) continue;
-                    const int n = fshost_search_prefilter(s, c3[k].data(), Ls[k], ident[k], ghits.data());
-                    if (n < 0) { if (!bad++) firstErr = fshost_search_error(s); break; }
-                    for (int h = 0; h < n; h++) {
-                        ids[k].push_back(ghits[h].id);
-                        if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[ghits[h].id], ghits[h].score, 0));
+                std::vector<const uint8_t *> gq; std::vector<int> gL, gn; std::vector<int64_t> gi; std::vector<size_t> gk;
+                for (size_t k = 0; k < nb; k++) if (Ls[k] > 0) { gq.push_back(c3[k].data()); gL.push_back(Ls[k]); gi.push_back(ident[k]); gk.push_back(k); }
+                gn.resize(gq.size());
+                ghits.resize(std::max<size_t>(1, gq.size()) * (size_t) par.maxResListLen);
+                if (!gq.empty() && fshost_search_prefilter_batch(s, (int) gq.size(), gq.data(), gL.data(), gi.data(), ghits.data(), gn.data()) != FSGPU_OK) {
+                    if (!bad++) firstErr = fshost_search_error(s);
+                    break;
+                }
+                for (size_t j = 0; j < gq.size(); j++) {
+                    const size_t k = gk[j];
+                    const fsgpu_hit *hh = ghits.data() + j * (size_t) par.maxResListLen;
+                    for (int h = 0; h < gn[j]; h++) {
+                        ids[k].push_back(hh[h].id);
+                        if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hh[h].id], hh[h].score, 0));
                     }
                 }
             }

@@ -188,6 +188,28 @@ int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_
     return nout;
 }
 
+// nq queries through fsgpu_gapless_scan_multi: hits[q * maxResListLen ...], nhits[q]; same results as nq fshost_search_prefilter calls
+int fshost_search_prefilter_batch(fshost_search *s, int nq, const uint8_t *const *q3di, const int *L, const int64_t *identityId,
+                                  fsgpu_hit *hits, int *nhits) {
+    if (!s || !s->ctx || nq < 0 || (nq > 0 && (!q3di || !L || !hits || !nhits))) return FSGPU_E_ARG;
+    const double t0 = nowSec();
+    std::vector<size_t> off(nq + 1, 0);
+    for (int i = 0; i < nq; i++) { if (!q3di[i] || L[i] <= 0) return FSGPU_E_ARG; off[i + 1] = off[i] + (size_t) s->matPref.n * L[i]; }
+    s->pssm.resize(off[nq]);
+    std::vector<fsgpu_gapless_query> gq(nq);
+    for (int i = 0; i < nq; i++) {
+        int cap = 0;
+        const int rc = prefilterProfile(s->matPref, q3di[i], L[i], s->par.compBiasCorrection != 0, s->par.prefCompBiasScale, s->pssm.data() + off[i], &cap);
+        if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
+        gq[i].pssm = s->pssm.data() + off[i]; gq[i].L = L[i]; gq[i].scoreCap = cap; gq[i].identityId = identityId ? identityId[i] : -1;
+    }
+    const double t1 = nowSec();
+    const int rc = fsgpu_gapless_scan_multi(s->ctx, gq.data(), nq, s->par.minDiagScoreThr, s->par.maxResListLen, hits, nhits);
+    s->stats[0] = t1 - t0; s->stats[1] = nowSec() - t1;
+    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    return FSGPU_OK;
+}
+
 } // extern "C"
 
 // ---- helpers restating small reference functions -------------------------------------------------------------

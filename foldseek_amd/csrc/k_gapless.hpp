@@ -60,7 +60,22 @@ __device__ __forceinline__ uint32_t f16ScaledBits(int i) {
 }
 constexpr uint32_t kDead2 = 0xBC00BC00u;     // packed (-1.0, -1.0): a dead profile row forces the cell to zero
 
+// One query of a launch.  A launch covers nQueries queries of the SAME register class: workgroups
+// [q * blocksPerQuery, (q + 1) * blocksPerQuery) serve query q (own profile image, own work queue, own score array).  The
+// hardware hands out workgroups in index order, so query q + 1's workgroups move in as query q's drain: the tail of one
+// scan is filled by the head of the next inside ONE launch -- what several host threads with a stream each only
+// approximate -- and a launch's duration is an honest per-launch figure.
+struct GaplessQuery {
+    const int8_t *pssm;         // [21][L] query profile (device copy)
+    uint8_t *scores;            // [nTargets]
+    uint32_t *queue;            // work counter, zeroed before launch
+    int L;
+    int cap;                    // min(cap, score)
+};
+
 struct GaplessArgs {
+    const GaplessQuery *queries; // [gridDim.x / blocksPerQuery]; nullptr: the single query described by pssm / L / cap / scores / queue below
+    uint32_t blocksPerQuery;
     const uint4 *scan;          // stripe-interleaved target residues (codes 0..20, 21 = past end)
     const uint64_t *stripeOff;  // [nStripes] offset in uint4 units
     const uint32_t *stripeLen;  // [nStripes] length in 16-column chunks
@@ -88,6 +103,14 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
     constexpr int NCH = gaplessChunks(R);         // ds_read_b128 per column; the last one may carry unused registers
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the kernel's only LDS: starts at LDS address 0
+    uint32_t blockInQuery = blockIdx.x, blocksOfQuery = gridDim.x;
+    if (a.queries) {                                  // multi-query launch: this workgroup's query (uniform scalar loads)
+        const uint32_t qi = blockIdx.x / a.blocksPerQuery;
+        blockInQuery = blockIdx.x - qi * a.blocksPerQuery;
+        blocksOfQuery = a.blocksPerQuery;
+        const GaplessQuery gq = a.queries[qi];
+        a.pssm = gq.pssm; a.scores = gq.scores; a.queue = gq.queue; a.L = gq.L; a.cap = gq.cap;
+    }
 
     // ---- build the LDS image from the int8 pssm (once per workgroup) ----
     // One item = (profile row, lane g, 4-register chunk k): 4 + 4 profile bytes -> one 16-byte slot, stored to both
@@ -136,8 +159,8 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
     // The first item of a wave is static (the nWaves longest items), the following ones come from the atomic queue: no
     // ticket ramp at kernel start, and one 16-byte record per item keeps the dependent loads per stripe at two
     // (record, first column chunk) -- what matters for short queries (tools/ubench/gapless_ablate.hip, "v6").
-    const uint32_t nWaves = gridDim.x * (kGaplessBlock / 64);
-    uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kGaplessBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t nWaves = blocksOfQuery * (kGaplessBlock / 64);
+    uint32_t w = __builtin_amdgcn_readfirstlane(blockInQuery * (kGaplessBlock / 64) + (threadIdx.x >> 6));
     for (; w < a.nItems;) {
         const uint4 item = a.items[w];
         const uint32_t stripe = item.x;

@@ -21,9 +21,15 @@ __device__ __forceinline__ bool selPasses(int score, uint32_t id, int minScore, 
 }
 
 // pass A: per-chunk histograms
+// Batched form of all three passes: blockIdx.y = query of a multi-query scan; per-query arrays follow each other
+// (scores: scoreStride bytes apart, histograms / bases: gridDim.x chunks apart, outputs: K apart); identityIds (may be
+// nullptr) holds one identity id per query and overrides the scalar.
 __global__ __launch_bounds__(kSelThreads) void k_sel_hist(const uint8_t *scores, uint32_t n, int minScore,
-                                                          int64_t identityId, uint32_t *chunkHist) {
+                                                          int64_t identityId, uint32_t *chunkHist, const int64_t *identityIds, uint64_t scoreStride) {
     __shared__ uint32_t h[256];
+    scores += (size_t) blockIdx.y * scoreStride;
+    chunkHist += (size_t) blockIdx.y * gridDim.x * 256;
+    if (identityIds) identityId = identityIds[blockIdx.y];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kSelChunk + threadIdx.x * 16;
@@ -43,6 +49,8 @@ __global__ __launch_bounds__(256) void k_sel_threshold(const uint32_t *chunkHist
                                                        SelMeta *meta, uint32_t *chunkBaseGt, uint32_t *chunkBaseTie) {
     __shared__ uint32_t hist[256];
     __shared__ SelMeta m;
+    chunkHist += (size_t) blockIdx.x * nChunks * 256;          // one workgroup per query
+    meta += blockIdx.x; chunkBaseGt += (size_t) blockIdx.x * nChunks; chunkBaseTie += (size_t) blockIdx.x * nChunks;
     uint32_t s = 0;
     for (uint32_t c = 0; c < nChunks; c++) s += chunkHist[(size_t) c * 256 + threadIdx.x];
     hist[threadIdx.x] = s;
@@ -84,8 +92,13 @@ __global__ __launch_bounds__(256) void k_sel_threshold(const uint32_t *chunkHist
 __global__ __launch_bounds__(kSelThreads) void k_sel_emit(const uint8_t *scores, uint32_t n, int minScore,
                                                           int64_t identityId, const SelMeta *meta,
                                                           const uint32_t *chunkBaseGt, const uint32_t *chunkBaseTie,
-                                                          uint32_t *outId, int32_t *outScore) {
+                                                          uint32_t *outId, int32_t *outScore, const int64_t *identityIds, uint64_t scoreStride,
+                                                          uint32_t K) {
     __shared__ uint32_t sg[kSelThreads], st[kSelThreads];
+    scores += (size_t) blockIdx.y * scoreStride;
+    meta += blockIdx.y; chunkBaseGt += (size_t) blockIdx.y * gridDim.x; chunkBaseTie += (size_t) blockIdx.y * gridDim.x;
+    outId += (size_t) blockIdx.y * K; outScore += (size_t) blockIdx.y * K;
+    if (identityIds) identityId = identityIds[blockIdx.y];
     const SelMeta m = *meta;
     const uint32_t base = blockIdx.x * kSelChunk + threadIdx.x * 16;
     uint32_t cnt = 0;

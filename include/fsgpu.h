@@ -113,6 +113,21 @@ uint64_t fsgpu_db_residues(const fsgpu_ctx *ctx);  /* sum of lengths */
  * (hit_t::compareHitsByScoreAndId, QueryMatcher.h:38-48) and returns the first maxRes in out[0..*nout). */
 int fsgpu_gapless_scan(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore,
                        int64_t identityId, int maxRes, fsgpu_hit *out, int *nout);
+/* The same for nq queries with as few device launches as their lengths allow (queries of equal ceil(L / 16) share one
+ * launch; the workgroups of one query move in as those of the previous one drain, so the device stays full across
+ * queries and a launch's duration is a per-launch figure worth quoting).  out[q * maxRes ...] / nout[q] per query. */
+typedef struct {
+    const int8_t *pssm;     /* int8 [21][L], as for fsgpu_gapless_scan */
+    int32_t L;
+    int32_t scoreCap;
+    int64_t identityId;     /* target id that is always kept, or -1 */
+} fsgpu_gapless_query;
+int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int nq, int minScore, int maxRes, fsgpu_hit *out, int *nout);
+/* scan kernel launches / device-batched queries of the last fsgpu_gapless_scan_multi; fsgpu_last_kernel_ms(ctx, 0) then is
+ * the device time of all its scan launches together */
+int fsgpu_gapless_last_batch(const fsgpu_ctx *ctx, int *launches, int *queries);
+/* raw scores of query `queryIndex` of the last fsgpu_gapless_scan_multi call (queries of <= 512 residues); for tests */
+int fsgpu_gapless_scores_multi(fsgpu_ctx *ctx, int queryIndex, uint8_t *scores_out);
 /* Raw per-target scores of the last scan (n bytes, already capped); for tests and statistics. */
 int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out);
 /* Asynchronous halves of fsgpu_gapless_scan for callers that pipeline several queries / time the device part:

@@ -130,6 +130,10 @@ const char *fshost_search_error(const fshost_search *s);
 
 /* Prefilter one query: fills hits (capacity maxResListLen) sorted like the reference; returns count or < 0. */
 int fshost_search_prefilter(fshost_search *s, const uint8_t *q3di, int L, int64_t identityId, fsgpu_hit *hits);
+/* Prefilter nq queries with as few scan launches as their lengths allow (fsgpu_gapless_scan_multi): hits[q * maxResListLen ...],
+ * nhits[q]; identityId may be NULL.  Same hit lists as nq fshost_search_prefilter calls.  Returns 0 or < 0. */
+int fshost_search_prefilter_batch(fshost_search *s, int nq, const uint8_t *const *q3di, const int *L, const int64_t *identityId,
+                                  fsgpu_hit *hits, int *nhits);
 /* Align one query against a hit list (target indices); results (capacity n * (1 + altAlignment)) sorted like structurealign writes them.
  * Returns number of accepted alignments or < 0. */
 int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, int64_t identityId,

@@ -99,6 +99,36 @@ def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, a
     s.close()
 
 
+def test_multi_query_scan_equals_single_query_scans(world):
+    """fsgpu_gapless_scan_multi (queries of one register class share ONE k_gapless launch: per-query work queues, score slices,
+    batched selection passes) == one fsgpu_gapless_scan per query: complete score vectors and hit lists, 100k targets"""
+    ctx = world["ctx"]
+    more3, _ = synth.make_queries(11, seed=5, lo=250, hi=300)            # R = 16..19: several queries per launch
+    qs = list(world["q3"]) + more3 + [more3[0][:33], more3[1][:16], more3[2][:1]]
+    ident = np.full(len(qs), -1, np.int64)
+    ident[2], ident[6] = 777, 31415
+    s = api.Search(ctx)
+    single, scores = [], []
+    for i, q in enumerate(qs):
+        single.append(s.prefilter(q, identity=int(ident[i])))
+        scores.append(ctx.gapless_scores())
+    multi = s.prefilter_batch(qs, identity=ident)
+    launches, batched = ctx.gapless_last_batch()
+    short = [i for i, q in enumerate(qs) if len(q) <= 512]
+    assert batched == len(short) == len(qs) - 1
+    assert launches == len({(len(qs[i]) + 15) // 16 for i in short}) < len(short)
+    for i in range(len(qs)):
+        assert len(multi[i]) == len(single[i]) and (multi[i] == single[i]).all(), i
+        if i in short:
+            assert (ctx.gapless_scores_multi(i) == scores[i]).all(), i
+    # a second batch in another order: slices / queues are reused
+    order = [5, 0, 9, 2]
+    again = s.prefilter_batch([qs[i] for i in order], identity=ident[order])
+    for k, i in enumerate(order):
+        assert (again[k] == single[i]).all()
+    s.close()
+
+
 def test_backtrace_pool_does_not_change_results(world):
     """the accepted hits' backtraces run on a host worker pool (search.cpp HostPool); any pool size gives the same records"""
     db, q3, qa = world["db"], world["q3"], world["qa"]
