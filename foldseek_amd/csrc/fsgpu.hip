@@ -66,6 +66,10 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->scanDoneEv) {
+        if (ctx->db) { std::lock_guard<std::mutex> g(ctx->db->scanMutex); if (ctx->db->lastScanDone == ctx->scanDoneEv) ctx->db->lastScanDone = nullptr; }
+        (void) hipEventDestroy(ctx->scanDoneEv);
+    }
     freeDb(ctx);
     ctx->kidx.reset();
     if (ctx->kmer) fsgpu_kmer_free_scratch(ctx->kmer);
@@ -661,15 +665,19 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             ident[k] = qq.identityId;
             ctx->mqSlot[batch[k]] = k;
         }
-        // one scan batch at a time per database: scans of different host threads would only stretch each other (each launch
-        // already fills the device), while the SW / selection kernels of the other threads co-run in the slots the scan leaves
+        // One scan batch at a time per database, ordered ON THE DEVICE: every launch already fills the chip, two batches in
+        // flight would only stretch each other.  The inputs go up first (they may overlap the previous owner's scans), then
+        // -- under the mutex, which covers enqueueing only -- this stream is made to wait for the event the previous batch's
+        // owner recorded behind its last scan launch, the scans are enqueued and this batch's event takes its place.  The
+        // selection passes, copies and the host wait happen outside the mutex; SW / selection kernels of other contexts
+        // co-run in the slots a scan leaves.  FSGPU_SCAN_EXCLUSIVE=0 drops the ordering (A/B measurements).
         static const bool exclusive = [] { const char *e = getenv("FSGPU_SCAN_EXCLUSIVE"); return !e || atoi(e) != 0; }();
-        std::unique_lock<std::mutex> scanLock(ctx->db->scanMutex, std::defer_lock);
-        if (exclusive) scanLock.lock();
+        if (!ctx->scanDoneEv) HIPCHK(hipEventCreateWithFlags(&ctx->scanDoneEv, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(ctx->mqPssm.p, ctx->hMqPssm.p, pOff[nb], hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->mqRec.p, ctx->hMqRec.p, (size_t) nb * sizeof(GaplessQuery), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->mqIdent.p, ctx->hMqIdent.p, (size_t) nb * 8, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->mqQueues.p, 0, (size_t) nb * 4, ctx->stream));
+        std::unique_lock<std::mutex> scanLock(ctx->db->scanMutex, std::defer_lock);
         using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
         static const LaunchFn table[kGaplessMaxR + 1] = {nullptr,
             launchGapless<1, false>, launchGapless<2, false>, launchGapless<3, false>, launchGapless<4, false>,
@@ -697,6 +705,10 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
         // column segments combine by atomic max into zeroed score bytes: clear all slices BEFORE the first launch (a memset
         // between launches would wipe what earlier groups stored)
         if (anySplitAtAll) HIPCHK(hipMemsetAsync(ctx->mqScores.p, 0, scoreStride * nb, ctx->stream));
+        if (exclusive) {
+            scanLock.lock();
+            if (ctx->db->lastScanDone && ctx->db->lastScanDone != ctx->scanDoneEv) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->db->lastScanDone, 0));
+        }
         HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
         for (const Group &g : groups) {
             GaplessArgs ga;
@@ -710,6 +722,11 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             ctx->mqLaunches++;
         }
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+        if (exclusive) {
+            HIPCHK(hipEventRecord(ctx->scanDoneEv, ctx->stream));
+            ctx->db->lastScanDone = ctx->scanDoneEv;
+            scanLock.unlock();
+        }
         ctx->evValid[0] = true;
         ctx->mqQueries = nb;
         hipLaunchKernelGGL(k_sel_hist, dim3(nChunks, nb), dim3(kSelThreads), 0, ctx->stream, (const uint8_t *) ctx->mqScores.p, n, minScore,
@@ -724,7 +741,6 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
         HIPCHK(hipMemcpyAsync(ctx->hMqOutId.p, ctx->mqOutId.p, (size_t) nb * K * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->hMqOutScore.p, ctx->mqOutScore.p, (size_t) nb * K * 4, hipMemcpyDeviceToHost, ctx->stream));
         if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
-        if (exclusive) scanLock.unlock();
         const SelMeta *meta = (const SelMeta *) ctx->hMqMeta.p;
         for (int k = 0; k < nb; k++) {
             const int qi = batch[k];

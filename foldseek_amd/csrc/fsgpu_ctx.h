@@ -52,7 +52,11 @@ struct DbStore {
     struct ItemList { uint4 *items = nullptr; uint32_t n = 0; bool split = false, built = false; };
     ItemList itemLists[kGaplessMaxR + 1];
     std::mutex itemMutex;
-    std::mutex scanMutex;        // multi-query scans of the contexts sharing this DB run one after the other (fsgpu_gapless_scan_multi)
+    // multi-query scans of the contexts sharing this DB run one after the other ON THE DEVICE: a context enqueues its scan
+    // launches behind the event the previous batch's owner recorded after its last scan launch (fsgpu_gapless_scan_multi).
+    // The mutex only orders the enqueueing (microseconds), not the execution.
+    std::mutex scanMutex;
+    hipEvent_t lastScanDone = nullptr;     // owned by the context that recorded it (ctx->scanDoneEv)
     ~DbStore() {
         for (ItemList &l : itemLists) (void) hipFree(l.items);
         (void) hipFree(scan); (void) hipFree(stripeOff); (void) hipFree(stripeLen); (void) hipFree(stripeTargets);
@@ -89,6 +93,7 @@ struct fsgpu_ctx {
     DevBuf mqPssm, mqScores, mqQueues, mqRec, mqHist, mqBaseGt, mqBaseTie, mqMeta, mqOutId, mqOutScore, mqIdent;
     PinBuf hMqPssm, hMqRec, hMqMeta, hMqOutId, hMqOutScore, hMqIdent;
     int mqLaunches = 0, mqQueries = 0;          // scan kernel launches / queries of the last batch
+    hipEvent_t scanDoneEv = nullptr;            // recorded after the last scan launch of a batch (chained through DbStore::lastScanDone)
     uint64_t mqScoreStride = 0;
     std::vector<int> mqSlot;                    // query index of the last call -> slice of mqScores (-1: went through the single-query path)
 
