@@ -3,7 +3,7 @@
 
 Workload = BASELINE.json's metric configuration (configs[2], it fits one GPU): queries vs a 1M-structure synthetic
 3Di(+AA) database (mean length 350, 50 planted homologs for EVERY query) resident in HBM.
-One STEP = one batch of --group (32) queries through the whole path on one host feeder thread: exhaustive gapless
+One STEP = one batch of --group (64) queries through the whole path on one host feeder thread: exhaustive gapless
 prefilter over every target + top --max-seqs selection per query, then ONE multi-query structure Smith-Waterman launch
 per pass over the batch's hit lists (forward over all pairs, reversed query over the pairs that pass the forward
 gates), host gates, block-aligner backtrace of every accepted hit, result ordering.  --host-threads feeder threads
@@ -42,7 +42,7 @@ def parse(argv=None):
     ap.add_argument("--homologs", type=int, default=50, help="planted homologs per query (SURVEY.md 8d)")
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1..2]), 2: 3Di+AA (configs[3])")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
-    ap.add_argument("--group", type=int, default=32, help="queries per step: prefiltered back to back, then ONE multi-query SW launch per pass")
+    ap.add_argument("--group", type=int, default=64, help="queries per step: prefiltered back to back, then ONE multi-query SW launch per pass")
     ap.add_argument("--dry-run", action="store_true", help="no device work: ranks, DB generation, broadcast and query sharding only (gloo on CPU when no GPU is visible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
