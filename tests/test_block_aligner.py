@@ -1,6 +1,12 @@
 """Known-answer tests for the C++ restatement of the block aligner, ported from the Rust crate's own unit tests
 (reference lib/mmseqs/lib/block-aligner/src/scan_block.rs:2337-2413: test_x_drop, test_trace).  The crate's BLOSUM62 /
-NW1 constants are replaced by matrices that agree with them on the letters the tests use (A, R / A, T, G, C)."""
+NW1 constants are replaced by matrices that agree with them on the letters the tests use (A, R / A, T, G, C).
+
+Ported: test_x_drop, test_trace, test_no_x_drop (:2267-2334; its one case with the nucleotide wildcard N needs NucMatrix).
+NOT portable: test_bytes (:2414-2431, ByteMatrix) and test_profile (:2433-2478, AAProfile) exercise matrix / profile types
+that Foldseek's path never instantiates and the restatement therefore does not contain (their C entry points are
+die()-stubs in oracle/ref_block_stub.cpp).  The 3Di + AA entry point Foldseek DOES use has no known answers in the crate;
+it is covered by the independent property test at the end of this file."""
 import ctypes as C
 import numpy as np
 import pytest
@@ -170,3 +176,102 @@ def test_no_x_drop_scores(ba):
     assert score(b"TTTTTTTTAAAAAAATTTTTTTTT", b"TTAAAAAAATTTTTTTTTTTT", nw, g2) == 7
     assert score(b"C", b"AAAA", nw, g2) == -5
     assert score(b"AAAA", b"C", nw, g2) == -5
+
+
+# ---- independent property test of the 3Di + AA path (align_3di: the one Foldseek uses) ---------------------------------
+# CIGAR parity against the Rust crate cannot be pinned in this environment (no cargo / rustc: the crate cannot be built, and
+# the compiled reference links THIS restatement for its block_* symbols).  What can be checked independently of the
+# restatement: every backtrace it emits, re-scored position by position against the 3Di + AA matrices, the position bias and
+# the affine gap costs, must add up to the optimum of a plain O(n^2) scalar Gotoh recurrence (written here, sharing no code
+# with the aligner) for the best alignment ENDING at the given cell -- and the start positions must be the ones the path
+# implies.  Ties between co-optimal paths stay unpinned (that is exactly what the crate's tie rules decide).
+def _gotoh_end_anchored(S, go, ge):
+    """best score of an alignment that ends exactly at the last cell of S (local start): scalar affine-gap DP, int64"""
+    n, m = S.shape
+    NEG = -10 ** 9
+    H = np.zeros((n + 1, m + 1), np.int64)
+    E = np.full((n + 1, m + 1), NEG, np.int64)
+    F = np.full((n + 1, m + 1), NEG, np.int64)
+    best_end = NEG
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            E[i, j] = max(E[i, j - 1] - ge, H[i, j - 1] - go)
+            F[i, j] = max(F[i - 1, j] - ge, H[i - 1, j] - go)
+            d = H[i - 1, j - 1] + S[i - 1, j - 1]
+            H[i, j] = max(0, d, E[i, j], F[i, j])
+    # value of the best path ending at (n, m) with a match: a path may START anywhere (local start = restart at 0)
+    return int(H[n - 1, m - 1] + S[n - 1, m - 1]) if n and m else 0
+
+
+def _rescore(bt, S, q0, t0, go, ge):
+    """score of the backtrace string (M / I = query only / D = target only) walked from (q0, t0)"""
+    i, j, score, prev = q0, t0, 0, "M"
+    for op in bt:
+        if op == "M":
+            score += int(S[i, j]); i += 1; j += 1
+        elif op == "I":
+            score -= go if prev != "I" else ge; i += 1
+        else:
+            score -= go if prev != "D" else ge; j += 1
+        prev = op
+    return score, i, j
+
+
+@pytest.mark.parametrize("atype", [2, 0])
+def test_align_3di_backtraces_rescore_to_the_scalar_optimum(atype):
+    from foldseek_amd import synth
+    rng = np.random.default_rng(20260924 + atype)
+    m3 = api.Matrix(0, 2.1, 0.0)
+    mA = api.Matrix(1, 1.4 if atype == 2 else 0.0, 0.0)
+    s3, sA = m3.scores().astype(np.int64), mA.scores().astype(np.int64)
+    checked = gapped = 0
+    for trial in range(140):
+        Lq, Lt = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+        q3 = rng.choice(20, size=Lq, p=synth.BACK_3DI / synth.BACK_3DI.sum()).astype(np.uint8)
+        qa = rng.choice(20, size=Lq, p=synth.BACK_AA / synth.BACK_AA.sum()).astype(np.uint8)
+        # target = mutated copy of a query window (substitutions + an indel or two), so alignments are long and gapped
+        a, b = sorted(rng.integers(0, Lq, size=2))
+        if b - a < 12:
+            a, b = 0, Lq
+        t3, ta = synth._mutate(rng, q3[a:b], qa[a:b], 0.25, 0.12)
+        pad = int(rng.integers(0, 12))
+        t3 = np.concatenate([rng.integers(0, 20, pad).astype(np.uint8), t3]); ta = np.concatenate([rng.integers(0, 20, pad).astype(np.uint8), ta])
+        if len(t3) < 8:
+            continue
+        _, _, cbA, cbS = api.align_profiles(mA, m3, qa, q3, comp_bias=True, scale=0.5)
+        S = s3[q3][:, t3] + sA[qa][:, ta] + (cbA.astype(np.int64) + cbS.astype(np.int64))[:, None]
+        # pick the end cell of the best local alignment (textbook recurrence) and the best score ending there
+        best, qe, te = -1, -1, -1
+        NEG = -10 ** 9
+        n, m = S.shape
+        H = np.zeros((n + 1, m + 1), np.int64); E = np.full((n + 1, m + 1), NEG, np.int64); F = np.full((n + 1, m + 1), NEG, np.int64)
+        for i in range(1, n + 1):
+            for j in range(1, m + 1):
+                E[i, j] = max(E[i, j - 1] - 1, H[i, j - 1] - 10); F[i, j] = max(F[i - 1, j] - 1, H[i - 1, j] - 10)
+                H[i, j] = max(0, H[i - 1, j - 1] + S[i - 1, j - 1], E[i, j], F[i, j])
+                if H[i, j] > best and H[i, j] == H[i - 1, j - 1] + S[i - 1, j - 1]:
+                    best, qe, te = int(H[i, j]), i - 1, j - 1
+        if best < 25:
+            continue
+        assert best == _gotoh_end_anchored(S[:qe + 1, :te + 1], 10, 1)
+        ok, qs, ds, ident, bt = api.block_backtrace(mA, m3, qa, q3, cbA, cbS, ta, t3, qe, te, best, 10, 1)
+        assert ok, (trial, best, qe, te)
+        score, qi, tj = _rescore(bt, S, qs, ds, 10, 1)
+        assert (qi, tj) == (qe + 1, te + 1), "the backtrace must end in the end cell"
+        assert score == best, (trial, score, best, bt)
+        assert ident == sum(1 for k, (i, j) in enumerate(_walk(bt, qs, ds)) if qa[i] == ta[j])
+        assert bt[0] == "M" and bt[-1] == "M"
+        checked += 1
+        gapped += ("I" in bt) or ("D" in bt)
+    assert checked >= 100 and gapped >= 30
+
+
+def _walk(bt, i, j):
+    for op in bt:
+        if op == "M":
+            yield i, j
+            i += 1; j += 1
+        elif op == "I":
+            i += 1
+        else:
+            j += 1
