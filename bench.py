@@ -43,6 +43,9 @@ def parse(argv=None):
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1..2]), 2: 3Di+AA (configs[3])")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
     ap.add_argument("--group", type=int, default=64, help="queries per step: prefiltered back to back, then ONE multi-query SW launch per pass")
+    ap.add_argument("--workload", choices=["search", "allvsall"], default="search",
+                    help="search: queries vs the DB (configs[1..3]); allvsall: every DB entry searches the DB (configs[4], easy-cluster's "
+                         "cascaded step: k-mer prefilter -s 4.5 --max-seqs 200 + structurealign -e 0.01 -c 0.8), use with --targets 200000")
     ap.add_argument("--dry-run", action="store_true", help="no device work: ranks, DB generation, broadcast and query sharding only (gloo on CPU when no GPU is visible)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmer", action="store_true", help="skip the k-mer prefilter (+align) section")
@@ -272,6 +275,113 @@ def kmer_cpu_baseline(args, synth, db):
             "index_build_s": t_build}
 
 
+def allvsall(args, api, synth, fdist, dev, rank, world, local_rank):
+    """configs[4]: all-vs-all of a --targets structure DB, the shape of easy-cluster's cascaded steps (F/data/structurecluster.sh via
+    `easy-cluster -v 3`): prefilter -s 4.5 --max-seqs 200 --min-ungapped-score 30 -c 0.8 --add-self-matches 1, then structurealign
+    -e 0.01 -c 0.8 --comp-bias-corr 0.  Prefilter dominated: one pass of the k-mer index per batch of 32 queries.  Every DB entry is a
+    query; the ids shard over the ranks (--steps batches each, 0 = all of them), the DB is replicated by one broadcast."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    t_gen = time.perf_counter()
+    db = synth.make_db_fast(args.targets, None, seed=20260923, homologs_per_query=0) if rank == 0 else None
+    t_gen = time.perf_counter() - t_gen
+    tensors, db = fdist.broadcast_db(db, dev)
+    torch.cuda.synchronize()
+    ctx0 = api.Context(local_rank)
+    ctx0.adopt_device_db(tensors[0].data_ptr(), tensors[1].data_ptr(), tensors[2].data_ptr(), tensors[3].data_ptr(), db.n, db.data3di.size)
+    ctx0._keep = (np.ascontiguousarray(db.data3di), np.ascontiguousarray(db.dataaa), np.ascontiguousarray(db.offsets, np.uint64), np.ascontiguousarray(db.lengths, np.int32))
+    del tensors
+    par = api.default_params()
+    par.alignmentType = 2
+    par.evalThr, par.covThr, par.covMode, par.compBiasCorrection = 0.01, 0.8, 0, 0
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    thr = api.kmer_threshold(4.5, 6)
+    t0 = time.perf_counter()
+    ctx0.kmer_index_build(m8, kmer_thr=thr)
+    t_index = time.perf_counter() - t0
+    KT = max(1, args.kmer_threads)
+    ctxs = [ctx0] + [ctx0.clone() for _ in range(KT - 1)]
+    searches = [api.Search(c, par) for c in ctxs]
+    lo, hi = fdist.shard_range(db.n, rank, world)
+    ids = np.arange(lo, hi)
+    nb_all = (len(ids) + 31) // 32
+    nb = nb_all if args.steps <= 0 else min(nb_all, args.steps + args.warmup)
+    # a spread sample of the shard when only some batches are run: the DB is length sorted
+    pick = np.linspace(0, nb_all - 1, nb).astype(np.int64) if nb < nb_all else np.arange(nb_all)
+    batches = [ids[b * 32:(b + 1) * 32] for b in pick]
+    warm, timed = (batches[:args.warmup], batches[args.warmup:]) if args.steps > 0 else (batches[:1], batches)
+    stat = {"hits": 0, "aln": 0, "q": 0, "res": 0, "dev": 0.0, "bad": 0}
+    lock = threading.Lock()
+
+    def run(t, b, count):
+        q3 = [db.seq(int(i), "3di") for i in b]
+        qa = [db.seq(int(i), "aa") for i in b]
+        prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in q3]
+        res, status = ctxs[t].kmer_search(prep, identity=b, max_res=200)
+        # Prefiltering.cpp:880-887: canBeCovered at -c 0.8, cov-mode 0
+        keep = []
+        for q, r in zip(q3, res):
+            lt = db.lengths[r["id"]].astype(np.float32)
+            lq = np.float32(len(q))
+            keep.append(r["id"][(lq / lt >= 0.8) & (lt / lq >= 0.8)])
+        aln = searches[t].align_batch(qa, q3, keep, identity=b)
+        if count:
+            with lock:
+                stat["hits"] += sum(len(k) for k in keep); stat["aln"] += sum(len(a) for a in aln); stat["q"] += len(b)
+                stat["res"] += int(sum(len(q) for q in q3)); stat["dev"] += ctxs[t].kmer_stage_ms()[0]; stat["bad"] += int((status < 0).sum())
+
+    for t in range(KT):
+        for b in warm[t::KT] or warm[:1]:
+            run(t, b, False)
+    ready, go = threading.Barrier(KT + 1), threading.Barrier(KT + 1)
+
+    def worker(t):
+        ready.wait(); go.wait()
+        for b in timed[t::KT]:
+            run(t, b, True)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(KT)]
+    for th in ths:
+        th.start()
+    ready.wait()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.disable()
+    t0 = time.perf_counter()
+    go.wait()
+    for th in ths:
+        th.join()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    gc.enable()
+    tot = fdist.gather_objects(stat)
+    if rank == 0:
+        nq = sum(x["q"] for x in tot)
+        out = {"metric": "residues aligned/sec (prefilter+align)", "value": nq * db.residues / dt, "unit": "residues/s", "n_gpus": world,
+               "steps": len(timed), "warmup": len(warm), "ms_per_step": 1e3 * dt / max(1, len(timed)), "higher_is_better": True,
+               "scaling": "strong" if args.steps <= 0 else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
+               "config": {"workload": f"all-vs-all (configs[4]): {nq} of the {db.n} DB entries as queries in batches of 32 (1 step = 1 batch), k-mer prefilter -s 4.5 --max-seqs 200 "
+                                      f"-c 0.8 + structurealign -e 0.01 -c 0.8 (3Di+AA) on its hits; queries shard over {world} rank(s), DB replicated by one broadcast",
+                          "targets": db.n, "db_residues": db.residues, "host_threads_per_gpu": KT, "kmer_threshold": thr},
+               "queries_per_s": nq / dt, "ms_per_query": 1e3 * dt / max(1, nq / world), "hits_per_query": sum(x["hits"] for x in tot) / max(1, nq),
+               "alignments_per_query": sum(x["aln"] for x in tot) / max(1, nq), "prefilter_device_ms_per_query": tot[0]["dev"] / max(1, tot[0]["q"]),
+               "unsupported_queries": sum(x["bad"] for x in tot), "index_build_s": t_index, "db_generation_s": t_gen,
+               "projected_full_all_vs_all_s": db.n / max(1e-9, nq / dt)}
+        print(json.dumps(out))
+    for x in searches:
+        x.close()
+    for c in ctxs[1:]:
+        c.close()
+    ctx0.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -299,6 +409,9 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
 
+    if args.workload == "allvsall" and not args.dry_run:
+        from foldseek_amd import api
+        return allvsall(args, api, synth, fdist, dev, rank, world, local_rank)
     import threading
     nthreads = max(1, args.host_threads)
     G = max(1, args.group)
