@@ -17,5 +17,5 @@ pass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ
 pass SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 pass FETCH_SIZE
 pass WRITE_SIZE
-python $R/tools/pmc_summary.py /tmp/pmc_SQ_WAVES /tmp/pmc_SQ_LDS_BANK_CONFLICT /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $O/${TAG}_pmc_bench_1M.txt 2>&1
-tail -3 /tmp/pmc_FETCH_SIZE.log >> $O/${TAG}_pmc_bench_1M.txt
+python $R/tools/pmc_family.py /tmp/pmc_SQ_WAVES /tmp/pmc_SQ_LDS_BANK_CONFLICT /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE --json $O/${TAG}_pmc_bench_1M.json > $O/${TAG}_pmc_bench_1M.txt 2>&1
+grep -h "^{" /tmp/pmc_FETCH_SIZE.log | tail -1 > $O/${TAG}_pmc_bench_1M_benchline.json
