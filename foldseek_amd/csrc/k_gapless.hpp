@@ -206,6 +206,11 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
                 for (int k = 0; k < NCH; k++) {
                     const u32x4 v = *(const u32x4 __attribute__((address_space(3))) *) (rowp + k * CHB);
                     P[4 * k + 0] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
+                    // R % 4 == 1: only v.x of the last chunk feeds the recurrence and the compiler narrows the access to a
+                    // ds_read_b32 -- whose 64 lanes are serviced together, so the four targets of a copy collide on one bank
+                    // (SQ_LDS_BANK_CONFLICT = 15-20 % of the LDS cycles for R = 17, 21, 25, 29, zero for every other R:
+                    // profiles/r02_a_pmc_*).  Keeping the unused words alive keeps the conflict-free 128-bit form.
+                    if constexpr (R % 4 == 1) { if (k == NCH - 1) asm volatile("" :: "v"(v.y), "v"(v.z), "v"(v.w)); }
                 }
                 // diagonal hand-off
                 uint32_t prev = __builtin_amdgcn_mov_dpp(S[R - 1], 0x111 /*row_shr:1*/, 0xf, 0xf, true);
