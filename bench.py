@@ -589,8 +589,8 @@ def main():
         try:   # HBM bytes per launch from a committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of the same kernel on the same DB size
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             e = tj.get(str(args.targets))
-            if e:
-                traffic = e["fetch_correction"] * e["fetch_size_kb"] * 1024 + e["write_size_kb"] * 1024
+            if e:   # the PMC entries are per query; a launch of the timed region covers q_per_launch of them
+                traffic = (e["fetch_correction"] * e["fetch_size_kb"] * 1024 + e["write_size_kb"] * 1024) * q_per_launch
                 traffic_src = e["source"]
         except Exception:
             traffic = None
