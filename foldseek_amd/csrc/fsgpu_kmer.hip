@@ -125,6 +125,7 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
 
     // extended 3-mer matrix
     int16_t *dSub = nullptr;
+    struct SubGuard { int16_t *&p; bool armed = true; ~SubGuard() { if (armed) (void) hipFree(p); } } subGuard{dSub};   // early returns below must not leak it
     RPCHK(hipMalloc((void **) &dSub, 441 * sizeof(int16_t)));
     RPCHK(hipMemcpy(dSub, kmerSub, 441 * sizeof(int16_t), hipMemcpyHostToDevice));
     RPCHK(hipMalloc((void **) &ix->s3, (size_t) kRow3 * kRow3 * sizeof(int16_t)));
@@ -152,6 +153,7 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     int8_t *dSelf = nullptr;
     DevBuf tmp;
     int rc = FSGPU_OK;
+    subGuard.armed = false;           // from here on cleanup() owns dSub
     auto cleanup = [&]() {
         (void) hipFree(dResOff); (void) hipFree(v0); (void) hipFree(v1); (void) hipFree(k0); (void) hipFree(k1);
         (void) hipFree(flags); (void) hipFree(scan); (void) hipFree(dSelf); (void) hipFree(tmp.p); (void) hipFree(dSub);

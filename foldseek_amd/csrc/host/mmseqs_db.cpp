@@ -109,33 +109,39 @@ uint64_t DbReader::residues() const {
 }
 
 bool DbWriter::open(const std::string &p, int dbtype, std::string &err) {
-    path = p; type = dbtype; off = 0; entries.clear();
+    path = p; type = dbtype; off = 0; entries.clear(); failed = false;
     f = fopen(p.c_str(), "wb");
     if (!f) { err = "cannot create " + p; return false; }
     return true;
 }
 
 void DbWriter::write(uint32_t key, const char *data, size_t size) {
-    if (size) fwrite(data, 1, size, f);
+    // a failed write (disk full, I/O error) is remembered and reported by close(): a truncated data file with a
+    // valid-looking index must never end in EXIT_SUCCESS
+    if (size && fwrite(data, 1, size, f) != size) failed = true;
     const char nul = 0;
-    fwrite(&nul, 1, 1, f);
+    if (fwrite(&nul, 1, 1, f) != 1) failed = true;
     DbReader::Entry e; e.key = key; e.offset = off; e.length = (uint32_t) (size + 1);
     entries.push_back(e);
     off += size + 1;
 }
 
 bool DbWriter::close(std::string &err) {
-    if (f) { fclose(f); f = nullptr; }
+    if (f) { if (fclose(f) != 0) failed = true; f = nullptr; }
+    if (failed) { err = "write error on " + path; return false; }
     std::stable_sort(entries.begin(), entries.end(), [](const DbReader::Entry &a, const DbReader::Entry &b) { return a.key < b.key; });
     FILE *fi = fopen((path + ".index").c_str(), "wb");
     if (!fi) { err = "cannot create " + path + ".index"; return false; }
-    for (const auto &e : entries) fprintf(fi, "%u\t%llu\t%u\n", e.key, (unsigned long long) e.offset, e.length);
-    fclose(fi);
+    bool ok = true;
+    for (const auto &e : entries) ok = (fprintf(fi, "%u\t%llu\t%u\n", e.key, (unsigned long long) e.offset, e.length) > 0) && ok;
+    ok = (fclose(fi) == 0) && ok;
+    if (!ok) { err = "write error on " + path + ".index"; return false; }
     FILE *ft = fopen((path + ".dbtype").c_str(), "wb");
     if (!ft) { err = "cannot create " + path + ".dbtype"; return false; }
     int32_t t = type;
-    fwrite(&t, 4, 1, ft);
-    fclose(ft);
+    ok = fwrite(&t, 4, 1, ft) == 1;
+    ok = (fclose(ft) == 0) && ok;
+    if (!ok) { err = "write error on " + path + ".dbtype"; return false; }
     return true;
 }
 

@@ -52,6 +52,7 @@ private:
     int type = 0;
     FILE *f = nullptr;
     uint64_t off = 0;
+    bool failed = false;                                                      // an fwrite / fclose failed: close() reports it
     std::vector<DbReader::Entry> entries;
 };
 
