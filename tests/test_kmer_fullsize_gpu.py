@@ -94,3 +94,31 @@ def test_equals_compiled_reference_at_full_size(world):
     for q in range(NQ):
         assert len(world["res"][q]) == len(rr[q]) and (world["res"][q] == rr[q]).all(), q
         assert np.allclose(world["stats"][q][:3], rs[q][:3])
+
+
+def test_equals_compiled_reference_at_1M_targets():
+    """configs[2] size: 1M targets (350 M residues, every query refills databaseHits several times).  Six queries against the
+    compiled reference's QueryMatcher over the same 1M sequences (index build ~10 s on the box's 16 cores)."""
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    q3, qa = synth.make_queries(6, seed=11, lo=200, hi=420)
+    db = synth.make_db_fast(1000000, (q3, qa), seed=271828, homologs_per_query=50)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=78)
+    prep = [api.kmer_query_prepare(m8, m2, q) for q in q3]
+    l2 = int(R.ref_l2_cache_size())
+    ident = np.full(len(q3), -1, np.int64)
+    ident[1] = 999999
+    res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=1000, l2_cache_size=l2, want_stats=True)
+    assert (status >= 0).all() and stats[:, 2].sum() >= len(q3)          # every query refills at this size
+    # targets as views into the padded buffer: no per-entry copies of 350 MB
+    r = K.RefKpf(R, [db.data3di[db.offsets[i]:db.offsets[i] + db.lengths[i]] for i in range(db.n)], threads=16)
+    rr, rs, _ = r.run(q3, ident, threads=16)
+    r.close()
+    ctx.close()
+    for q in range(len(q3)):
+        assert len(res[q]) == len(rr[q]) and (res[q] == rr[q]).all(), q
+        assert np.allclose(stats[q][:3], rs[q][:3])
