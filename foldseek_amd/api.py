@@ -130,6 +130,8 @@ def lib():
         "fsgpu_diag_rescore": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]),
         "fshost_search_prefilter_batch": (i32, [vp, i32, vp, vp, vp, vp, vp]),
         "fshost_search_rescore_diagonal_batch": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "fshost_banded_backtrace": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
+        "fshost_search_startpos_backtrace": (i32, [vp, vp, vp, i32, C.c_uint32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
         "fshost_set_host_workers": (None, [i32]),
         "fshost_host_workers": (i32, []),
         "fshost_usable_cores": (i32, []),
@@ -533,6 +535,17 @@ class Search:
             return out, bts
         return out
 
+    def startpos_backtrace(self, qAA, q3di, target_id, q_end, db_end, score):
+        """alignStartPosBacktrace (SSW-style start + CIGAR: device reverse pass + host banded trace-back); (ok, qStart, dbStart, ids, cigar)"""
+        qa, q3 = np.ascontiguousarray(qAA, np.uint8), np.ascontiguousarray(q3di, np.uint8)
+        qs, ds, ident = C.c_int(), C.c_int(), C.c_uint()
+        buf = C.create_string_buffer(len(q3) + 70000)
+        rc = lib().fshost_search_startpos_backtrace(self.h, _ptr(qa), _ptr(q3), len(q3), int(target_id), int(q_end), int(db_end), int(score),
+                                                    C.byref(qs), C.byref(ds), C.byref(ident), buf, len(buf))
+        if rc < 0:
+            raise FsgpuError(f"startpos_backtrace rc={rc}: {lib().fshost_search_error(self.h).decode()}")
+        return rc == 1, qs.value, ds.value, ident.value, buf.value.decode()
+
     def stats(self):
         out = np.zeros(8)
         lib().fshost_search_stats(self.h, _ptr(out))
@@ -570,6 +583,18 @@ def block_backtrace(mAA, m3Di, qAA, q3Di, cbAA, cbSS, tAA, t3Di, q_end, db_end, 
                                       int(q_end), int(db_end), int(score), gap_open, gap_extend, C.byref(qs), C.byref(ds), C.byref(ident),
                                       buf, len(buf))
     return bool(ok), qs.value, ds.value, ident.value, buf.value.decode()
+
+
+def banded_backtrace(mAA, m3Di, qAA, q3Di, cbAA, cbSS, tAA, t3Di, q_start, q_end, db_start, db_end, score, gap_open=10, gap_extend=1):
+    """host banded_sw + computerBacktrace of a pair with known start and end cells; returns (ok, identicalAA, backtrace)"""
+    qa, q3 = np.ascontiguousarray(qAA, np.uint8), np.ascontiguousarray(q3Di, np.uint8)
+    ta, t3 = np.ascontiguousarray(tAA, np.uint8), np.ascontiguousarray(t3Di, np.uint8)
+    ca, cs = np.ascontiguousarray(cbAA, np.int8), np.ascontiguousarray(cbSS, np.int8)
+    ident = C.c_uint()
+    buf = C.create_string_buffer(len(qa) + len(ta) + 8)
+    ok = lib().fshost_banded_backtrace(mAA.h, m3Di.h, _ptr(qa), _ptr(q3), _ptr(ca), _ptr(cs), _ptr(ta), _ptr(t3), int(q_start), int(q_end), int(db_start),
+                                       int(db_end), int(score), gap_open, gap_extend, C.byref(ident), buf, len(buf))
+    return ok == 1, ident.value, buf.value.decode()
 
 
 def set_host_workers(n):

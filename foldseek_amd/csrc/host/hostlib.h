@@ -44,4 +44,9 @@ void blockBacktrace(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, c
                     const int8_t *cbSS, int Lq, const uint8_t *tAA, const uint8_t *t3Di, int Lt, int qEnd, int dbEnd,
                     int targetScore, int gapOpen, int gapExtend, BlockAlnOut &out);
 
+// banded_sw with band doubling + trace-back (StructureSmithWaterman.cpp:1723-1957) over the rectangle that starts at the
+// given pointers; path = M / I / D string from the start cell to the end cell.  false: impossible direction code.
+bool bandedBacktrace(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, const uint8_t *q3Di, const int8_t *cbAA, const int8_t *cbSS,
+                     int qLen, const uint8_t *tAA, const uint8_t *t3Di, int dbLen, int score, int gapOpen, int gapExtend, std::string &path);
+
 } // namespace fsh

@@ -696,6 +696,64 @@ int fshost_search_rescore_diagonal_batch(fshost_search *s, int nq, const uint8_t
     return FSGPU_OK;
 }
 
+// alignStartPosBacktrace for a sequence query (StructureSmithWaterman.cpp:540-739): start position by the
+// reverse pass on the device, CIGAR by the banded DP on the host (banded_backtrace.cpp).  (qEnd, dbEnd, score) = the forward
+// alignScoreEndPos result of the pair.  Returns 1 and fills the outputs; 0 when the reverse pass does not reproduce `score`
+// (the reference prints "Score of forward/backward SW differ" and exits) or the trace-back fails; < 0 on errors.
+int fshost_search_startpos_backtrace(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, uint32_t targetId, int qEnd, int dbEnd,
+                                     int score, int *qStart, int *dbStart, unsigned int *identicalAA, char *backtrace, size_t btCap) {
+    if (!s || !s->ctx || !qAA || !q3di || L <= 0 || !qStart || !dbStart || !backtrace || btCap == 0) return FSGPU_E_ARG;
+    if (targetId >= s->keys.size() || qEnd < 0 || qEnd >= L || dbEnd < 0 || dbEnd >= s->lengths[targetId]) { s->err = "startpos_backtrace: bad end position"; return FSGPU_E_ARG; }
+    const fshost_params &par = s->par;
+    const bool useAA = par.alignmentType == 2;
+    const int A = s->mat3Di.n;
+    AlignQuery aq;
+    aq.qAA = qAA; aq.q3di = q3di; aq.L = L;
+    int rc = prepareAlign(s, aq, s->rAA, s->r3Di);                 // forward profiles give the rounded biases cbAA / cbSS
+    if (rc != FSGPU_OK) return rc;
+    // reversed query prefix [0, qEnd] with its position biases (createQueryProfile on query_*_rev_sequence + queryOffset, :617-620)
+    const int Lp = qEnd + 1, Lt = dbEnd + 1;
+    std::vector<int16_t> pA((size_t) A * Lp), p3((size_t) A * Lp);
+    for (int a = 0; a < A; a++)
+        for (int i = 0; i < Lp; i++) {
+            const int src = qEnd - i;
+            pA[(size_t) a * Lp + i] = (int16_t) (s->matAA.tiny[(size_t) a * A + qAA[src]] + aq.cbAA[src]);
+            p3[(size_t) a * Lp + i] = (int16_t) (s->mat3Di.tiny[(size_t) a * A + q3di[src]] + aq.cbSS[src]);
+        }
+    std::vector<uint8_t> tA(Lt), t3(Lt), fA(Lt), f3(Lt);
+    for (int k = 0; k < Lt; k++) {
+        uint8_t c = s->data3di[s->offsets[targetId] + k]; c = c >= 32 ? c - 32 : c; f3[k] = c > 20 ? 20 : c;
+        uint8_t a = s->dataAA ? s->dataAA[s->offsets[targetId] + k] : 20; a = a >= 32 ? a - 32 : a; fA[k] = a > 20 ? 20 : a;
+    }
+    for (int k = 0; k < Lt; k++) { t3[k] = f3[dbEnd - k]; tA[k] = fA[dbEnd - k]; }
+    const uint64_t offs[2] = {0, (uint64_t) Lt};
+    const int32_t lens[1] = {Lt};
+    fsgpu_swres f, r;
+    rc = fsgpu_sw_batch_seqs(s->ctx, useAA ? pA.data() : nullptr, p3.data(), useAA ? pA.data() : nullptr, p3.data(), Lp, tA.data(), t3.data(), offs, lens, 1,
+                             par.gapOpen, par.gapExtend, &f, &r);
+    if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    if (f.score != score) return 0;
+    const int qs = qEnd - f.qEnd, ds = dbEnd - f.dbEnd;
+    *qStart = qs; *dbStart = ds;
+    std::string path;
+    const int qLen = qEnd - qs + 1, dbLen = dbEnd - ds + 1;
+    if (!bandedBacktrace(s->matAA, s->mat3Di, qAA + qs, q3di + qs, aq.cbAA.data() + qs, aq.cbSS.data() + qs, qLen, fA.data() + ds, f3.data() + ds, dbLen,
+                         score, par.gapOpen, par.gapExtend, path))
+        return 0;
+    // computerBacktrace (:746-773)
+    unsigned int ids = 0;
+    int qp = qs, tp = ds;
+    for (char c : path) {
+        if (c == 'M') { ids += fA[tp] == qAA[qp]; qp++; tp++; }
+        else if (c == 'I') qp++;
+        else tp++;
+    }
+    if (identicalAA) *identicalAA = ids;
+    if (path.size() + 1 > btCap) { s->err = "startpos_backtrace: backtrace buffer too small"; return FSGPU_E_ARG; }
+    memcpy(backtrace, path.c_str(), path.size() + 1);
+    return 1;
+}
+
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r) { return s->cigars.c_str() + r->backtraceOff; }
 
 void fshost_search_stats(const fshost_search *s, double *out8) { memcpy(out8, s->stats, sizeof(s->stats)); }

@@ -257,6 +257,29 @@ int fshost_align_profiles(const fshost_matrix *mAA, const fshost_matrix *m3Di, c
     return fsh::alignProfiles(mAA->m, m3Di->m, qAA, q3Di, L, compBias != 0, scale3Di, pAA, p3Di, cbAA, cbSS);
 }
 
+// banded_sw + computerBacktrace alone (host only): rectangle [qStart, qEnd] x [dbStart, dbEnd] of a pair given by codes; for callers
+// that already know the start cell, and for tests without a GPU
+int fshost_banded_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di, const int8_t *cbAA,
+                            const int8_t *cbSS, const uint8_t *tAA, const uint8_t *t3Di, int qStart, int qEnd, int dbStart, int dbEnd, int score,
+                            int gapOpen, int gapExtend, unsigned int *identicalAA, char *backtrace, size_t btCap) {
+    if (!mAA || !m3Di || !qAA || !q3Di || !cbAA || !cbSS || !tAA || !t3Di || !backtrace || qStart < 0 || dbStart < 0 || qEnd < qStart || dbEnd < dbStart) return FSGPU_E_ARG;
+    std::string path;
+    if (!fsh::bandedBacktrace(mAA->m, m3Di->m, qAA + qStart, q3Di + qStart, cbAA + qStart, cbSS + qStart,
+                         qEnd - qStart + 1, tAA + dbStart, t3Di + dbStart, dbEnd - dbStart + 1, score, gapOpen, gapExtend, path))
+        return 0;
+    unsigned int ids = 0;
+    int qp = qStart, tp = dbStart;
+    for (char c : path) {
+        if (c == 'M') { ids += tAA[tp] == qAA[qp]; qp++; tp++; }
+        else if (c == 'I') qp++;
+        else tp++;
+    }
+    if (identicalAA) *identicalAA = ids;
+    if (path.size() + 1 > btCap) return FSGPU_E_ARG;
+    memcpy(backtrace, path.c_str(), path.size() + 1);
+    return 1;
+}
+
 int fshost_block_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di, const int8_t *cbAA,
                            const int8_t *cbSS, int Lq, const uint8_t *tAA, const uint8_t *t3Di, int Lt, int qEnd, int dbEnd, int score,
                            int gapOpen, int gapExtend, int *qStart, int *dbStart, unsigned int *identicalAA, char *backtrace, size_t btCap) {

@@ -149,6 +149,13 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
 int fshost_search_rescore_diagonal_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
                                          const int64_t *identityId, const uint32_t *const *targetIds, const int16_t *const *diagonals,
                                          const int *n, fshost_result *const *results, int *nres);
+/* alignStartPosBacktrace for a sequence query (F/src/commons/StructureSmithWaterman.cpp:540-739, banded_sw :1723-1957, computerBacktrace
+ * :746-773): the reverse pass runs on the device (same SW kernels, reversed prefixes), the banded trace-back on the
+ * host.  The reference reaches this function for profile queries and in a fall-back that never fires (structurealign.cpp:83-100);
+ * it is exported for callers that want the SSW-style start / CIGAR instead of the block aligner's.  (qEnd, dbEnd, score): forward
+ * alignScoreEndPos result.  Returns 1 + outputs, 0 if the reverse pass does not reproduce `score` or the trace-back fails, < 0 on error. */
+int fshost_search_startpos_backtrace(fshost_search *s, const uint8_t *qAA, const uint8_t *q3di, int L, uint32_t targetId, int qEnd, int dbEnd,
+                                     int score, int *qStart, int *dbStart, unsigned int *identicalAA, char *backtrace, size_t btCap);
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r);
 /* Host wall time (seconds) spent in the stages of the last prefilter/align calls: [0] prefilter profile build,
  * [1] fsgpu_gapless_scan incl. wait, [2] align profiles + e-value net, [3] fsgpu_sw_batch incl. wait, [4] gates,
@@ -172,6 +179,13 @@ int fshost_block_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, 
                            const int8_t *cbAA, const int8_t *cbSS, int Lq, const uint8_t *tAA, const uint8_t *t3Di, int Lt,
                            int qEnd, int dbEnd, int score, int gapOpen, int gapExtend, int *qStart, int *dbStart,
                            unsigned int *identicalAA, char *backtrace, size_t btCap);
+
+/* banded_sw + computerBacktrace (F/src/commons/StructureSmithWaterman.cpp:1723-1957, 746-773) on the host for a pair whose start AND end
+ * cells are known: CIGAR string (M / I / D, start -> end) of the rectangle [qStart, qEnd] x [dbStart, dbEnd], band |dbLen - qLen| + 1 doubled
+ * until `score` is reached.  q* / t* / cb* point at position 0 of the sequences.  Returns 1, 0 (trace-back failed) or < 0. */
+int fshost_banded_backtrace(const fshost_matrix *mAA, const fshost_matrix *m3Di, const uint8_t *qAA, const uint8_t *q3Di, const int8_t *cbAA,
+                            const int8_t *cbSS, const uint8_t *tAA, const uint8_t *t3Di, int qStart, int qEnd, int dbStart, int dbEnd, int score,
+                            int gapOpen, int gapExtend, unsigned int *identicalAA, char *backtrace, size_t btCap);
 
 /* text formats: QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:120-132), Matcher::resultToBuffer (Matcher.cpp:282) */
 size_t fshost_format_prefilter_hit(char *buf, uint32_t key, int score, int diagonal);

@@ -235,6 +235,57 @@ double ref_structure_align(const uint8_t *qAA, const uint8_t *q3Di, int Lq, int 
     return secs;
 }
 
+// alignStartPosBacktrace<PROFILE> of the reference (F/src/commons/StructureSmithWaterman.cpp:540-739: reverse striped pass, banded_sw,
+// computerBacktrace) for one query against n targets, the way structurealign would call it for a sequence query if its fall-back
+// fired (structurealign.cpp:91-100: alignmentMode 3, covMode 0 / covThr 0, maskLen = Lq / 2).  out[id] = {qStart, dbStart, identicalAA,
+// status (0 ok, 1 forward score 0)}; cigars appended to cigarOut separated by '\n'.
+void ref_structure_startpos(const uint8_t *qAA, const uint8_t *q3Di, int Lq, int alignmentType, int compBias, float compBiasScale,
+                            int gapOpen, int gapExtend, const uint8_t *tAAcat, const uint8_t *t3Dicat, const int64_t *toff,
+                            const int32_t *tlen, int64_t n, int32_t *out4, char *cigarOut, int64_t cigarCap) {
+    SubstitutionMatrix subMat3Di(matText(0), 2.1, 0.0);
+    float aaFactor = (alignmentType == 2) ? 1.4 : 0.0;
+    SubstitutionMatrix subMatAA(matText(1), aaFactor, 0.0);
+    int8_t tinyAA[32 * 32], tiny3Di[32 * 32];
+    const int A = subMat3Di.alphabetSize;
+    for (int i = 0; i < A; i++)
+        for (int j = 0; j < A; j++) { tiny3Di[i * A + j] = subMat3Di.subMatrix[i][j]; tinyAA[i * A + j] = subMatAA.subMatrix[i][j]; }
+    int maxLen = Lq;
+    for (int64_t i = 0; i < n; i++) maxLen = std::max(maxLen, (int) tlen[i]);
+    maxLen += 2;
+    std::string qaa = toAscii(subMatAA, qAA, Lq), q3 = toAscii(subMat3Di, q3Di, Lq);
+    StructureSmithWaterman fwd(maxLen, A, compBias, compBiasScale, &subMatAA, &subMat3Di);
+    Sequence qSeqAA(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &subMatAA, 0, false, compBias);
+    Sequence qSeq3Di(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &subMat3Di, 0, false, compBias);
+    Sequence tSeqAA(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &subMatAA, 0, false, compBias);
+    Sequence tSeq3Di(maxLen, Parameters::DBTYPE_AMINO_ACIDS, &subMat3Di, 0, false, compBias);
+    qSeq3Di.mapSequence(0, 0, q3.c_str(), Lq);
+    qSeqAA.mapSequence(0, 0, qaa.c_str(), Lq);
+    fwd.ssw_init(&qSeqAA, &qSeq3Di, tinyAA, tiny3Di, &subMatAA);
+    std::string backtrace;
+    int64_t p = 0;
+    for (int64_t id = 0; id < n; id++) {
+        const int L = tlen[id];
+        std::string taa = toAscii(subMatAA, tAAcat + toff[id], L), t3 = toAscii(subMat3Di, t3Dicat + toff[id], L);
+        tSeq3Di.mapSequence(id, id, t3.c_str(), L);
+        tSeqAA.mapSequence(id, id, taa.c_str(), L);
+        StructureSmithWaterman::s_align a = fwd.alignScoreEndPos<StructureSmithWaterman::PROFILE>(tSeqAA.numSequence, tSeq3Di.numSequence, L, gapOpen, gapExtend, Lq / 2);
+        int32_t *o = out4 + id * 4;
+        o[0] = o[1] = -1; o[2] = 0; o[3] = 1;
+        backtrace.clear();
+        if (a.score1 > 0) {
+            StructureSmithWaterman::s_align b = fwd.alignStartPosBacktrace<StructureSmithWaterman::PROFILE>(
+                tSeqAA.numSequence, tSeq3Di.numSequence, L, gapOpen, gapExtend, 3, backtrace, a, 0, 0.0f, Lq / 2);
+            o[0] = b.qStartPos1; o[1] = b.dbStartPos1; o[2] = (int32_t) b.identicalAACnt; o[3] = 0;
+        }
+        if (cigarOut && p + (int64_t) backtrace.size() + 2 <= cigarCap) {
+            memcpy(cigarOut + p, backtrace.data(), backtrace.size());
+            p += backtrace.size();
+            cigarOut[p++] = '\n';
+        }
+    }
+    if (cigarOut) cigarOut[p] = '\0';
+}
+
 void ref_mu_lambda(const uint8_t *q3Di, int L, int64_t dbResidues, double *lambda, double *mu) {
     SubstitutionMatrix subMat3Di(matText(0), 2.1, 0.0);
     EvalueNeuralNet evaluer(dbResidues, &subMat3Di);

@@ -76,6 +76,10 @@ def load_ref():
                                       u8p, u8p, i64p, i32p, C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.ref_structure_align.restype = C.c_double
+    if hasattr(L, "ref_structure_startpos"):
+        L.ref_structure_startpos.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, u8p, u8p, i64p, i32p, C.c_int64,
+                                             i32p, C.c_void_p, C.c_int64]
+        L.ref_structure_startpos.restype = None
     L.ref_mu_lambda.argtypes = [u8p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ref_evalue_corr.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int64]
     L.ref_evalue_corr.restype = C.c_double
