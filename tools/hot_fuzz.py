@@ -1,7 +1,9 @@
 """Randomised GPU-vs-oracle comparison of the gapless prefilter and the structure SW (single and multi-query launches).
 usage: hot_fuzz.py [rounds] [seed]"""
 import sys, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as H
 from foldseek_amd import api, synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -23,9 +25,13 @@ for rd in range(rounds):
     s = api.Search(ctx, par)
     ok = True
     hit_lists = []
+    idents = [int(rng.integers(n)) if rng.random() < 0.3 else -1 for _ in range(nq)]
+    multi = s.prefilter_batch(q3, identity=np.array(idents, np.int64))      # multi-query scan launches (round 2)
     for i in range(nq):
-        ident = int(rng.integers(n)) if rng.random() < 0.3 else -1
+        ident = idents[i]
         hits = s.prefilter(q3[i], ident)
+        if not (len(multi[i]) == len(hits) and (multi[i] == hits).all()):
+            ok = False; print("  MULTI-SCAN MISMATCH round", rd, "q", i, "L", lens[i], "n", n)
         want = H.o_prefilter_select(H.o_ungapped_scores(q3[i], db, cb), 30, ident, max_res)
         if not (len(hits) == len(want) and (hits["id"] == want["key"]).all() and (hits["score"] == want["score"]).all()):
             ok = False; print("  PREFILTER MISMATCH round", rd, "q", i, "L", lens[i], "n", n, "cb", cb, "max_res", max_res, len(hits), len(want))
@@ -45,6 +51,8 @@ for rd in range(rounds):
             w = H.o_sw(pAf, p3f, lens[i], ta, t3); w2 = H.o_sw(pAr, p3r, lens[i], ta, t3)
             if (f[k]["score"], f[k]["qEnd"], f[k]["dbEnd"]) != (w["score"], w["qEnd"], w["dbEnd"]) or (r[k]["score"], r[k]["qEnd"], r[k]["dbEnd"]) != (w2["score"], w2["qEnd"], w2["dbEnd"]):
                 ok = False; print("  SW MISMATCH round", rd, "q", i, "L", lens[i], "t", int(t), "Lt", len(t3), "atype", atype, f[k], w, r[k], w2)
+    if rng.random() < 0.5:
+        api.set_host_workers(int(rng.integers(0, 6)))
     batch, bts = s.align_batch(qa, q3, hit_lists, with_backtrace=True)
     for i in range(nq):
         r1, b1 = single[i]
