@@ -20,10 +20,65 @@ static bool fileSize(const std::string &p, uint64_t &sz) {
 }
 
 DbReader::~DbReader() {
-    if (mapped && base) munmap((void *) base, bytes);
+    if (mapped && mapBase) munmap((void *) mapBase, mapBytes);
+    else if (mapped && base) munmap((void *) base, bytes);
 }
 
-bool DbReader::open(const std::string &path, std::string &err) {
+static bool endsWith(const std::string &s, const std::string &suf) { return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0; }
+
+std::string dbPathWithSuffix(const std::string &db, const std::string &suffix) {
+    if (!endsWith(db, ".idx")) return db + suffix;
+    const std::string plain = db.substr(0, db.size() - 4) + suffix;
+    uint64_t sz;
+    return fileSize(plain + ".idx.dbtype", sz) ? plain + ".idx" : plain;
+}
+
+// sequence DB stored inside a precomputed index: DBR1INDEX (key 5) = DBReader::serialize (DBReader.cpp:824-840: size, dataSize,
+// lastKey, dbtype, maxSeqLen, then `size` records {u32 id; u64 offset; u32 length} with natural alignment = 24 bytes),
+// DBR1DATA (key 6) = the data file's bytes
+bool DbReader::openInsideIndex(const std::string &idxPath, std::string &err) {
+    DbReader outer;
+    // the index DB itself is an ordinary MMseqs DB (its .dbtype is INDEX_DB = 16: no sequence semantics needed here)
+    if (!outer.open(idxPath + "\x01raw", err)) return false;
+    const int64_t iIdx = outer.idOf(5), iDat = outer.idOf(6);
+    if (iIdx < 0 || iDat < 0) { err = idxPath + ": no sequence database inside the index (DBR1INDEX / DBR1DATA missing)"; return false; }
+    const char *p = outer.data((size_t) iIdx);
+    const uint64_t need = 8 + 8 + 4 + 4 + 4;
+    if (outer.entryLen((size_t) iIdx) < need) { err = idxPath + ": truncated DBR1INDEX"; return false; }
+    uint64_t n, dataSize; int32_t dbt;
+    memcpy(&n, p, 8); memcpy(&dataSize, p + 8, 8); memcpy(&dbt, p + 20, 4);
+    if (outer.entryLen((size_t) iIdx) < need + n * 24) { err = idxPath + ": truncated DBR1INDEX"; return false; }
+    const char *rec = p + 28;
+    entries.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t id, len; uint64_t off;
+        memcpy(&id, rec + i * 24, 4); memcpy(&off, rec + i * 24 + 8, 8); memcpy(&len, rec + i * 24 + 16, 4);
+        entries[i] = {id, off, len};
+    }
+    std::stable_sort(entries.begin(), entries.end(), [](const Entry &a, const Entry &b) { return a.key < b.key; });
+    type = dbt;
+    // keep the outer mapping alive, point at the data blob
+    base = outer.data((size_t) iDat);
+    bytes = outer.entryLen((size_t) iDat);
+    mapBase = outer.base; mapBytes = outer.bytes; mapped = outer.mapped;
+    owned.swap(outer.owned);
+    if (!mapped) { base = owned.data() + (base - outer.base); }
+    outer.mapped = false; outer.base = nullptr;
+    for (const Entry &e : entries)
+        if (e.offset + e.length > bytes + 1) { err = idxPath + ": sequence entry beyond the data blob inside the index"; return false; }
+    return true;
+}
+
+bool DbReader::open(const std::string &pathIn, std::string &err) {
+    std::string path = pathIn;
+    const bool raw = endsWith(path, "\x01raw");          // internal: open an index DB as the plain DB it is
+    if (raw) path.resize(path.size() - 4);
+    if (!raw && endsWith(path, ".idx")) {
+        const std::string plain = path.substr(0, path.size() - 4);
+        uint64_t sz;
+        if (fileSize(plain + ".dbtype", sz) && fileSize(plain + ".index", sz)) path = plain;      // the sequence DB is still there
+        else return openInsideIndex(path, err);
+    }
     // .dbtype
     {
         FILE *f = fopen((path + ".dbtype").c_str(), "rb");

@@ -19,6 +19,11 @@ class DbReader {
 public:
     struct Entry { uint32_t key; uint64_t offset; uint32_t length; };
     ~DbReader();
+    // `path` may name a precomputed index (<db>.idx, what the workflows pass once `createindex` has run:
+    // F/data/structuresearch.sh "${TARGET_PREFILTER}${INDEXEXT}"): the sequence database is then taken from <db> if it still
+    // exists, else from the copy INSIDE the index (entries DBR1INDEX = 5 / DBR1DATA = 6 of the index DB,
+    // M/src/prefiltering/PrefilteringIndexReader.cpp:15-18,116-128: a serialised DBReader index + the data blob).  The
+    // persisted k-mer table itself is not read: the device rebuilds it from the sequences in 0.02-0.07 s.
     bool open(const std::string &path, std::string &err);
     size_t size() const { return entries.size(); }
     uint32_t key(size_t id) const { return entries[id].key; }
@@ -39,7 +44,14 @@ private:
     int type = 0;
     bool mapped = false;
     std::vector<char> owned;                                                  // multi-file DBs are read into memory
+    const char *mapBase = nullptr;                                            // what to munmap (base may point into it)
+    uint64_t mapBytes = 0;
+    bool openInsideIndex(const std::string &idxPath, std::string &err);
 };
+
+// <db>[.idx] + suffix the way StructureUtil::getIndexWithSuffix does (F/src/commons/StructureUtil.h:9-21): "db.idx" + "_ss" ->
+// "db_ss.idx" if that index exists, else "db_ss"; "db" + "_ss" -> "db_ss"
+std::string dbPathWithSuffix(const std::string &db, const std::string &suffix);
 
 class DbWriter {
 public:

@@ -776,7 +776,7 @@ int fsmod_search(int argc, const char **argv) {
         return fail("usage: search <queryDB> <targetDB> <outAlnDB> [<outPrefDB>] [--prefilter-mode 0|1] [-s S] [--max-seqs N] [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
     DbReader qA, q3, tA, t3;
-    if (!qA.open(o.pos[0], err) || !q3.open(o.pos[0] + "_ss", err) || !tA.open(o.pos[1], err) || !t3.open(o.pos[1] + "_ss", err)) return fail(err);
+    if (!qA.open(o.pos[0], err) || !q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || !tA.open(o.pos[1], err) || !t3.open(dbPathWithSuffix(o.pos[1], "_ss"), err)) return fail(err);
     if (qA.size() != q3.size()) return fail("query AA and 3Di databases differ in size");
     const bool sameDB = o.pos[0] == o.pos[1];
     const bool includeIdentical = o.geti("--add-self-matches", 0) != 0;
@@ -946,7 +946,7 @@ int fsmod_structurealign(int argc, const char **argv) {
     if (o.pos.size() != 4) return fail("usage: structurealign <queryDB> <targetDB> <prefDB> <outAlnDB> [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
     DbReader qA, q3, tA, t3, pref;
-    if (!qA.open(o.pos[0], err) || !q3.open(o.pos[0] + "_ss", err) || !tA.open(o.pos[1], err) || !t3.open(o.pos[1] + "_ss", err) ||
+    if (!qA.open(o.pos[0], err) || !q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || !tA.open(o.pos[1], err) || !t3.open(dbPathWithSuffix(o.pos[1], "_ss"), err) ||
         !pref.open(o.pos[2], err))
         return fail(err);
     const bool sameDB = o.pos[0] == o.pos[1];
@@ -1057,7 +1057,7 @@ int fsmod_structurerescorediagonal(int argc, const char **argv) {
     if (o.geti("--alt-ali", 0) != 0) return fail("structurerescorediagonal: --alt-ali is not read by this module");
     std::string err;
     DbReader qA, q3, tA, t3, pref;
-    if (!qA.open(o.pos[0], err) || !q3.open(o.pos[0] + "_ss", err) || !tA.open(o.pos[1], err) || !t3.open(o.pos[1] + "_ss", err) ||
+    if (!qA.open(o.pos[0], err) || !q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || !tA.open(o.pos[1], err) || !t3.open(dbPathWithSuffix(o.pos[1], "_ss"), err) ||
         !pref.open(o.pos[2], err))
         return fail(err);
     const bool sameDB = o.pos[0] == o.pos[1];

@@ -113,6 +113,21 @@ RESCORE_RUNS = {
 }
 
 
+# precomputed indexes (F/data/structureindex.sh: `createindex` = two `indexdb` calls; the C-alpha append step is skipped, no _ca DB here).
+# The .idx files (900 MB each: 20^6 offsets + 3-mer matrices) are NOT frozen: the tests recreate them with the reference binary.
+INDEXDB_COMMON = ["--seed-sub-mat", SUBMAT, "-k", "0", "--alph-size", "aa:21,nucl:5", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "1",
+                  "--max-seq-len", "65535", "--max-seqs", "1000", "--mask", "0", "--mask-prob", "0.999995", "--mask-lower-case", "1",
+                  "--mask-n-repeat", "6", "--spaced-kmer-mode", "1", "-s", "9.5", "--k-score", "seq:2147483647,prof:2147483647",
+                  "--check-compatible", "0", "--search-type", "0", "--split", "0", "--split-memory-limit", "0", "-v", "1", "--threads", "1"]
+INDEXDB = [["indexdb", "db", "db"] + INDEXDB_COMMON + ["--index-subset", "2"],
+           ["indexdb", "db_ss", "db_ss"] + INDEXDB_COMMON + ["--index-dbsuffix", "_ss", "--index-subset", "5"]]
+INDEX_RUNS = {
+    # what the search workflow runs once indexes exist: the TARGET is the index (structuresearch.sh "${TARGET_PREFILTER}${INDEXEXT}")
+    "pref_kmer_idx": ("prefilter", ["db_ss", "db_ss.idx"], override(PREFILTER_PAR, **{"-k": "0"})),
+    "aln_t2_a_idx": ("structurealign", ["db", "db.idx", "pref_kmer_idx"], align_par(2, 1)),
+}
+
+
 def read_db(path):
     data = open(path, "rb").read()
     out = {}
@@ -175,6 +190,16 @@ def main():
     for name, (module, pos, par) in RESCORE_RUNS.items():
         run([FS, module] + pos + [name] + par, work)
         manifest["runs"][name] = {"module": module, "positional": pos, "parameters": par}
+    for ext in ("", ".index", ".dbtype"):       # structureindex.sh links the header DB next to the 3Di DB first (lndb)
+        if not os.path.exists(os.path.join(work, "db_ss_h" + ext)):
+            os.symlink(os.path.join(work, "db_h" + ext), os.path.join(work, "db_ss_h" + ext))
+    for cmd in INDEXDB:
+        run([FS] + cmd, work)
+    manifest["indexdb"] = INDEXDB
+    for name, (module, pos, par) in INDEX_RUNS.items():
+        run([FS, module] + pos + [name] + par, work)
+        manifest["runs_with_index"] = manifest.get("runs_with_index", {})
+        manifest["runs_with_index"][name] = {"module": module, "positional": pos, "parameters": par}
     shutil.rmtree(OUT, ignore_errors=True)
     os.makedirs(OUT)
     for f in sorted(os.listdir(work)):
@@ -182,7 +207,7 @@ def main():
         if os.path.islink(p):            # makepaddedseqdb links the AA / header data files to the source DB's
             manifest["links"][f] = os.path.basename(os.readlink(p))
             continue
-        if os.path.isdir(p) or f.endswith(".source") or "_tmp" in f:
+        if os.path.isdir(p) or f.endswith(".source") or "_tmp" in f or ".idx" in f:
             continue
         shutil.copy(p, os.path.join(OUT, f))
     json.dump(manifest, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)

@@ -46,7 +46,8 @@ def test_makepaddedseqdb_equals_reference_written_db(scop):
     """host-only module: base:makepaddedseqdb of the reference on db_ss (+ headers) == ours, all seven files byte for byte
     (M/src/util/makepaddedseqdb.cpp:14-154; the workflow links <db>_h next to the 3Di DB first, F/data/makepaddeddb.sh:10-19)"""
     for ext in ("", ".index", ".dbtype"):
-        shutil.copy(scop / ("db_h" + ext), scop / ("db_ss_h" + ext))
+        if not os.path.exists(scop / ("db_ss_h" + ext)):
+            shutil.copy(scop / ("db_h" + ext), scop / ("db_ss_h" + ext))
     subprocess.check_call([BIN, "makepaddedseqdb", str(scop / "db_ss"), str(scop / "mine_ss"), "--threads", "1", "-v", "1"])
     for ext in ("", ".index", ".lookup", ".dbtype", "_h", "_h.index", "_h.dbtype"):
         assert open(scop / ("mine_ss" + ext), "rb").read() == open(scop / ("db_pad_ss" + ext), "rb").read(), ext
@@ -124,3 +125,37 @@ def test_rescorediagonal_undefined_pairs_are_refused_or_skipped(scop):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     assert read_db(out) == read_db(str(scop / "resc_t2_a"))
+
+
+FS_REF = os.path.join(ROOT, "oracle", "_ref_full", "bin", "foldseek")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FS_REF), reason="oracle/_ref_full/bin/foldseek not built (oracle/build_ref_full.sh cpu)")
+def test_modules_take_precomputed_indexes_as_targets(scop):
+    """SURVEY 8f rank 4.  Once `createindex` has run, the search workflow hands the modules the INDEX as target
+    (`prefilter db_ss db_ss.idx`, `structurealign db db.idx`, F/data/structuresearch.sh "${TARGET_PREFILTER}${INDEXEXT}").  The indexes
+    are written here by the reference binary (`indexdb`, 900 MB each -- not frozen); our modules must produce the result DBs the
+    reference produced with them (note: with an index target the query and target DB names differ, so the self hit is no longer
+    forced to the top -- pref_kmer_idx differs from pref_kmer in exactly that).  Second pass: the plain target DBs are DELETED,
+    the sequences then come out of the index files themselves (DBR1INDEX / DBR1DATA entries)."""
+    # query side under its own name, so that the target's plain files can be removed later
+    for f in os.listdir(scop):
+        if f.startswith("db") and not f.startswith("db_pad") and not os.path.islink(scop / f):
+            shutil.copy(scop / f, scop / ("q" + f))
+    for cmd in MANIFEST["indexdb"]:
+        r = subprocess.run([FS_REF] + cmd, cwd=scop, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+    runs = MANIFEST["runs_with_index"]
+    for attempt in ("plain DB next to the index", "index files only"):
+        for name in ("pref_kmer_idx", "aln_t2_a_idx"):
+            run = runs[name]
+            pos = ["q" + run["positional"][0]] + run["positional"][1:]
+            out = str(scop / f"mine_{name}_{attempt[:5].strip()}")
+            cmd = [BIN, run["module"]] + [str(scop / p) for p in pos] + [out] + run["parameters"]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert r.returncode == 0, (attempt, name, r.stderr)
+            assert read_db(out) == read_db(str(scop / name)), (attempt, name)
+        for f in ("db", "db.index", "db.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype"):     # second pass: sequences from inside the indexes
+            if os.path.exists(scop / f):
+                os.remove(scop / f)
