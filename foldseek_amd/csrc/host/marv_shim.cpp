@@ -20,12 +20,25 @@ struct ShimDb {                       // what loadDb hands back: borrowed host p
     size_t n, bytes;
 };
 
-struct ShimState {
+// libmarv uses every visible device inside ONE Marv object and shards the TARGETS over them (marv.cu:57-60,
+// cudasw4.cuh:1477-1553), because its caller hands it one query at a time.  Same here: device k holds the targets
+// k, k + N, k + 2N, ... of the (length-sorted) database -- every shard sees the whole length range --, a scan runs on all
+// devices at once (asynchronous halves of the C ABI, one host thread) and the per-device top lists are merged in the CPU path's
+// order.  FSGPU_MARV_SHARDS=n puts n shards on device 0 (tests on a one-GPU box).
+struct Shard {
     fsgpu_ctx *ctx = nullptr;
+    std::vector<uint64_t> offsets;        // of this shard's targets (into the full data buffer)
+    std::vector<int32_t> lengths;
+    std::vector<uint32_t> globalId;
+    std::vector<fsgpu_hit> hits;
+};
+
+struct ShimState {
+    std::vector<Shard> shards;
     const ShimDb *resident = nullptr;
     size_t maxSeqs = 0;
     int maxSeqLength = 0;
-    std::vector<fsgpu_hit> hits;
+    std::vector<fsgpu_hit> merged;
     std::chrono::steady_clock::time_point timer;
 };
 
@@ -44,14 +57,21 @@ Marv::Marv(size_t dbEntries, int alphabetSize, int maxSeqLength, size_t maxSeqs,
     ShimState *s = new ShimState();
     s->maxSeqs = maxSeqs;
     s->maxSeqLength = maxSeqLength;
-    if (fsgpu_create(0, &s->ctx) != FSGPU_OK) die(fsgpu_last_error(nullptr));
-    s->hits.resize(std::max<size_t>(maxSeqs, 1));
+    std::vector<int> devs = getDeviceIds();
+    if (devs.empty()) die("no GPU visible");
+    if (const char *e = getenv("FSGPU_MARV_SHARDS")) devs.assign((size_t) std::max(1, atoi(e)), devs[0]);
+    if (devs.size() > dbEntries && dbEntries > 0) devs.resize(dbEntries);
+    s->shards.resize(devs.size());
+    for (size_t k = 0; k < devs.size(); k++) {
+        if (fsgpu_create(devs[k], &s->shards[k].ctx) != FSGPU_OK) die(fsgpu_last_error(nullptr));
+        s->shards[k].hits.resize(std::max<size_t>(maxSeqs, 1));
+    }
     cudasw = s;
 }
 
 Marv::~Marv() {
     ShimState *s = static_cast<ShimState *>(cudasw);
-    if (s) { fsgpu_destroy(s->ctx); delete s; }
+    if (s) { for (Shard &sh : s->shards) fsgpu_destroy(sh.ctx); delete s; }
 }
 
 std::vector<int> Marv::getDeviceIds() {
@@ -78,7 +98,15 @@ void Marv::setDb(void *dbhandle) {
     const ShimDb *db = static_cast<const ShimDb *>(dbhandle);
     if (!db) die("setDb: null database handle");
     if (s->resident != db) {
-        if (fsgpu_db_load(s->ctx, db->data, nullptr, db->offsets.data(), db->lengths, db->n, db->bytes) != FSGPU_OK) die(fsgpu_last_error(s->ctx));
+        const size_t N = s->shards.size();
+        for (size_t k = 0; k < N; k++) {
+            Shard &sh = s->shards[k];
+            sh.offsets.clear(); sh.lengths.clear(); sh.globalId.clear();
+            for (size_t i = k; i < db->n; i += N) { sh.offsets.push_back(db->offsets[i]); sh.lengths.push_back(db->lengths[i]); sh.globalId.push_back((uint32_t) i); }
+            sh.offsets.push_back(db->bytes);
+            if (sh.lengths.empty()) continue;
+            if (fsgpu_db_load(sh.ctx, db->data, nullptr, sh.offsets.data(), sh.lengths.data(), sh.lengths.size(), db->bytes) != FSGPU_OK) die(fsgpu_last_error(sh.ctx));
+        }
         s->resident = db;
     }
     dbmanager = dbhandle;
@@ -91,8 +119,9 @@ std::string Marv::getDbMemoryHandle() { return std::string(); }
 
 void Marv::printInfo() {
     ShimState *s = static_cast<ShimState *>(cudasw);
-    fprintf(stderr, "Marv (fsgpu): device %d, %llu targets, %llu residues resident\n", fsgpu_device(s->ctx),
-            (unsigned long long) fsgpu_db_size(s->ctx), (unsigned long long) fsgpu_db_residues(s->ctx));
+    for (const Shard &sh : s->shards)
+        fprintf(stderr, "Marv (fsgpu): device %d, %llu targets, %llu residues resident\n", fsgpu_device(sh.ctx),
+                (unsigned long long) fsgpu_db_size(sh.ctx), (unsigned long long) fsgpu_db_residues(sh.ctx));
 }
 void Marv::prefetch() {}                  // setDb already placed the database in HBM
 void Marv::startTimer() { static_cast<ShimState *>(cudasw)->timer = std::chrono::steady_clock::now(); }
@@ -138,11 +167,25 @@ Marv::Stats Marv::scan(const char *sequence, size_t sequenceLength, int8_t *pssm
     }
     const int cap = 255 - (abs(matMin) + abs(cbMin));
     const auto t0 = std::chrono::steady_clock::now();
-    int nout = 0;
-    if (fsgpu_gapless_scan(s->ctx, pssm, (int) L, std::max(cap, 0), -1, -1, (int) s->maxSeqs, s->hits.data(), &nout) != FSGPU_OK) die(fsgpu_last_error(s->ctx));
+    // all devices scan their shard of the targets concurrently; every shard returns ITS top maxSeqs, the global top maxSeqs
+    // is among them
+    for (Shard &sh : s->shards)
+        if (!sh.lengths.empty() && fsgpu_gapless_launch(sh.ctx, pssm, (int) L, std::max(cap, 0), -1, -1, (int) s->maxSeqs) != FSGPU_OK) die(fsgpu_last_error(sh.ctx));
+    s->merged.clear();
+    uint64_t residues = 0;
+    for (Shard &sh : s->shards) {
+        if (sh.lengths.empty()) continue;
+        int n = 0;
+        if (fsgpu_gapless_finish(sh.ctx, sh.hits.data(), &n) != FSGPU_OK) die(fsgpu_last_error(sh.ctx));
+        for (int k = 0; k < n; k++) s->merged.push_back({sh.globalId[sh.hits[k].id], sh.hits[k].score});
+        residues += fsgpu_db_residues(sh.ctx);
+    }
+    if (s->shards.size() > 1)
+        std::sort(s->merged.begin(), s->merged.end(), [](const fsgpu_hit &a, const fsgpu_hit &b) { return a.score != b.score ? a.score > b.score : a.id < b.id; });
+    const int nout = (int) std::min(s->merged.size(), s->maxSeqs);
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (int k = 0; k < nout; k++) results[k] = Result(s->hits[k].id, s->hits[k].score, 0, 0);
+    for (int k = 0; k < nout; k++) results[k] = Result(s->merged[k].id, s->merged[k].score, 0, 0);
     st.results = (size_t) nout;
-    st.gcups = st.seconds > 0 ? (double) fsgpu_db_residues(s->ctx) * (double) L / st.seconds * 1e-9 : 0;
+    st.gcups = st.seconds > 0 ? (double) residues * (double) L / st.seconds * 1e-9 : 0;
     return st;
 }

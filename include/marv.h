@@ -14,8 +14,9 @@
  *   - results are ordered (score desc, id asc), the order hit_t::compareHitsByScoreAndId gives the CPU path.
  *   - AlignmentType GAPLESS only; the other two types (gapped end-position scan) terminate with a message, the way libmarv
  *     terminates on a CUDA error (CUERR).
- *   - one device per Marv object (the first visible one); multi-GPU runs shard QUERIES over replicated DBs
- *     (fsgpu_db_broadcast / fsgpu-modules --gpus), not targets inside scan().
+ *   - like libmarv, one Marv object drives every visible device and shards the TARGETS over them (device k holds targets
+ *     k, k + N, ...; per-device top lists merged in the CPU path's order) because its caller hands it one query at a time; the
+ *     throughput path shards QUERIES over replicated DBs instead (fsgpu_db_broadcast / fsgpu-modules --gpus).
  */
 #ifndef MARV_H
 #define MARV_H

@@ -43,6 +43,19 @@ def test_reference_ungappedprefilter_gpu_path_through_our_marv(scop):
     assert read_db(out) == read_db(str(scop / "pref_ung_pad"))
 
 
+def test_marv_shards_targets_over_its_devices(scop):
+    """libmarv drives all visible devices from one Marv object and shards the TARGETS (one query at a time by contract); so does
+    the shim.  FSGPU_MARV_SHARDS=3 puts three shards on the one device of the test box: interleaved target subsets, concurrent
+    scans, merged top lists == the single-shard result == the CPU path's"""
+    env = _env()
+    env["FSGPU_MARV_SHARDS"] = "3"
+    out = str(scop / "mine_gpu3")
+    r = subprocess.run([FS_GPU, "ungappedprefilter", str(scop / "db_ss"), str(scop / "db_pad_ss"), out] + _gpu_par(),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert read_db(out) == read_db(str(scop / "pref_ung_pad"))
+
+
 def test_reference_gpuserver_and_client_through_our_marv(scop):
     env = _env()
     srv = subprocess.Popen([FS_GPU, "gpuserver", str(scop / "db_pad_ss"), "--max-seqs", "1000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
