@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes per kernel FAMILY (template arguments stripped): dispatches and counter totals, plus
-derived per-query figures for the scan kernel (a multi-query k_gapless launch runs grid / (768 workgroups x 256 threads)
-queries: 3 workgroups per CU x 256 CUs per query, fsgpu.hip::launchGapless).
+derived per-query figures for the scan kernel (a multi-query k_gapless launch runs grid / (512 workgroups x 256 threads)
+queries: 2 workgroups per CU x 256 CUs per query, fsgpu.hip::launchGapless; --wg-per-query N overrides).
 usage: pmc_family.py <dir-with-counter_collection.csv> ... [--json out.json]"""
 import collections
 import csv
@@ -11,7 +11,8 @@ import os
 import re
 import sys
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+WG = int(sys.argv[sys.argv.index("--wg-per-query") + 1]) if "--wg-per-query" in sys.argv else 512
+args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()]
 out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 if out_json in args:
     args.remove(out_json)
@@ -33,7 +34,7 @@ for name, e in sorted(fam.items(), key=lambda kv: -max(kv[1]["sum"].values())):
     for c in sorted(e["sum"]):
         row["counters"][c] = {"dispatches": e["dispatches"][c], "total": e["sum"][c]}
         if "k_gapless" in name:
-            queries = e["grid"][c] / (768 * 256)
+            queries = e["grid"][c] / (WG * 256)
             row["counters"][c]["queries"] = queries
             row["counters"][c]["per_query"] = e["sum"][c] / max(queries, 1e-9)
     res[name] = row
