@@ -1,0 +1,123 @@
+"""Module-level cross-check AT SCALE against the reference BINARY (oracle/_ref_full/bin/foldseek, the whole reference built by
+oracle/build_ref_full.sh; a built file that travels to the GPU box): both read the SAME on-disk databases (3000 synthetic targets
+up to 1200 residues with soft-masked stretches, 48 queries with planted homologs), the reference runs its CPU modules with the
+workflow's complete parameter strings, `fsgpu-modules` gets the same argument vectors, and every entry of every result DB must be
+byte-identical: k-mer prefilter, ungapped prefilter (plain and reference-padded target), structurealign on both (3Di+AA and 3Di
+only, with backtraces), structurerescorediagonal on the defined lines.  The padded target is written by the REFERENCE's
+makepaddedseqdb from the ASCII DB.  scop_v1 covers real structures at 30 entries; this covers length classes, masking, row tiles
+(queries > 512 residues), score ties at the --max-seqs cut and thousands of alignments."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from foldseek_amd import dbio, synth
+from test_scop_golden import BIN, GOLD, read_db
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FS = os.path.join(ROOT, "oracle", "_ref_full", "bin", "foldseek")
+MANIFEST = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(FS), reason="oracle/_ref_full/bin/foldseek not built")]
+
+
+def _run(cmd, cwd):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, " ".join(cmd[:4]) + "\n" + r.stdout[-3000:]
+
+
+def _par(name, threads, **over):
+    par = list(MANIFEST["runs"][name]["parameters"])
+    par[par.index("--threads") + 1] = str(threads)
+    for k, v in over.items():
+        par[par.index(k) + 1] = str(v)
+    return par
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    w = tmp_path_factory.mktemp("refbin")
+    q3, qa = synth.make_queries(48, seed=4242, mean_len=260, lo=40, hi=900)      # a few queries beyond 512 residues (row tiles)
+    db = synth.make_db(3000, (q3, qa), seed=4243, homologs_per_query=25, mean_len=240, lo=20, hi=1200, mask_frac=0.03)
+    tkeys = (np.arange(db.n) * 2 + 11).astype(np.uint32)
+    seqs3 = [db.seq(i, "3di", unmask=True) for i in range(db.n)]
+    masks = [db.data3di[db.offsets[i]:db.offsets[i] + db.lengths[i]] >= 32 for i in range(db.n)]
+    seqsa = [db.seq(i, "aa") for i in range(db.n)]
+    dbio.write_seq_db(str(w / "t"), seqsa, tkeys)
+    dbio.write_seq_db(str(w / "t_ss"), seqs3, tkeys, masks)
+    qkeys = [7 + 3 * i for i in range(len(q3))]
+    dbio.write_seq_db(str(w / "q"), qa, qkeys)
+    dbio.write_seq_db(str(w / "q_ss"), q3, qkeys)
+    # headers (makepaddedseqdb wants them) and the reference-written padded 3Di target
+    hdr = [np.frombuffer(f"s{k}".encode(), np.uint8) for k in tkeys]
+    with open(w / "t_ss_h", "wb") as f, open(w / "t_ss_h.index", "w") as fi:
+        off = 0
+        for k, h in zip(tkeys, hdr):
+            b = h.tobytes() + b"\n\0"
+            f.write(b); fi.write(f"{k}\t{off}\t{len(b)}\n"); off += len(b)
+    np.array([12], np.int32).tofile(str(w / "t_ss_h.dbtype"))
+    _run([FS, "base:makepaddedseqdb", "t_ss", "tp_ss", "--threads", "1", "-v", "1"], w)
+    return w
+
+
+def _same(w, a, b):
+    ta, da = read_db(str(w / a))
+    tb, dbb = read_db(str(w / b))
+    assert ta == tb and sorted(da) == sorted(dbb), (a, b)
+    for k in sorted(da):
+        assert da[k] == dbb[k], f"{a} vs {b}: entry {k}\n{da[k][:400]!r}\n{dbb[k][:400]!r}"
+    return sum(v.count(b"\n") for v in da.values())
+
+
+def test_prefilters_and_alignments_equal_the_reference_binary(world):
+    w = world
+    lines = {}
+    # ---- prefilters ----
+    for name, mod, tgt, par in (("kmer", "prefilter", "t_ss", _par("pref_kmer", 8, **{"--max-seqs": "300"})),
+                                ("ung", "ungappedprefilter", "t_ss", _par("pref_ung", 8, **{"--max-seqs": "300"})),
+                                ("ungp", "ungappedprefilter", "tp_ss", _par("pref_ung", 8, **{"--max-seqs": "300"}))):
+        _run([FS, mod, "q_ss", tgt, "ref_" + name] + par, w)
+        _run([BIN, mod, "q_ss", tgt, "mine_" + name] + par, w)
+        lines[name] = _same(w, "ref_" + name, "mine_" + name)
+    assert lines["kmer"] > 3000 and lines["ung"] == 48 * 300
+    # ---- structurealign on the reference's prefilter output ----
+    for name, pref, atype in (("aln2", "ref_kmer", 2), ("aln0", "ref_ung", 0)):
+        par = _par("aln_t2_a", 8, **{"--alignment-type": atype})
+        _run([FS, "structurealign", "q", "t", pref, "ref_" + name] + par, w)
+        _run([BIN, "structurealign", "q", "t", pref, "mine_" + name] + par, w)
+        lines[name] = _same(w, "ref_" + name, "mine_" + name)
+    assert lines["aln2"] > 800 and lines["aln0"] > 800
+    # ---- fused search == the reference's two steps ----
+    _run([BIN, "search", "q", "t", "mine_fused", "mine_fused_pref", "--prefilter-mode", "0", "-a", "1", "--alignment-type", "2", "--sort-by-structure-bits", "0",
+          "--max-seqs", "300", "-s", "9.5", "-e", "10", "--threads", "3"], w)
+    _same(w, "ref_kmer", "mine_fused_pref")
+    _same(w, "ref_aln2", "mine_fused")
+
+
+def test_rescorediagonal_equals_the_reference_binary_on_defined_lines(world):
+    """the k-mer prefilter's (target, diagonal) lines restricted to the pairs the reference defines (fsgpu_diag.hip): both binaries"""
+    w = world
+    if not os.path.exists(w / "ref_kmer"):
+        _run([FS, "prefilter", "q_ss", "t_ss", "ref_kmer"] + _par("pref_kmer", 8, **{"--max-seqs": "300"}), w)
+    qlen = {int(l.split()[0]): int(l.split()[2]) - 2 for l in open(w / "q_ss.index")}
+    tlen = {int(l.split()[0]): int(l.split()[2]) - 2 for l in open(w / "t_ss.index")}
+    _, pref = read_db(str(w / "ref_kmer"))
+    blob, index, off, kept = b"", [], 0, 0
+    for q in sorted(pref):
+        keep = []
+        for ln in pref[q].decode().splitlines():
+            t, _, d = ln.split("\t")
+            d, lq, lt = int(d), qlen[q], tlen[int(t)]
+            if (d >= 0 and d < lq) or (d < 0 and -d < lt and lt <= lq):
+                keep.append(ln)
+        kept += len(keep)
+        body = ("\n".join(keep) + "\n" if keep else "").encode() + b"\0"
+        index.append(f"{q}\t{off}\t{len(body)}\n"); blob += body; off += len(body)
+    open(w / "pref_def", "wb").write(blob); open(w / "pref_def.index", "w").write("".join(index))
+    np.array([7], np.int32).tofile(str(w / "pref_def.dbtype"))
+    assert kept > 1000
+    par = _par("resc_t2_a", 8)
+    _run([FS, "structurerescorediagonal", "q", "t", "pref_def", "ref_resc"] + par, w)
+    _run([BIN, "structurerescorediagonal", "q", "t", "pref_def", "mine_resc"] + par, w)
+    assert _same(w, "ref_resc", "mine_resc") > 300
