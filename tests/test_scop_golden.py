@@ -24,7 +24,13 @@ NOT_IMPLEMENTED = {}
 def read_db(path):
     """(dbtype int32, {key: entry bytes without the terminator}) straight from the files, no project code involved"""
     t = int.from_bytes(open(path + ".dbtype", "rb").read(4), "little", signed=True)
-    data = open(path, "rb").read()
+    if os.path.exists(path):
+        data = open(path, "rb").read()
+    else:      # DBWriter with several threads leaves the data in <db>.0, <db>.1, ... (offsets run through their concatenation)
+        data, k = b"", 0
+        while os.path.exists(f"{path}.{k}"):
+            data += open(f"{path}.{k}", "rb").read()
+            k += 1
     out = {}
     for line in open(path + ".index"):
         k, off, ln = line.split()
