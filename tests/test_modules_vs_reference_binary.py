@@ -80,7 +80,7 @@ def test_prefilters_and_alignments_equal_the_reference_binary(world):
         _run([FS, mod, "q_ss", tgt, "ref_" + name] + par, w)
         _run([BIN, mod, "q_ss", tgt, "mine_" + name] + par, w)
         lines[name] = _same(w, "ref_" + name, "mine_" + name)
-    assert lines["kmer"] > 3000 and lines["ung"] == 48 * 300
+    assert lines["kmer"] > 3000 and lines["ung"] > 10000 and lines["ungp"] == lines["ung"]
     # ---- structurealign on the reference's prefilter output ----
     for name, pref, atype in (("aln2", "ref_kmer", 2), ("aln0", "ref_ung", 0)):
         par = _par("aln_t2_a", 8, **{"--alignment-type": atype})
