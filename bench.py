@@ -400,14 +400,19 @@ def main():
     have_gpu = torch.cuda.is_available()
     if not have_gpu and not args.dry_run:
         raise SystemExit("bench.py: no GPU visible (the hot path has no CPU fallback); --dry-run exercises the rank / broadcast / sharding plumbing only")
+    # one rank per GPU.  FSGPU_BENCH_BACKEND=gloo + more ranks than devices (ranks share devices round robin) is a plumbing check
+    # for boxes with a single GPU: everything but the RCCL transport of the one broadcast is the code the 8-GPU run executes.
+    backend = os.environ.get("FSGPU_BENCH_BACKEND", "nccl" if have_gpu else "gloo")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if have_gpu else 0
     if world > 1:
-        if have_gpu:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group(backend)
     if have_gpu:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
+    local_rank = dev_index
 
     if args.workload == "allvsall" and not args.dry_run:
         from foldseek_amd import api
