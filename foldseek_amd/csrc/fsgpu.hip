@@ -66,6 +66,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->swLong) (void) hipStreamSynchronize(ctx->swLong);
     if (ctx->scanDoneEv) {
         if (ctx->db) { std::lock_guard<std::mutex> g(ctx->db->scanMutex); if (ctx->db->lastScanDone == ctx->scanDoneEv) ctx->db->lastScanDone = nullptr; }
         (void) hipEventDestroy(ctx->scanDoneEv);
@@ -74,14 +75,15 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     ctx->kidx.reset();
     if (ctx->kmer) fsgpu_kmer_free_scratch(ctx->kmer);
     DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
-                      &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys,
+                      &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys, &ctx->lbuf, &ctx->lres,
                       &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen,
                       &ctx->mqPssm, &ctx->mqScores, &ctx->mqQueues, &ctx->mqRec, &ctx->mqHist, &ctx->mqBaseGt, &ctx->mqBaseTie, &ctx->mqMeta,
                       &ctx->mqOutId, &ctx->mqOutScore, &ctx->mqIdent};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     hipFree(ctx->dMeta); hipFree(ctx->queue);
     hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId.p); hipHostFree(ctx->hOutScore.p);
-    hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p);
+    hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p); hipHostFree(ctx->hLbuf.p); hipHostFree(ctx->hLres.p);
+    if (ctx->swLong) (void) hipStreamDestroy(ctx->swLong);
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
     hipHostFree(ctx->hMqPssm.p); hipHostFree(ctx->hMqRec.p); hipHostFree(ctx->hMqMeta.p); hipHostFree(ctx->hMqOutId.p); hipHostFree(ctx->hMqOutScore.p); hipHostFree(ctx->hMqIdent.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
@@ -934,6 +936,197 @@ static int runSwPass(fsgpu_ctx *ctx, bool packed, const int16_t *pAA0, const int
     return FSGPU_OK;
 }
 
+// ---- multi-query row-tiled SW: the queries of a fsgpu_sw_multi_dir call that are longer than 64 * kSwMaxR rows ----
+// One k_sw launch per tile LEVEL serves the tiles of that level of ALL such queries (workgroup = up to 8 pairs of one query,
+// SwTileBlock); levels follow each other on a side stream (ctx->swLong) next to the single-tile launches of the same call.
+// k_sw carries the forward and the reversed query in the int16 halves, so the forward call already has the reversed-query
+// results: they are kept per query (with a hash of what they depend on) and handed out by the following reversed call.
+struct SwLongPlan {
+    std::vector<uint32_t> slotQ, slotJ;         // launch slot -> query, index into its targetIds
+    size_t n = 0;
+};
+
+static uint64_t hashWords(uint64_t h, const void *p, size_t bytes) {
+    const unsigned char *c = (const unsigned char *) p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, c + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    for (; i < bytes; i++) h = (h ^ c[i]) * 0x100000001B3ull;
+    return h;
+}
+static uint64_t swLongHash(const fsgpu_sw_query &q) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t) q.L ^ ((uint64_t) q.n << 32);
+    h = hashWords(h, q.targetIds, (size_t) q.n * 4);
+    h = hashWords(h, q.p3Di_rev, (size_t) q.L * kAlphabet * 2);
+    if (q.pAA_rev) h = hashWords(h, q.pAA_rev, (size_t) q.L * kAlphabet * 2);
+    return h ? h : 1;
+}
+
+template <bool HAS_AA>
+static int launchSwTilesT(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
+    const int lds = (HAS_AA ? 2 : 1) * kAlphabet * swRowDwords(kSwMaxR) * 4;
+    static thread_local uint64_t attrDevs = 0;
+    const uint64_t devBit = 1ull << (ctx->device & 63);
+    if (!(attrDevs & devBit)) {
+        HIPCHK(hipFuncSetAttribute((const void *) k_sw<kSwMaxR, HAS_AA, Pk16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attrDevs |= devBit;
+    }
+    hipLaunchKernelGGL((k_sw<kSwMaxR, HAS_AA, Pk16>), dim3(nBlocks), dim3(512), lds, stream, sa);
+    HIPCHK(hipGetLastError());
+    return FSGPU_OK;
+}
+
+// isLong[i]: query i is row-tiled and has selected pairs.  Pairs answered from the forward call's results go straight to out[].
+static int swLongEnqueue(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, const std::vector<char> &isLong, const int32_t *const *sel, const int32_t *nsel,
+                         const std::vector<size_t> &base, bool hasAA, int gapOpen, int gapExtend, int dir, fsgpu_swres *out, SwLongPlan &plan) {
+    plan.n = 0; plan.slotQ.clear(); plan.slotJ.clear();
+    if (dir == 0) ctx->swLongRev.assign((size_t) nq, fsgpu_ctx::LongRev());
+    const std::vector<int32_t> &len = ctx->db->hLengths;
+    std::vector<size_t> qFirst(nq + 1, 0);                 // slots of query i: [qFirst[i], qFirst[i + 1])
+    std::vector<uint64_t> lkey;
+    for (int i = 0; i < nq; i++) {
+        qFirst[i] = plan.n;
+        if (!isLong[i]) continue;
+        const int ns = sel ? nsel[i] : q[i].n;
+        const fsgpu_ctx::LongRev *have = nullptr;
+        if (dir == 1 && (size_t) i < ctx->swLongRev.size() && ctx->swLongRev[i].hash != 0 && ctx->swLongRev[i].res.size() == (size_t) q[i].n * 4 &&
+            ctx->swLongRev[i].hash == swLongHash(q[i]))
+            have = &ctx->swLongRev[i];
+        lkey.clear();
+        for (int k = 0; k < ns; k++) {
+            const int j = sel ? sel[i][k] : k;
+            if (have && have->res[(size_t) j * 4 + 3] != 0) { memcpy(&out[base[i] + j], &have->res[(size_t) j * 4], 16); continue; }
+            lkey.push_back(((uint64_t) (0xFFFFFF - len[q[i].targetIds[j]]) << 32) | (uint32_t) j);
+        }
+        std::sort(lkey.begin(), lkey.end());               // longest target first: the waves of a workgroup are of similar length
+        for (uint64_t k : lkey) { plan.slotQ.push_back((uint32_t) i); plan.slotJ.push_back((uint32_t) k); }
+        plan.n += lkey.size();
+        if (dir == 0) { ctx->swLongRev[i].hash = swLongHash(q[i]); ctx->swLongRev[i].res.assign((size_t) q[i].n * 4, 0); }
+    }
+    qFirst[nq] = plan.n;
+    if (plan.n == 0) return FSGPU_OK;
+    const size_t n = plan.n;
+    const int R = kSwMaxR, rowsPerTile = 64 * R, rowDw = swRowDwords(R);
+    const size_t tblDw = (size_t) kAlphabet * rowDw, imgDw = tblDw * (hasAA ? 2 : 1);
+    // geometry: tiles per query, image offsets, blocks per level
+    int maxTiles = 0;
+    std::vector<int> nTiles(nq, 0);
+    std::vector<size_t> imgFirst(nq, 0);                   // dword offset of tile 0 of query i inside the image section
+    size_t imgTotalDw = 0;
+    for (int i = 0; i < nq; i++) {
+        if (qFirst[i + 1] == qFirst[i]) continue;
+        nTiles[i] = (q[i].L + rowsPerTile - 1) / rowsPerTile;
+        maxTiles = std::max(maxTiles, nTiles[i]);
+        imgFirst[i] = imgTotalDw;
+        imgTotalDw += imgDw * (size_t) nTiles[i];
+    }
+    if (imgTotalDw >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir: tile images of one call exceed 16 GiB"; return FSGPU_E_NOMEM; }
+    std::vector<size_t> levelFirst(maxTiles + 1, 0);
+    for (int t = 0; t < maxTiles; t++) {
+        size_t nb = 0;
+        for (int i = 0; i < nq; i++) if (nTiles[i] > t) nb += (qFirst[i + 1] - qFirst[i] + 7) / 8;
+        levelFirst[t + 1] = levelFirst[t] + nb;
+    }
+    auto align16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t offTids = 0, offBase = align16(n * 4), offBlocks = align16(offBase + n * 4), offImg = align16(offBlocks + levelFirst[maxTiles] * sizeof(SwTileBlock));
+    const size_t bytes = offImg + imgTotalDw * 4;
+    int rc;
+    if ((rc = ensurePinned(ctx, ctx->hLbuf, bytes)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->lbuf, bytes)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->lres, n * 32)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hLres, n * 32)) != FSGPU_OK) return rc;
+    unsigned char *h = (unsigned char *) ctx->hLbuf.p;
+    uint32_t *hT = (uint32_t *) (h + offTids), *hB = (uint32_t *) (h + offBase);
+    SwTileBlock *hBlk = (SwTileBlock *) (h + offBlocks);
+    uint32_t *hImg = (uint32_t *) (h + offImg);
+    uint64_t cols = 0;
+    for (size_t s2 = 0; s2 < n; s2++) {
+        const uint32_t tid = q[plan.slotQ[s2]].targetIds[plan.slotJ[s2]];
+        hT[s2] = tid;
+        if (cols >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir: tile borders of one call exceed 2^32 columns"; return FSGPU_E_NOMEM; }
+        hB[s2] = (uint32_t) cols;
+        cols += (uint64_t) ((len[tid] + 63) / 64 * 64);
+    }
+    for (int t = 0; t < maxTiles; t++) {
+        SwTileBlock *b = hBlk + levelFirst[t];
+        size_t nb = 0;
+        for (int i = 0; i < nq; i++) {
+            if (nTiles[i] <= t) continue;
+            const int L = q[i].L;
+            for (size_t p0 = qFirst[i]; p0 < qFirst[i + 1]; p0 += 8) {
+                SwTileBlock &d = b[nb++];
+                d.imgOff = (uint32_t) (imgFirst[i] + imgDw * (size_t) t); d.firstPair = (uint32_t) p0; d.nPairs = (uint16_t) std::min<size_t>(8, qFirst[i + 1] - p0);
+                d.rowsInTile = (uint16_t) std::min(rowsPerTile, L - t * rowsPerTile); d.segLen = (uint32_t) ((L + 15) / 16);
+                d.tileBase = (uint32_t) (t * rowsPerTile); d.flags = (t > 0 ? 1u : 0u) | (t + 1 < nTiles[i] ? 2u : 0u);
+            }
+        }
+        std::stable_sort(b, b + nb, [&](const SwTileBlock &x, const SwTileBlock &y) { return len[hT[x.firstPair]] > len[hT[y.firstPair]]; });
+    }
+    for (int i = 0; i < nq; i++) {
+        if (nTiles[i] == 0) continue;
+        const int L = q[i].L;
+        for (int t = 0; t < nTiles[i]; t++) {
+            const int rowBase = t * rowsPerTile;
+            for (int tbl = 0; tbl < (hasAA ? 2 : 1); tbl++) {
+                const int16_t *f = tbl == 0 ? q[i].p3Di_fwd : q[i].pAA_fwd;
+                const int16_t *r = tbl == 0 ? q[i].p3Di_rev : q[i].pAA_rev;
+                uint32_t *dst = hImg + imgFirst[i] + imgDw * (size_t) t + tblDw * tbl;
+                for (int a = 0; a < kAlphabet; a++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int rr = 0; rr < R; rr++) {
+                            const int row = rowBase + lane * R + rr;
+                            uint32_t v = 0;
+                            if (row < L) v = (uint32_t) (uint16_t) f[(size_t) a * L + row] | ((uint32_t) (uint16_t) r[(size_t) a * L + row] << 16);
+                            dst[(size_t) a * rowDw + swDwordIndex(R, lane, rr)] = v;
+                        }
+            }
+        }
+    }
+    if (maxTiles > 1) {
+        if ((rc = ensure(ctx, ctx->border0, cols * 12)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->border1, cols * 12)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->keys, n * 2 * 8)) != FSGPU_OK) return rc;
+    }
+    if (!ctx->swLong) HIPCHK(hipStreamCreateWithFlags(&ctx->swLong, hipStreamNonBlocking));
+    HIPCHK(hipMemcpyAsync(ctx->lbuf.p, h, bytes, hipMemcpyHostToDevice, ctx->swLong));
+    const unsigned char *d = (const unsigned char *) ctx->lbuf.p;
+    for (int t = 0; t < maxTiles; t++) {
+        SwArgs sa;
+        sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
+        sa.targetIds = (const uint32_t *) (d + offTids); sa.nPairs = (int) n;
+        sa.profSS = (const uint32_t *) (d + offImg); sa.profAA = nullptr;
+        sa.tileBase = 0; sa.rowsInTile = 0; sa.segLen = 1;
+        sa.go = (uint32_t) gapOpen | ((uint32_t) gapOpen << 16);
+        sa.ge = (uint32_t) gapExtend | ((uint32_t) gapExtend << 16);
+        sa.tileIn = 0; sa.tileOut = 0;
+        sa.borderIn = (const uint32_t *) ((t & 1) ? ctx->border1.p : ctx->border0.p);
+        sa.borderOut = (uint32_t *) ((t & 1) ? ctx->border0.p : ctx->border1.p);
+        sa.borderStride = 0;
+        sa.keys = (uint64_t *) ctx->keys.p;
+        sa.res0 = (int32_t *) ctx->lres.p; sa.res1 = (int32_t *) ctx->lres.p + n * 4;
+        sa.blocks = nullptr; sa.dir = 0;
+        sa.tblocks = (const SwTileBlock *) (d + offBlocks) + levelFirst[t];
+        sa.borderBase = (const uint32_t *) (d + offBase);
+        const int nb = (int) (levelFirst[t + 1] - levelFirst[t]);
+        rc = hasAA ? launchSwTilesT<true>(ctx, sa, nb, ctx->swLong) : launchSwTilesT<false>(ctx, sa, nb, ctx->swLong);
+        if (rc != FSGPU_OK) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->hLres.p, ctx->lres.p, n * 32, hipMemcpyDeviceToHost, ctx->swLong));
+    return FSGPU_OK;
+}
+
+static int swLongCollect(fsgpu_ctx *ctx, const SwLongPlan &plan, const std::vector<size_t> &base, int dir, fsgpu_swres *out) {
+    if (plan.n == 0) return FSGPU_OK;
+    int rc = syncStreamOf(ctx, ctx->swLong);
+    if (rc != FSGPU_OK) return rc;
+    const int32_t *fwd = (const int32_t *) ctx->hLres.p, *rev = fwd + plan.n * 4;
+    for (size_t s2 = 0; s2 < plan.n; s2++) {
+        const uint32_t i = plan.slotQ[s2], j = plan.slotJ[s2];
+        memcpy(&out[base[i] + j], (dir == 0 ? fwd : rev) + s2 * 4, 16);
+        if (dir == 0) memcpy(&ctx->swLongRev[i].res[(size_t) j * 4], rev + s2 * 4, 16);
+    }
+    return FSGPU_OK;
+}
+
 extern "C" {
 
 static int swLaunchImpl(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd, const int16_t *pAA_rev,
@@ -1075,7 +1268,7 @@ int fsgpu_sw_batch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_f
 // the bulk of the others.  One call runs ONE direction (dir 0: forward query, 1: reversed query) over the selected
 // pairs with k_sw2 (two targets per wave): structurealign looks at the reversed-query score only for pairs that pass
 // the forward gates, so the caller runs dir 0 over everything, gates, and runs dir 1 over the survivors.
-// Longer queries and int16-saturated pairs go through the single-query path (k_sw, both directions at once).
+// Longer queries run as multi-query row-tiled k_sw launches (swLongEnqueue); int16-saturated pairs go through the single-query path.
 int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, int dir,
                        const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out) {
     if (!ctx || nq < 0 || (nq > 0 && (!q || !out)) || (dir != 0 && dir != 1) || ((sel == nullptr) != (nsel == nullptr))) return FSGPU_E_ARG;
@@ -1106,6 +1299,19 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
     auto nSel = [&](int i) { return (int) (sbase[i + 1] - sbase[i]); };
     auto selIdx = [&](int i, int k) { return sel ? sel[i][k] : k; };
     int rc;
+    // row-tiled queries: own launches on a side stream, next to the single-tile launches below
+    SwLongPlan longPlan;
+    {
+        std::vector<char> isLong(nq, 0);
+        bool any = false;
+        for (int i = 0; i < nq; i++) if (q[i].L > 64 * kSwMaxR && nSel(i) > 0) { isLong[i] = 1; any = true; }
+        if (any && (rc = swLongEnqueue(ctx, q, nq, isLong, sel, nsel, base, hasAA, gapOpen, gapExtend, dir, out, longPlan)) != FSGPU_OK) {
+            if (ctx->swLong) (void) hipStreamSynchronize(ctx->swLong);
+            return rc;
+        }
+    }
+    // whatever goes wrong below: the side stream must be idle before its buffers are reused
+    struct LongGuard { fsgpu_ctx *c; bool armed; ~LongGuard() { if (armed && c->swLong) (void) hipStreamSynchronize(c->swLong); } } longGuard{ctx, longPlan.n > 0};
     std::vector<uint32_t> perm;       // launch slot -> index into q[i].targetIds
     std::vector<uint64_t> lkey;
     // ---- launch groups by register class ----
@@ -1226,7 +1432,11 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
             if (cls[i] > 0)
                 for (int k = 0; k < nSel(i); k++) out[base[i] + perm[sbase[i] + k]] = r0[sbase[i] + k];
     }
-    // long (row-tiled) queries and int16-saturated pairs: the single-query path (computes both directions, keeps `dir`)
+    rc = swLongCollect(ctx, longPlan, base, dir, out);
+    longGuard.armed = false;
+    if (rc != FSGPU_OK) return rc;
+    if (dir == 1) ctx->swLongRev.clear();
+    // int16-saturated pairs: the single-query path re-runs them with the int32 kernel (computes both directions, keeps `dir`)
     std::vector<fsgpu_swres> f2, r2;
     for (int i = 0; i < nq; i++) {
         const int ns = nSel(i);
@@ -1235,7 +1445,7 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
         std::vector<int> where;
         for (int k = 0; k < ns; k++) {
             const int j = selIdx(i, k);
-            if (cls[i] < 0 || out[base[i] + j].score == 32767) { ids.push_back(q[i].targetIds[j]); where.push_back(j); }
+            if (out[base[i] + j].score == 32767) { ids.push_back(q[i].targetIds[j]); where.push_back(j); }
         }
         if (ids.empty()) continue;
         f2.resize(ids.size()); r2.resize(ids.size());

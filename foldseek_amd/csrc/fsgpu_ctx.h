@@ -101,6 +101,12 @@ struct fsgpu_ctx {
     hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
     hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf img, tids, res0, res1, border0, border1, keys;
+    // multi-query row-tiled launches (queries longer than 512 rows inside fsgpu_sw_multi_dir): own stream, own staging
+    hipStream_t swLong = nullptr;
+    DevBuf lbuf, lres;                             // [ids | border bases | tile blocks per level | images], [fwd results | rev results]
+    PinBuf hLbuf, hLres;
+    struct LongRev { uint64_t hash = 0; std::vector<int32_t> res; };   // reversed-query results of the forward call's k_sw launches (4 int32 per pair, word 0 = not computed)
+    std::vector<LongRev> swLongRev;                // per query of the last dir-0 call
     DevBuf ovAA, ovSS, ovOff, ovLen;               // explicit target sequences of fsgpu_sw_batch_seqs (instead of database entries)
     PinBuf hRes0, hRes1;                           // pinned result staging
     struct {
@@ -129,11 +135,11 @@ struct fsgpu_ctx {
 // wants the result right away), then back off to short sleeps: a host thread that waits must not burn a core -- several
 // feeder threads per GPU times eight GPUs exceeds the CPU quota of a container long before it exceeds the GPUs.
 // FSGPU_SPIN_US overrides the polling window (microseconds, default 40; 0 = sleep immediately).
-inline int syncStream(fsgpu_ctx *ctx) {
+inline int syncStreamOf(fsgpu_ctx *ctx, hipStream_t stream) {
     static const long spinUs = [] { const char *e = getenv("FSGPU_SPIN_US"); return e ? atol(e) : 40L; }();
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned polls = 0;; polls++) {
-        hipError_t e = hipStreamQuery(ctx->stream);
+        hipError_t e = hipStreamQuery(stream);
         if (e == hipSuccess) return FSGPU_OK;
         if (e != hipErrorNotReady) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
         if ((polls & 15) == 15 || spinUs == 0) {
@@ -142,6 +148,8 @@ inline int syncStream(fsgpu_ctx *ctx) {
         }
     }
 }
+
+inline int syncStream(fsgpu_ctx *ctx) { return syncStreamOf(ctx, ctx->stream); }
 
 inline int ensurePinned(fsgpu_ctx *ctx, PinBuf &b, size_t bytes) {
     if (b.cap >= bytes && b.p) return FSGPU_OK;

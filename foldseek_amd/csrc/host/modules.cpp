@@ -131,6 +131,11 @@ const FlagSpec kServerFlags[] = {              // Parameters::gpuserver (Paramet
     {"--shm-name", false, USE, nullptr}, {"--gpu-server-version", false, USE, nullptr},
     {nullptr, false, USE, nullptr}};
 
+// FSGPU_MODULE_TIMING=1: phase times of a module run on stderr (wall clock of the calling thread; the per-thread phases are summed
+// over the host threads, so they can exceed the loop's wall time)
+static double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool moduleTiming() { const char *e = getenv("FSGPU_MODULE_TIMING"); return e && *e && *e != '0'; }
+
 const FlagSpec *findFlag(const std::string &a, std::initializer_list<const FlagSpec *> tables) {
     for (const FlagSpec *t : tables)
         for (; t->name; t++)
@@ -775,6 +780,8 @@ int fsmod_search(int argc, const char **argv) {
     if (o.pos.size() != 3 && o.pos.size() != 4)
         return fail("usage: search <queryDB> <targetDB> <outAlnDB> [<outPrefDB>] [--prefilter-mode 0|1] [-s S] [--max-seqs N] [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
+    const double tStart = nowSec();
+    std::atomic<int64_t> usPrep(0), usPref(0), usAlign(0), usFormat(0), usAlnPrep(0), usAlnDev(0), usAlnGate(0), usAlnBack(0), nRev(0), nPairs(0);
     DbReader qA, q3, tA, t3;
     if (!qA.open(o.pos[0], err) || !q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || !tA.open(o.pos[1], err) || !t3.open(dbPathWithSuffix(o.pos[1], "_ss"), err)) return fail(err);
     if (qA.size() != q3.size()) return fail("query AA and 3Di databases differ in size");
@@ -798,6 +805,7 @@ int fsmod_search(int argc, const char **argv) {
     if (!m8 || !m2) return fail("matrix construction failed");
     PaddedTarget pt;
     if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
+    const double tLoaded = nowSec();
     DeviceSet ds;
     if (!ds.open(o, pt, true, 3, err)) { ds.close(); return fail(err); }
     const int maxRes = (int) std::min<uint64_t>((uint64_t) par.maxResListLen, std::max<uint64_t>(t3.size(), 1));
@@ -808,6 +816,7 @@ int fsmod_search(int argc, const char **argv) {
         for (fsgpu_ctx *c : ds.root)
             if (fsgpu_kmer_index_build(c, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(c); ds.close(); return fail(err); }
     }
+    const double tDevice = nowSec();
     fsgpu_kmer_search_params sp;
     memset(&sp, 0, sizeof(sp));
     sp.maxResListLen = maxRes; sp.minDiagScoreThr = par.minDiagScoreThr;
@@ -860,12 +869,14 @@ int fsmod_search(int argc, const char **argv) {
             }
             if (bad) break;
             // ---- prefilter ----
+            double t0 = nowSec();
             if (prefMode == 0) {
                 for (size_t k = 0; k < nb; k++) {
                     thr[k].resize(Ls[k] + 1); prof[k].resize((size_t) Ls[k] * 21 + 1);
                     fshost_kmer_query_prepare(m8, m2, c3[k].data(), Ls[k], par.compBiasCorrection, par.prefCompBiasScale, kmerThr, 6, spaced, thr[k].data(), prof[k].data());
                     kq[k].seq = c3[k].data(); kq[k].kmerThr = thr[k].data(); kq[k].profile = prof[k].data(); kq[k].L = Ls[k]; kq[k].reserved = 0; kq[k].identity = ident[k];
                 }
+                { const double t1 = nowSec(); usPrep += (int64_t) ((t1 - t0) * 1e6); t0 = t1; }
                 if (fsgpu_kmer_search(ctx, &sp, kq.data(), (int) nb, khits.data(), nout.data(), status.data(), nullptr) != FSGPU_OK) { if (!bad++) firstErr = fsgpu_last_error(ctx); break; }
                 for (size_t k = 0; k < nb && !bad; k++) {
                     if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(b0 + k)) + ": hit buffers of the reference would overflow"; break; }
@@ -896,6 +907,7 @@ int fsmod_search(int argc, const char **argv) {
                 }
             }
             if (bad) break;
+            { const double t1 = nowSec(); usPref += (int64_t) ((t1 - t0) * 1e6); t0 = t1; }
             // ---- align: one multi-query launch for the batch (queries without hits keep an empty entry) ----
             std::vector<size_t> live;
             for (size_t k = 0; k < nb; k++) if (!ids[k].empty() && Ls[k] > 0) live.push_back(k);
@@ -913,11 +925,20 @@ int fsmod_search(int argc, const char **argv) {
                 if (!bad++) firstErr = fshost_search_error(s);
                 break;
             }
+            { const double t1 = nowSec(); usAlign += (int64_t) ((t1 - t0) * 1e6); t0 = t1; }
+            {
+                double st[8];
+                fshost_search_stats(s, st);
+                usAlnPrep += (int64_t) (st[2] * 1e6); usAlnDev += (int64_t) (st[3] * 1e6); usAlnGate += (int64_t) (st[4] * 1e6); usAlnBack += (int64_t) (st[5] * 1e6);
+                nRev += (int64_t) st[7];
+                for (int x : lN) nPairs += x;
+            }
             for (size_t j = 0; j < live.size(); j++) {
                 std::string &out = results[b0 + live[j]];
                 for (int r = 0; r < lres[j]; r++)
                     out.append(line.data(), fshost_format_result(line.data(), &res[live[j]][r], fshost_search_backtrace(s, &res[live[j]][r]), par.addBacktrace));
             }
+            usFormat += (int64_t) ((nowSec() - t0) * 1e6);
         }
         fshost_search_free(s);
         if (owned) fsgpu_destroy(ctx);
@@ -926,6 +947,7 @@ int fsmod_search(int argc, const char **argv) {
     for (int i = 1; i < nthreads; i++) ths.emplace_back(work, i);
     work(0);
     for (auto &th : ths) th.join();
+    const double tLoop = nowSec();
     fshost_matrix_free(m8); fshost_matrix_free(m2);
     ds.close();
     if (bad) return fail("search failed: " + firstErr);
@@ -934,6 +956,10 @@ int fsmod_search(int argc, const char **argv) {
         if (writePref) wp.write(q3.key(id), prefs[id].data(), prefs[id].size());
     }
     if (!w.close(err) || (writePref && !wp.close(err))) return fail(err);
+    if (moduleTiming())
+        fprintf(stderr, "search timing: load %.2f s, device open + index %.2f s, query loop %.2f s (%d threads; summed over threads: prepare %.2f, prefilter %.2f, align %.2f [profiles %.2f, SW launches + waits %.2f, gates %.2f, "
+                "backtrace %.2f; %lld pairs, %lld reversed], format %.2f), close + write %.2f s\n", tLoaded - tStart, tDevice - tLoaded, tLoop - tDevice, nthreads, usPrep / 1e6, usPref / 1e6,
+                usAlign / 1e6, usAlnPrep / 1e6, usAlnDev / 1e6, usAlnGate / 1e6, usAlnBack / 1e6, (long long) nPairs.load(), (long long) nRev.load(), usFormat / 1e6, nowSec() - tLoop);
     return EXIT_SUCCESS;
 }
 

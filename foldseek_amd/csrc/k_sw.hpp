@@ -82,6 +82,21 @@ struct SwArgs {
     // k_sw2 (multi-query launches, single-tile queries of one R class): workgroup b serves blocks[b]
     const struct SwBlockDesc *blocks;
     int dir;                      // k_sw2 only: 0 = forward-query halves of the image, 1 = reversed-query halves
+    // k_sw, multi-query row-tiled launches (queries longer than 64*R rows): workgroup b serves tblocks[b] -- one row tile of up
+    // to blockDim.x/64 pairs of one query; tile geometry and image come from the descriptor instead of the fields above, the
+    // border columns of pair p start at slot borderBase[p] instead of p * borderStride
+    const struct SwTileBlock *tblocks = nullptr;
+    const uint32_t *borderBase = nullptr;
+};
+
+struct SwTileBlock {
+    uint32_t imgOff;              // dword offset of this (query, tile) image inside SwArgs::profSS ([SS table][AA table])
+    uint32_t firstPair;           // global pair index of wave 0
+    uint16_t nPairs;              // live waves of this workgroup
+    uint16_t rowsInTile;          // valid rows of this tile (<= 64R)
+    uint32_t segLen;
+    uint32_t tileBase;            // first query row of this tile
+    uint32_t flags;               // bit 0: continues a previous tile (border in), bit 1: is continued (border out)
 };
 
 // One workgroup of a multi-query launch (k_sw2): up to 2 * (blockDim.x / 64) consecutive pairs of one query.
@@ -131,7 +146,19 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     constexpr int TBL = kAlphabet * ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t *profSS = a.profSS, *profAA = a.profAA;
-    const int rowsInTile = a.rowsInTile, segLen = a.segLen;
+    int rowsInTile = a.rowsInTile, segLen = a.segLen, tileBase = a.tileBase;
+    bool tileIn = a.tileIn != 0, tileOut = a.tileOut != 0;
+    int pairFirst = (int) (blockIdx.x * (blockDim.x >> 6)), pairEnd = a.nPairs;
+    if (a.tblocks) {                                   // workgroup-uniform descriptor -> SGPRs
+        const SwTileBlock bd = a.tblocks[blockIdx.x];
+        profSS = a.profSS + __builtin_amdgcn_readfirstlane(bd.imgOff);
+        profAA = profSS + TBL / 4;
+        rowsInTile = __builtin_amdgcn_readfirstlane((int) bd.rowsInTile); segLen = __builtin_amdgcn_readfirstlane((int) bd.segLen);
+        tileBase = __builtin_amdgcn_readfirstlane((int) bd.tileBase);
+        const uint32_t fl = __builtin_amdgcn_readfirstlane(bd.flags);
+        tileIn = (fl & 1u) != 0; tileOut = (fl & 2u) != 0;
+        pairFirst = __builtin_amdgcn_readfirstlane((int) bd.firstPair); pairEnd = pairFirst + __builtin_amdgcn_readfirstlane((int) bd.nPairs);
+    }
     {
         const uint4 *s3 = (const uint4 *) profSS;
         uint4 *d3 = (uint4 *) smem;
@@ -147,10 +174,9 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     // of another query) shares the SIMD, win the issue arbitration so this kernel's latency does not stretch.
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
-    const int wavesPerBlock = blockDim.x >> 6;
     const int waveInBlock = (int) (threadIdx.x >> 6);
-    const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * wavesPerBlock + waveInBlock);
-    if (pair >= a.nPairs) return;
+    const int pair = __builtin_amdgcn_readfirstlane(pairFirst + waveInBlock);
+    if (pair >= pairEnd) return;
 
     // wave-uniform pair parameters -> SGPRs, scalar loop control
     const uint32_t tid = __builtin_amdgcn_readfirstlane(a.targetIds[pair]);
@@ -158,14 +184,14 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     const uint64_t off64 = a.offsets[tid];
     const uint64_t off = ((uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) (off64 >> 32)) << 32) |
                          (uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) off64);
-    const int nLanes = a.tileOut ? 64 : (rowsInTile + R - 1) / R;
+    const int nLanes = tileOut ? 64 : (rowsInTile + R - 1) / R;
     const int steps = Lt > 0 ? Lt + nLanes - 1 : 0;
     const bool laneActive = lane < nLanes;
 
     // segment-start masks for my rows
     uint32_t segmask[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) segmask[r] = ((a.tileBase + lane * R + r) % segLen == 0) ? 0u : 0xffffffffu;
+    for (int r = 0; r < R; r++) segmask[r] = ((tileBase + lane * R + r) % segLen == 0) ? 0u : 0xffffffffu;
 
     uint32_t E[R], Hp[R], snap[R];
 #pragma unroll
@@ -175,7 +201,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     uint32_t chunkCur = 0, chunkNxt = 0;
     uint32_t bh = 0, bfs = 0, bff = 0, bhN = 0, bfsN = 0, bffN = 0;   // border-in chunks
     uint32_t oh = 0, ofs = 0, off_ = 0;                                // border-out accumulators
-    const size_t bBase = (size_t) pair * a.borderStride;
+    const size_t bBase = a.tblocks ? (size_t) __builtin_amdgcn_readfirstlane(a.borderBase[pair]) : (size_t) pair * a.borderStride;
 
     auto loadChunk = [&](int s0) -> uint32_t {
         int col = s0 + lane;
@@ -188,7 +214,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
         return v;
     };
     chunkNxt = loadChunk(0);
-    if (a.tileIn && lane < Lt) {
+    if (tileIn && lane < Lt) {
         const uint32_t *p = a.borderIn + (bBase + lane) * 3;
         bhN = p[0]; bfsN = p[1]; bffN = p[2];
     }
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
         if ((s & 63) == 0) {
             chunkCur = chunkNxt;
             chunkNxt = loadChunk(s + 64);
-            if (a.tileIn) {
+            if (tileIn) {
                 bh = bhN; bfs = bfsN; bff = bffN;
                 int col = s + 64 + lane;
                 if (col < Lt) {
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
         {
             const uint32_t tv = __builtin_amdgcn_readlane(chunkCur, s & 63);
             if (lane == 0) tval = tv;
-            if (a.tileIn) {
+            if (tileIn) {
                 const uint32_t x0 = __builtin_amdgcn_readlane(bh, s & 63);
                 const uint32_t x1 = __builtin_amdgcn_readlane(bfs, s & 63);
                 const uint32_t x2 = __builtin_amdgcn_readlane(bff, s & 63);
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
             }
         }
         hUpPrev = hUpNew;
-        if (a.tileOut) {
+        if (tileOut) {
             const int c63 = s - 63;
             if (c63 >= 0 && c63 < Lt) {
                 const uint32_t x0 = __builtin_amdgcn_readlane(hOut, 63);
@@ -292,12 +318,12 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
             if constexpr (A::packed) v = (snap[r] >> (16 * d)) & 0xffffu; else v = snap[r];
             if (v == b) row = r;
         }
-        const uint32_t q = (uint32_t) (a.tileBase + lane * R + row);
+        const uint32_t q = (uint32_t) (tileBase + lane * R + row);
         uint64_t key = ((uint64_t) b << 32) | ((uint64_t) (0xffffu - (c & 0xffffu)) << 16) | (uint64_t) (0xffffu - (q & 0xffffu));
         key = waveMaxU64(key);
-        if (a.tileIn) { const uint64_t pk = a.keys[(size_t) pair * 2 + d]; key = pk > key ? pk : key; }
+        if (tileIn) { const uint64_t pk = a.keys[(size_t) pair * 2 + d]; key = pk > key ? pk : key; }
         if (lane == 0) {
-            if (a.tileOut) {
+            if (tileOut) {
                 a.keys[(size_t) pair * 2 + d] = key;
             } else {
                 int32_t *res = (d == 0 ? a.res0 : a.res1) + (size_t) pair * 4;

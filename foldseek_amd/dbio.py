@@ -49,3 +49,27 @@ def read_padded_db(path):
     offsets = np.array([r[1] for r in rows] + [data.size], dtype=np.int64)
     lengths = np.array([r[2] - 2 for r in rows], dtype=np.int32)
     return t, data, offsets, lengths
+
+
+def write_seq_db_from_padded(path, db: PaddedDB, which="3di", keys=None):
+    """ASCII sequence DB (letters + '\\n' + '\\0' per entry, soft-masked residues in lower case) of every entry of a PaddedDB, vectorised:
+    200k entries in well under a second.  keys default to 0..n-1."""
+    data = db.data3di if which == "3di" else db.dataaa
+    n = db.n
+    lens = db.lengths.astype(np.int64)
+    out_off = np.zeros(n + 1, np.int64)
+    out_off[1:] = np.cumsum(lens + 2)
+    # source index of every residue: entry offset + position inside the entry
+    ent = np.repeat(np.arange(n), lens)
+    pos = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
+    codes = data[db.offsets[:-1][ent] + pos]
+    lut = np.frombuffer((ALPHABET + "X" * 11 + ALPHABET.lower() + "x" * 11).encode(), np.uint8)      # code + 32 = soft-masked -> lower case
+    out = np.empty(int(out_off[-1]), np.uint8)
+    out[out_off[:-1][ent] + pos] = lut[np.minimum(codes, 63)]
+    out[out_off[1:] - 2] = ord("\n")
+    out[out_off[1:] - 1] = 0
+    out.tofile(path)
+    keys = np.arange(n) if keys is None else np.asarray(keys)
+    with open(path + ".index", "w") as fi:
+        fi.write("".join(f"{int(k)}\t{int(o)}\t{int(l) + 2}\n" for k, o, l in zip(keys, out_off[:-1], lens)))
+    np.array([0], dtype=np.int32).tofile(path + ".dbtype")

@@ -353,3 +353,98 @@ def test_sw_multi_dir_two_targets_per_wave():
             assert (got[i]["score"][mask] == want_r[i]["score"][mask]).all() and (got[i]["dbEnd"][mask] == want_r[i]["dbEnd"][mask]).all()
             assert (got[i]["score"][~mask] == 0).all() and (got[i]["word"][~mask] == 0).all()
     ctx.close()
+
+
+def test_sw_multi_dir_row_tiled_queries():
+    """Queries longer than 512 rows inside a multi-query call: one k_sw launch per tile level over all of them (SwTileBlock) against
+    the single-query path (fsgpu_sw_batch) and the oracle; the reversed call is answered from the forward call's launches, must not be
+    when the profiles changed in between, and works on its own; selections; short queries mixed in; int16-saturated pairs re-run."""
+    rng = np.random.default_rng(77)
+    lens = [513, 600, 1024, 350, 1025, 1600, 3000, 64]
+    q3 = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    qa = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
+    db = synth.make_db(700, (q3, qa), seed=56, homologs_per_query=6, lo=1, hi=2500, mask_frac=0.02)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    npairs = [1, 9, 17, 30, 8, 40, 5, 12]
+    for atype in (0, 2):
+        mA, m3 = api.Matrix(1, 1.4 if atype == 2 else 0.0), api.Matrix(0, 2.1)
+        use_aa = atype == 2
+
+        def build(q3s, qas):
+            out = []
+            for i, L in enumerate(lens):
+                pAf, p3f, _, _ = api.align_profiles(mA, m3, qas[i], q3s[i], True, 0.5)
+                pAr, p3r, _, _ = api.align_profiles(mA, m3, qas[i][::-1].copy(), q3s[i][::-1].copy(), True, 0.5)
+                out.append([pAf if use_aa else None, p3f, pAr if use_aa else None, p3r, L, None])
+            return out
+        queries = build(q3, qa)
+        hom = [np.nonzero(helpers.o_ungapped_scores(q3[i], db, False) > 200)[0] for i in range(len(lens))]
+        want_f, want_r = [], []
+        for i in range(len(lens)):
+            ids = rng.choice(db.n, size=npairs[i], replace=False).astype(np.uint32)
+            k = min(len(hom[i]), max(1, npairs[i] // 3))
+            ids[:k] = hom[i][:k]                                     # planted relatives
+            ids = np.unique(ids).astype(np.uint32)
+            queries[i][5] = ids
+            f, r = ctx.sw_batch(*queries[i][:4], ids)
+            want_f.append(f); want_r.append(r)
+
+        def check(got, want, what):
+            for i in range(len(lens)):
+                for fld in ("score", "qEnd", "dbEnd"):
+                    assert (got[i][fld] == want[i][fld]).all(), (atype, what, lens[i], fld)
+        qs = [tuple(q) for q in queries]
+        check(ctx.sw_multi_dir(qs, 0), want_f, "forward")
+        check(ctx.sw_multi_dir(qs, 1), want_r, "reversed, from the forward call's launches")
+        check(ctx.sw_multi_dir(qs, 1), want_r, "reversed on its own")
+        # forward call, then a reversed call whose reversed profiles differ: must be computed, not taken from the forward call
+        other = build([x[::-1].copy() for x in q3], [x[::-1].copy() for x in qa])
+        mixed = [(q[0], q[1], o[2], o[3], q[4], q[5]) for q, o in zip(queries, other)]
+        want_mixed = [ctx.sw_batch(*m[:4], m[5])[1] for m in mixed]
+        ctx.sw_multi_dir(qs, 0)
+        check(ctx.sw_multi_dir(mixed, 1), want_mixed, "reversed with other profiles after a forward call")
+        # selections after a forward call, and without one
+        sels = [np.array(sorted(rng.choice(len(q[5]), size=(len(q[5]) + 1) // 2, replace=False)), np.int32) for q in qs]
+        for with_forward in (True, False):
+            if with_forward:
+                ctx.sw_multi_dir(qs, 0)
+            got = ctx.sw_multi_dir(qs, 1, selections=sels)
+            for i in range(len(lens)):
+                mask = np.zeros(len(qs[i][5]), bool); mask[sels[i]] = True
+                assert (got[i]["score"][mask] == want_r[i]["score"][mask]).all() and (got[i]["dbEnd"][mask] == want_r[i]["dbEnd"][mask]).all() and (got[i]["qEnd"][mask] == want_r[i]["qEnd"][mask]).all()
+                assert (got[i]["score"][~mask] == 0).all() and (got[i]["word"][~mask] == 0).all()
+        # oracle spot check (forward, one long query with three tiles and one with two)
+        for i in (4, 0):
+            pA, p3 = helpers.o_align_profiles(qa[i], q3[i], atype)[:2]
+            for k in range(min(4, len(qs[i][5]))):
+                ta, t3 = helpers.target_seqs(db, int(qs[i][5][k]))
+                if len(t3) == 0:
+                    continue
+                w = helpers.o_sw(pA, p3, lens[i], ta, t3)
+                assert (int(want_f[i][k]["score"]), int(want_f[i][k]["qEnd"]), int(want_f[i][k]["dbEnd"])) == (w["score"], w["qEnd"], w["dbEnd"])
+    ctx.close()
+    # int16-saturated pairs of a row-tiled query inside a multi-query call: re-run by the int32 kernel, both directions
+    rng = np.random.default_rng(9)
+    L = 3000
+    q3s = np.where(rng.random(L) < 0.1, rng.choice(20, size=L), 10).astype(np.uint8)
+    qas = np.where(rng.random(L) < 0.1, rng.choice(20, size=L), 18).astype(np.uint8)
+    seqs3 = [rng.choice(20, size=int(l)).astype(np.uint8) for l in rng.integers(50, 2500, size=14)] + [q3s.copy(), q3s[100:2900].copy()]
+    seqsa = [rng.choice(20, size=len(x)).astype(np.uint8) for x in seqs3[:14]] + [qas.copy(), qas[100:2900].copy()]
+    db = _manual_db(seqs3, seqsa)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    mA, m3 = api.Matrix(1, 1.4), api.Matrix(0, 2.1)
+    qs = []
+    for a3, aa in ((q3s, qas), (seqs3[3], seqsa[3]), (q3s[:700].copy(), qas[:700].copy())):
+        pAf, p3f, _, _ = api.align_profiles(mA, m3, aa, a3, False, 0.5)
+        pAr, p3r, _, _ = api.align_profiles(mA, m3, aa[::-1].copy(), a3[::-1].copy(), False, 0.5)
+        qs.append((pAf, p3f, pAr, p3r, len(a3), np.arange(db.n, dtype=np.uint32)))
+    want = [ctx.sw_batch(*q[:4], q[5]) for q in qs]
+    assert (want[0][0]["word"] == 2).any() and (want[0][1]["word"] == 2).any()
+    for direction in (0, 1):
+        got = ctx.sw_multi_dir(qs, direction)
+        for i in range(len(qs)):
+            for fld in ("score", "qEnd", "dbEnd", "word"):
+                assert (got[i][fld] == want[i][direction][fld]).all(), (direction, i, fld)
+    ctx.close()
