@@ -126,6 +126,12 @@ const FlagSpec kPaddedFlags[] = {              // Parameters::makepaddedseqdb (P
     {"--mask-lower-case", false, IGNORE, nullptr}, {"--mask-n-repeat", false, IGNORE, nullptr}, {"--write-lookup", false, USE, nullptr},
     {nullptr, false, USE, nullptr}};
 
+const FlagSpec kConvertFlags[] = {             // LocalParameters::convertalignments (Parameters.cpp:661-672, LocalParameters.cpp:117)
+    {"--format-mode", false, ONLY, "0|2|4"},   // 1 SAM and 3 HTML end in "Not implemented yet" / need the C-alpha DB in the reference too; 5 superposed PDB needs it
+    {"--format-output", false, USE, nullptr}, {"--translation-table", false, IGNORE, nullptr}, {"--gap-open", false, IGNORE, nullptr},
+    {"--gap-extend", false, IGNORE, nullptr}, {"--db-output", true, USE, "0"}, {"--search-type", false, IGNORE, nullptr},
+    {"--exact-tmscore", false, IGNORE, nullptr}, {nullptr, false, USE, nullptr}};
+
 const FlagSpec kServerFlags[] = {              // Parameters::gpuserver (Parameters.cpp:1638-1640)
     {"--max-seqs", false, USE, nullptr}, {"--prefilter-mode", false, ONLY, "0|1"}, {"--max-seq-len", false, USE, nullptr},
     {"--shm-name", false, USE, nullptr}, {"--gpu-server-version", false, USE, nullptr},
@@ -1258,3 +1264,293 @@ int fsmod_gpuserver(int argc, const char **argv) {
 }
 
 } // extern "C"
+
+// ---- convertalis -------------------------------------------------------------------------------------------------
+// F/src/strucclustutils/structureconvertalis.cpp:253-1445 for the BLAST-tab family (--format-mode 0, 2, 4) and every
+// --format-output column that is a function of the alignment record, the sequences and the headers.  Columns computed from
+// C-alpha coordinates (lddt, lddtfull, alntmscore, qtmscore, ttmscore, rmsd, u, t, qca, tca), taxonomy, set / source and multimer
+// columns are refused by name.  `prob` only reads the score (CalcProbTP.h), so it is answered without the _ca DB the reference
+// insists on opening for it.
+namespace {
+
+enum ConvCol { C_QUERY, C_TARGET, C_QKEY, C_TKEY, C_EVALUE, C_GAPOPEN, C_PIDENT, C_FIDENT, C_NIDENT, C_QSTART, C_QEND, C_QLEN, C_TSTART, C_TEND,
+               C_TLEN, C_ALNLEN, C_BITS, C_CIGAR, C_QSEQ, C_TSEQ, C_Q3DI, C_T3DI, C_QHEADER, C_THEADER, C_QALN, C_TALN, C_Q3DIALN, C_T3DIALN,
+               C_MISMATCH, C_QCOV, C_TCOV, C_EMPTY, C_PROB };
+
+struct ConvColSpec { const char *name; ConvCol col; bool needSeq, need3Di, needBt; };
+const ConvColSpec kConvCols[] = {        // LocalParameters::getOutputFormat (LocalParameters.cpp:464-553)
+    {"query", C_QUERY, false, false, false}, {"target", C_TARGET, false, false, false}, {"qkey", C_QKEY, false, false, false}, {"tkey", C_TKEY, false, false, false},
+    {"evalue", C_EVALUE, false, false, false}, {"gapopen", C_GAPOPEN, false, false, false}, {"pident", C_PIDENT, false, false, false},
+    {"fident", C_FIDENT, false, false, false}, {"nident", C_NIDENT, false, false, false}, {"qstart", C_QSTART, false, false, false},
+    {"qend", C_QEND, false, false, false}, {"qlen", C_QLEN, false, false, false}, {"tstart", C_TSTART, false, false, false}, {"tend", C_TEND, false, false, false},
+    {"tlen", C_TLEN, false, false, false}, {"alnlen", C_ALNLEN, false, false, false}, {"bits", C_BITS, false, false, false}, {"cigar", C_CIGAR, false, false, true},
+    {"qseq", C_QSEQ, true, false, false}, {"tseq", C_TSEQ, true, false, false}, {"q3di", C_Q3DI, false, true, false}, {"t3di", C_T3DI, false, true, false},
+    {"qheader", C_QHEADER, false, false, false}, {"theader", C_THEADER, false, false, false}, {"qaln", C_QALN, true, false, true}, {"taln", C_TALN, true, false, true},
+    {"q3dialn", C_Q3DIALN, false, true, true}, {"t3dialn", C_T3DIALN, false, true, true}, {"mismatch", C_MISMATCH, false, false, false},
+    {"qcov", C_QCOV, false, false, false}, {"tcov", C_TCOV, false, false, false}, {"empty", C_EMPTY, false, false, false}, {"prob", C_PROB, false, false, false}};
+const char *const kConvRefused[] = {"qca", "tca", "u", "t", "alntmscore", "qtmscore", "ttmscore", "rmsd", "lddt", "lddtfull", "qset", "qsetid", "tset", "tsetid",
+                                    "taxid", "taxname", "taxlineage", "complexqtmscore", "multimerqtmscore", "complexttmscore", "multimerttmscore",
+                                    "complexassignid", "multimerassignid", "complexu", "multimeru", "complext", "multimert", "qcomplexcoverage",
+                                    "qmultimercoverage", "tcomplexcoverage", "tmultimercoverage", "qchaintms", "tchaintms", "qchains", "tchains", "interfacelddt"};
+
+// one line of an alignment DB (Matcher::parseAlignmentRecord, Matcher.cpp:205-282; 10 columns, 11 with the run-length backtrace)
+struct AlnRecord {
+    uint32_t dbKey; int score; float seqId; double eval; int qStart, qEnd, qLen, dbStart, dbEnd, dbLen;
+    float qcov, dbcov; unsigned int alnLength; std::string backtrace;
+};
+
+bool parseAlnRecord(const char *line, const char *end, AlnRecord &r, std::string &err) {
+    const char *w[16];
+    size_t n = 0;
+    const char *p = line;
+    while (p < end && n < 16) {
+        while (p < end && (*p == ' ' || *p == '\t')) p++;
+        if (p >= end || *p == '\n') break;
+        w[n++] = p;
+        while (p < end && *p != ' ' && *p != '\t' && *p != '\n') p++;
+    }
+    if (n < 10) { err = "Invalid alignment result record."; return false; }
+    if (n != 10 && n != 11) { err = "alignment records with ORF columns are not produced on this path"; return false; }
+    auto wordEnd = [&](size_t i) { const char *e = w[i]; while (e < end && *e != ' ' && *e != '\t' && *e != '\n') e++; return e; };
+    r.dbKey = (uint32_t) strtoul(w[0], nullptr, 10);
+    r.score = atoi(w[1]);
+    const double seqId = strtod(std::string(w[2], wordEnd(2)).c_str(), nullptr);
+    r.eval = strtod(std::string(w[3], wordEnd(3)).c_str(), nullptr);
+    r.qStart = atoi(w[4]); r.qEnd = atoi(w[5]); r.qLen = atoi(w[6]); r.dbStart = atoi(w[7]); r.dbEnd = atoi(w[8]); r.dbLen = atoi(w[9]);
+    const int aq = r.qStart == -1 ? 0 : r.qStart, ad = r.dbStart == -1 ? 0 : r.dbStart;
+    auto cov = [](unsigned int s, unsigned int e, unsigned int len) { return (std::min(len, std::max(s, e)) - std::min(s, e) + 1) / (float) len; };   // SmithWaterman::computeCov
+    r.qcov = (float) (double) cov((unsigned) aq, (unsigned) r.qEnd, (unsigned) r.qLen);
+    r.dbcov = (float) (double) cov((unsigned) ad, (unsigned) r.dbEnd, (unsigned) r.dbLen);
+    r.alnLength = (unsigned int) (std::max(abs(r.qEnd - aq), abs(r.dbEnd - ad)) + 1);
+    r.seqId = (float) seqId;
+    r.backtrace = n == 11 ? std::string(w[10], wordEnd(10)) : std::string();
+    return true;
+}
+
+std::string expandBacktrace(const std::string &cbt) {          // Matcher::uncompressAlignment (Matcher.cpp:189-203)
+    std::string bt;
+    size_t count = 0;
+    for (char c : cbt) {
+        if (c >= '0' && c <= '9') count = count * 10 + (size_t) (c - '0');
+        else { bt.append(count == 0 ? 1 : count, c); count = 0; }
+    }
+    return bt;
+}
+
+// structurePrintSeqBasedOnAln (structureconvertalis.cpp:133-171) without the nucleotide branches; target = the `reverse` argument
+void appendAlignedSeq(std::string &out, const char *seq, unsigned int offset, const std::string &bt, bool target) {
+    unsigned int pos = 0;
+    for (char c : bt) {
+        const char ch = seq[offset + pos];
+        if (c == 'M') { out.push_back(ch); pos++; }
+        else if (c == 'I') { if (target) out.push_back('-'); else { out.push_back(ch); pos++; } }
+        else if (c == 'D') { if (target) { out.push_back(ch); pos++; } else out.push_back('-'); }
+    }
+}
+
+void appendF3(std::string &out, float x) { char b[64]; out.append(b, (size_t) snprintf(b, sizeof(b), "%.3f", (double) x)); }        // SSTR(float): fmt "{:.3f}"
+void appendE3(std::string &out, double x) { char b[64]; out.append(b, (size_t) snprintf(b, sizeof(b), "%.3E", x)); }               // SSTR(double): fmt "{:.3E}"
+
+float probTruePositive(float score) {          // CalcProbTP::calculate (F/src/commons/CalcProbTP.h:8-32), float arithmetic as written there
+    if (score <= 10) return 0;
+    if (score >= 100) return 1.0;
+    auto gammaPdf = [](const float alpha, const float beta, const float x) -> float {
+        return exp(alpha * log(beta) + (alpha - 1) * log(x) + (-beta * x) - lgamma(alpha));
+    };
+    float p_tp = (0.8279 * gammaPdf(1.8123, 1 / 46.0042, score) + 0.1721 * gammaPdf(1.0057, 1 / 563.5014, score)) * 0.1023;
+    float p_fp = (0.34 * gammaPdf(4.9259, 1 / 4.745, score) + 0.66 * gammaPdf(9.4834, 1 / 1.3136, score)) * 0.8977;
+    return 1 / (1 + (p_fp / p_tp));
+}
+
+} // namespace
+
+extern "C" int fsmod_convertalis(int argc, const char **argv) {
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "convertalis", {kConvertFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
+    if (o.pos.size() != 4) return fail("usage: convertalis <queryDB> <targetDB> <alignmentDB> <outFile> [--format-mode 0|2|4] [--format-output col,col,...] [--db-output 0|1]");
+    int format = o.geti("--format-mode", 0);
+    const bool columnHeaders = format == 4;
+    if (columnHeaders) format = 0;
+    const bool dbOut = o.geti("--db-output", 0) != 0;
+    if (dbOut && columnHeaders) return fail("convertalis: --format-mode 4 with --db-output 1 is not implemented");
+    const std::string outfmt = o.has("--format-output") ? o.kv["--format-output"] : "query,target,fident,alnlen,mismatch,gapopen,qstart,qend,tstart,tend,evalue,bits";
+    std::vector<ConvCol> cols;
+    std::vector<std::string> colNames;
+    bool needSeq = false, need3Di = false, needBt = false;
+    for (size_t b = 0; b <= outfmt.size();) {                      // Util::split(outfmt, ","): empty fields are skipped
+        size_t e = outfmt.find(',', b);
+        if (e == std::string::npos) e = outfmt.size();
+        const std::string name = outfmt.substr(b, e - b);
+        b = e + 1;
+        if (name.empty()) continue;
+        const ConvColSpec *spec = nullptr;
+        for (const ConvColSpec &c : kConvCols) if (name == c.name) spec = &c;
+        if (!spec) {
+            for (const char *r : kConvRefused)
+                if (name == r) return fail("convertalis: column " + name + " is not implemented on this path (needs the C-alpha, taxonomy, set or multimer data)");
+            return fail("Format code " + name + " does not exist.");
+        }
+        cols.push_back(spec->col); colNames.push_back(name);
+        needSeq = needSeq || spec->needSeq; need3Di = need3Di || spec->need3Di; needBt = needBt || spec->needBt;
+    }
+    const bool sameDB = o.pos[0] == o.pos[1];
+    std::string err;
+    DbReader qSeq, tSeqOwn, q3, t3Own, qHdr, tHdrOwn, aln;
+    if (!qHdr.open(dbPathWithSuffix(o.pos[0], "_h"), err)) return fail(err);
+    if (!sameDB && !tHdrOwn.open(dbPathWithSuffix(o.pos[1], "_h"), err)) return fail(err);
+    if (needSeq && (!qSeq.open(o.pos[0], err) || (!sameDB && !tSeqOwn.open(o.pos[1], err)))) return fail(err);
+    if (need3Di && (!q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || (!sameDB && !t3Own.open(dbPathWithSuffix(o.pos[1], "_ss"), err)))) return fail(err);
+    if (!aln.open(o.pos[2], err)) return fail(err);
+    const DbReader &tHdr = sameDB ? qHdr : tHdrOwn, &tSeq = sameDB ? qSeq : tSeqOwn, &t3 = sameDB ? q3 : t3Own;
+    // entries of a padded (GPU layout) database are handed out as letters, soft-masked residues in lower case (DBReader::getUnpadded,
+    // M/src/commons/DBReader.cpp:349-371)
+    auto seqText = [](const DbReader &r, size_t id, std::string &buf) -> const char * {
+        if (!(r.extended() & DBTYPE_EXTENDED_GPU)) return r.data(id);
+        static const char letters[] = "ACDEFGHIKLMNPQRSTVWYX";
+        const unsigned char *d = (const unsigned char *) r.data(id);
+        const size_t n = r.seqLen(id);
+        buf.resize(n);
+        for (size_t k = 0; k < n; k++) {
+            const unsigned char code = d[k], base = code >= 32 ? (unsigned char) (code - 32) : code;
+            const char ch = letters[base <= 20 ? base : 20];
+            buf[k] = code >= 32 ? (char) (ch | ' ') : ch;
+        }
+        return buf.c_str();
+    };
+    std::string qSeqBuf, q3Buf, tSeqBuf, t3Buf;
+
+    // the reference walks the alignment DB in data-file order (DBReader::LINEAR_ACCCESS, structureconvertalis.cpp:451) and
+    // concatenates the per-query blocks
+    std::vector<size_t> order(aln.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return aln.offset(a) < aln.offset(b); });
+
+    FILE *plain = nullptr;
+    DbWriter w;
+    if (dbOut) { if (!w.open(o.pos[3], 12 /* DBTYPE_GENERIC_DB */, err)) return fail(err); }
+    else if (!(plain = fopen(o.pos[3].c_str(), "wb"))) return fail("cannot open " + o.pos[3] + " for writing");
+    bool ioOk = true;
+    if (columnHeaders && !cols.empty()) {
+        std::string h;
+        for (size_t i = 0; i < colNames.size(); i++) { if (i) h.push_back('\t'); h += colNames[i]; }
+        h.push_back('\n');
+        ioOk = fwrite(h.data(), 1, h.size(), plain) == h.size();
+    }
+    std::string result, bt;
+    char buffer[1024];
+    for (size_t oi = 0; oi < order.size(); oi++) {
+        const size_t i = order[oi];
+        const uint32_t queryKey = aln.key(i);
+        const int64_t qh = qHdr.idOf(queryKey);
+        if (qh < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " has no header entry");
+        const char *qHeader = qHdr.data((size_t) qh);
+        const size_t qHeaderLen = qHdr.seqLen((size_t) qh);
+        const std::string queryId = fastaHeaderName(qHeader);
+        const char *qSeqData = nullptr, *q3Data = nullptr;
+        if (needSeq) { const int64_t id = qSeq.idOf(queryKey); if (id < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " is not in " + o.pos[0]); qSeqData = seqText(qSeq, (size_t) id, qSeqBuf); }
+        if (need3Di) { const int64_t id = q3.idOf(queryKey); if (id < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " is not in the query 3Di database"); q3Data = seqText(q3, (size_t) id, q3Buf); }
+        result.clear();
+        const char *data = aln.data(i), *dataEnd = data + aln.entryLen(i);
+        while (data < dataEnd && *data != '\0') {
+            const char *lineEnd = data;
+            while (lineEnd < dataEnd && *lineEnd != '\n' && *lineEnd != '\0') lineEnd++;
+            AlnRecord res;
+            if (!parseAlnRecord(data, lineEnd, res, err)) return fail(err);
+            data = (lineEnd < dataEnd && *lineEnd == '\n') ? lineEnd + 1 : lineEnd;
+            if (res.backtrace.empty() && needBt)
+                return fail("Backtrace cigar is missing in the alignment result. Please recompute the alignment with the -a flag.");
+            const int64_t th = tHdr.idOf(res.dbKey);
+            if (th < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " has no header entry");
+            const char *tHeader = tHdr.data((size_t) th);
+            const size_t tHeaderLen = tHdr.seqLen((size_t) th);
+            const std::string targetId = fastaHeaderName(tHeader);
+            // alignment length, gap opens, identities, mismatches (structureconvertalis.cpp:731-768)
+            unsigned int gapOpenCount = 0, alnLen = res.alnLength, missMatchCount = 0, identical = 0;
+            if (!res.backtrace.empty()) {
+                size_t matchCount = 0;
+                alnLen = 0;
+                const std::string &b = res.backtrace;
+                for (size_t pos = 0; pos < b.size(); pos++) {
+                    int cnt = 0;
+                    if (isdigit((unsigned char) b[pos])) {
+                        cnt += atoi(b.c_str() + pos);
+                        while (pos < b.size() && isdigit((unsigned char) b[pos])) pos++;
+                    }
+                    alnLen += (unsigned int) cnt;
+                    if (pos >= b.size()) break;
+                    if (b[pos] == 'M') matchCount += (size_t) cnt;
+                    else if (b[pos] == 'D' || b[pos] == 'I') gapOpenCount += 1;
+                }
+                identical = static_cast<unsigned int>(res.seqId * static_cast<float>(alnLen) + 0.5);
+                missMatchCount = static_cast<unsigned int>(matchCount - identical);
+            } else {
+                const int adjustQstart = (res.qStart == -1) ? 0 : res.qStart;
+                const int adjustDBstart = (res.dbStart == -1) ? 0 : res.dbStart;
+                const float bestMatchEstimate = static_cast<float>(std::min(abs(res.qEnd - adjustQstart), abs(res.dbEnd - adjustDBstart)));
+                missMatchCount = static_cast<unsigned int>(bestMatchEstimate * (1.0f - res.seqId) + 0.5);
+            }
+            if (format == 2) {                     // FORMAT_ALIGNMENT_BLAST_WITH_LEN (:1198-1227)
+                const int count = snprintf(buffer, sizeof(buffer), "%s\t%s\t%1.3f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.2E\t%d\t%d\t%d\n", queryId.c_str(), targetId.c_str(),
+                                           res.seqId, alnLen, missMatchCount, gapOpenCount, res.qStart + 1, res.qEnd + 1, res.dbStart + 1, res.dbEnd + 1, res.eval,
+                                           res.score, res.qLen, res.dbLen);
+                if (count < 0 || (size_t) count >= sizeof(buffer)) { fprintf(stderr, "Truncated line in entry%zu!\n", i); continue; }
+                result.append(buffer, (size_t) count);
+                continue;
+            }
+            const char *tSeqData = nullptr, *t3Data = nullptr;
+            if (needSeq) { const int64_t id = tSeq.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in " + o.pos[1]); tSeqData = seqText(tSeq, (size_t) id, tSeqBuf); }
+            if (need3Di) { const int64_t id = t3.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in the target 3Di database"); t3Data = seqText(t3, (size_t) id, t3Buf); }
+            if (needBt) bt = expandBacktrace(res.backtrace);
+            for (size_t c = 0; c < cols.size(); c++) {
+                switch (cols[c]) {
+                    case C_QUERY: result += queryId; break;
+                    case C_TARGET: result += targetId; break;
+                    case C_QKEY: result += std::to_string(queryKey); break;
+                    case C_TKEY: result += std::to_string(res.dbKey); break;
+                    case C_EVALUE: appendE3(result, res.eval); break;
+                    case C_GAPOPEN: result += std::to_string(gapOpenCount); break;
+                    case C_FIDENT: appendF3(result, res.seqId); break;
+                    case C_PIDENT: appendF3(result, res.seqId * 100); break;
+                    case C_NIDENT: result += std::to_string(identical); break;
+                    case C_QSTART: result += std::to_string(res.qStart + 1); break;
+                    case C_QEND: result += std::to_string(res.qEnd + 1); break;
+                    case C_QLEN: result += std::to_string(res.qLen); break;
+                    case C_TSTART: result += std::to_string(res.dbStart + 1); break;
+                    case C_TEND: result += std::to_string(res.dbEnd + 1); break;
+                    case C_TLEN: result += std::to_string(res.dbLen); break;
+                    case C_ALNLEN: result += std::to_string(alnLen); break;
+                    case C_BITS: result += std::to_string(res.score); break;
+                    case C_CIGAR: result += res.backtrace; break;
+                    case C_QSEQ: result.append(qSeqData, (size_t) res.qLen); break;
+                    case C_TSEQ: result.append(tSeqData, (size_t) res.dbLen); break;
+                    case C_Q3DI: result.append(q3Data, (size_t) res.qLen); break;
+                    case C_T3DI: result.append(t3Data, (size_t) res.dbLen); break;
+                    case C_QHEADER: result.append(qHeader, qHeaderLen); break;
+                    case C_THEADER: result.append(tHeader, tHeaderLen); break;
+                    case C_QALN: appendAlignedSeq(result, qSeqData, (unsigned int) res.qStart, bt, false); break;
+                    case C_Q3DIALN: appendAlignedSeq(result, q3Data, (unsigned int) res.qStart, bt, false); break;
+                    case C_TALN: appendAlignedSeq(result, tSeqData, (unsigned int) res.dbStart, bt, true); break;
+                    case C_T3DIALN: appendAlignedSeq(result, t3Data, (unsigned int) res.dbStart, bt, true); break;
+                    case C_MISMATCH: result += std::to_string(missMatchCount); break;
+                    case C_QCOV: appendF3(result, res.qcov); break;
+                    case C_TCOV: appendF3(result, res.dbcov); break;
+                    case C_EMPTY: result.push_back('-'); break;
+                    case C_PROB: appendF3(result, probTruePositive((float) res.score)); break;
+                }
+                if (c + 1 < cols.size()) result.push_back('\t');
+            }
+            result.push_back('\n');
+        }
+        if (dbOut) w.write(queryKey, result.data(), result.size());
+        else ioOk = ioOk && fwrite(result.data(), 1, result.size(), plain) == result.size();
+    }
+    if (dbOut) { if (!w.close(err)) return fail(err); }
+    else {
+        ioOk = (fclose(plain) == 0) && ioOk;
+        if (!ioOk) return fail("write error on " + o.pos[3]);
+    }
+    return EXIT_SUCCESS;
+}

@@ -128,6 +128,24 @@ INDEX_RUNS = {
 }
 
 
+# convertalis (F/data/easystructuresearch.sh) -- first the complete parameter string `easy-search -v 3` prints for it
+CONVERT_PAR = ["--sub-mat", SUBMAT, "--format-mode", "0", "--format-output", "query,target,fident,alnlen,mismatch,gapopen,qstart,qend,tstart,tend,evalue,bits",
+               "--translation-table", "1", "--gap-open", "aa:10,nucl:10", "--gap-extend", "aa:1,nucl:1", "--db-output", "0", "--db-load-mode", "0",
+               "--search-type", "0", "--threads", "1", "--compressed", "0", "-v", "1", "--exact-tmscore", "0"]
+ALL_COLUMNS = ("query,target,qkey,tkey,evalue,gapopen,pident,fident,nident,qstart,qend,qlen,tstart,tend,tlen,alnlen,bits,cigar,qseq,tseq,q3di,t3di,"
+               "qheader,theader,qaln,taln,q3dialn,t3dialn,mismatch,qcov,tcov,empty")
+CONVERT_RUNS = {
+    "conv_default.m8": ("convertalis", ["db", "db", "aln_t2_a"], CONVERT_PAR),
+    "conv_nobt.m8": ("convertalis", ["db", "db", "aln_t2"], CONVERT_PAR),                      # no backtrace: estimated mismatches, gap opens 0
+    "conv_t0.m8": ("convertalis", ["db", "db", "aln_t0_a"], ["--threads", "1", "-v", "1"]),      # module defaults
+    "conv_fmt2.m8": ("convertalis", ["db", "db", "aln_t2_a_altali"], override(CONVERT_PAR, **{"--format-mode": "2"})),
+    "conv_fmt4_all.m8": ("convertalis", ["db", "db", "aln_t2_a"], override(CONVERT_PAR, **{"--format-mode": "4", "--format-output": ALL_COLUMNS})),
+    "conv_pad.m8": ("convertalis", ["db", "db_pad", "aln_t2_a_pad"], override(CONVERT_PAR, **{"--format-output": "query,target,tkey,theader,taln,t3dialn,bits"})),
+    "conv_resc.m8": ("convertalis", ["db", "db", "resc_t2_a"], override(CONVERT_PAR, **{"--format-output": "query,target,fident,nident,alnlen,mismatch,gapopen,cigar,qcov,tcov,evalue,bits"})),
+    "conv_dbout": ("convertalis", ["db", "db", "aln_t2_a"], override(CONVERT_PAR, **{"--db-output": "1"})),
+}
+
+
 def read_db(path):
     data = open(path, "rb").read()
     out = {}
@@ -190,6 +208,10 @@ def main():
     for name, (module, pos, par) in RESCORE_RUNS.items():
         run([FS, module] + pos + [name] + par, work)
         manifest["runs"][name] = {"module": module, "positional": pos, "parameters": par}
+    manifest["convert_runs"] = {}
+    for name, (module, pos, par) in CONVERT_RUNS.items():
+        run([FS, module] + pos + [name] + par, work)
+        manifest["convert_runs"][name] = {"module": module, "positional": pos, "parameters": par}
     for ext in ("", ".index", ".dbtype"):       # structureindex.sh links the header DB next to the 3Di DB first (lndb)
         if not os.path.exists(os.path.join(work, "db_ss_h" + ext)):
             os.symlink(os.path.join(work, "db_h" + ext), os.path.join(work, "db_ss_h" + ext))
@@ -208,6 +230,11 @@ def main():
             manifest["links"][f] = os.path.basename(os.readlink(p))
             continue
         if os.path.isdir(p) or f.endswith(".source") or "_tmp" in f or ".idx" in f:
+            continue
+        if f.endswith(".m8") and os.path.getsize(p) > 100000:      # large text outputs are frozen gzip-compressed (mtime 0: reproducible bytes)
+            import gzip
+            with open(os.path.join(OUT, f + ".gz"), "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as gz:
+                gz.write(open(p, "rb").read())
             continue
         shutil.copy(p, os.path.join(OUT, f))
     json.dump(manifest, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)

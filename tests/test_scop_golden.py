@@ -165,3 +165,55 @@ def test_modules_take_precomputed_indexes_as_targets(scop):
         for f in ("db", "db.index", "db.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype"):     # second pass: sequences from inside the indexes
             if os.path.exists(scop / f):
                 os.remove(scop / f)
+
+
+def _frozen_text(scop, name):
+    import gzip
+    p = scop / name
+    return open(p, "rb").read() if os.path.exists(p) else gzip.open(str(p) + ".gz", "rb").read()
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["convert_runs"]))
+def test_convertalis_equals_reference_output(scop, name):
+    """`convertalis` (host-only text formatting, runs without a GPU) on the reference-written alignment DBs with the reference's
+    positional arguments and parameter strings: the output FILE must be byte-identical (BLAST-tab, with lengths, with column
+    headers and every supported --format-output column; alignments without backtrace; padded target; --db-output 1)"""
+    run = MANIFEST["convert_runs"][name]
+    out = str(scop / ("mine_" + name))
+    cmd = [BIN, run["module"]] + [str(scop / p) for p in run["positional"]] + [out] + run["parameters"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    if "--db-output" in run["parameters"] and run["parameters"][run["parameters"].index("--db-output") + 1] == "1":
+        want_t, want = read_db(str(scop / name))
+        got_t, got = read_db(out)
+        assert (got_t, sorted(got)) == (want_t, sorted(want))
+        assert all(got[k] == want[k] for k in want)
+        return
+    want, got = _frozen_text(scop, name), open(out, "rb").read()
+    assert len(want) > 1000
+    if got != want:
+        for i, (a, b) in enumerate(zip(want.split(b"\n"), got.split(b"\n"))):
+            assert a == b, f"{name}: line {i + 1}\nwant {a[:400]!r}\ngot  {b[:400]!r}"
+    assert got == want
+    assert not os.path.exists(out + ".index") and not os.path.exists(out + ".dbtype")      # a plain file, like the reference leaves it
+
+
+@pytest.mark.parametrize("args,needle", [
+    (["--format-output", "query,target,lddt"], "column lddt is not implemented on this path"),
+    (["--format-output", "query,target,alntmscore"], "column alntmscore is not implemented"),
+    (["--format-output", "query,nosuchcolumn"], "Format code nosuchcolumn does not exist."),
+    (["--format-mode", "3"], "--format-mode 3 is not implemented on the device path"),
+    (["--format-mode", "1"], "--format-mode 1 is not implemented"),
+    (["--no-such-flag", "1"], 'Unrecognized parameter "--no-such-flag"'),
+])
+def test_convertalis_refuses_what_it_does_not_implement(scop, args, needle):
+    r = subprocess.run([BIN, "convertalis", str(scop / "db"), str(scop / "db"), str(scop / "aln_t2_a"), str(scop / "out.m8")] + args,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and needle in r.stderr, r.stderr
+    assert not os.path.exists(scop / "out.m8")
+
+
+def test_convertalis_needs_the_backtrace_for_alignment_columns(scop):
+    r = subprocess.run([BIN, "convertalis", str(scop / "db"), str(scop / "db"), str(scop / "aln_t2"), str(scop / "out.m8"), "--format-output", "query,target,qaln,taln"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "Backtrace cigar is missing in the alignment result" in r.stderr
