@@ -118,6 +118,21 @@ def test_fused_search_equals_reference_two_step(scop):
 
 
 @pytest.mark.gpu
+def test_search_then_convertalis_equals_reference_m8(scop):
+    """easy-search without the structure parsing: `search` + `convertalis` on the reference-written sequence DBs == the .m8 the
+    reference's prefilter + structurealign + convertalis produce (the search runs with 3 host threads, so the entries of its alignment DB
+    are written in key order whatever the thread interleaving was)"""
+    aln, m8 = str(scop / "mine_aln"), str(scop / "mine.m8")
+    r = subprocess.run([BIN, "search", str(scop / "db"), str(scop / "db"), aln, "--prefilter-mode", "0", "-a", "1", "--alignment-type", "2",
+                        "--sort-by-structure-bits", "0", "--threads", "3", "-s", "9.5", "--max-seqs", "1000", "-e", "10"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([BIN, "convertalis", str(scop / "db"), str(scop / "db"), aln, m8] + MANIFEST["convert_runs"]["conv_default.m8"]["parameters"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(m8, "rb").read() == open(scop / "conv_default.m8", "rb").read()
+
+
+@pytest.mark.gpu
 def test_rescorediagonal_undefined_pairs_are_refused_or_skipped(scop):
     """pref_kmer holds 297 (query, target, diagonal) lines whose reference result is undefined (negative diagonal, target longer
     than the query: the reference's reverse pass reads past the query, structurerescorediagonal.cpp:96-99).  Default: the module
