@@ -12,7 +12,7 @@ bad = 0
 for rd in range(rounds):
     n = int(rng.integers(1, 700))
     nq = int(rng.integers(1, 6))
-    lens = [int(rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 600, 1025])) if rng.random() < 0.5
+    lens = [int(rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 600, 1025, 1100, 1537, 2049])) if rng.random() < 0.5
             else int(rng.integers(1, 900)) for _ in range(nq)]
     q3 = [rng.integers(0, 21 if rng.random() < 0.3 else 20, size=L).astype(np.uint8) for L in lens]
     qa = [rng.integers(0, 21 if rng.random() < 0.3 else 20, size=L).astype(np.uint8) for L in lens]
