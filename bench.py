@@ -40,6 +40,8 @@ def parse(argv=None):
     ap.add_argument("--targets", type=int, default=1000000)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--homologs", type=int, default=50, help="planted homologs per query (SURVEY.md 8d)")
+    ap.add_argument("--query-len", default="250,450", help="lo,hi: query lengths are drawn from the DB's length model (mean 350) clipped to this range; "
+                    "30,2000 = the DB's own range (queries longer than 512 residues run row-tiled)")
     ap.add_argument("--alignment-type", type=int, default=0, help="0: 3Di only (configs[1..2]), 2: 3Di+AA (configs[3])")
     ap.add_argument("--host-threads", type=int, default=3, help="host feeder threads per GPU (each with its own stream)")
     ap.add_argument("--group", type=int, default=64, help="queries per step: prefiltered back to back, then ONE multi-query SW launch per pass")
@@ -424,7 +426,8 @@ def main():
     per_rank_timed = args.steps * G if args.scaling == "weak" else None
     n_timed_total = args.steps * G * (world if args.scaling == "weak" else 1)
     n_warm = args.warmup * G
-    all_q3, all_qa = synth.make_queries(n_timed_total + world * n_warm, seed=1000, lo=250, hi=450)   # around the mean length 350; same on every rank
+    q_lo, q_hi = (int(x) for x in args.query_len.split(","))
+    all_q3, all_qa = synth.make_queries(n_timed_total + world * n_warm, seed=1000, lo=q_lo, hi=q_hi)   # default 250..450: around the mean length 350; same on every rank
     if args.scaling == "weak":
         t_lo, t_hi = rank * per_rank_timed, (rank + 1) * per_rank_timed
     else:
@@ -609,7 +612,7 @@ def main():
                                    f"gapless prefilter (all targets; queries of one register class share one multi-query scan launch) + top-1000 per query, then one multi-query fwd/rev structure SW launch per pass "
                                    f"(--alignment-type {args.alignment_type}; forward over all pairs, reversed over the pairs that pass the forward gates) "
                                    f"+ host gates + block-aligner backtrace of every accepted hit; {nthreads} host feeder threads per GPU run their steps concurrently",
-                       "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "max_seqs": 1000, "homologs_per_query": args.homologs,
+                       "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "query_len_range": [q_lo, q_hi], "max_seqs": 1000, "homologs_per_query": args.homologs,
                        "queries_per_step": G, "queries_total": nq_total, "host_threads_per_gpu": nthreads, "host_backtrace_workers_per_gpu": api.host_workers(),
                        "parallelism": f"query-shard x{world} ({args.scaling}), DB replicated by one RCCL broadcast"},
             "queries_per_s": nq_total / dt, "ms_per_query": 1e3 * dt / (nq_total / world),
