@@ -21,7 +21,9 @@ def _queries():
     q3, qa = synth.make_queries(6, seed=77, lo=120, hi=480)
     q3[3] = np.concatenate([q3[3], q3[4], q3[5]])[:777]            # row-tiled query (> 512 rows)
     qa[3] = np.concatenate([qa[3], qa[4], qa[5]])[:777]
-    return q3[:4], qa[:4]
+    m3, ma = synth.make_queries(4, seed=78, lo=300, hi=480)
+    q3[4], qa[4] = np.concatenate(m3)[:1300], np.concatenate(ma)[:1300]      # three row tiles; two row-tiled queries share the SW tile launches
+    return q3[:5], qa[:5]
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +43,7 @@ def _ref_scores(ref, db, q, threads=16):
 
 
 def test_gapless_scores_and_hit_lists_equal_reference_at_100k(world):
-    """every one of the 100k per-target scores + the selected hit list, four query lengths (R classes 8..30 and a row-tiled one)"""
+    """every one of the 100k per-target scores + the selected hit list, five query lengths (R classes 8..30 and two row-tiled ones)"""
     ref, db = world["ref"], world["db"]
     if ref is None:
         pytest.skip("oracle/_ref not built")
@@ -115,7 +117,7 @@ def test_multi_query_scan_equals_single_query_scans(world):
     multi = s.prefilter_batch(qs, identity=ident)
     launches, batched = ctx.gapless_last_batch()
     short = [i for i, q in enumerate(qs) if len(q) <= 512]
-    assert batched == len(short) == len(qs) - 1
+    assert batched == len(short) == len(qs) - 2
     assert launches == len({(len(qs[i]) + 15) // 16 for i in short}) < len(short)
     for i in range(len(qs)):
         assert len(multi[i]) == len(single[i]) and (multi[i] == single[i]).all(), i
