@@ -20,6 +20,7 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <cmath>
 #include <csignal>
 #include <cstdio>
 #include <cstdlib>
@@ -1355,7 +1356,7 @@ float probTruePositive(float score) {          // CalcProbTP::calculate (F/src/c
     if (score <= 10) return 0;
     if (score >= 100) return 1.0;
     auto gammaPdf = [](const float alpha, const float beta, const float x) -> float {
-        return exp(alpha * log(beta) + (alpha - 1) * log(x) + (-beta * x) - lgamma(alpha));
+        return std::exp(alpha * std::log(beta) + (alpha - 1) * std::log(x) + (-beta * x) - std::lgamma(alpha));    // float overloads, as <cmath> resolves them there
     };
     float p_tp = (0.8279 * gammaPdf(1.8123, 1 / 46.0042, score) + 0.1721 * gammaPdf(1.0057, 1 / 563.5014, score)) * 0.1023;
     float p_fp = (0.34 * gammaPdf(4.9259, 1 / 4.745, score) + 0.66 * gammaPdf(9.4834, 1 / 1.3136, score)) * 0.8977;

@@ -232,3 +232,34 @@ def test_convertalis_needs_the_backtrace_for_alignment_columns(scop):
     r = subprocess.run([BIN, "convertalis", str(scop / "db"), str(scop / "db"), str(scop / "aln_t2"), str(scop / "out.m8"), "--format-output", "query,target,qaln,taln"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "Backtrace cigar is missing in the alignment result" in r.stderr
+
+
+def test_convertalis_prob_column(scop):
+    """`prob` = CalcProbTP::calculate(bits) (F/src/commons/CalcProbTP.h:8-32): 0 up to 10 bits, 1 from 100 bits, the fitted gamma
+    mixture ratio in between -- checked against a double-precision restatement (the reference computes it in float: 3 printed decimals agree
+    to +-0.001).  The reference opens the _ca DB for this column although the value only depends on the score; this module does not need it."""
+    import math
+    out = str(scop / "prob.m8")
+    r = subprocess.run([BIN, "convertalis", str(scop / "db"), str(scop / "db"), str(scop / "aln_t2_a"), out, "--format-output", "bits,prob"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def gamma_pdf(alpha, beta, x):
+        return math.exp(alpha * math.log(beta) + (alpha - 1) * math.log(x) - beta * x - math.lgamma(alpha))
+
+    def want(score):
+        if score <= 10:
+            return 0.0
+        if score >= 100:
+            return 1.0
+        tp = (0.8279 * gamma_pdf(1.8123, 1 / 46.0042, score) + 0.1721 * gamma_pdf(1.0057, 1 / 563.5014, score)) * 0.1023
+        fp = (0.34 * gamma_pdf(4.9259, 1 / 4.745, score) + 0.66 * gamma_pdf(9.4834, 1 / 1.3136, score)) * 0.8977
+        return 1 / (1 + fp / tp)
+    rows = [l.split("\t") for l in open(out).read().splitlines()]
+    assert len(rows) > 500
+    seen_mid = 0
+    for bits, prob in rows:
+        w = want(int(bits))
+        assert abs(float(prob) - w) <= 0.0011, (bits, prob, w)
+        seen_mid += 10 < int(bits) < 100
+    assert seen_mid > 100
