@@ -497,6 +497,14 @@ std::string fastaHeaderName(const char *headerPtr) {
     return header.substr(offset, end == std::string::npos ? std::string::npos : end - offset);
 }
 
+// entry numbers of a sequence DB, longest first (stable)
+std::vector<size_t> lengthOrder(const DbReader &r) {
+    std::vector<size_t> order(r.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return r.seqLen(x) > r.seqLen(y); });
+    return order;
+}
+
 } // namespace
 
 extern "C" {
@@ -602,6 +610,9 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
     if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();
     std::vector<std::string> results(q.size());
+    // queries are taken in order of decreasing length (the result DB is keyed, the order of the work is free): the queries of a batch
+    // then fall into one or two register classes and share their scan launches (fsgpu_gapless_scan_multi)
+    const std::vector<size_t> order = lengthOrder(q);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     std::string firstErr;
@@ -623,7 +634,8 @@ int fsmod_ungappedprefilter(int argc, const char **argv) {
             const size_t b0 = next.fetch_add(batch);
             if (b0 >= q.size() || bad) break;
             size_t m = 0;
-            for (size_t id = b0; id < std::min(q.size(), b0 + batch); id++) {
+            for (size_t oi = b0; oi < std::min(q.size(), b0 + batch); oi++) {
+                const size_t id = order[oi];
                 const uint32_t L = q.seqLen(id);
                 if (L == 0) continue;
                 codes[m].resize(L);
@@ -837,6 +849,8 @@ int fsmod_search(int argc, const char **argv) {
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     std::string firstErr;
+    // longest queries first (see fsmod_ungappedprefilter): queries of a batch share scan launches and SW register classes
+    const std::vector<size_t> order = lengthOrder(q3);
     auto work = [&](int tix) {
         bool owned = false;
         fsgpu_ctx *ctx = ds.forThread(tix, owned);
@@ -856,6 +870,7 @@ int fsmod_search(int argc, const char **argv) {
         std::vector<fshost_result *> pR(batch);
         std::vector<int> Ls(batch), ns(batch), nres(batch);
         std::vector<int64_t> ident(batch);
+        std::vector<size_t> qid(batch);
         std::vector<char> line(1024 + 2 * 65536 * 2);
         char pl[128];
         for (;;) {
@@ -863,7 +878,8 @@ int fsmod_search(int argc, const char **argv) {
             if (b0 >= q3.size() || bad) break;
             const size_t nb = std::min(batch, q3.size() - b0);
             for (size_t k = 0; k < nb; k++) {
-                const size_t id = b0 + k;
+                const size_t id = order[b0 + k];
+                qid[k] = id;
                 const uint32_t L = q3.seqLen(id);
                 const int64_t aid = qA.idOf(q3.key(id));
                 if (aid < 0 || qA.seqLen((size_t) aid) != L) { if (!bad++) firstErr = "query AA / 3Di entries do not match"; break; }
@@ -886,13 +902,13 @@ int fsmod_search(int argc, const char **argv) {
                 { const double t1 = nowSec(); usPrep += (int64_t) ((t1 - t0) * 1e6); t0 = t1; }
                 if (fsgpu_kmer_search(ctx, &sp, kq.data(), (int) nb, khits.data(), nout.data(), status.data(), nullptr) != FSGPU_OK) { if (!bad++) firstErr = fsgpu_last_error(ctx); break; }
                 for (size_t k = 0; k < nb && !bad; k++) {
-                    if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(b0 + k)) + ": hit buffers of the reference would overflow"; break; }
+                    if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(qid[k])) + ": hit buffers of the reference would overflow"; break; }
                     for (int h = 0; h < nout[k]; h++) {
                         const fsgpu_kmer_hit &hit = khits[k * (size_t) maxRes + h];
                         if (par.covThr > 0.0 && (par.covMode == 0 || par.covMode == 2 || par.covMode == 5) &&
                             !canBeCovered(par.covThr, par.covMode, (float) Ls[k], (float) pt.lengths[hit.id])) continue;   // Prefiltering.cpp:880-887
                         ids[k].push_back(hit.id);
-                        if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
+                        if (writePref) prefs[qid[k]].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
                     }
                 }
             } else {
@@ -909,7 +925,7 @@ int fsmod_search(int argc, const char **argv) {
                     const fsgpu_hit *hh = ghits.data() + j * (size_t) par.maxResListLen;
                     for (int h = 0; h < gn[j]; h++) {
                         ids[k].push_back(hh[h].id);
-                        if (writePref) prefs[b0 + k].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hh[h].id], hh[h].score, 0));
+                        if (writePref) prefs[qid[k]].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hh[h].id], hh[h].score, 0));
                     }
                 }
             }
@@ -926,7 +942,7 @@ int fsmod_search(int argc, const char **argv) {
                 lA.push_back(pA[k]); l3.push_back(p3[k]); lT.push_back(ids[k].data()); lR.push_back(res[k].data());
                 lL.push_back(Ls[k]); lN.push_back((int) ids[k].size());
                 // structurealign compares the query's and the target's INDEX in their readers (structurealign.cpp:359)
-                lI.push_back((sameDB || includeIdentical) ? (int64_t) (b0 + k) : -1);
+                lI.push_back((sameDB || includeIdentical) ? (int64_t) qid[k] : -1);
             }
             if (fshost_search_align_batch(s, (int) live.size(), lA.data(), l3.data(), lL.data(), lI.data(), lT.data(), lN.data(), lR.data(), lres.data()) != FSGPU_OK) {
                 if (!bad++) firstErr = fshost_search_error(s);
@@ -941,7 +957,7 @@ int fsmod_search(int argc, const char **argv) {
                 for (int x : lN) nPairs += x;
             }
             for (size_t j = 0; j < live.size(); j++) {
-                std::string &out = results[b0 + live[j]];
+                std::string &out = results[qid[live[j]]];
                 for (int r = 0; r < lres[j]; r++)
                     out.append(line.data(), fshost_format_result(line.data(), &res[live[j]][r], fshost_search_backtrace(s, &res[live[j]][r]), par.addBacktrace));
             }
