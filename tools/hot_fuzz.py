@@ -14,6 +14,10 @@ for rd in range(rounds):
     nq = int(rng.integers(1, 6))
     lens = [int(rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 255, 256, 257, 383, 384, 385, 511, 512, 513, 600, 1025, 1100, 1537, 2049])) if rng.random() < 0.5
             else int(rng.integers(1, 900)) for _ in range(nq)]
+    if nq >= 2 and rng.random() < 0.4:          # two or three row-tiled queries of one register class: multi-query tile launches
+        L0 = int(rng.choice([560, 600, 1000, 1100, 1537]))
+        for i in range(min(nq, int(rng.integers(2, 4)))):
+            lens[i] = L0 + int(rng.integers(0, 6))
     q3 = [rng.integers(0, 21 if rng.random() < 0.3 else 20, size=L).astype(np.uint8) for L in lens]
     qa = [rng.integers(0, 21 if rng.random() < 0.3 else 20, size=L).astype(np.uint8) for L in lens]
     big = [q for q in zip(q3, qa) if len(q[0]) >= 30]
