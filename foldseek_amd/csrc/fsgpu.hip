@@ -467,14 +467,14 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &gaIn) {
     const uint64_t devBit = 1ull << (ctx->device & 63);
     if (!(attrDevs & devBit)) {
         HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, kGaplessBlock, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, gaplessBlockThreads(R), lds));
         attrDevs |= devBit;
     }
     int perCU = perCUcached;
     // Workgroups of 4 waves, each with its own LDS image; 3 per CU (12 waves, <= 135 KB LDS): more does not issue faster
     // (profiles/r01_q_gapless_ablation_ubench.txt, tools/bench_ab2.sh) and this leaves wave slots for the latency-bound SW
     // wavefront kernels of other in-flight queries to co-reside.  FSGPU_GAPLESS_BLOCKS_PER_CU overrides.
-    constexpr int wavesPerBlock = kGaplessBlock / 64;
+    constexpr int wavesPerBlock = gaplessBlockThreads(R) / 64;
     perCU = std::max(1, std::min(perCU, ctx->gaplessBlocksPerCU));
     // multi-query launch: 2 workgroups per CU and query (the third resident slot goes to the next query's workgroups, which
     // start while this query's tail drains): 2.75 vs 2.79 ms per query at 1M targets, tools: FSGPU_GAPLESS_BLOCKS_PER_CU sweep
@@ -488,7 +488,7 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &gaIn) {
     // multi-query launch: ga.blocksPerQuery carries the number of queries on entry; every query gets `blocks` workgroups
     const uint32_t nQueries = ga.queries ? std::max(1u, ga.blocksPerQuery) : 1u;
     ga.blocksPerQuery = blocks;
-    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks * nQueries), dim3(kGaplessBlock), lds, ctx->stream, ga);
+    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks * nQueries), dim3(gaplessBlockThreads(R)), lds, ctx->stream, ga);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
@@ -501,8 +501,9 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
     if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
     const int rows = (L + 15) / 16;                       // rows per strip per lane
-    const int nTiles = (L + 16 * kGaplessMaxR - 1) / (16 * kGaplessMaxR);
-    // row tiles of equal height: L = 513 runs as 2 x 272 rows (R = 17), not as 512 + 1 row at the full R = 32 cost each
+    // up to 16 * kGaplessMaxRUntiled rows in one piece; beyond that row tiles of at most 512 rows and equal height: L = 1025 runs as
+    // 3 x 352 rows (R = 22), not as 512 + 512 + 1 rows at the full R = 32 cost each
+    const int nTiles = L <= 16 * kGaplessMaxRUntiled ? 1 : (L + 16 * kGaplessMaxR - 1) / (16 * kGaplessMaxR);
     const int R = nTiles > 1 ? ((L + nTiles - 1) / nTiles + 15) / 16 : std::max(1, rows);
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = (uint32_t) ctx->db->n;
@@ -543,7 +544,7 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
         HIPCHK(hipMemsetAsync(ctx->queue, 0, 4, ctx->stream));
         // one instantiation per register count: a query of L residues runs with R = ceil(L / 16) (16-row granularity)
         using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
-        static const LaunchFn table[kGaplessMaxR + 1] = {nullptr,
+        static const LaunchFn table[kGaplessMaxRUntiled + 1] = {nullptr,
             launchGapless<1, false>, launchGapless<2, false>, launchGapless<3, false>, launchGapless<4, false>,
             launchGapless<5, false>, launchGapless<6, false>, launchGapless<7, false>, launchGapless<8, false>,
             launchGapless<9, false>, launchGapless<10, false>, launchGapless<11, false>, launchGapless<12, false>,
@@ -551,14 +552,20 @@ int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap
             launchGapless<17, false>, launchGapless<18, false>, launchGapless<19, false>, launchGapless<20, false>,
             launchGapless<21, false>, launchGapless<22, false>, launchGapless<23, false>, launchGapless<24, false>,
             launchGapless<25, false>, launchGapless<26, false>, launchGapless<27, false>, launchGapless<28, false>,
-            launchGapless<29, false>, launchGapless<30, false>, launchGapless<31, false>, launchGapless<32, false>};
-        if (R < 1 || R > kGaplessMaxR) { ctx->err = "internal: bad R"; return FSGPU_E_ARG; }
+            launchGapless<29, false>, launchGapless<30, false>, launchGapless<31, false>, launchGapless<32, false>,
+            launchGapless<33, false>, launchGapless<34, false>, launchGapless<35, false>, launchGapless<36, false>,
+            launchGapless<37, false>, launchGapless<38, false>, launchGapless<39, false>, launchGapless<40, false>,
+            launchGapless<41, false>, launchGapless<42, false>, launchGapless<43, false>, launchGapless<44, false>,
+            launchGapless<45, false>, launchGapless<46, false>, launchGapless<47, false>, launchGapless<48, false>,
+            launchGapless<49, false>, launchGapless<50, false>, launchGapless<51, false>, launchGapless<52, false>,
+            launchGapless<53, false>, launchGapless<54, false>, launchGapless<55, false>, launchGapless<56, false>};
+        if (R < 1 || R > kGaplessMaxRUntiled) { ctx->err = "internal: bad R"; return FSGPU_E_ARG; }
         rc = table[R](ctx, ga);
         if (rc != FSGPU_OK) return rc;
     } else {
         // query row tiles of 16 R <= 512 rows: tile t+1 continues every diagonal of tile t through the border arrays in HBM
         using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
-        static const LaunchFn tiled[16] = {            // more than one tile means L > 512, so a tile has more than 256 rows: R = 17..32
+        static const LaunchFn tiled[16] = {            // more than one tile means L > 896, so a tile has more than 256 rows: R = 17..32
             launchGapless<17, true>, launchGapless<18, true>, launchGapless<19, true>, launchGapless<20, true>,
             launchGapless<21, true>, launchGapless<22, true>, launchGapless<23, true>, launchGapless<24, true>,
             launchGapless<25, true>, launchGapless<26, true>, launchGapless<27, true>, launchGapless<28, true>,
@@ -631,7 +638,7 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
     ctx->mqSlot.assign(nq, -1);
     // ---- device batch: the single-tile queries, grouped by register class ----
     std::vector<int> batch, longQ;
-    for (int i = 0; i < nq; i++) (q[i].L <= 16 * kGaplessMaxR ? batch : longQ).push_back(i);
+    for (int i = 0; i < nq; i++) (q[i].L <= 16 * kGaplessMaxRUntiled ? batch : longQ).push_back(i);
     std::stable_sort(batch.begin(), batch.end(), [&](int x, int y) { return (q[x].L + 15) / 16 > (q[y].L + 15) / 16; });   // long queries first
     const int nb = (int) batch.size();
     const uint32_t n = (uint32_t) ctx->db->n;
@@ -687,7 +694,7 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
         HIPCHK(hipMemsetAsync(ctx->mqQueues.p, 0, (size_t) nb * 4, ctx->stream));
         std::unique_lock<std::mutex> scanLock(ctx->db->scanMutex, std::defer_lock);
         using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
-        static const LaunchFn table[kGaplessMaxR + 1] = {nullptr,
+        static const LaunchFn table[kGaplessMaxRUntiled + 1] = {nullptr,
             launchGapless<1, false>, launchGapless<2, false>, launchGapless<3, false>, launchGapless<4, false>,
             launchGapless<5, false>, launchGapless<6, false>, launchGapless<7, false>, launchGapless<8, false>,
             launchGapless<9, false>, launchGapless<10, false>, launchGapless<11, false>, launchGapless<12, false>,
@@ -695,7 +702,13 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             launchGapless<17, false>, launchGapless<18, false>, launchGapless<19, false>, launchGapless<20, false>,
             launchGapless<21, false>, launchGapless<22, false>, launchGapless<23, false>, launchGapless<24, false>,
             launchGapless<25, false>, launchGapless<26, false>, launchGapless<27, false>, launchGapless<28, false>,
-            launchGapless<29, false>, launchGapless<30, false>, launchGapless<31, false>, launchGapless<32, false>};
+            launchGapless<29, false>, launchGapless<30, false>, launchGapless<31, false>, launchGapless<32, false>,
+            launchGapless<33, false>, launchGapless<34, false>, launchGapless<35, false>, launchGapless<36, false>,
+            launchGapless<37, false>, launchGapless<38, false>, launchGapless<39, false>, launchGapless<40, false>,
+            launchGapless<41, false>, launchGapless<42, false>, launchGapless<43, false>, launchGapless<44, false>,
+            launchGapless<45, false>, launchGapless<46, false>, launchGapless<47, false>, launchGapless<48, false>,
+            launchGapless<49, false>, launchGapless<50, false>, launchGapless<51, false>, launchGapless<52, false>,
+            launchGapless<53, false>, launchGapless<54, false>, launchGapless<55, false>, launchGapless<56, false>};
         struct Group { int R, k0, k1; const uint4 *items; uint32_t nItems; };
         std::vector<Group> groups;
         bool anySplitAtAll = false;

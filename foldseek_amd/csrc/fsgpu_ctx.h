@@ -50,7 +50,7 @@ struct DbStore {
     // use by gaplessItems() (fsgpu.hip), shared by all contexts of this DB
     std::vector<uint32_t> hStripeLen;
     struct ItemList { uint4 *items = nullptr; uint32_t n = 0; bool split = false, built = false; };
-    ItemList itemLists[kGaplessMaxR + 1];
+    ItemList itemLists[kGaplessMaxRUntiled + 1];
     std::mutex itemMutex;
     // multi-query scans of the contexts sharing this DB run one after the other ON THE DEVICE: a context enqueues its scan
     // launches behind the event the previous batch's owner recorded after its last scan launch (fsgpu_gapless_scan_multi).

@@ -97,8 +97,9 @@ struct GaplessArgs {
 };
 
 template <int R, bool TILED>
-__global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
-    static_assert(R >= 1 && R <= kGaplessMaxR, "1 <= R <= kGaplessMaxR");
+__global__ __launch_bounds__(gaplessBlockThreads(R)) void k_gapless(GaplessArgs a) {
+    static_assert(R >= 1 && R <= (TILED ? kGaplessMaxR : kGaplessMaxRUntiled), "register count out of range");
+    constexpr int BLOCK = gaplessBlockThreads(R);
     constexpr int CHB = gaplessChunkBytes();
     constexpr int NCH = gaplessChunks(R);         // ds_read_b128 per column; the last one may carry unused registers
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -119,10 +120,10 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
     {
         const int L = a.L;
         constexpr int nItems = (kAlphabet + 1) * 8 * NCH;
-        constexpr int nIter = (nItems + kGaplessBlock - 1) / kGaplessBlock;
+        constexpr int nIter = (nItems + BLOCK - 1) / BLOCK;
 #pragma unroll
         for (int it = 0; it < nIter; it++) {
-            const int idx = it * kGaplessBlock + threadIdx.x;
+            const int idx = it * BLOCK + threadIdx.x;
             if (idx < nItems) {
                 const int g = idx & 7, k = (idx >> 3) % NCH, row = (idx >> 3) / NCH;
                 uint32_t v[4];
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(kGaplessBlock) void k_gapless(GaplessArgs a) {
     // The first item of a wave is static (the nWaves longest items), the following ones come from the atomic queue: no
     // ticket ramp at kernel start, and one 16-byte record per item keeps the dependent loads per stripe at two
     // (record, first column chunk) -- what matters for short queries (tools/ubench/gapless_ablate.hip, "v6").
-    const uint32_t nWaves = blocksOfQuery * (kGaplessBlock / 64);
-    uint32_t w = __builtin_amdgcn_readfirstlane(blockInQuery * (kGaplessBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t nWaves = blocksOfQuery * (BLOCK / 64);
+    uint32_t w = __builtin_amdgcn_readfirstlane(blockInQuery * (BLOCK / 64) + (threadIdx.x >> 6));
     for (; w < a.nItems;) {
         const uint4 item = a.items[w];
         const uint32_t stripe = item.x;

@@ -126,7 +126,7 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
 /* scan kernel launches / device-batched queries of the last fsgpu_gapless_scan_multi; fsgpu_last_kernel_ms(ctx, 0) then is
  * the device time of all its scan launches together */
 int fsgpu_gapless_last_batch(const fsgpu_ctx *ctx, int *launches, int *queries);
-/* raw scores of query `queryIndex` of the last fsgpu_gapless_scan_multi call (queries of <= 512 residues); for tests */
+/* raw scores of query `queryIndex` of the last fsgpu_gapless_scan_multi call (queries of <= 896 residues); for tests */
 int fsgpu_gapless_scores_multi(fsgpu_ctx *ctx, int queryIndex, uint8_t *scores_out);
 /* Raw per-target scores of the last scan (n bytes, already capped); for tests and statistics. */
 int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out);
@@ -164,7 +164,7 @@ int fsgpu_sw_batch_seqs(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p
                         const int32_t *lengths, int n, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev);
 /* Several queries per call (what a host thread of structurealign would do one after the other, structurealign.cpp:322-452):
  * same semantics per query as fsgpu_sw_batch; results are concatenated in query order (sum of n entries).  All queries of
- * at most 512 residues that share a register class run in ONE launch, which fills the device where a single query's
+ * at most 896 residues that share a register class run in ONE launch, which fills the device where a single query's
  * ~1000 pairs cannot.  Either all or none of the queries carry AA profiles. */
 typedef struct {
     const int16_t *pAA_fwd, *p3Di_fwd, *pAA_rev, *p3Di_rev;

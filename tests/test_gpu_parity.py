@@ -46,9 +46,11 @@ def test_gapless_scores_and_hits(small_db, qi, comp_bias):
 
 
 def test_gapless_every_register_count():
-    """one query per 16-row register count R = 1..32 (L = 16R - 15 ... 16R) plus the length extremes of each class"""
+    """one query per 16-row register count R = 1..56 (L = 16R - 15 ... 16R; R > 32: the untiled long-query instantiations with
+    6-wave workgroups) plus the length extremes of some classes and the first row-tiled length (897)"""
     rng = np.random.default_rng(4242)
-    lens = sorted(set([1, 2, 15, 16, 17] + [16 * r - int(rng.integers(0, 16)) for r in range(1, 33)] + [16 * r for r in (5, 11, 23, 31, 32)] + [16 * r + 1 for r in (5, 22, 31)]))
+    lens = sorted(set([1, 2, 15, 16, 17] + [16 * r - int(rng.integers(0, 16)) for r in range(1, 57)] + [16 * r for r in (5, 11, 23, 31, 32, 33, 36, 37, 48, 49, 56)] +
+                      [16 * r + 1 for r in (5, 22, 31, 32, 36, 48, 55, 56)]))
     q3 = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
     qa = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
     db = synth.make_db(600, (q3, qa), seed=19, homologs_per_query=6, mask_frac=0.02)
@@ -158,9 +160,10 @@ def test_sw_long_query_row_tiles():
 
 
 def test_gapless_long_query_row_tiles():
-    """queries longer than 512 residues: 512-row tiles, diagonals continue through border arrays in HBM"""
+    """long queries: up to 896 residues in one piece (R = 33..56), beyond that row tiles of at most 512 rows whose diagonals continue
+    through border arrays in HBM"""
     rng = np.random.default_rng(321)
-    lens = (513, 700, 1024, 1300, 2100)
+    lens = (513, 700, 896, 897, 1024, 1300, 2100)
     q3 = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
     qa = [rng.choice(20, size=L).astype(np.uint8) for L in lens]
     db = synth.make_db(500, (q3, qa), seed=12, homologs_per_query=25, hi=2400, mask_frac=0.02)
