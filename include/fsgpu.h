@@ -164,8 +164,8 @@ int fsgpu_sw_batch_seqs(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p
                         const int32_t *lengths, int n, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev);
 /* Several queries per call (what a host thread of structurealign would do one after the other, structurealign.cpp:322-452):
  * same semantics per query as fsgpu_sw_batch; results are concatenated in query order (sum of n entries).  All queries of
- * at most 896 residues that share a register class run in ONE launch, which fills the device where a single query's
- * ~1000 pairs cannot.  Either all or none of the queries carry AA profiles. */
+ * at most 512 residues that share a register class run in ONE launch, which fills the device where a single query's
+ * ~1000 pairs cannot; longer queries run row-tiled, one launch per tile level for all of them.  Either all or none of the queries carry AA profiles. */
 typedef struct {
     const int16_t *pAA_fwd, *p3Di_fwd, *pAA_rev, *p3Di_rev;
     int32_t L;
