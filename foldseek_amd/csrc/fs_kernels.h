@@ -15,11 +15,15 @@ constexpr int kStripeTargets = 8;      // targets interleaved per 128-byte line 
 constexpr int kGaplessBlock = FSGPU_GAPLESS_BLOCK;   // threads per workgroup of the gapless scan (one LDS image each)
 constexpr int kGaplessMaxR = 32;       // register rows per strip per lane of a ROW TILE: a tile covers 16*R <= 512 query rows
 // Queries of up to 16 * kGaplessMaxRUntiled = 896 residues run untiled as well: R = 33..56 registers per lane (92 VGPRs at R = 48, no
-// scratch), an LDS image of up to 14 chunks = 79 KB, two workgroups of 6 waves per CU instead of three of 4.  Per column the 3
-// non-DP instructions then weigh 4 % instead of the row-tiled kernel's border hand-over.
+// scratch), an LDS image of up to 14 chunks = 79 KB, two workgroups of 8 waves per CU instead of three of 4 (measured on 513..896-residue
+// queries at 1M targets: 4 / 6 / 8 waves per workgroup = 5.00 / 4.97 / 4.89 ms per query).  Per column the 3 non-DP instructions then
+// weigh 4 % instead of the row-tiled kernel's border hand-over.
 constexpr int kGaplessMaxRUntiled = 56;
-// threads per workgroup for a register count: 12 waves per CU in both shapes
-__host__ __device__ constexpr int gaplessBlockThreads(int R) { return R <= 36 ? kGaplessBlock : kGaplessBlock + kGaplessBlock / 2; }
+// threads per workgroup for a register count
+#ifndef FSGPU_GAPLESS_BIGBLOCK
+#define FSGPU_GAPLESS_BIGBLOCK (2 * FSGPU_GAPLESS_BLOCK)
+#endif
+__host__ __device__ constexpr int gaplessBlockThreads(int R) { return R <= 36 ? kGaplessBlock : FSGPU_GAPLESS_BIGBLOCK; }
 constexpr int kSwMaxR = 8;             // register rows per lane in the SW wavefront -> 64*R <= 512 rows per tile
 constexpr uint32_t kFloor2 = 0x80008000u; // packed (INT16_MIN, INT16_MIN): the gapless recurrence's "zero"
 

@@ -458,7 +458,7 @@ static int gaplessItems(fsgpu_ctx *ctx, int ov, const uint4 **items, uint32_t *n
 // ------------------------------------------------------------------------------------------------------------
 // gapless scan
 // ------------------------------------------------------------------------------------------------------------
-template <int R, bool TILED>
+template <int R, bool TILED, bool PAIRED = false>
 static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &gaIn) {
     GaplessArgs ga = gaIn;
     const int lds = gaplessLdsBytes(R);
@@ -466,8 +466,8 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &gaIn) {
     static thread_local int perCUcached = 0;
     const uint64_t devBit = 1ull << (ctx->device & 63);
     if (!(attrDevs & devBit)) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED>, gaplessBlockThreads(R), lds));
+        HIPCHK(hipFuncSetAttribute((const void *) k_gapless<R, TILED, PAIRED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCUcached, k_gapless<R, TILED, PAIRED>, gaplessBlockThreads(R), lds));
         attrDevs |= devBit;
     }
     int perCU = perCUcached;
@@ -488,7 +488,7 @@ static int launchGapless(fsgpu_ctx *ctx, const GaplessArgs &gaIn) {
     // multi-query launch: ga.blocksPerQuery carries the number of queries on entry; every query gets `blocks` workgroups
     const uint32_t nQueries = ga.queries ? std::max(1u, ga.blocksPerQuery) : 1u;
     ga.blocksPerQuery = blocks;
-    hipLaunchKernelGGL((k_gapless<R, TILED>), dim3(blocks * nQueries), dim3(gaplessBlockThreads(R)), lds, ctx->stream, ga);
+    hipLaunchKernelGGL((k_gapless<R, TILED, PAIRED>), dim3(blocks * nQueries), dim3(gaplessBlockThreads(R)), lds, ctx->stream, ga);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
@@ -651,8 +651,9 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
         for (int k = 0; k < nb; k++) pOff[k + 1] = pOff[k] + ((size_t) kAlphabet * q[batch[k]].L + 63) / 64 * 64;
         if ((rc = ensure(ctx, ctx->mqPssm, pOff[nb])) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->mqScores, scoreStride * nb)) != FSGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->mqQueues, (size_t) nb * 4)) != FSGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->mqRec, (size_t) nb * sizeof(GaplessQuery))) != FSGPU_OK) return rc;
+        const size_t nRecMax = (size_t) nb + (size_t) nb / 2 + 1;          // one record per query + one per pair of short queries
+        if ((rc = ensure(ctx, ctx->mqQueues, nRecMax * 4)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->mqRec, nRecMax * sizeof(GaplessQuery))) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->mqHist, (size_t) nb * nChunks * 256 * 4)) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->mqBaseGt, (size_t) nb * nChunks * 4)) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->mqBaseTie, (size_t) nb * nChunks * 4)) != FSGPU_OK) return rc;
@@ -661,7 +662,7 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
         if ((rc = ensure(ctx, ctx->mqOutScore, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->mqIdent, (size_t) nb * 8)) != FSGPU_OK) return rc;
         if ((rc = ensurePinned(ctx, ctx->hMqPssm, pOff[nb])) != FSGPU_OK) return rc;
-        if ((rc = ensurePinned(ctx, ctx->hMqRec, (size_t) nb * sizeof(GaplessQuery))) != FSGPU_OK) return rc;
+        if ((rc = ensurePinned(ctx, ctx->hMqRec, nRecMax * sizeof(GaplessQuery))) != FSGPU_OK) return rc;
         if ((rc = ensurePinned(ctx, ctx->hMqMeta, (size_t) nb * sizeof(SelMeta))) != FSGPU_OK) return rc;
         if ((rc = ensurePinned(ctx, ctx->hMqOutId, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
         if ((rc = ensurePinned(ctx, ctx->hMqOutScore, (size_t) nb * K * 4)) != FSGPU_OK) return rc;
@@ -677,8 +678,39 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             rec[k].queue = (uint32_t *) ctx->mqQueues.p + k;
             rec[k].L = qq.L;
             rec[k].cap = std::max(0, std::min(qq.scoreCap, 255));
+            rec[k].pssmB = nullptr; rec[k].scoresB = nullptr; rec[k].LB = 0; rec[k].capB = 0;
             ident[k] = qq.identityId;
             ctx->mqSlot[batch[k]] = k;
+        }
+        // Short queries (<= 256 residues) of one 16-row class run two to a kernel (k_gapless<2R, false, PAIRED>: the per-column
+        // instructions that do not scale with the rows are shared); an odd one out runs alone.  FSGPU_GAPLESS_PAIR=0: A/B switch.
+        struct PairLaunch { int Rq; size_t rec0; int count; };
+        std::vector<PairLaunch> pairLaunches;
+        std::vector<char> isPaired(nb, 0);
+        size_t nRec = (size_t) nb;
+        {
+            static const bool pairing = [] { const char *e = getenv("FSGPU_GAPLESS_PAIR"); return !e || atoi(e) != 0; }();
+            // classes up to 16 registers (256 residues): beyond that the pair would need the 6-wave workgroups of R > 36, which was measured
+            // and loses (pairs up to class 20 / 24 / 28 at 1M targets: 2.74 / 2.77 / 2.84 ms per query against 2.76 without)
+            static const int pairMaxR = [] { const char *e = getenv("FSGPU_GAPLESS_PAIR_MAXR"); return e ? std::max(1, std::min(atoi(e), kGaplessMaxR / 2)) : kGaplessMaxR / 2; }();
+            for (int k0 = 0; pairing && k0 < nb;) {
+                const int R = std::max(1, (q[batch[k0]].L + 15) / 16);
+                int k1 = k0;
+                while (k1 < nb && std::max(1, (q[batch[k1]].L + 15) / 16) == R) k1++;
+                if (R <= pairMaxR && k1 - k0 >= 2) {
+                    PairLaunch pl{R, nRec, (k1 - k0) / 2};
+                    for (int p2 = 0; p2 < pl.count; p2++) {
+                        const int ka = k0 + 2 * p2, kb = ka + 1;
+                        rec[nRec] = rec[ka];
+                        rec[nRec].queue = (uint32_t *) ctx->mqQueues.p + nRec;
+                        rec[nRec].pssmB = rec[kb].pssm; rec[nRec].scoresB = rec[kb].scores; rec[nRec].LB = rec[kb].L; rec[nRec].capB = rec[kb].cap;
+                        isPaired[ka] = isPaired[kb] = 1;
+                        nRec++;
+                    }
+                    pairLaunches.push_back(pl);
+                }
+                k0 = k1;
+            }
         }
         // One scan batch at a time per database, ordered ON THE DEVICE: every launch already fills the chip, two batches in
         // flight would only stretch each other.  The inputs go up first (they may overlap the previous owner's scans), then
@@ -689,9 +721,9 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
         static const bool exclusive = [] { const char *e = getenv("FSGPU_SCAN_EXCLUSIVE"); return !e || atoi(e) != 0; }();
         if (!ctx->scanDoneEv) HIPCHK(hipEventCreateWithFlags(&ctx->scanDoneEv, hipEventDisableTiming));
         HIPCHK(hipMemcpyAsync(ctx->mqPssm.p, ctx->hMqPssm.p, pOff[nb], hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->mqRec.p, ctx->hMqRec.p, (size_t) nb * sizeof(GaplessQuery), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->mqRec.p, ctx->hMqRec.p, nRec * sizeof(GaplessQuery), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->mqIdent.p, ctx->hMqIdent.p, (size_t) nb * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->mqQueues.p, 0, (size_t) nb * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->mqQueues.p, 0, nRec * 4, ctx->stream));
         std::unique_lock<std::mutex> scanLock(ctx->db->scanMutex, std::defer_lock);
         using LaunchFn = int (*)(fsgpu_ctx *, const GaplessArgs &);
         static const LaunchFn table[kGaplessMaxRUntiled + 1] = {nullptr,
@@ -716,11 +748,13 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             const int R = std::max(1, (q[batch[k0]].L + 15) / 16);
             int k1 = k0;
             while (k1 < nb && std::max(1, (q[batch[k1]].L + 15) / 16) == R) k1++;
-            Group g{R, k0, k1, nullptr, 0};
+            int kFree = k0;                                   // the paired queries of a class are its first ones
+            while (kFree < k1 && isPaired[kFree]) kFree++;
+            Group g{R, kFree, k1, nullptr, 0};
             bool split = false;
             if ((rc = gaplessItems(ctx, R, &g.items, &g.nItems, &split)) != FSGPU_OK) return rc;
             anySplitAtAll = anySplitAtAll || split;
-            groups.push_back(g);
+            if (kFree < k1) groups.push_back(g);
             k0 = k1;
         }
         // column segments combine by atomic max into zeroed score bytes: clear all slices BEFORE the first launch (a memset
@@ -740,6 +774,23 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             ga.nTargets = n; ga.pssm = nullptr; ga.L = 0; ga.cap = 0; ga.scores = nullptr; ga.queue = nullptr;
             ga.tileBase = 0; ga.firstTile = 1; ga.lastTile = 1; ga.borderIn = nullptr; ga.borderOut = nullptr; ga.scoreAcc = nullptr;
             if ((rc = table[g.R](ctx, ga)) != FSGPU_OK) return rc;
+            ctx->mqLaunches++;
+        }
+        for (const PairLaunch &pl : pairLaunches) {
+            static const LaunchFn paired[kGaplessMaxR / 2 + 1] = {nullptr,
+                launchGapless<2, false, true>, launchGapless<4, false, true>, launchGapless<6, false, true>, launchGapless<8, false, true>,
+                launchGapless<10, false, true>, launchGapless<12, false, true>, launchGapless<14, false, true>, launchGapless<16, false, true>,
+                launchGapless<18, false, true>, launchGapless<20, false, true>, launchGapless<22, false, true>, launchGapless<24, false, true>,
+                launchGapless<26, false, true>, launchGapless<28, false, true>, launchGapless<30, false, true>, launchGapless<32, false, true>};
+            GaplessArgs ga;
+            ga.scan = ctx->db->scan; ga.stripeOff = ctx->db->stripeOff; ga.stripeLen = ctx->db->stripeLen; ga.stripeTargets = ctx->db->stripeTargets;
+            bool split = false;
+            if ((rc = gaplessItems(ctx, pl.Rq, &ga.items, &ga.nItems, &split)) != FSGPU_OK) return rc;     // warm-up of a column segment = the QUERY's rows
+            ga.queries = (const GaplessQuery *) ctx->mqRec.p + pl.rec0;
+            ga.blocksPerQuery = (uint32_t) pl.count;
+            ga.nTargets = n; ga.pssm = nullptr; ga.L = 0; ga.cap = 0; ga.scores = nullptr; ga.queue = nullptr;
+            ga.tileBase = 0; ga.firstTile = 1; ga.lastTile = 1; ga.borderIn = nullptr; ga.borderOut = nullptr; ga.scoreAcc = nullptr;
+            if ((rc = paired[pl.Rq](ctx, ga)) != FSGPU_OK) return rc;
             ctx->mqLaunches++;
         }
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));

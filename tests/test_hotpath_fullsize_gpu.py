@@ -107,6 +107,10 @@ def test_multi_query_scan_equals_single_query_scans(world):
     ctx = world["ctx"]
     more3, _ = synth.make_queries(11, seed=5, lo=250, hi=300)            # R = 16..19: several queries per launch
     qs = list(world["q3"]) + more3 + [more3[0][:33], more3[1][:16], more3[2][:1]]
+    # short queries of one 16-row class run two to a kernel (PAIRED): three of class 7 (one pair + one alone), two of class 3, two of
+    # class 16 with different lengths, four of class 1
+    qs += [more3[3][:100], more3[4][:101], more3[5][:112], more3[6][:40], more3[7][:45], more3[8][:241], more3[9][:256],
+           more3[0][:2], more3[1][:7], more3[2][:16], more3[3][:15]]
     ident = np.full(len(qs), -1, np.int64)
     ident[2], ident[6] = 777, 31415
     s = api.Search(ctx)
@@ -118,7 +122,11 @@ def test_multi_query_scan_equals_single_query_scans(world):
     launches, batched = ctx.gapless_last_batch()
     short = [i for i, q in enumerate(qs) if len(q) <= 896]           # one-piece queries share launches per register class
     assert batched == len(short) == len(qs) - 1
-    assert launches == len({(len(qs[i]) + 15) // 16 for i in short}) < len(short)
+    members = {}
+    for i in short:
+        members[(len(qs[i]) + 15) // 16] = members.get((len(qs[i]) + 15) // 16, 0) + 1
+    assert launches == sum((1 + m % 2) if (c <= 16 and m >= 2) else 1 for c, m in members.items()) < len(short)
+    assert sum(1 for c, m in members.items() if c <= 16 and m >= 2) >= 4
     for i in range(len(qs)):
         assert len(multi[i]) == len(single[i]) and (multi[i] == single[i]).all(), i
         if i in short:
