@@ -213,6 +213,17 @@ struct PaddedTarget {
     uint64_t bytes = 0;
 };
 
+// contiguous ranges of [0, n) on up to 8 host threads (DB encoding at start-up: 350 M residues per alphabet at 1M targets)
+template <typename F>
+void parallelRanges(size_t n, F fn) {
+    const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t) 8, (size_t) std::max(1, fshost_usable_cores()), n / 4096 + 1}));
+    if (T == 1) { fn((size_t) 0, n); return; }
+    std::vector<std::thread> ths;
+    for (size_t t = 1; t < T; t++) ths.emplace_back(fn, n * t / T, n * (t + 1) / T);
+    fn((size_t) 0, n / T);
+    for (auto &th : ths) th.join();
+}
+
 bool loadPadded(const DbReader &r3, const DbReader *rA, const Matrix &m3, const Matrix *mA, PaddedTarget &t, std::string &err) {
     const size_t n = r3.size();
     t.offsets.resize(n + 1); t.lengths.resize(n); t.keys.resize(n);
@@ -233,13 +244,16 @@ bool loadPadded(const DbReader &r3, const DbReader *rA, const Matrix &m3, const 
         }
         t.offsets[n] = off; t.bytes = off;
         t.own3di.assign(off, 20);
-        for (size_t i = 0; i < n; i++) {
-            const char *s = r3.data(i);
-            for (int k = 0; k < t.lengths[i]; k++) {
-                uint8_t c = m3.aa2num[(unsigned char) s[k]];
-                t.own3di[t.offsets[i] + k] = (uint8_t) (islower((unsigned char) s[k]) ? c + 32 : c);
+        parallelRanges(n, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                const char *s = r3.data(i);
+                uint8_t *dst = t.own3di.data() + t.offsets[i];
+                for (int k = 0; k < t.lengths[i]; k++) {
+                    const uint8_t c = m3.aa2num[(unsigned char) s[k]];
+                    dst[k] = (uint8_t) (islower((unsigned char) s[k]) ? c + 32 : c);
+                }
             }
-        }
+        });
         t.d3 = t.own3di.data();
     }
     if (!rA) return true;
@@ -256,12 +270,22 @@ bool loadPadded(const DbReader &r3, const DbReader *rA, const Matrix &m3, const 
     // name with an index whose keys were renamed to the padded ids (renamedbkeys).  The device wants the AA codes at the
     // 3Di offsets, so they are encoded here, entry by entry, matched by KEY.
     t.ownAA.assign(t.bytes, 20);
-    for (size_t i = 0; i < n; i++) {
-        const int64_t ia = rA->idOf(t.keys[i]);
-        if (ia < 0) { err = "AA target database has no entry with key " + std::to_string(t.keys[i]); return false; }
-        if ((int32_t) rA->seqLen((size_t) ia) != t.lengths[i]) { err = "AA and 3Di entries of key " + std::to_string(t.keys[i]) + " differ in length"; return false; }
-        const char *a = rA->data((size_t) ia);
-        for (int k = 0; k < t.lengths[i]; k++) t.ownAA[t.offsets[i] + k] = mA->aa2num[(unsigned char) a[k]];
+    std::atomic<int64_t> badEntry(-1);
+    std::atomic<int> badKind(0);
+    parallelRanges(n, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1 && badEntry.load(std::memory_order_relaxed) < 0; i++) {
+            const int64_t ia = rA->idOf(t.keys[i]);
+            if (ia < 0) { badKind = 1; badEntry = (int64_t) i; return; }
+            if ((int32_t) rA->seqLen((size_t) ia) != t.lengths[i]) { badKind = 2; badEntry = (int64_t) i; return; }
+            const char *a = rA->data((size_t) ia);
+            uint8_t *dst = t.ownAA.data() + t.offsets[i];
+            for (int k = 0; k < t.lengths[i]; k++) dst[k] = mA->aa2num[(unsigned char) a[k]];
+        }
+    });
+    if (badEntry >= 0) {
+        const std::string key = std::to_string(t.keys[(size_t) badEntry.load()]);
+        err = badKind == 1 ? "AA target database has no entry with key " + key : "AA and 3Di entries of key " + key + " differ in length";
+        return false;
     }
     t.dA = t.ownAA.data();
     return true;
