@@ -260,6 +260,13 @@ struct AlignQuery {
 // structurealign.cpp:322-347: e-value network + forward / reversed-query profiles
 int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, std::vector<uint8_t> &r3Di) {
     const fshost_params &par = s->par;
+    // the block aligner takes NEGATIVE gap costs with open < extend (block-aligner scan_block.rs: "Gap costs must be negative!"; the
+    // reference process dies in that assertion with --gap-extend 0) and the device SW reproduces the striped kernel for open > extend:
+    // refuse here, with a message, instead of aborting in the backtrace
+    if (!(par.gapExtend >= 1 && par.gapOpen > par.gapExtend && par.gapOpen < 32768)) {
+        s->err = "gap costs must satisfy gapOpen > gapExtend >= 1 (got " + std::to_string(par.gapOpen) + " / " + std::to_string(par.gapExtend) + ")";
+        return FSGPU_E_UNSUPPORTED;
+    }
     const int A = s->mat3Di.n, L = aq.L;
     s->evaluer.predictMuLambda(aq.q3di, L, A, &aq.lambda, &aq.mu);
     aq.pAAf.resize((size_t) A * L); aq.p3f.resize((size_t) A * L); aq.pAAr.resize((size_t) A * L); aq.p3r.resize((size_t) A * L);

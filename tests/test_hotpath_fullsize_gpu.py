@@ -60,44 +60,76 @@ def test_gapless_scores_and_hit_lists_equal_reference_at_100k(world):
     s.close()
 
 
-@pytest.mark.parametrize("atype", [0, 2])
-def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, atype):
-    """prefilter hit lists (1000 targets each, 50 planted homologs among them) through the batch path (k_sw2 forward over all
-    pairs, reversed over the gate survivors, host gates, block-aligner backtrace): forward score / end positions of EVERY pair
-    and the complete accepted records (scores, e-value bits, start/end, CIGAR, order) against the reference's alignStructure"""
+def _align_against_reference(world, atype, go, ge, queries, max_hits):
     ref, db, q3, qa = world["ref"], world["db"], world["q3"], world["qa"]
-    if ref is None:
-        pytest.skip("oracle/_ref not built")
     par = api.default_params()
     par.alignmentType = atype
     par.addBacktrace = 1
+    par.gapOpen, par.gapExtend = go, ge
     s = api.Search(world["ctx"], par)
-    hit_lists = [s.prefilter(q)["id"] for q in q3]
-    res, bts = s.align_batch(qa, q3, hit_lists, with_backtrace=True)
+    pre = api.Search(world["ctx"])
+    hit_lists = {qi: pre.prefilter(q3[qi])["id"][:max_hits] for qi in queries}
+    pre.close()
+    res, bts = s.align_batch([qa[qi] for qi in queries], [q3[qi] for qi in queries], [hit_lists[qi] for qi in queries], with_backtrace=True)
     t3 = np.where(db.data3di >= 32, db.data3di - 32, db.data3di).astype(np.uint8)
     accepted = 0
-    for qi in range(len(q3)):
+    for slot, qi in enumerate(queries):
         h = np.ascontiguousarray(hit_lists[qi].astype(np.int64))
         n = len(h)
         aln = np.zeros(n, oracle_lib.REFALN_DT)
         cig = np.zeros(1 << 22, np.uint8)
-        ref.ref_structure_align(qa[qi], q3[qi], len(q3[qi]), atype, 1, 0.5, 10, 1, db.dataaa, t3,
+        ref.ref_structure_align(qa[qi], q3[qi], len(q3[qi]), atype, 1, 0.5, go, ge, db.dataaa, t3,
                                 np.ascontiguousarray(db.offsets[:-1][h]), np.ascontiguousarray(db.lengths[h]), n,
                                 db.residues, 10.0, 1, 16, None, None, aln.ctypes.data, cig.ctypes.data, cig.size)
         cigs = cig.tobytes().split(b"\0")[0].decode().split("\n")
         ok = np.flatnonzero(aln["status"] == 0)
         # reference records in structurealign's output order (Matcher::compareHits: e-value asc, score desc, dbLen asc, key asc)
         want = sorted(ok, key=lambda k: (aln["evalue"][k], -int(aln["score"][k]), int(db.lengths[h[k]]), int(h[k])))
-        got = res[qi]
-        assert len(got) == len(want), (qi, len(got), len(want))
-        for r, k, bt in zip(got, want, bts[qi]):
+        got = res[slot]
+        assert len(got) == len(want), (qi, go, ge, len(got), len(want))
+        for r, k, bt in zip(got, want, bts[slot]):
             a = aln[k]
             assert (r["dbKey"], r["score"], r["qStartPos"], r["qEndPos"], r["dbStartPos"], r["dbEndPos"]) == \
-                   (h[k], a["score"], a["qStart"], a["qEnd"], a["dbStart"], a["dbEnd"]), (qi, k)
+                   (h[k], a["score"], a["qStart"], a["qEnd"], a["dbStart"], a["dbEnd"]), (qi, k, go, ge)
             assert r["eval"] == a["evalue"] and r["alnLength"] == a["alnLen"] and abs(r["seqId"] - a["seqId"]) == 0
-            assert bt == cigs[k], (qi, k)
+            assert bt == cigs[k], (qi, k, go, ge)
         accepted += len(want)
+    s.close()
+    return accepted
+
+
+@pytest.mark.parametrize("atype", [0, 2])
+def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, atype):
+    """prefilter hit lists (1000 targets each, 50 planted homologs among them) through the batch path (k_sw2 forward over all
+    pairs, reversed over the gate survivors, host gates, block-aligner backtrace): forward score / end positions of EVERY pair
+    and the complete accepted records (scores, e-value bits, start/end, CIGAR, order) against the reference's alignStructure"""
+    if world["ref"] is None:
+        pytest.skip("oracle/_ref not built")
+    accepted = _align_against_reference(world, atype, 10, 1, list(range(len(world["q3"]))), 1000)
     assert accepted >= 150            # the planted homologs are found and aligned, not just random pairs
+
+
+@pytest.mark.parametrize("go,ge", [(8, 2), (15, 3), (3, 1), (2, 1), (25, 1)])
+def test_structure_alignment_with_other_gap_costs_equals_reference(world, go, ge):
+    """--gap-open / --gap-extend other than 10 / 1 (any gapOpen > gapExtend >= 1 is on the device path): the same comparison against the
+    reference's alignStructure run with those costs -- SW kernels (single tile and the 777-residue row-tiled query), gates, backtraces"""
+    if world["ref"] is None:
+        pytest.skip("oracle/_ref not built")
+    accepted = _align_against_reference(world, 2, go, ge, [0, 1, 3], 300)
+    assert accepted >= 60
+
+
+@pytest.mark.parametrize("go,ge", [(11, 0), (5, 5), (3, 7)])
+def test_gap_costs_the_path_does_not_cover_are_refused(world, go, ge):
+    """gap extend 0 kills the reference in the block aligner's assertion, gapOpen <= gapExtend is outside what the device SW reproduces:
+    an error code and a message, not an abort"""
+    par = api.default_params()
+    par.gapOpen, par.gapExtend = go, ge
+    s = api.Search(world["ctx"], par)
+    with pytest.raises(RuntimeError, match="gap costs must satisfy"):
+        s.align(world["qa"][0], world["q3"][0], np.arange(10, dtype=np.uint32))
+    with pytest.raises(RuntimeError, match="gap costs must satisfy"):
+        s.align_batch([world["qa"][0]], [world["q3"][0]], [np.arange(10, dtype=np.uint32)])
     s.close()
 
 
