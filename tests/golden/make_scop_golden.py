@@ -88,6 +88,23 @@ RUNS = {
     "aln_t2_a_maxacc": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--max-accept": "3", "--max-rejected": "2"})),
     "aln_t2_a_altali": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--alt-ali": "2"})),
     "aln_t2_a_nocb": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--comp-bias-corr": "0"})),
+    # ---- acceptance criteria other than the workflow's (Alignment::checkCriteria, Util::hasCoverage / canBeCovered, seq-id modes) ----
+    "aln_t2_a_sid1": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--min-seq-id": "0.3", "--seq-id-mode": "1"})),
+    "aln_t2_a_sid2": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--min-seq-id": "0.2", "--seq-id-mode": "2"})),
+    "aln_t2_a_minlen": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--min-aln-len": "60"})),
+    "aln_t2_a_cov1": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"-c": "0.7", "--cov-mode": "1"})),
+    "aln_t2_a_cov3": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"-c": "0.6", "--cov-mode": "3"})),
+    "aln_t2_a_cov4": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"-c": "0.6", "--cov-mode": "4"})),
+    "aln_t2_a_cov5": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"-c": "0.6", "--cov-mode": "5"})),
+    "aln_t0_a_gap": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(0, 1), **{"--gap-open": "aa:8,nucl:8", "--gap-extend": "aa:2,nucl:2"})),
+    "aln_t2_a_cbs": ("structurealign", ["db", "db", "pref_kmer"], override(align_par(2, 1), **{"--comp-bias-corr-scale": "0.25"})),
+    "pref_kmer_c08": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"-c": "0.8", "--cov-mode": "0"})),
+    "pref_kmer_c07m2": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"-c": "0.7", "--cov-mode": "2"})),
+    "pref_kmer_c07m5": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"-c": "0.7", "--cov-mode": "5"})),
+    "pref_kmer_nospace": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"--spaced-kmer-mode": "0"})),
+    "pref_kmer_nomasklc": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"--mask-lower-case": "0"})),
+    "pref_kmer_cbs0": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"--comp-bias-corr": "0"})),
+    "pref_kmer_minung45": ("prefilter", ["db_ss", "db_ss"], override(PREFILTER_PAR, **{"--min-ungapped-score": "45"})),
 }
 
 
