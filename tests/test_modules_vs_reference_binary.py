@@ -121,3 +121,24 @@ def test_rescorediagonal_equals_the_reference_binary_on_defined_lines(world):
     _run([FS, "structurerescorediagonal", "q", "t", "pref_def", "ref_resc"] + par, w)
     _run([BIN, "structurerescorediagonal", "q", "t", "pref_def", "mine_resc"] + par, w)
     assert _same(w, "ref_resc", "mine_resc") > 300
+
+
+@pytest.mark.parametrize("run", ["aln_t2_a_cov1", "aln_t2_a_cov3", "aln_t2_a_cov5", "aln_t2_a_sid2", "aln_t2_a_minlen", "aln_t0_a_gap", "aln_t2_a_altali",
+                                 "aln_t2_a_cbs", "aln_t2_a_e001_c08", "aln_t2_a_maxacc", "pref_kmer_c07m5", "pref_kmer_nospace", "pref_kmer_s75",
+                                 "pref_kmer_minung45", "pref_ung_max7", "pref_ung_nocb"])
+def test_parameter_variants_equal_the_reference_binary_at_scale(world, run):
+    """the parameter variants frozen for the SCOP example set (tests/golden/make_scop_golden.py), here on the 3000-target / 48-query
+    databases with both binaries side by side: acceptance criteria, coverage and sequence-identity modes, gap costs, alternative
+    alignments, k-mer options"""
+    w = world
+    spec = MANIFEST["runs"][run]
+    par = _par(run, 8)
+    if spec["module"] == "structurealign":
+        if not os.path.exists(w / "ref_kmer"):
+            _run([FS, "prefilter", "q_ss", "t_ss", "ref_kmer"] + _par("pref_kmer", 8, **{"--max-seqs": "300"}), w)
+        pos = ["q", "t", "ref_kmer"]
+    else:
+        pos = ["q_ss", "t_ss"]
+    _run([FS, spec["module"]] + pos + ["ref_" + run] + par, w)
+    _run([BIN, spec["module"]] + pos + ["mine_" + run] + par, w)
+    assert _same(w, "ref_" + run, "mine_" + run) > 50
