@@ -184,3 +184,27 @@ def test_edge_values_behave_like_the_reference_binary(world, module, base, over)
         return
     assert mine.returncode == 0, mine.stdout[-1500:]
     _same(w, "ref_" + tag, "mine_" + tag)
+
+
+def test_convertalis_equals_the_reference_binary_at_scale(world):
+    """convertalis of a few thousand alignments (with backtraces): default columns, every sequence / alignment column, format modes 2 and 4"""
+    w = world
+    if not os.path.exists(w / "ref_aln2"):
+        if not os.path.exists(w / "ref_kmer"):
+            _run([FS, "prefilter", "q_ss", "t_ss", "ref_kmer"] + _par("pref_kmer", 8, **{"--max-seqs": "300"}), w)
+        _run([FS, "structurealign", "q", "t", "ref_kmer", "ref_aln2"] + _par("aln_t2_a", 8), w)
+    for name, keys in (("q", [7 + 3 * i for i in range(48)]), ("t", [int(l.split()[0]) for l in open(w / "t.index")])):
+        if os.path.exists(w / f"{name}_h"):
+            continue
+        with open(w / f"{name}_h", "wb") as f, open(w / f"{name}_h.index", "w") as fi:
+            off = 0
+            for k in keys:
+                b = f"{name}{k} some description {k % 7}".encode() + b"\n\0"
+                f.write(b); fi.write(f"{k}\t{off}\t{len(b)}\n"); off += len(b)
+        np.array([12], np.int32).tofile(str(w / f"{name}_h.dbtype"))
+    conv = MANIFEST["convert_runs"]
+    for tag, par in (("default", conv["conv_default.m8"]["parameters"]), ("all", conv["conv_fmt4_all.m8"]["parameters"]), ("fmt2", conv["conv_fmt2.m8"]["parameters"])):
+        _run([FS, "convertalis", "q", "t", "ref_aln2", f"ref_{tag}.m8"] + par, w)
+        _run([BIN, "convertalis", "q", "t", "ref_aln2", f"mine_{tag}.m8"] + par, w)
+        a, b = open(w / f"ref_{tag}.m8", "rb").read(), open(w / f"mine_{tag}.m8", "rb").read()
+        assert len(a) > 50000 and a == b, tag
