@@ -1316,9 +1316,9 @@ namespace {
 
 enum ConvCol { C_QUERY, C_TARGET, C_QKEY, C_TKEY, C_EVALUE, C_GAPOPEN, C_PIDENT, C_FIDENT, C_NIDENT, C_QSTART, C_QEND, C_QLEN, C_TSTART, C_TEND,
                C_TLEN, C_ALNLEN, C_BITS, C_CIGAR, C_QSEQ, C_TSEQ, C_Q3DI, C_T3DI, C_QHEADER, C_THEADER, C_QALN, C_TALN, C_Q3DIALN, C_T3DIALN,
-               C_MISMATCH, C_QCOV, C_TCOV, C_EMPTY, C_PROB };
+               C_MISMATCH, C_QCOV, C_TCOV, C_EMPTY, C_PROB, C_QSET, C_QSETID, C_TSET, C_TSETID };
 
-struct ConvColSpec { const char *name; ConvCol col; bool needSeq, need3Di, needBt; };
+struct ConvColSpec { const char *name; ConvCol col; bool needSeq, need3Di, needBt; int needSets = 0; };   // needSets: 1 = .lookup, 2 = .source
 const ConvColSpec kConvCols[] = {        // LocalParameters::getOutputFormat (LocalParameters.cpp:464-553)
     {"query", C_QUERY, false, false, false}, {"target", C_TARGET, false, false, false}, {"qkey", C_QKEY, false, false, false}, {"tkey", C_TKEY, false, false, false},
     {"evalue", C_EVALUE, false, false, false}, {"gapopen", C_GAPOPEN, false, false, false}, {"pident", C_PIDENT, false, false, false},
@@ -1328,8 +1328,11 @@ const ConvColSpec kConvCols[] = {        // LocalParameters::getOutputFormat (Lo
     {"qseq", C_QSEQ, true, false, false}, {"tseq", C_TSEQ, true, false, false}, {"q3di", C_Q3DI, false, true, false}, {"t3di", C_T3DI, false, true, false},
     {"qheader", C_QHEADER, false, false, false}, {"theader", C_THEADER, false, false, false}, {"qaln", C_QALN, true, false, true}, {"taln", C_TALN, true, false, true},
     {"q3dialn", C_Q3DIALN, false, true, true}, {"t3dialn", C_T3DIALN, false, true, true}, {"mismatch", C_MISMATCH, false, false, false},
-    {"qcov", C_QCOV, false, false, false}, {"tcov", C_TCOV, false, false, false}, {"empty", C_EMPTY, false, false, false}, {"prob", C_PROB, false, false, false}};
-const char *const kConvRefused[] = {"qca", "tca", "u", "t", "alntmscore", "qtmscore", "ttmscore", "rmsd", "lddt", "lddtfull", "qset", "qsetid", "tset", "tsetid",
+    {"qcov", C_QCOV, false, false, false}, {"tcov", C_TCOV, false, false, false}, {"empty", C_EMPTY, false, false, false}, {"prob", C_PROB, false, false, false},
+    // set columns: `tset` asks for the lookup only (LocalParameters.cpp:519), so on its own it prints the empty source name -- reproduced
+    {"qset", C_QSET, false, false, false, 3}, {"qsetid", C_QSETID, false, false, false, 3}, {"tset", C_TSET, false, false, false, 1},
+    {"tsetid", C_TSETID, false, false, false, 3}};
+const char *const kConvRefused[] = {"qca", "tca", "u", "t", "alntmscore", "qtmscore", "ttmscore", "rmsd", "lddt", "lddtfull",
                                     "taxid", "taxname", "taxlineage", "complexqtmscore", "multimerqtmscore", "complexttmscore", "multimerttmscore",
                                     "complexassignid", "multimerassignid", "complexu", "multimeru", "complext", "multimert", "qcomplexcoverage",
                                     "qmultimercoverage", "tcomplexcoverage", "tmultimercoverage", "qchaintms", "tchaintms", "qchains", "tchains", "interfacelddt"};
@@ -1339,6 +1342,53 @@ struct AlnRecord {
     uint32_t dbKey; int score; float seqId; double eval; int qStart, qEnd, qLen, dbStart, dbEnd, dbLen;
     float qcov, dbcov; unsigned int alnLength; std::string backtrace;
 };
+
+// <db>.lookup: key \t name \t set id (structureReadKeyToSet, structureconvertalis.cpp:204-227); <db>.source: set id \t source name, the
+// name being the rest of the line (structureReadSetToSource, :230-251)
+bool readWholeFile(const std::string &path, std::string &out, std::string &err) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+bool readKeyToSet(const std::string &path, std::map<unsigned int, unsigned int> &m, std::string &err) {
+    std::string text;
+    if (!readWholeFile(path, text, err)) return false;
+    size_t p = 0;
+    while (p < text.size()) {
+        size_t e = text.find('\n', p);
+        if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(p, e - p);
+        p = e + 1;
+        unsigned int key = 0, set = 0;
+        char name[4096];
+        if (sscanf(line.c_str(), "%u %4095s %u", &key, name, &set) == 3) m.emplace(key, set);
+    }
+    return true;
+}
+bool readSetToSource(const std::string &path, std::map<unsigned int, std::string> &m, std::string &err) {
+    std::string text;
+    if (!readWholeFile(path, text, err)) return false;
+    size_t p = 0;
+    while (p < text.size()) {
+        size_t e = text.find('\n', p);
+        if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(p, e - p);
+        p = e + 1;
+        size_t a = 0;
+        while (a < line.size() && (line[a] == ' ' || line[a] == '\t')) a++;
+        size_t b = a;
+        while (b < line.size() && line[b] != ' ' && line[b] != '\t') b++;
+        size_t c = b;
+        while (c < line.size() && (line[c] == ' ' || line[c] == '\t')) c++;
+        if (a == b || c >= line.size()) continue;
+        m.emplace((unsigned int) strtoul(line.c_str() + a, nullptr, 10), line.substr(c));
+    }
+    return true;
+}
 
 bool parseAlnRecord(const char *line, const char *end, AlnRecord &r, std::string &err) {
     const char *w[16];
@@ -1421,6 +1471,7 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
     std::vector<ConvCol> cols;
     std::vector<std::string> colNames;
     bool needSeq = false, need3Di = false, needBt = false;
+    int needSets = 0;
     for (size_t b = 0; b <= outfmt.size();) {                      // Util::split(outfmt, ","): empty fields are skipped
         size_t e = outfmt.find(',', b);
         if (e == std::string::npos) e = outfmt.size();
@@ -1436,6 +1487,14 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
         }
         cols.push_back(spec->col); colNames.push_back(name);
         needSeq = needSeq || spec->needSeq; need3Di = need3Di || spec->need3Di; needBt = needBt || spec->needBt;
+        needSets |= spec->needSets;
+    }
+    std::map<unsigned int, unsigned int> qKeyToSet, tKeyToSet;
+    std::map<unsigned int, std::string> qSetToSource, tSetToSource;
+    {
+        std::string serr;
+        if ((needSets & 1) && (!readKeyToSet(o.pos[0] + ".lookup", qKeyToSet, serr) || !readKeyToSet(o.pos[1] + ".lookup", tKeyToSet, serr))) return fail(serr);
+        if ((needSets & 2) && (!readSetToSource(o.pos[0] + ".source", qSetToSource, serr) || !readSetToSource(o.pos[1] + ".source", tSetToSource, serr))) return fail(serr);
     }
     const bool sameDB = o.pos[0] == o.pos[1];
     std::string err;
@@ -1580,6 +1639,10 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
                     case C_TCOV: appendF3(result, res.dbcov); break;
                     case C_EMPTY: result.push_back('-'); break;
                     case C_PROB: appendF3(result, probTruePositive((float) res.score)); break;
+                    case C_QSET: result += qSetToSource[qKeyToSet[queryKey]]; break;          // std::map::operator[] like the reference: absent -> 0 / ""
+                    case C_QSETID: result += std::to_string(qKeyToSet[queryKey]); break;
+                    case C_TSET: result += tSetToSource[tKeyToSet[res.dbKey]]; break;
+                    case C_TSETID: result += std::to_string(tKeyToSet[res.dbKey]); break;
                 }
                 if (c + 1 < cols.size()) result.push_back('\t');
             }

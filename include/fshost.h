@@ -207,7 +207,7 @@ int fsmod_makepaddedseqdb(int argc, const char **argv);
 int fsmod_structurerescorediagonal(int argc, const char **argv);
 /* convertalis <queryDB> <targetDB> <alnDB> <outFile>   F/src/strucclustutils/structureconvertalis.cpp:253-1445: the BLAST-tab family
  * (--format-mode 0 / 2 / 4) with every --format-output column that is a function of the alignment record, the sequences and the
- * headers; columns that need C-alpha coordinates, taxonomy, set or multimer data are refused by name.  Host only (text formatting). */
+ * headers (+ the set columns from <db>.lookup / <db>.source); columns that need C-alpha coordinates, taxonomy or multimer data are refused by name.  Host only (text formatting). */
 int fsmod_convertalis(int argc, const char **argv);
 /* gpuserver <targetDB_ss[_pad]>: keeps the target DB resident in HBM and serves gapless scans over the reference's
  * shared-memory protocol until SIGINT/SIGTERM (M/src/util/gpuserver.cpp:24-101, M/src/commons/GpuUtil.h:9-49);

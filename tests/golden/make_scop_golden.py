@@ -160,6 +160,9 @@ CONVERT_RUNS = {
     "conv_pad.m8": ("convertalis", ["db", "db_pad", "aln_t2_a_pad"], override(CONVERT_PAR, **{"--format-output": "query,target,tkey,theader,taln,t3dialn,bits"})),
     "conv_resc.m8": ("convertalis", ["db", "db", "resc_t2_a"], override(CONVERT_PAR, **{"--format-output": "query,target,fident,nident,alnlen,mismatch,gapopen,cigar,qcov,tcov,evalue,bits"})),
     "conv_dbout": ("convertalis", ["db", "db", "aln_t2_a"], override(CONVERT_PAR, **{"--db-output": "1"})),
+    # set columns (<db>.lookup / <db>.source); `tset` on its own prints the EMPTY source name in the reference (it asks for the lookup only)
+    "conv_sets.m8": ("convertalis", ["db", "db", "aln_t2_a"], override(CONVERT_PAR, **{"--format-output": "query,target,qset,qsetid,tset,tsetid,bits"})),
+    "conv_tset_alone.m8": ("convertalis", ["db", "db_pad", "aln_t2_a_pad"], override(CONVERT_PAR, **{"--format-output": "query,target,tset,tkey"})),
 }
 
 
@@ -246,7 +249,7 @@ def main():
         if os.path.islink(p):            # makepaddedseqdb links the AA / header data files to the source DB's
             manifest["links"][f] = os.path.basename(os.readlink(p))
             continue
-        if os.path.isdir(p) or f.endswith(".source") or "_tmp" in f or ".idx" in f:
+        if os.path.isdir(p) or "_tmp" in f or ".idx" in f:
             continue
         if f.endswith(".m8") and os.path.getsize(p) > 100000:      # large text outputs are frozen gzip-compressed (mtime 0: reproducible bytes)
             import gzip
