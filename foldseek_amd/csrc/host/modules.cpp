@@ -1309,7 +1309,7 @@ int fsmod_gpuserver(int argc, const char **argv) {
 // ---- convertalis -------------------------------------------------------------------------------------------------
 // F/src/strucclustutils/structureconvertalis.cpp:253-1445 for the BLAST-tab family (--format-mode 0, 2, 4) and every
 // --format-output column that is a function of the alignment record, the sequences and the headers.  Columns computed from
-// C-alpha coordinates (lddt, lddtfull, alntmscore, qtmscore, ttmscore, rmsd, u, t, qca, tca), taxonomy, set / source and multimer
+// C-alpha coordinates (lddt, lddtfull, alntmscore, qtmscore, ttmscore, rmsd, u, t, qca, tca), taxonomy and multimer
 // columns are refused by name.  `prob` only reads the score (CalcProbTP.h), so it is answered without the _ca DB the reference
 // insists on opening for it.
 namespace {
@@ -1482,7 +1482,7 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
         for (const ConvColSpec &c : kConvCols) if (name == c.name) spec = &c;
         if (!spec) {
             for (const char *r : kConvRefused)
-                if (name == r) return fail("convertalis: column " + name + " is not implemented on this path (needs the C-alpha, taxonomy, set or multimer data)");
+                if (name == r) return fail("convertalis: column " + name + " is not implemented on this path (needs the C-alpha, taxonomy or multimer data)");
             return fail("Format code " + name + " does not exist.");
         }
         cols.push_back(spec->col); colNames.push_back(name);
