@@ -47,3 +47,53 @@ def test_makepaddedseqdb_edge_cases_equal_the_reference_binary(tmp_path, write_l
         if os.path.exists(a):
             assert open(a, "rb").read() == open(b, "rb").read(), ext
     assert os.path.exists(os.path.join(w, "ref_pad.lookup")) == (write_lookup == "1")
+
+
+def test_convertalis_hand_written_records_equal_the_reference_binary(tmp_path):
+    """alignment records no module run produces but the parser must take like the reference: an empty entry, a record without backtrace next to
+    ones with it (start -1), e-values 0 / 1e-301 / 1e+10, a count-less "M", an UNCOMPRESSED backtrace, interleaved single-column gaps; default
+    columns in the three BLAST-tab modes, then every alignment / sequence / set column"""
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "scop_v1")
+    w = str(tmp_path)
+    for f in ("db", "db.index", "db.dbtype", "db_h", "db_h.index", "db_h.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype", "db.lookup", "db.source"):
+        shutil.copy(os.path.join(gold, f), os.path.join(w, f))
+    lens = {int(l.split()[0]): int(l.split()[2]) - 2 for l in open(os.path.join(w, "db.index"))}
+    keys = sorted(lens)
+
+    def rec(t, score, sid, ev, qs, qe, ql, ts, te, tl, bt=None):
+        return f"{t}\t{score}\t{sid}\t{ev}\t{qs}\t{qe}\t{ql}\t{ts}\t{te}\t{tl}" + (f"\t{bt}" if bt else "") + "\n"
+
+    def write_aln(with_plain_record):
+        q0, q1, q2 = keys[0], keys[1], keys[5]
+        e = {q0: rec(keys[0], 2131, "1.00", "1.318E-55", 0, lens[q0] - 1, lens[q0], 0, lens[keys[0]] - 1, lens[keys[0]], f"{lens[q0]}M") +
+                 rec(keys[2], 0, "0.000", "0.000E+00", 3, 10, lens[q0], 5, 14, lens[keys[2]], "3M2I3M2D2M") +
+                 (rec(keys[3], 17, "0.125", "1.5E+01", -1, 40, lens[q0], -1, 33, lens[keys[3]]) if with_plain_record else ""),
+             q1: "",
+             q2: rec(keys[4], 55, "0.333", "9.999E-301", 10, 20, lens[q2], 12, 20, lens[keys[4]], "1M1I1M1I1M1I1M1I1M1I1M") +
+                 rec(keys[6], 99, "0.999", "1.000E+10", 0, 0, lens[q2], 0, 0, lens[keys[6]], "M") +
+                 rec(keys[7], 30000, "0.5", "1e-5", 5, 24, lens[q2], 7, 20, lens[keys[7]], "MMMIIIDDD10M2I1D")}
+        blob, idx, off = b"", [], 0
+        for k in sorted(e):
+            b = e[k].encode() + b"\0"
+            idx.append(f"{k}\t{off}\t{len(b)}\n"); blob += b; off += len(b)
+        open(os.path.join(w, "aln"), "wb").write(blob)
+        open(os.path.join(w, "aln.index"), "w").write("".join(idx))
+        np.array([5], np.int32).tofile(os.path.join(w, "aln.dbtype"))
+
+    default = "query,target,fident,alnlen,mismatch,gapopen,qstart,qend,tstart,tend,evalue,bits"
+    full = "query,target,pident,nident,qcov,tcov,cigar,qaln,taln,q3dialn,t3dialn,qlen,tlen,qkey,tkey,qheader,theader,qset,tsetid,alnlen,mismatch,gapopen,qseq,t3di"
+    for with_plain, cols, modes in ((True, default, ("0", "2", "4")), (False, full, ("0", "4"))):
+        write_aln(with_plain)
+        for fm in modes:
+            par = ["--format-mode", fm, "--format-output", cols, "--threads", "1", "-v", "1"]
+            r = subprocess.run([FS, "convertalis", "db", "db", "aln", "ref.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            m = subprocess.run([BIN, "convertalis", "db", "db", "aln", "mine.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            assert r.returncode == 0 and m.returncode == 0, (r.stdout[-500:], m.stdout[-500:])
+            a, b = open(os.path.join(w, "ref.m8"), "rb").read(), open(os.path.join(w, "mine.m8"), "rb").read()
+            assert a == b and a.count(b"\n") >= 5, (with_plain, fm)
+    # a record without backtrace + an alignment column: both refuse
+    write_aln(True)
+    par = ["--format-output", "query,target,qaln", "--threads", "1", "-v", "1"]
+    assert subprocess.run([FS, "convertalis", "db", "db", "aln", "ref.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode != 0
+    assert subprocess.run([BIN, "convertalis", "db", "db", "aln", "mine.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode != 0
