@@ -106,6 +106,7 @@ extern "C" int fsgpu_diag_rescore(fsgpu_ctx *ctx, const uint8_t *qAA, const uint
     if (!qAA || !q3Di || !qOffsets || !qLengths || nq < 0 || !mat3Di || !matAA || n < 0 || (n > 0 && (!pairs || !out))) { ctx->err = "fsgpu_diag_rescore: bad argument"; return FSGPU_E_ARG; }
     if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (!ctx->db->hasAA) { ctx->err = "fsgpu_diag_rescore needs the AA half of the database"; return FSGPU_E_NODB; }
+    if (ctx->sw.pending || ctx->gaplessPending) { ctx->err = "fsgpu_diag_rescore: a scan or SW batch of this context is still in flight (it shares the scratch buffers)"; return FSGPU_E_ARG; }
     if (n == 0) return FSGPU_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t qBytes = qOffsets[nq];

@@ -66,8 +66,9 @@ bool bandedBacktrace(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, 
             for (int j = 1; j <= u; j++) hPrev[j] = hCur[j];
         }
         band *= 2;
-    } while (best < score && band / 2 < (dbLen + qLen) * 2);       // the reference doubles without a bound; past the rectangle nothing can change
+    } while (best < score && band / 2 < std::max(qLen, dbLen));    // the reference doubles without a bound; a band of max(qLen, dbLen) IS the rectangle
     band /= 2;
+    if (best < score) return false;                                // a score the rectangle cannot reach (the reference would keep doubling until memory runs out)
     // trace back from the end cell in the H state
     int i = qLen - 1, j = dbLen - 1, state = 2;
     char op = 'M';

@@ -27,7 +27,7 @@ struct ShimDb {                       // what loadDb hands back: borrowed host p
 // order.  FSGPU_MARV_SHARDS=n puts n shards on device 0 (tests on a one-GPU box).
 struct Shard {
     fsgpu_ctx *ctx = nullptr;
-    std::vector<uint64_t> offsets;        // of this shard's targets (into the full data buffer)
+    std::vector<uint64_t> offsets;        // of this shard's targets in the shard's own packed buffer
     std::vector<int32_t> lengths;
     std::vector<uint32_t> globalId;
     std::vector<fsgpu_hit> hits;
@@ -99,13 +99,32 @@ void Marv::setDb(void *dbhandle) {
     if (!db) die("setDb: null database handle");
     if (s->resident != db) {
         const size_t N = s->shards.size();
+        std::vector<uint8_t> packed;              // one shard's entries, contiguous, offsets rebased: a device holds ITS targets only
         for (size_t k = 0; k < N; k++) {
             Shard &sh = s->shards[k];
             sh.offsets.clear(); sh.lengths.clear(); sh.globalId.clear();
-            for (size_t i = k; i < db->n; i += N) { sh.offsets.push_back(db->offsets[i]); sh.lengths.push_back(db->lengths[i]); sh.globalId.push_back((uint32_t) i); }
-            sh.offsets.push_back(db->bytes);
+            if (N == 1) {                         // the whole database: no host copy, the caller's buffer goes up as it is
+                sh.offsets = db->offsets;
+                sh.lengths.assign(db->lengths, db->lengths + db->n);
+                sh.globalId.resize(db->n);
+                for (size_t i = 0; i < db->n; i++) sh.globalId[i] = (uint32_t) i;
+                if (db->n && fsgpu_db_load(sh.ctx, db->data, nullptr, sh.offsets.data(), sh.lengths.data(), db->n, db->bytes) != FSGPU_OK) die(fsgpu_last_error(sh.ctx));
+                continue;
+            }
+            size_t bytes = 0;
+            auto extent = [&](size_t i) { return ((size_t) db->lengths[i] + 3) & ~(size_t) 3; };   // residues + padding to 4 (makepaddedseqdb.cpp:88-89)
+            for (size_t i = k; i < db->n; i += N) bytes += extent(i);
+            packed.resize(bytes);
+            size_t at = 0;
+            for (size_t i = k; i < db->n; i += N) {
+                const size_t len = extent(i);
+                memcpy(packed.data() + at, db->data + db->offsets[i], len);
+                sh.offsets.push_back(at); sh.lengths.push_back(db->lengths[i]); sh.globalId.push_back((uint32_t) i);
+                at += len;
+            }
+            sh.offsets.push_back(at);
             if (sh.lengths.empty()) continue;
-            if (fsgpu_db_load(sh.ctx, db->data, nullptr, sh.offsets.data(), sh.lengths.data(), sh.lengths.size(), db->bytes) != FSGPU_OK) die(fsgpu_last_error(sh.ctx));
+            if (fsgpu_db_load(sh.ctx, packed.data(), nullptr, sh.offsets.data(), sh.lengths.data(), sh.lengths.size(), bytes) != FSGPU_OK) die(fsgpu_last_error(sh.ctx));
         }
         s->resident = db;
     }
@@ -135,35 +154,47 @@ Marv::Stats Marv::scan(const char *sequence, size_t sequenceLength, int8_t *pssm
     if (L == 0) return st;
     if (!s->resident) die("scan before setDb");
     // The CPU kernel saturates at 255 - bias with bias = |min(matrix)| + |min(rounded composition bias)|
-    // (StripedSmithWaterman.cpp:1375-1406).  Both come out of what the caller passes: the X row of every MMseqs matrix is
-    // zero, so pssm[X][i] is position i's rounded composition bias, and pssm[a][i] - pssm[X][i] is matrix[a][q_i]; the
-    // matrix is symmetric, so the minimum over all entries with one index in the query is the matrix minimum as soon
-    // as a residue of a minimal pair occurs in the query (see below for the matrices known to this library); a query that
-    // fails the consistency test (profile queries: no zero X row semantics) is refused.
+    // (StripedSmithWaterman.cpp:1375-1406); the caller passes pssm[a][i] = matrix[a][q_i] + round(bias_i) only.
+    // (1) A profile that decomposes exactly over a matrix this library carries (3di.out, whose X row is zero, and blosum62.out,
+    //     whose X row is -1; both at the prefilter's 2.0 bits) gets that matrix's true minimum and the exact per-position bias
+    //     pssm[X][i] - matrix[X][q_i], even if the query lacks the residues of a minimal pair.
+    // (2) Any other profile is read under the assumption matrix[X][*] == 0 (then pssm[X][i] IS the rounded bias and
+    //     pssm[a][i] - pssm[X][i] the matrix entry).  A non-zero X row would shift both terms silently, so the assumption is
+    //     tested where the profile allows it (query residue X: the whole column must equal the bias; and a rounded composition
+    //     bias is small) and the scan is refused when it fails.
     const int A = alphabetSize, X = A - 1;
     int cbMin = 0, matMin = 0;
-    for (size_t i = 0; i < L; i++) {
-        const int q = (unsigned char) sequence[i];
-        if (q >= A) die("query residue code out of range");
-        const int cb = pssm[(size_t) X * L + i];
-        cbMin = std::min(cbMin, cb);
-        for (int a = 0; a < A; a++) matMin = std::min(matMin, (int) pssm[(size_t) a * L + i] - cb);
-        if (q == X && (pssm[(size_t) 0 * L + i] - cb) != 0) die("profile does not come from a substitution matrix with a zero X row (profile queries are not supported)");
-    }
-    // Exact for the matrices this library carries (3di.out / blosum62.out at the prefilter's 2.0 bits): when every derived
-    // entry agrees with one of them, its true minimum is used even if the query lacks the residues that reach it.
+    for (size_t i = 0; i < L; i++) if ((unsigned char) sequence[i] >= A) die("query residue code out of range");
+    bool known = false;
     for (int which : {FSHOST_MAT_3DI, FSHOST_MAT_BLOSUM62}) {
         fshost_matrix *m = fshost_matrix_create(which, 2.0f, 0.0f);
         if (!m) continue;
         const int16_t *sub = fshost_matrix_scores(m);
         bool same = fshost_matrix_size(m) == A;
+        int cbm = 0;
         for (size_t i = 0; i < L && same; i++) {
-            const int q = (unsigned char) sequence[i], cb = pssm[(size_t) X * L + i];
+            const int q = (unsigned char) sequence[i], cb = (int) pssm[(size_t) X * L + i] - (int) sub[X * A + q];
+            cbm = std::min(cbm, cb);
             for (int a = 0; a < A && same; a++) same = ((int) pssm[(size_t) a * L + i] - cb) == (int) sub[a * A + q];
         }
-        if (same) for (int k = 0; k < A * A; k++) matMin = std::min(matMin, (int) sub[k]);
+        if (same) {
+            for (int k = 0; k < A * A; k++) matMin = std::min(matMin, (int) sub[k]);
+            cbMin = cbm; known = true;
+        }
         fshost_matrix_free(m);
         if (same) break;
+    }
+    if (!known) {
+        for (size_t i = 0; i < L; i++) {
+            const int q = (unsigned char) sequence[i];
+            const int cb = pssm[(size_t) X * L + i];
+            if (abs(cb) > 8) die("profile of an unknown substitution matrix whose X row is not a plain composition bias: the CPU path's saturation cap cannot be derived from it");
+            cbMin = std::min(cbMin, cb);
+            for (int a = 0; a < A; a++) {
+                matMin = std::min(matMin, (int) pssm[(size_t) a * L + i] - cb);
+                if (q == X && (int) pssm[(size_t) a * L + i] != cb) die("profile does not come from a substitution matrix with a zero X row (profile queries are not supported)");
+            }
+        }
     }
     const int cap = 255 - (abs(matMin) + abs(cbMin));
     const auto t0 = std::chrono::steady_clock::now();

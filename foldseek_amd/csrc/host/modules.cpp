@@ -1604,6 +1604,13 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
             if (needSeq) { const int64_t id = tSeq.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in " + o.pos[1]); tSeqData = seqText(tSeq, (size_t) id, tSeqBuf); }
             if (need3Di) { const int64_t id = t3.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in the target 3Di database"); t3Data = seqText(t3, (size_t) id, t3Buf); }
             if (needBt) bt = expandBacktrace(res.backtrace);
+            if (cols.empty()) {                    // no column survived Util::split: the reference's fixed 12-column BLAST line (:776-800)
+                const int count = snprintf(buffer, sizeof(buffer), "%s\t%s\t%1.3f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.2E\t%d\n", queryId.c_str(), targetId.c_str(),
+                                           res.seqId, alnLen, missMatchCount, gapOpenCount, res.qStart + 1, res.qEnd + 1, res.dbStart + 1, res.dbEnd + 1, res.eval, res.score);
+                if (count < 0 || (size_t) count >= sizeof(buffer)) { fprintf(stderr, "Truncated line in entry%zu!\n", i); continue; }
+                result.append(buffer, (size_t) count);
+                continue;
+            }
             for (size_t c = 0; c < cols.size(); c++) {
                 switch (cols[c]) {
                     case C_QUERY: result += queryId; break;

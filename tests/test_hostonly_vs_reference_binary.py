@@ -92,6 +92,17 @@ def test_convertalis_hand_written_records_equal_the_reference_binary(tmp_path):
             assert r.returncode == 0 and m.returncode == 0, (r.stdout[-500:], m.stdout[-500:])
             a, b = open(os.path.join(w, "ref.m8"), "rb").read(), open(os.path.join(w, "mine.m8"), "rb").read()
             assert a == b and a.count(b"\n") >= 5, (with_plain, fm)
+    # a column list that Util::split leaves empty ("" or ","): the reference falls back to its fixed 12-column line (structureconvertalis.cpp:776-800)
+    write_aln(True)
+    for empty in ("", ","):
+        for fm in ("0", "4"):
+            par = ["--format-mode", fm, "--format-output", empty, "--threads", "1", "-v", "1"]
+            r = subprocess.run([FS, "convertalis", "db", "db", "aln", "ref.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            m = subprocess.run([BIN, "convertalis", "db", "db", "aln", "mine.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            assert r.returncode == m.returncode, (r.stdout[-500:], m.stdout[-500:])
+            if r.returncode == 0:
+                a, b = open(os.path.join(w, "ref.m8"), "rb").read(), open(os.path.join(w, "mine.m8"), "rb").read()
+                assert a == b and a.count(b"\n") >= 5, (empty, fm)
     # a record without backtrace + an alignment column: both refuse
     write_aln(True)
     par = ["--format-output", "query,target,qaln", "--threads", "1", "-v", "1"]
