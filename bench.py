@@ -56,6 +56,13 @@ def parse(argv=None):
     ap.add_argument("--kmer-cpu-queries", type=int, default=64, help="queries the reference k-mer prefilter is timed on")
     ap.add_argument("--cpu-sample-targets", type=int, default=100000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
+    ap.add_argument("--type2-steps", type=int, default=6, help="configs[3] leg of the default run: that many extra steps with --alignment-type 2 (3Di+AA) on the same "
+                    "resident DB, reported under `align_type2` (0 = skip; skipped when the main run already is type 2)")
+    ap.add_argument("--allvsall-steps", type=int, default=96, help="configs[4] leg of the default run: that many batches of 32 DB entries as queries (k-mer prefilter "
+                    "+ structurealign on a --allvsall-targets DB), reported under `allvsall` (0 = skip)")
+    ap.add_argument("--allvsall-targets", type=int, default=200000)
+    ap.add_argument("--emulate-rank-share", type=int, default=0, help="N: on ONE GPU, run what ONE rank of an N-rank node runs: CPU affinity cut to usable_cores / N, "
+                    "backtrace pool sized for that, and with --scaling strong only 1/N of the queries (step size adapted like a real rank's)")
     return ap.parse_args(argv)
 
 
@@ -94,7 +101,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(db, q3, qa, hits_ids, atype, sample_targets, more_queries=()):
+def cpu_baseline(db, q3, qa, hits_ids, atype, sample_targets, more_queries=(), reuse_prefilter=None):
     """reference AVX2 code (or the C port) on the host cores: prefilter over a target sample + align over the hit list.
     The prefilter is timed over several queries back to back (about 20 core-seconds of work at the defaults) so that the
     OpenMP start-up of a single 5 ms parallel region does not dominate the figure."""
@@ -110,9 +117,12 @@ def cpu_baseline(db, q3, qa, hits_ids, atype, sample_targets, more_queries=()):
     if ref is not None:
         scores = np.zeros(ns, np.int32)
         qs = [q3] + [q for q in more_queries]
-        ref.ref_ungapped(q3, len(q3), 1, 0.15, db.data3di, offs, lens, ns, threads, scores)          # warm the thread pool
-        # best of 2 passes over the query set: the reference's "omp for schedule(static)" over targets is noisy at this thread count
-        t_pref = min(sum(ref.ref_ungapped(q, len(q), 1, 0.15, db.data3di, offs, lens, ns, threads, scores) for q in qs) for _ in range(2)) / len(qs)
+        if reuse_prefilter is not None:          # the gapless prefilter does not depend on the alignment type: one timing serves both legs
+            t_pref = reuse_prefilter
+        else:
+            ref.ref_ungapped(q3, len(q3), 1, 0.15, db.data3di, offs, lens, ns, threads, scores)          # warm the thread pool
+            # best of 2 passes over the query set: the reference's "omp for schedule(static)" over targets is noisy at this thread count
+            t_pref = min(sum(ref.ref_ungapped(q, len(q), 1, 0.15, db.data3di, offs, lens, ns, threads, scores) for q in qs) for _ in range(2)) / len(qs)
         t3 = np.where(db.data3di >= 32, db.data3di - 32, db.data3di).astype(np.uint8)
         h = np.ascontiguousarray(hits_ids.astype(np.int64))
         aln = np.zeros(max(1, len(h)), oracle_lib.REFALN_DT)
@@ -226,14 +236,8 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     reg_ms = float(np.mean(stat["lists"]))
     reg_probes = float(np.mean([c[0] for c in stat["counts"]]))
     reg_alg = reg_probes * 8.0
-    traffic, traffic_src = None, None
-    try:   # HBM bytes per probe from a committed rocprofv3 --pmc pass of the same kernel on the same DB size
-        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json"))).get(str(args.targets))
-        if e:
-            traffic = e["k_kmer_lists_bytes_per_probe"] * probes
-            traffic_src = e["source"]
-    except Exception:
-        traffic = None
+    e, traffic_src = pmc_traffic_entry(os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json"), args.targets)
+    traffic = None if e is None else e["k_kmer_lists_bytes_per_probe"] * probes
     out = {"workload": f"{nqk} queries in batches of 32 vs the same {db.n}-structure DB: k-mer prefilter (-s 9.5, k=6 spaced, "
                        f"--max-seqs 1000, double-diagonal + ungapped scoring) + fwd/rev structure SW on its hits (one multi-query SW launch per register class)",
            "value": world * nqk * db.residues / dt, "unit": "residues/s", "queries_per_s": world * nqk / dt,
@@ -277,16 +281,78 @@ def kmer_cpu_baseline(args, synth, db):
             "index_build_s": t_build}
 
 
-def allvsall(args, api, synth, fdist, dev, rank, world, local_rank):
-    """configs[4]: all-vs-all of a --targets structure DB, the shape of easy-cluster's cascaded steps (F/data/structurecluster.sh via
+def sw_roofline(passes, has_aa, solo=None):
+    """issue-rate roofline of k_sw2: a wave-instruction of the DP row loop updates 64 lanes x 2 int16 halves = 128 cells and the
+    row costs 14 packed VALU instructions (16 with the AA table); packed 16-bit ops issue once per 4.3 cycles per SIMD (measured,
+    profiles/r01_valu_lds_issue_rate_ubench.txt) -> 1024 SIMDs x 128 / 14 / 4.3 cyc x 2.4 GHz.  `passes` = fsgpu_sw_last_passes() arrays
+    of the timed batches (forward + reversed-query pass each); achieved = DP cells of those passes / their device time (HIP events)."""
+    per = 16.0 if has_aa else 14.0
+    peak = 1024 * 128 / per / 4.3 * 2.4          # Gcell/s
+    cells = sum(float(p[d][1]) for p in passes for d in (0, 1) if p[d][0] >= 0)
+    ms = sum(float(p[d][0]) for p in passes for d in (0, 1) if p[d][0] >= 0)
+    instr = sum(float(p[d][3]) for p in passes for d in (0, 1) if p[d][0] >= 0)
+    out = {"bound": "valu-issue", "kernel": "k_sw2", "unit": "Gcell/s", "peak": peak, "achieved": cells / max(ms, 1e-9) / 1e6,
+           "frac": cells / max(ms, 1e-9) / 1e6 / peak, "cells_per_pass_pair": cells / max(1, len(passes)), "kernel_ms_per_pass_pair": ms / max(1, len(passes)),
+           "traffic": None,
+           # the same passes priced in what the waves really issue (two targets per wave run max(LtA, LtB) + lanes - 1 steps of `per` x R rows):
+           # the gap to `frac` is lane padding, wavefront fill / drain and the shorter target of a wave
+           "issued_dp_instr_frac": instr / max(ms, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3),
+           "note": "co-running with the other feeder threads' scans; DP cells = query rows x target columns of every pair of both passes"}
+    if solo is not None:
+        c = sum(float(solo[d][1]) for d in (0, 1) if solo[d][0] >= 0)
+        m = sum(float(solo[d][0]) for d in (0, 1) if solo[d][0] >= 0)
+        out["solo"] = {"note": "one batch alone on the device", "kernel_ms": m, "achieved": c / max(m, 1e-9) / 1e6, "frac": c / max(m, 1e-9) / 1e6 / peak}
+    return out
+
+
+def allvsall_cpu_baseline(db, thr, sample_queries=64):
+    """reference k-mer prefilter (-s 4.5 --max-seqs 200) + reference structurealign (3Di+AA, -e 0.01 -c 0.8) on a sample of the DB's own entries"""
+    import kmer_lib as K
+    import oracle_lib
+    R = K.load_ref()
+    ref = oracle_lib.load_ref()
+    if R is None or ref is None:
+        return None
+    threads = usable_cores()
+    ids = np.linspace(0, db.n - 1, sample_queries).astype(np.int64)
+    q3 = [db.seq(int(i), "3di") for i in ids]
+    qa = [db.seq(int(i), "aa") for i in ids]
+    t0 = time.perf_counter()
+    r = K.RefKpf(R, [db.seq(i, "3di", unmask=False) for i in range(db.n)], threads=threads, kmerThr=thr, maxResListLen=200)
+    t_build = time.perf_counter() - t0
+    res, _, secs = r.run(q3, ids, threads=threads)
+    res, _, secs = r.run(q3, ids, threads=threads)
+    r.close()
+    t3 = np.where(db.data3di >= 32, db.data3di - 32, db.data3di).astype(np.uint8)
+    t_aln = 0.0
+    for q, a, hits in zip(q3, qa, res):
+        lt = db.lengths[hits["id"]].astype(np.float32)
+        lq = np.float32(len(q))
+        h = np.ascontiguousarray(hits["id"][(lq / lt >= 0.8) & (lt / lq >= 0.8)].astype(np.int64))
+        if not len(h):
+            continue
+        aln = np.zeros(len(h), oracle_lib.REFALN_DT)
+        t_aln += ref.ref_structure_align(a, q, len(q), 2, 0, 0.5, 10, 1, db.dataaa, t3, np.ascontiguousarray(db.offsets[:-1][h]), np.ascontiguousarray(db.lengths[h]),
+                                         len(h), db.residues, 0.01, 1, threads, None, None, aln.ctypes.data, None, 0)
+    tot = secs + t_aln
+    return {"value": sample_queries * db.residues / tot, "unit": "residues/s", "queries_per_s": sample_queries / tot, "cores": threads, "kind": "reference",
+            "sample": f"{sample_queries} DB entries spread over the length range as queries: QueryMatcher::matchQuery of the reference (k-mer threshold {thr}, --max-seqs 200, "
+                      f"{threads} OpenMP threads, second of two runs, index build {t_build:.1f}s not included) + the reference's alignStructure (3Di+AA, no composition bias correction) "
+                      f"on the coverage-filtered hits, one query after the other with {threads} threads over its hits",
+            "prefilter_s": secs, "align_s": t_aln, "index_build_s": t_build}
+
+
+def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets, steps, warmup, with_cpu=False):
+    """configs[4]: all-vs-all of a `targets`-structure DB, the shape of easy-cluster's cascaded steps (F/data/structurecluster.sh via
     `easy-cluster -v 3`): prefilter -s 4.5 --max-seqs 200 --min-ungapped-score 30 -c 0.8 --add-self-matches 1, then structurealign
     -e 0.01 -c 0.8 --comp-bias-corr 0.  Prefilter dominated: one pass of the k-mer index per batch of 32 queries.  Every DB entry is a
-    query; the ids shard over the ranks (--steps batches each, 0 = all of them), the DB is replicated by one broadcast."""
+    query; the ids shard over the ranks (`steps` batches each, 0 = all of them), the DB is replicated by one broadcast.  Returns the
+    result object on rank 0 (None elsewhere)."""
     import threading
     import torch
     import torch.distributed as dist
     t_gen = time.perf_counter()
-    db = synth.make_db_fast(args.targets, None, seed=20260923, homologs_per_query=0) if rank == 0 else None
+    db = synth.make_db_fast(targets, None, seed=20260923, homologs_per_query=0) if rank == 0 else None
     t_gen = time.perf_counter() - t_gen
     tensors, db = fdist.broadcast_db(db, dev)
     torch.cuda.synchronize()
@@ -308,12 +374,17 @@ def allvsall(args, api, synth, fdist, dev, rank, world, local_rank):
     lo, hi = fdist.shard_range(db.n, rank, world)
     ids = np.arange(lo, hi)
     nb_all = (len(ids) + 31) // 32
-    nb = nb_all if args.steps <= 0 else min(nb_all, args.steps + args.warmup)
+    nb = nb_all if steps <= 0 else min(nb_all, steps + warmup)
     # a spread sample of the shard when only some batches are run: the DB is length sorted
     pick = np.linspace(0, nb_all - 1, nb).astype(np.int64) if nb < nb_all else np.arange(nb_all)
     batches = [ids[b * 32:(b + 1) * 32] for b in pick]
-    warm, timed = (batches[:args.warmup], batches[args.warmup:]) if args.steps > 0 else (batches[:1], batches)
-    stat = {"hits": 0, "aln": 0, "q": 0, "res": 0, "dev": 0.0, "bad": 0}
+    if steps > 0:            # warm-up batches spread over the length range as well, so every register class has been launched once
+        wsel = set(np.linspace(0, len(batches) - 1, min(warmup, len(batches))).astype(np.int64).tolist()) if warmup > 0 else set()
+        warm = [b for i, b in enumerate(batches) if i in wsel]
+        timed = [b for i, b in enumerate(batches) if i not in wsel]
+    else:
+        warm, timed = batches[:1], batches
+    stat = {"hits": 0, "aln": 0, "q": 0, "res": 0, "dev": 0.0, "bad": 0, "stage": np.zeros(11), "cnt": np.zeros(4), "nb": 0, "swp": [], "diag_bytes": 0.0}
     lock = threading.Lock()
 
     def run(t, b, count):
@@ -321,6 +392,7 @@ def allvsall(args, api, synth, fdist, dev, rank, world, local_rank):
         qa = [db.seq(int(i), "aa") for i in b]
         prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in q3]
         res, status = ctxs[t].kmer_search(prep, identity=b, max_res=200)
+        ms, cnt = ctxs[t].kmer_stage_ms(), ctxs[t].kmer_counts()
         # Prefiltering.cpp:880-887: canBeCovered at -c 0.8, cov-mode 0
         keep = []
         for q, r in zip(q3, res):
@@ -328,10 +400,13 @@ def allvsall(args, api, synth, fdist, dev, rank, world, local_rank):
             lq = np.float32(len(q))
             keep.append(r["id"][(lq / lt >= 0.8) & (lt / lq >= 0.8)])
         aln = searches[t].align_batch(qa, q3, keep, identity=b)
+        swp = ctxs[t].sw_last_passes()
         if count:
             with lock:
                 stat["hits"] += sum(len(k) for k in keep); stat["aln"] += sum(len(a) for a in aln); stat["q"] += len(b)
-                stat["res"] += int(sum(len(q) for q in q3)); stat["dev"] += ctxs[t].kmer_stage_ms()[0]; stat["bad"] += int((status < 0).sum())
+                stat["res"] += int(sum(len(q) for q in q3)); stat["dev"] += ms[0]; stat["bad"] += int((status < 0).sum())
+                stat["stage"] += np.array(ms[:11]); stat["cnt"] += np.array(cnt, float); stat["nb"] += 1; stat["swp"].append(swp)
+                stat["diag_bytes"] += float(cnt[2]) * float(np.mean([len(q) for q in q3]))
 
     for t in range(KT):
         for b in warm[t::KT] or warm[:1]:
@@ -361,27 +436,143 @@ def allvsall(args, api, synth, fdist, dev, rank, world, local_rank):
         dist.barrier()
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
     gc.enable()
+    stat["stage"] = stat["stage"].tolist(); stat["cnt"] = stat["cnt"].tolist()
+    mine_swp = stat.pop("swp")
     tot = fdist.gather_objects(stat)
+    out = None
     if rank == 0:
         nq = sum(x["q"] for x in tot)
+        s0 = tot[0]
+        nb0 = max(1, s0["nb"])
+        names = ["device_total", "count", "lists", "emit", "sort", "dupflags", "score", "replay", "select", "host_tail", "k_kmer_lists"]
+        # HBM roofline of the k-mer prefilter batch (rank 0's batches, HIP events over the whole device part of a batch): algorithmic bytes =
+        # 8 per similar k-mer (two u32 offsets of the probe) + 8 per index hit (the entry gathered) + the target residues under every scored diagonal
+        alg = 8.0 * s0["cnt"][0] + 8.0 * s0["cnt"][1] + s0["diag_bytes"]
+        dev_s = s0["stage"][0] * 1e-3
         out = {"metric": "residues aligned/sec (prefilter+align)", "value": nq * db.residues / dt, "unit": "residues/s", "n_gpus": world,
                "steps": len(timed), "warmup": len(warm), "ms_per_step": 1e3 * dt / max(1, len(timed)), "higher_is_better": True,
-               "scaling": "strong" if args.steps <= 0 else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
+               "scaling": "strong" if steps <= 0 else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
                "config": {"workload": f"all-vs-all (configs[4]): {nq} of the {db.n} DB entries as queries in batches of 32 (1 step = 1 batch), k-mer prefilter -s 4.5 --max-seqs 200 "
                                       f"-c 0.8 + structurealign -e 0.01 -c 0.8 (3Di+AA) on its hits; queries shard over {world} rank(s), DB replicated by one broadcast",
                           "targets": db.n, "db_residues": db.residues, "host_threads_per_gpu": KT, "kmer_threshold": thr},
                "queries_per_s": nq / dt, "ms_per_query": 1e3 * dt / max(1, nq / world), "hits_per_query": sum(x["hits"] for x in tot) / max(1, nq),
-               "alignments_per_query": sum(x["aln"] for x in tot) / max(1, nq), "prefilter_device_ms_per_query": tot[0]["dev"] / max(1, tot[0]["q"]),
+               "alignments_per_query": sum(x["aln"] for x in tot) / max(1, nq), "prefilter_device_ms_per_query": s0["dev"] / max(1, s0["q"]),
                "unsupported_queries": sum(x["bad"] for x in tot), "index_build_s": t_index, "db_generation_s": t_gen,
-               "projected_full_all_vs_all_s": db.n / max(1e-9, nq / dt)}
-        print(json.dumps(out))
+               "projected_full_all_vs_all_s": db.n / max(1e-9, nq / dt),
+               "stage_ms_per_batch32": {k: s0["stage"][i] / nb0 for i, k in enumerate(names)},
+               "similar_kmers_per_query": s0["cnt"][0] / max(1, s0["q"]), "index_hits_per_query": s0["cnt"][1] / max(1, s0["q"]),
+               "candidates_per_query": s0["cnt"][2] / max(1, s0["q"]),
+               "roofline": {"bound": "hbm", "kernel": "k_kmer_* (the device part of one prefilter batch of 32 queries, all kernels)", "unit": "GB/s", "peak": 8000.0,
+                            "achieved": alg / max(dev_s, 1e-12) / 1e9, "frac": alg / max(dev_s, 1e-12) / 1e9 / 8000.0, "traffic": None,
+                            "algorithmic_bytes": alg / nb0, "kernel_ms": s0["stage"][0] / nb0,
+                            "note": "co-running with the other feeder threads' batches and SW launches; bytes = 8 per similar k-mer + 8 per index hit + diagonal residues"},
+               "align_roofline": sw_roofline(mine_swp, True)}
+        if with_cpu:
+            out["cpu_baseline"] = allvsall_cpu_baseline(db, thr)
     for x in searches:
         x.close()
     for c in ctxs[1:]:
         c.close()
     ctx0.close()
+    return out
+
+
+def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev, fdist, class_warm, nq_all):
+    """The timed region of one search leg: every feeder thread (own context clone = own HIP stream, shared resident DB) runs its share of
+    `batches`; a step = ONE multi-query scan call for the batch (queries of equal ceil(L / 16) share a launch), then ONE multi-query SW
+    launch per pass over all their hit lists.  Bracketed by barrier + device synchronisation on both sides, max over ranks."""
+    import gc
+    import threading
+    import torch
+    import torch.distributed as dist
+    nthreads = len(ctxs)
+    rec = {"kms": [], "sms": [], "counts": [0, 0], "swp": [], "trace": [],
+           "host": {"backtrace_s": 0.0, "rev_pairs": 0.0, "gates_s": 0.0, "profiles_s": 0.0, "sw_wait_s": 0.0}}
+    lock = threading.Lock()
+    ready = threading.Barrier(nthreads + 1)
+    go = threading.Barrier(nthreads + 1)
+    t_go = [0.0]
+
+    def step(t, ids):
+        hl = searches[t].prefilter_batch([q3[i] for i in ids])
+        scan_ms = ctxs[t].kernel_ms(0)
+        launches, nbatched = ctxs[t].gapless_last_batch()
+        rs = searches[t].align_batch([qa[i] for i in ids], [q3[i] for i in ids], [h["id"] for h in hl])
+        return hl, rs, (scan_ms, launches, nbatched, sum(len(q3[i]) for i in ids))
+
+    def worker(t):
+        # untimed warm-up inside the worker: the first HIP calls of a host thread initialise per-thread state
+        for b in warm_batches[t::nthreads]:
+            step(t, b)
+        if not warm_batches[t::nthreads]:
+            step(t, (warm_batches[0] if warm_batches else batches[0]))
+        if class_warm:
+            # one query of every 16-row length class (one gapless instantiation each; the SW classes are coarser): the first
+            # launch of a kernel instantiation (lazy code-object load, attribute set-up, scratch growth) must not land in
+            # the timed region
+            cls = {}
+            for i in range(nq_all):
+                cls.setdefault((len(q3[i]) + 15) // 16, i)
+            step(t, sorted(cls.values()))
+        ready.wait()
+        go.wait()
+        for b in batches[t::nthreads]:
+            tg = time.perf_counter()
+            hl, rs, km = step(t, b)
+            st = searches[t].stats()
+            swp = ctxs[t].sw_last_passes()
+            with lock:
+                if os.environ.get("FS_BENCH_TRACE"):
+                    rec["trace"].append((t, tg - t_go[0], time.perf_counter() - tg))
+                rec["kms"].append(km); rec["sms"].append(ctxs[t].kernel_ms(1) / len(b)); rec["swp"].append(swp)
+                rec["counts"][0] += sum(len(h) for h in hl); rec["counts"][1] += sum(len(r) for r in rs)
+                h = rec["host"]
+                h["profiles_s"] += st[2]; h["sw_wait_s"] += st[3]; h["gates_s"] += st[4]; h["backtrace_s"] += st[5]; h["rev_pairs"] += st[7]
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    ready.wait()
     if world > 1:
-        dist.destroy_process_group()
+        dist.barrier()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()            # a generation-2 collection of the interpreter (torch is imported: ~50 ms) would stall every feeder thread at once
+    t0 = time.perf_counter()
+    t_go[0] = t0
+    go.wait()
+    for th in ths:
+        th.join()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    gc.enable()
+    if os.environ.get("FS_BENCH_TRACE"):
+        for r in sorted(rec["trace"], key=lambda r: r[1]):
+            print("trace thread %d start %.2f ms dur %.2f ms" % (r[0], r[1] * 1e3, r[2] * 1e3), file=sys.stderr)
+    return dt, rec, step
+
+
+def pmc_traffic_entry(path, key):
+    """HBM bytes from a committed rocprofv3 --pmc pass (profiles/pmc_traffic*.json).  The entry is only used when it was collected on the
+    kernel sources that are running now: it carries the hash of foldseek_amd/csrc/*.{hip,hpp,h} at collection time (tools/csrc_hash.py)."""
+    try:
+        e = json.load(open(path)).get(str(key))
+    except Exception:
+        return None, "no PMC file"
+    if not e:
+        return None, "no PMC entry for this DB size"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import csrc_hash
+        now = csrc_hash.csrc_hash(e.get("csrc_files"))
+    except Exception:
+        now = None
+    if e.get("csrc_hash") != now or now is None:
+        print(f"bench.py: WARNING: {os.path.basename(path)}[{key}] was collected on other kernel sources (hash {e.get('csrc_hash')} != {now}): traffic = null", file=sys.stderr)
+        return None, f"stale: PMC pass belongs to kernel sources {e.get('csrc_hash')}, running {now}"
+    return e, e.get("source")
 
 
 def main():
@@ -391,6 +582,13 @@ def main():
     # host feeder threads spend their time inside the library (ctypes releases the GIL); a thread returning from a call
     # must not wait a whole default switch interval (5 ms) for the GIL while another one runs a few Python lines
     sys.setswitchinterval(1e-4)
+    emu = max(0, args.emulate_rank_share)
+    cores_before = usable_cores()
+    if emu > 1:
+        # what one rank of an `emu`-rank node has: its share of the cores this job may use (cgroup quota), pinned
+        share = max(1, cores_before // emu)
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:share]))
+        os.environ["OMP_NUM_THREADS"] = str(share)
     import torch
     import torch.distributed as dist
     from foldseek_amd import synth
@@ -408,6 +606,8 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count()) if have_gpu else 0
     if world > 1:
         if backend == "nccl":
+            if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
+                raise SystemExit(f"bench.py: {world} ranks over RCCL need one GPU each, {torch.cuda.device_count()} visible (FSGPU_BENCH_BACKEND=gloo shares devices for a plumbing check)")
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
@@ -418,11 +618,16 @@ def main():
 
     if args.workload == "allvsall" and not args.dry_run:
         from foldseek_amd import api
-        return allvsall(args, api, synth, fdist, dev, rank, world, local_rank)
-    import threading
+        out = allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, args.targets, args.steps, args.warmup, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     nthreads = max(1, args.host_threads)
     G = max(1, args.group)
     # ---- queries: weak = every rank its own steps; strong = the same steps*G queries split contiguously over the ranks ----
+    share_world = emu if (emu > 1 and args.scaling == "strong") else world          # --emulate-rank-share: this process is rank 0 of `emu`
     per_rank_timed = args.steps * G if args.scaling == "weak" else None
     n_timed_total = args.steps * G * (world if args.scaling == "weak" else 1)
     n_warm = args.warmup * G
@@ -431,12 +636,17 @@ def main():
     if args.scaling == "weak":
         t_lo, t_hi = rank * per_rank_timed, (rank + 1) * per_rank_timed
     else:
-        t_lo, t_hi = fdist.shard_range(n_timed_total, rank, world)
+        t_lo, t_hi = fdist.shard_range(n_timed_total, rank, share_world)
     w_lo = n_timed_total + rank * n_warm
     q3 = all_q3[w_lo:w_lo + n_warm] + all_q3[t_lo:t_hi]            # this rank: warm-up queries first, then its timed shard
     qa = all_qa[w_lo:w_lo + n_warm] + all_qa[t_lo:t_hi]
     nq = len(q3)
     n_mine = t_hi - t_lo
+    # a rank with few queries (strong scaling: 1000 queries / 8 ranks = 125) takes smaller steps, so that every feeder thread has a batch
+    # and the fill / drain of the pipeline (first scan before any SW, last SW after the last scan) is a batch of 16-32, not of 64
+    G_eff = G
+    while args.scaling == "strong" and n_mine < (nthreads + 1) * G_eff and G_eff > 16:
+        G_eff //= 2
     # ---- target DB: generated on rank 0 (vectorised), ONE broadcast (RCCL over xGMI), then resident in every GPU's HBM ----
     t_gen = time.perf_counter()
     db = synth.make_db_fast(args.targets, (all_q3, all_qa), seed=20260923, homologs_per_query=args.homologs) if rank == 0 else None
@@ -448,6 +658,12 @@ def main():
     if have_gpu:
         torch.cuda.synchronize()
     t_bcast = time.perf_counter() - tb if world > 1 else 0.0
+    bcast_backend = dist.get_backend() if world > 1 else "none"
+    if world > 1 and have_gpu and backend == "nccl":
+        # the one collective of the path must have gone over RCCL with one rank per device -- no silent fallback
+        devs = fdist.gather_objects((rank, torch.cuda.current_device(), str(tensors[0].device)))
+        if rank == 0:
+            assert bcast_backend == "nccl" and len({d[1] for d in devs}) == world and all(d[2].startswith("cuda") for d in devs), (bcast_backend, devs)
     if args.dry_run:
         # everything up to here is the multi-rank plumbing; check what the other ranks received and stop
         import zlib
@@ -458,7 +674,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "residues aligned/sec (prefilter+align)", "value": 0.0, "unit": "residues/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": args.scaling,
-                              "backend": dist.get_backend() if world > 1 else "none", "db_broadcast_s": t_bcast, "db_generation_s": t_gen,
+                              "backend": bcast_backend, "db_broadcast_s": t_bcast, "db_generation_s": t_gen, "queries_per_step_effective": G_eff,
                               "ranks": [{"rank": r, "timed_queries": m, "db_entries": n, "db_digest": d} for r, m, n, d in sizes],
                               "config": {"workload": "dry run: no device work", "targets": int(db.n), "queries_per_step": G}}))
         if world > 1:
@@ -487,92 +703,55 @@ def main():
     ctxs = [ctx0] + [ctx0.clone() for _ in range(nthreads - 1)]
     searches = [api.Search(c, par) for c in ctxs]
 
-    def step1(t, i):
-        hits = searches[t].prefilter(q3[i])
-        res = searches[t].align(qa[i], q3[i], hits["id"])
+    def step1(t, i, ss=None):
+        ss = ss or searches
+        hits = ss[t].prefilter(q3[i])
+        res = ss[t].align(qa[i], q3[i], hits["id"])
         return hits, res
-
-    kms, sms, counts = [], [], [0, 0]
-    host = {"backtrace_s": 0.0, "rev_pairs": 0.0, "gates_s": 0.0, "profiles_s": 0.0, "sw_wait_s": 0.0}
-    lock = threading.Lock()
-    ready = threading.Barrier(nthreads + 1)
-    go = threading.Barrier(nthreads + 1)
-    trace, t_go = [], [0.0]
-
-    def step(t, ids):
-        """one step: ONE multi-query scan call for the batch (queries of equal ceil(L / 16) share a launch), then ONE
-        multi-query SW launch per pass over all their hit lists"""
-        hl = searches[t].prefilter_batch([q3[i] for i in ids])
-        scan_ms = ctxs[t].kernel_ms(0)
-        launches, nbatched = ctxs[t].gapless_last_batch()
-        rs = searches[t].align_batch([qa[i] for i in ids], [q3[i] for i in ids], [h["id"] for h in hl])
-        return hl, rs, (scan_ms, launches, nbatched, sum(len(q3[i]) for i in ids))
 
     # the rank's queries are processed in length order (the order is free; the reference sorts its GPU database by length for
     # the same reason): a batch then spans few register classes, i.e. few scan launches
     timed = sorted(range(n_warm, nq), key=lambda i: len(q3[i]))
-    batches = [timed[k:k + G] for k in range(0, len(timed), G)]
+    batches = [timed[k:k + G_eff] for k in range(0, len(timed), G_eff)]
     warm = [list(range(k, min(k + G, n_warm))) for k in range(0, n_warm, G)]
-
-    def worker(t):
-        # untimed warm-up inside the worker: the first HIP calls of a host thread initialise per-thread state
-        for b in warm[t::nthreads]:
-            step(t, b)
-        if not warm[t::nthreads]:
-            step(t, list(range(min(G, nq))))
-        # one query of every 16-row length class (one gapless instantiation each; the SW classes are coarser): the first
-        # launch of a kernel instantiation (lazy code-object load, attribute set-up, scratch growth) must not land in
-        # the timed region
-        cls = {}
-        for i in range(nq):
-            cls.setdefault((len(q3[i]) + 15) // 16, i)
-        step(t, sorted(cls.values()))
-        ready.wait()
-        go.wait()
-        for b in batches[t::nthreads]:
-            tg = time.perf_counter()
-            hl, rs, km = step(t, b)
-            st = searches[t].stats()
-            with lock:
-                if os.environ.get("FS_BENCH_TRACE"):
-                    trace.append((t, tg - t_go[0], time.perf_counter() - tg))
-                kms.append(km); sms.append(ctxs[t].kernel_ms(1) / len(b))
-                counts[0] += sum(len(h) for h in hl); counts[1] += sum(len(r) for r in rs)
-                host["profiles_s"] += st[2]; host["sw_wait_s"] += st[3]; host["gates_s"] += st[4]; host["backtrace_s"] += st[5]
-                host["rev_pairs"] += st[7]
-
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
-    for th in ths:
-        th.start()
-    ready.wait()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    import gc
-    gc.collect()
-    gc.disable()            # a generation-2 collection of the interpreter (torch is imported: ~50 ms) would stall every feeder thread at once
-    t0 = time.perf_counter()
-    t_go[0] = t0
-    go.wait()
-    for th in ths:
-        th.join()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
-    gc.enable()
-    if os.environ.get("FS_BENCH_TRACE"):
-        for rec in sorted(trace, key=lambda r: r[1]):
-            print("trace thread %d start %.2f ms dur %.2f ms" % (rec[0], rec[1] * 1e3, rec[2] * 1e3), file=sys.stderr)
+    dt, rec, step = search_region(api, ctxs, searches, q3, qa, warm, batches, world, dev, fdist, True, nq)
+    kms, sms, counts, host = rec["kms"], rec["sms"], rec["counts"], rec["host"]
     # dominant-kernel duration on an otherwise idle GPU (in the timed region the feeder threads' launches overlap, which
     # stretches each kernel's wall time)
     solo_g, solo_s = [], []
     for i in range(n_warm, min(nq, n_warm + 8)):
         step1(0, i)
         solo_g.append(ctxs[0].kernel_ms(0)); solo_s.append(ctxs[0].kernel_ms(1))
+    step(0, batches[len(batches) // 2])                       # one whole batch alone on the device: the SW passes' solo figure
+    solo_swp = ctxs[0].sw_last_passes()
     tot = fdist.gather_objects((counts[0], counts[1], n_mine, host))
     ctx = ctx0
 
+    def gapless_roofline(kms_, lq_list, q_lo_solo=None):
+        """HBM figures the contract asks for + the VALU issue roofline that actually binds the scan"""
+        residues = db.residues
+        VALU_PEAK = 1024 * 64 * (4.0 / 3.0) / 4.3 * 2.4
+        n_launch = sum(k[1] for k in kms_)
+        n_batched = sum(k[2] for k in kms_)
+        scan_s = sum(k[0] for k in kms_) * 1e-3
+        kreg = scan_s / max(1, n_launch)                   # average duration of ONE scan launch
+        q_per_launch = n_batched / max(1, n_launch)
+        cells_reg = float(np.mean(lq_list)) * residues * q_per_launch     # DP cells of one launch
+        alg_q = residues + db.n                            # per query: every target residue read once (1 B) + 1 score byte written
+        alg_bytes = alg_q * q_per_launch                   # per launch
+        e, src = pmc_traffic_entry(os.path.join(ROOT, "profiles", "pmc_traffic.json"), args.targets)
+        traffic = None if e is None else (e["fetch_correction"] * e["fetch_size_kb"] * 1024 + e["write_size_kb"] * 1024) * q_per_launch
+        return {"bound": "hbm", "achieved": alg_bytes / kreg / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": alg_bytes / kreg / 1e9 / 8000.0, "traffic": traffic, "traffic_source": src, "algorithmic_bytes": alg_bytes,
+                "kernel": "k_gapless", "kernel_ms": kreg * 1e3, "queries_per_launch": q_per_launch, "launches": n_launch,
+                "note": "the scan is VALU/LDS bound (Lq cell updates per target byte), see valu below and DESIGN.md",
+                # 0.75 packed VALU lane-ops per DP cell (2 x v_pk_add_f16 clamp + 1 x v_pk_maximum3_f16 per 4 cells); these
+                # issue once per 4.3 cycles per SIMD (measured, profiles/r01_valu_lds_issue_rate_ubench.txt):
+                # 1024 SIMDs x 64 lanes x 4/3 cells / 4.3 cyc x 2.4 GHz
+                "valu": {"achieved_gcups": cells_reg / kreg / 1e9, "peak_gcups": VALU_PEAK, "frac": cells_reg / kreg / 1e9 / VALU_PEAK}}
+
+    out = None
+    t_pref_cpu = None
     if rank == 0:
         residues = db.residues
         nq_total = sum(x[2] for x in tot)
@@ -580,29 +759,18 @@ def main():
         value = nq_total * residues / dt
         VALU_PEAK = 1024 * 64 * (4.0 / 3.0) / 4.3 * 2.4
         kavg = float(np.mean(solo_g)) * 1e-3
-        # scan launches of the timed region: device time of a batch's launches (HIP events on the library's stream) / their number
-        n_launch = sum(k[1] for k in kms)
-        n_batched = sum(k[2] for k in kms)
-        scan_s = sum(k[0] for k in kms) * 1e-3
-        kreg = scan_s / max(1, n_launch)                   # average duration of ONE scan launch
-        q_per_launch = n_batched / max(1, n_launch)
         lq_timed = [len(q3[i]) for i in timed]
-        cells_reg = float(np.mean(lq_timed)) * residues * q_per_launch     # DP cells of one launch
         solo_lq = float(np.mean([len(q3[i]) for i in range(n_warm, min(nq, n_warm + 8))]))
-        alg_q = residues + db.n                            # per query: every target residue read once (1 B) + 1 score byte written
-        alg_bytes = alg_q * q_per_launch                   # per launch
+        alg_q = residues + db.n
         mean_lq = float(np.mean(lq_timed))
         cells = solo_lq * residues
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from a committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of the same kernel on the same DB size
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            e = tj.get(str(args.targets))
-            if e:   # the PMC entries are per query; a launch of the timed region covers q_per_launch of them
-                traffic = (e["fetch_correction"] * e["fetch_size_kb"] * 1024 + e["write_size_kb"] * 1024) * q_per_launch
-                traffic_src = e["source"]
-        except Exception:
-            traffic = None
         mine = tot[0][3]
+        rf = gapless_roofline(kms, lq_timed)
+        rf["valu"].update({"device_level_gcups": nq_total / world * mean_lq * residues / dt / 1e9,
+                           "device_level_frac": nq_total / world * mean_lq * residues / dt / 1e9 / VALU_PEAK,
+                           "note": "per launch = one multi-query k_gapless launch (scan batches of the feeder threads run one at a time, SW / selection kernels of the other threads co-run); device_level = cells of all timed queries of one rank / wall time"})
+        rf["solo"] = {"note": "one single-query launch on an idle device", "kernel_ms": kavg * 1e3, "achieved": alg_q / kavg / 1e9, "frac": alg_q / kavg / 1e9 / 8000.0,
+                      "valu_achieved_gcups": cells / kavg / 1e9, "valu_frac": cells / kavg / 1e9 / VALU_PEAK}
         out = {
             "metric": "residues aligned/sec (prefilter+align)",
             "value": value, "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -613,8 +781,8 @@ def main():
                                    f"(--alignment-type {args.alignment_type}; forward over all pairs, reversed over the pairs that pass the forward gates) "
                                    f"+ host gates + block-aligner backtrace of every accepted hit; {nthreads} host feeder threads per GPU run their steps concurrently",
                        "targets": db.n, "db_residues": residues, "mean_query_len": mean_lq, "query_len_range": [q_lo, q_hi], "max_seqs": 1000, "homologs_per_query": args.homologs,
-                       "queries_per_step": G, "queries_total": nq_total, "host_threads_per_gpu": nthreads, "host_backtrace_workers_per_gpu": api.host_workers(),
-                       "parallelism": f"query-shard x{world} ({args.scaling}), DB replicated by one RCCL broadcast"},
+                       "queries_per_step": G, "queries_per_step_effective": G_eff, "queries_total": nq_total, "host_threads_per_gpu": nthreads, "host_backtrace_workers_per_gpu": api.host_workers(),
+                       "usable_cores": usable_cores(), "parallelism": f"query-shard x{world} ({args.scaling}), DB replicated by one RCCL broadcast"},
             "queries_per_s": nq_total / dt, "ms_per_query": 1e3 * dt / (nq_total / world),
             "hits_per_query": nh / nq_total, "alignments_per_query": nr / nq_total,
             # rank 0's host-side accounting of the align leg (sums over its feeder threads, per query)
@@ -623,30 +791,54 @@ def main():
                           "host_gates_ms_per_query": 1e3 * mine["gates_s"] / max(1, n_mine),
                           "host_profiles_ms_per_query": 1e3 * mine["profiles_s"] / max(1, n_mine),
                           "sw_call_wall_ms_per_query": 1e3 * mine["sw_wait_s"] / max(1, n_mine),
-                          "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s))},
+                          "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s)),
+                          "roofline": sw_roofline(rec["swp"], args.alignment_type == 2, solo_swp)},
             # per-launch duration of the dominant kernel from HIP events on the library's stream, averaged over the launches
             # of the TIMED region (the host threads overlap their launches there, which stretches each one); the same
             # kernel alone on the device is reported under "solo"
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / kreg / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_bytes / kreg / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
-                         "kernel": "k_gapless", "kernel_ms": kreg * 1e3, "queries_per_launch": q_per_launch, "launches": n_launch,
-                         "note": "the scan is VALU/LDS bound (Lq cell updates per target byte), see valu below and DESIGN.md",
-                         # 0.75 packed VALU lane-ops per DP cell (2 x v_pk_add_f16 clamp + 1 x v_pk_maximum3_f16 per 4 cells); these
-                         # issue once per 4.3 cycles per SIMD (measured, profiles/r01_valu_lds_issue_rate_ubench.txt):
-                         # 1024 SIMDs x 64 lanes x 4/3 cells / 4.3 cyc x 2.4 GHz
-                         "valu": {"achieved_gcups": cells_reg / kreg / 1e9, "peak_gcups": VALU_PEAK,
-                                  "frac": cells_reg / kreg / 1e9 / VALU_PEAK,
-                                  "device_level_gcups": nq_total / world * mean_lq * residues / dt / 1e9,
-                                  "device_level_frac": nq_total / world * mean_lq * residues / dt / 1e9 / VALU_PEAK,
-                                  "note": "per launch = one multi-query k_gapless launch (scan batches of the feeder threads run one at a time, SW / selection kernels of the other threads co-run); device_level = cells of all timed queries of one rank / wall time"},
-                         "solo": {"note": "one single-query launch on an idle device", "kernel_ms": kavg * 1e3, "achieved": alg_q / kavg / 1e9, "frac": alg_q / kavg / 1e9 / 8000.0,
-                                  "valu_achieved_gcups": cells / kavg / 1e9, "valu_frac": cells / kavg / 1e9 / VALU_PEAK}},
-            "db_broadcast_s": t_bcast, "db_generation_s": t_gen,
+            "roofline": rf,
+            "db_broadcast_s": t_bcast, "db_generation_s": t_gen, "broadcast_backend": bcast_backend, "rccl_ranks": world if bcast_backend == "nccl" else 0,
         }
+        if emu > 1:
+            out["emulated_rank_share"] = {"ranks": emu, "cores_of_this_rank": usable_cores(), "cores_of_the_job": cores_before,
+                                          "timed_queries_of_this_rank": n_mine, "projected_value_all_ranks": emu * value,
+                                          "note": "ONE rank's share of an N-rank node run on one GPU: value is this rank's rate; with a replicated DB and no per-step collective the ranks do not interact"}
         if not args.no_cpu_baseline and world == 1:          # the CPU baselines are an N = 1 item (rank 0 has the host to itself)
             hits, _ = step1(0, n_warm)
             out["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], args.alignment_type, args.cpu_sample_targets,
                                                [q3[i] for i in range(n_warm + 1, min(nq, n_warm + max(1, args.cpu_sample_queries)))])
+            t_pref_cpu = out["cpu_baseline"].get("prefilter_s_sample")
+
+    # ---- configs[3]: the same search with --alignment-type 2 (3Di + AA substitution scores, Gotoh affine gaps) on the resident DB ----
+    if args.type2_steps > 0 and args.alignment_type != 2:
+        par2 = api.default_params()
+        par2.alignmentType = 2
+        searches2 = [api.Search(c, par2) for c in ctxs]
+        nb2 = min(len(batches), max(nthreads, args.type2_steps))
+        pick = np.linspace(0, len(batches) - 1, nb2 + nthreads).astype(np.int64)          # spread over the length-sorted batches
+        sel2 = [batches[i] for i in pick]
+        dt2, rec2, step2 = search_region(api, ctxs, searches2, q3, qa, sel2[:nthreads], sel2[nthreads:], world, dev, fdist, False, nq)
+        step2(0, sel2[nthreads + (len(sel2) - nthreads) // 2])
+        solo2 = ctxs[0].sw_last_passes()
+        n2 = sum(len(b) for b in sel2[nthreads:])
+        tot2 = fdist.gather_objects((rec2["counts"][0], rec2["counts"][1], n2))
+        if rank == 0:
+            n2t = sum(x[2] for x in tot2)
+            lq2 = [len(q3[i]) for b in sel2[nthreads:] for i in b]
+            leg = {"workload": f"configs[3]: {len(sel2) - nthreads} more steps of {G_eff} queries on the same resident {db.n}-structure DB with --alignment-type 2 "
+                               f"(3Di + AA scores at aaFactor 1.4, affine gaps 10/1): same gapless prefilter, k_sw2 with two LDS tables, host gates, backtraces",
+                   "value": n2t * db.residues / dt2, "unit": "residues/s", "steps": len(sel2) - nthreads, "ms_per_step": 1e3 * dt2 / max(1, len(sel2) - nthreads),
+                   "queries_per_s": n2t / dt2, "ms_per_query": 1e3 * dt2 / max(1, n2t / world), "mean_query_len": float(np.mean(lq2)),
+                   "hits_per_query": sum(x[0] for x in tot2) / max(1, n2t), "alignments_per_query": sum(x[1] for x in tot2) / max(1, n2t),
+                   "sw_kernels_ms_per_query": float(np.mean(rec2["sms"])),
+                   "roofline": gapless_roofline(rec2["kms"], lq2), "align_roofline": sw_roofline(rec2["swp"], True, solo2)}
+            if not args.no_cpu_baseline and world == 1:
+                hits, _ = step1(0, n_warm, searches2)
+                leg["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], 2, args.cpu_sample_targets, reuse_prefilter=t_pref_cpu)
+            out["align_type2"] = leg
+        for x in searches2:
+            x.close()
+
     for x in searches[1:]:
         x.close()
     for c in ctxs[1:]:
@@ -655,16 +847,25 @@ def main():
     kout = None
     if not args.no_kmer:
         kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist, [q3[i] for i in timed], [qa[i] for i in timed])
-    if rank == 0:
-        if kout is not None:
-            if not args.no_cpu_baseline and world == 1:
-                kout["cpu_baseline"] = kmer_cpu_baseline(args, synth, db)
-            out["kmer_prefilter"] = kout
-        print(json.dumps(out))
+    if rank == 0 and kout is not None:
+        if not args.no_cpu_baseline and world == 1:
+            kout["cpu_baseline"] = kmer_cpu_baseline(args, synth, db)
+        out["kmer_prefilter"] = kout
     for x in searches:
         x.close()
     for c in ctxs:
         c.close()
+    del db
+    # ---- configs[4]: all-vs-all of a 200k-structure DB (easy-cluster's prefilter + align step), own DB, same process ----
+    if args.allvsall_steps > 0:
+        av = allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, args.allvsall_targets, args.allvsall_steps, 8,
+                          with_cpu=(world == 1 and not args.no_cpu_baseline))
+        if rank == 0:
+            for k in ("metric", "higher_is_better", "vs_baseline", "data"):
+                av.pop(k, None)
+            out["allvsall"] = av
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

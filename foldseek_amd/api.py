@@ -83,6 +83,7 @@ def lib():
         "fsgpu_sw_launch": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32]),
         "fsgpu_sw_finish": (i32, [vp, vp, vp]),
         "fsgpu_last_kernel_ms": (f64, [vp, i32]),
+        "fsgpu_sw_last_passes": (None, [vp, vp]),
         "fsgpu_kmer_index_build": (i32, [vp, vp, vp]),
         "fsgpu_kmer_index_entries": (u64, [vp]),
         "fsgpu_kmer_search": (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
@@ -149,7 +150,7 @@ def exported_symbols():
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_db_broadcast", "fsgpu_device_count", "fsgpu_gapless_plan_items",
-            "fsgpu_last_kernel_ms", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
+            "fsgpu_last_kernel_ms", "fsgpu_sw_last_passes", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
             "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts"]
 
 
@@ -450,6 +451,12 @@ class Context:
 
     def kernel_ms(self, which):
         return lib().fsgpu_last_kernel_ms(self.h, which)
+
+    def sw_last_passes(self):
+        """[[ms, cells, pairs, DP wave-instructions] forward, [...] reversed] of the last multi-query SW passes (k_sw2 launches only)"""
+        out = np.zeros(8)
+        lib().fsgpu_sw_last_passes(self.h, _ptr(out))
+        return out.reshape(2, 4)
 
     def close(self):
         if getattr(self, "h", None):

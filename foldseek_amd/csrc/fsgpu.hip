@@ -87,6 +87,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
     hipHostFree(ctx->hMqPssm.p); hipHostFree(ctx->hMqRec.p); hipHostFree(ctx->hMqMeta.p); hipHostFree(ctx->hMqOutId.p); hipHostFree(ctx->hMqOutScore.p); hipHostFree(ctx->hMqIdent.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 4; i++) if (ctx->swDirEv[i]) hipEventDestroy(ctx->swDirEv[i]);
     for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamDestroy(ctx->swAux[i]);
     for (int i = 0; i < 7; i++) if (ctx->swAuxEv[i]) (void) hipEventDestroy(ctx->swAuxEv[i]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -859,6 +860,17 @@ int fsgpu_gapless_scores(fsgpu_ctx *ctx, uint8_t *scores_out) {
     return FSGPU_OK;
 }
 
+/* out[2][4]: per direction (0 forward, 1 reversed query) of the last fsgpu_sw_multi_dir calls: device ms of the pass's k_sw2 launches (HIP events
+ * on the context stream, -1 when the pass did not run), DP cells, pairs, VALU wave-instructions of the DP rows (the roofline denominator) */
+void fsgpu_sw_last_passes(const fsgpu_ctx *ctx, double *out) {
+    for (int d = 0; d < 2; d++) {
+        float ms = -1;
+        if (!ctx || !ctx->swDirValid[d] || hipEventElapsedTime(&ms, ctx->swDirEv[2 * d], ctx->swDirEv[2 * d + 1]) != hipSuccess) { ms = -1; (void) hipGetLastError(); }
+        out[d * 4 + 0] = ms;
+        out[d * 4 + 1] = ctx ? ctx->swDirCells[d] : 0; out[d * 4 + 2] = ctx ? ctx->swDirPairs[d] : 0; out[d * 4 + 3] = ctx ? ctx->swDirWaveSteps[d] : 0;
+    }
+}
+
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which) {
     if (ctx && which >= 2 && which < 14) return ctx->kmerMs[which - 2];
     if (!ctx || which < 0 || which > 1 || !ctx->evValid[which]) return -1.0;
@@ -1406,6 +1418,28 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
         HIPCHK(hipMemcpyAsync(ctx->tids.p, ctx->hTids.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     if (dir == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));     // a forward + reversed pass pair is timed as one
+    if (!ctx->swDirEv[3]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->swDirEv[i]));
+    ctx->swDirValid[dir] = false;
+    if (dir == 0) ctx->swDirValid[1] = false;
+    {
+        // work of this pass in the units of the kernel's roofline: DP cells (query rows x target columns of every single-tile pair) and
+        // wave-steps (a wave carries two targets of one query and runs max(LtA, LtB) + lanes - 1 steps)
+        double cells = 0, pairs = 0, wsteps = 0;
+        const std::vector<int32_t> &len = ctx->db->hLengths;
+        for (int i = 0; i < nq; i++) {
+            if (cls[i] <= 0) continue;
+            const int ns = nSel(i), R = cls[i], lanes = (q[i].L + R - 1) / R;
+            const uint32_t *p = perm.data() + sbase[i];
+            for (int k = 0; k < ns; k++) {
+                const int lt = len[q[i].targetIds[p[k]]];
+                cells += (double) q[i].L * lt;
+                if ((k & 1) == 0 && lt > 0) wsteps += (double) (lt + lanes - 1) * (14.0 * R + (hasAA ? 2.0 * R : 0.0));   // pairs are longest first: the even one sets the wave's length
+            }
+            pairs += ns;
+        }
+        ctx->swDirCells[dir] = cells; ctx->swDirPairs[dir] = pairs; ctx->swDirWaveSteps[dir] = wsteps;
+    }
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir], ctx->stream));
     
     if (nBlocks) {
         if ((rc = ensurePinned(ctx, ctx->hImg, imgDwTotal * 4 + nBlocks * sizeof(SwBlockDesc) + 64)) != FSGPU_OK) return rc;
@@ -1487,6 +1521,8 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir + 1], ctx->stream));
+    ctx->swDirValid[dir] = true;
     ctx->evValid[1] = true;
     if (total) {
         HIPCHK(hipMemcpyAsync(ctx->hRes0.p, ctx->res0.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -101,6 +101,11 @@ struct fsgpu_ctx {
     hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
     hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf img, tids, res0, res1, border0, border1, keys;
+    // per-pass accounting of the last fsgpu_sw_multi_dir calls (fsgpu_sw_last_passes): k_sw2 launches only (single-tile queries),
+    // events on the context stream around the launches of one direction (the side streams of the register classes join it)
+    hipEvent_t swDirEv[4] = {nullptr, nullptr, nullptr, nullptr};   // fwd start / stop, rev start / stop
+    bool swDirValid[2] = {false, false};
+    double swDirCells[2] = {0, 0}, swDirPairs[2] = {0, 0}, swDirWaveSteps[2] = {0, 0};
     // multi-query row-tiled launches (queries longer than 512 rows inside fsgpu_sw_multi_dir): own stream, own staging
     hipStream_t swLong = nullptr;
     DevBuf lbuf, lres;                             // [ids | border bases | tile blocks per level | images], [fwd results | rev results]

@@ -294,6 +294,10 @@ void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4);
  * selection), 11 host tail, 12 the index-probe kernel (k_kmer_lists) alone.
  * Returns < 0 if nothing was recorded. */
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which);
+/* out[2][4], per direction (0 forward, 1 reversed query) of the last fsgpu_sw_multi_dir calls of this context: device ms of that pass's
+ * k_sw2 launches (HIP events on the context stream; -1 when the pass did not run), DP cells (query rows x target columns over the
+ * single-tile pairs), pairs, and the packed VALU wave-instructions of the DP rows its waves issue (the issue-rate roofline's unit). */
+void fsgpu_sw_last_passes(const fsgpu_ctx *ctx, double *out);
 
 #ifdef __cplusplus
 }

@@ -85,3 +85,24 @@ def test_bench_gpus2_dry_run_starts_two_ranks(scaling):
     assert ranks[0]["db_digest"] == ranks[1]["db_digest"] and ranks[0]["db_entries"] == ranks[1]["db_entries"] == 2500
     timed = [x["timed_queries"] for x in ranks]
     assert timed == ([12, 12] if scaling == "weak" else [6, 6])     # weak: steps x group per rank; strong: the same 12 split
+
+
+def test_bench_gpus8_dry_run_strong_scaling_shares():
+    """the 8-rank shape of the driver's largest run, through the bench code path (gloo, no device work): every rank gets the one broadcast
+    DB, the metric's 1k-query strong-scaling job splits into 8 contiguous shares of 128, and a rank with that few queries takes steps of 32"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--targets", "2000", "--steps", "16",
+                        "--warmup", "1", "--group", "64", "--scaling", "strong"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["backend"] == "gloo"
+    ranks = out["ranks"]
+    assert [x["rank"] for x in ranks] == list(range(8))
+    assert len({x["db_digest"] for x in ranks}) == 1 and all(x["db_entries"] == 2000 for x in ranks)
+    assert [x["timed_queries"] for x in ranks] == [128] * 8 and sum(x["timed_queries"] for x in ranks) == 16 * 64
+    assert out["queries_per_step_effective"] == 32

@@ -193,18 +193,24 @@ def test_backtrace_pool_does_not_change_results(world):
     s.close()
 
 
-def test_gapless_properties_at_1M_targets():
-    """configs[2] size (1M targets, 350 M residues).  The reference needs ~0.3 s per query here even on 16 cores, so: a
-    3000-target sample spread over the whole length range is checked against it, the full score vector through properties
-    (every score in [0, cap], planted homologs score above the random background, hit list = exact top-1000 of the vector
-    in (score desc, id asc) order, a second run is identical: the atomic queue order must not leak into results)."""
+@pytest.fixture(scope="module")
+def world1m():
+    """configs[2] / configs[3] size: 1M targets, 350 M residues, 50 planted homologs for each of three queries"""
     q3, qa = synth.make_queries(3, seed=99, lo=250, hi=450)
     db = synth.make_db_fast(1000000, (q3, qa), seed=31337, homologs_per_query=50)
     ctx = api.Context(0)
     ctx.load_db(db)
-    ref = oracle_lib.load_ref()
+    yield dict(db=db, q3=q3, qa=qa, ctx=ctx, ref=oracle_lib.load_ref())
+    ctx.close()
+
+
+def test_gapless_properties_at_1M_targets(world1m):
+    """configs[2] size (1M targets, 350 M residues).  The reference needs ~0.3 s per query here even on 16 cores, so: a
+    3000-target sample spread over the whole length range is checked against it, the full score vector through properties
+    (every score in [0, cap], planted homologs score above the random background, hit list = exact top-1000 of the vector
+    in (score desc, id asc) order, a second run is identical: the atomic queue order must not leak into results)."""
+    q3, db, ctx, ref = world1m["q3"], world1m["db"], world1m["ctx"], world1m["ref"]
     s = api.Search(ctx)
-    sub, pb = helpers.o_submat("MAT3DI", 2.0)
     for q in q3:
         hits = s.prefilter(q)
         got = ctx.gapless_scores().astype(np.int32)
@@ -226,4 +232,14 @@ def test_gapless_properties_at_1M_targets():
                              len(top), 16, want)
             assert (hits["score"][:300] == want).all()
     s.close()
-    ctx.close()
+
+
+@pytest.mark.parametrize("atype", [0, 2])
+def test_structure_alignment_of_real_hit_lists_equals_reference_at_1M(world1m, atype):
+    """configs[2] (--alignment-type 0) and configs[3] (--alignment-type 2, 3Di + AA) at their stated size: the 3 x 1000 prefilter hit lists of
+    the 1M-target database through the batch path, the COMPLETE alignStructure records (forward / reverse scores, e-value bits, start / end
+    positions, alignment length, identity, CIGAR, output order) against the compiled reference's alignStructure on the same pairs"""
+    if world1m["ref"] is None:
+        pytest.skip("oracle/_ref not built")
+    accepted = _align_against_reference(world1m, atype, 10, 1, [0, 1, 2], 1000)
+    assert accepted >= 120            # the planted homologs are among the accepted records
