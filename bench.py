@@ -58,9 +58,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
     ap.add_argument("--type2-steps", type=int, default=6, help="configs[3] leg of the default run: that many extra steps with --alignment-type 2 (3Di+AA) on the same "
                     "resident DB, reported under `align_type2` (0 = skip; skipped when the main run already is type 2)")
-    ap.add_argument("--allvsall-steps", type=int, default=96, help="configs[4] leg of the default run: that many batches of 32 DB entries as queries (k-mer prefilter "
+    ap.add_argument("--allvsall-steps", type=int, default=48, help="configs[4] leg of the default run: that many batches of 32 DB entries as queries (k-mer prefilter "
                     "+ structurealign on a --allvsall-targets DB), reported under `allvsall` (0 = skip)")
     ap.add_argument("--allvsall-targets", type=int, default=200000)
+    ap.add_argument("--allvsall-batch", type=int, default=256, help="queries per device batch of the all-vs-all leg")
     ap.add_argument("--emulate-rank-share", type=int, default=0, help="N: on ONE GPU, run what ONE rank of an N-rank node runs: CPU affinity cut to usable_cores / N, "
                     "backtrace pool sized for that, and with --scaling strong only 1/N of the queries (step size adapted like a real rank's)")
     return ap.parse_args(argv)
@@ -247,7 +248,7 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
            "similar_kmers_per_query": float(np.mean([c[0] for c in stat["counts"]])) / 32, "index_hits_per_query": float(np.mean([c[1] for c in stat["counts"]])) / 32,
            "candidates_per_query": float(np.mean([c[2] for c in stat["counts"]])) / 32,
            "hits_per_query": stat["hits"] / nqk, "alignments_per_query": stat["aln"] / nqk, "unsupported_queries": stat.get("bad", 0),
-           "stage_ms_per_batch32_solo": {k: solo_ms[i] for i, k in enumerate(["device_total", "count", "lists", "emit", "sort", "dupflags", "score", "replay", "select", "host_tail", "k_kmer_lists"])},
+           "stage_ms_per_batch32_solo": {k: solo_ms[i] for i, k in enumerate(["device_total", "count", "lists", "emit", "partition", "dup", "score", "replay", "select", "host_tail", "k_kmer_lists"])},
            # k_kmer_lists per-launch duration: HIP events on the library's stream, mean over the batches of the timed region
            # (the host threads overlap their batches); "solo" = the same launch alone on the device
            "roofline": {"bound": "hbm", "kernel": "k_kmer_lists", "kernel_ms": reg_ms, "achieved": reg_alg / (reg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
@@ -371,13 +372,14 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
     KT = max(1, args.kmer_threads)
     ctxs = [ctx0] + [ctx0.clone() for _ in range(KT - 1)]
     searches = [api.Search(c, par) for c in ctxs]
+    AB = max(32, args.allvsall_batch // 32 * 32)        # queries per device batch: the low-sensitivity prefilter yields ~10^4 index hits per query, far too few to fill the device in 32s
     lo, hi = fdist.shard_range(db.n, rank, world)
     ids = np.arange(lo, hi)
-    nb_all = (len(ids) + 31) // 32
+    nb_all = (len(ids) + AB - 1) // AB
     nb = nb_all if steps <= 0 else min(nb_all, steps + warmup)
     # a spread sample of the shard when only some batches are run: the DB is length sorted
     pick = np.linspace(0, nb_all - 1, nb).astype(np.int64) if nb < nb_all else np.arange(nb_all)
-    batches = [ids[b * 32:(b + 1) * 32] for b in pick]
+    batches = [ids[b * AB:(b + 1) * AB] for b in pick]
     if steps > 0:            # warm-up batches spread over the length range as well, so every register class has been launched once
         wsel = set(np.linspace(0, len(batches) - 1, min(warmup, len(batches))).astype(np.int64).tolist()) if warmup > 0 else set()
         warm = [b for i, b in enumerate(batches) if i in wsel]
@@ -444,7 +446,7 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         nq = sum(x["q"] for x in tot)
         s0 = tot[0]
         nb0 = max(1, s0["nb"])
-        names = ["device_total", "count", "lists", "emit", "sort", "dupflags", "score", "replay", "select", "host_tail", "k_kmer_lists"]
+        names = ["device_total", "count", "lists", "emit", "partition", "dup", "score", "replay", "select", "host_tail", "k_kmer_lists"]
         # HBM roofline of the k-mer prefilter batch (rank 0's batches, HIP events over the whole device part of a batch): algorithmic bytes =
         # 8 per similar k-mer (two u32 offsets of the probe) + 8 per index hit (the entry gathered) + the target residues under every scored diagonal
         alg = 8.0 * s0["cnt"][0] + 8.0 * s0["cnt"][1] + s0["diag_bytes"]
@@ -452,17 +454,17 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         out = {"metric": "residues aligned/sec (prefilter+align)", "value": nq * db.residues / dt, "unit": "residues/s", "n_gpus": world,
                "steps": len(timed), "warmup": len(warm), "ms_per_step": 1e3 * dt / max(1, len(timed)), "higher_is_better": True,
                "scaling": "strong" if steps <= 0 else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
-               "config": {"workload": f"all-vs-all (configs[4]): {nq} of the {db.n} DB entries as queries in batches of 32 (1 step = 1 batch), k-mer prefilter -s 4.5 --max-seqs 200 "
+               "config": {"workload": f"all-vs-all (configs[4]): {nq} of the {db.n} DB entries as queries in batches of {AB} (1 step = 1 batch), k-mer prefilter -s 4.5 --max-seqs 200 "
                                       f"-c 0.8 + structurealign -e 0.01 -c 0.8 (3Di+AA) on its hits; queries shard over {world} rank(s), DB replicated by one broadcast",
                           "targets": db.n, "db_residues": db.residues, "host_threads_per_gpu": KT, "kmer_threshold": thr},
                "queries_per_s": nq / dt, "ms_per_query": 1e3 * dt / max(1, nq / world), "hits_per_query": sum(x["hits"] for x in tot) / max(1, nq),
                "alignments_per_query": sum(x["aln"] for x in tot) / max(1, nq), "prefilter_device_ms_per_query": s0["dev"] / max(1, s0["q"]),
                "unsupported_queries": sum(x["bad"] for x in tot), "index_build_s": t_index, "db_generation_s": t_gen,
                "projected_full_all_vs_all_s": db.n / max(1e-9, nq / dt),
-               "stage_ms_per_batch32": {k: s0["stage"][i] / nb0 for i, k in enumerate(names)},
+               "queries_per_batch": AB, "stage_ms_per_batch": {k: s0["stage"][i] / nb0 for i, k in enumerate(names)},
                "similar_kmers_per_query": s0["cnt"][0] / max(1, s0["q"]), "index_hits_per_query": s0["cnt"][1] / max(1, s0["q"]),
                "candidates_per_query": s0["cnt"][2] / max(1, s0["q"]),
-               "roofline": {"bound": "hbm", "kernel": "k_kmer_* (the device part of one prefilter batch of 32 queries, all kernels)", "unit": "GB/s", "peak": 8000.0,
+               "roofline": {"bound": "hbm", "kernel": f"k_kmer_* (the device part of one prefilter batch of {AB} queries, all kernels)", "unit": "GB/s", "peak": 8000.0,
                             "achieved": alg / max(dev_s, 1e-12) / 1e9, "frac": alg / max(dev_s, 1e-12) / 1e9 / 8000.0, "traffic": None,
                             "algorithmic_bytes": alg / nb0, "kernel_ms": s0["stage"][0] / nb0,
                             "note": "co-running with the other feeder threads' batches and SW launches; bytes = 8 per similar k-mer + 8 per index hit + diagonal residues"},

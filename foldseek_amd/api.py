@@ -90,6 +90,8 @@ def lib():
         "fsgpu_kmer_index_copy": (i32, [vp, vp, vp, vp]),
         "fsgpu_kmer_row_copy": (i32, [vp, i32, vp, vp]),
         "fsgpu_kmer_last_counts": (None, [vp, vp]),
+        "fsgpu_kmer_last_segments": (None, [vp, vp]),
+        "fsgpu_kmer_plan_bins": (i32, [vp, u64, u64, vp, vp, C.c_uint32]),
         "fshost_kmer_query_prepare": (i32, [vp, vp, vp, i32, i32, f32, i32, i32, i32, vp, vp]),
         "fshost_kmer_threshold": (i32, [f32, i32]),
         "fshost_matrix_create": (vp, [i32, f32, f32]),
@@ -151,7 +153,7 @@ def exported_symbols():
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_db_broadcast", "fsgpu_device_count", "fsgpu_gapless_plan_items",
             "fsgpu_last_kernel_ms", "fsgpu_sw_last_passes", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
-            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts"]
+            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_bins"]
 
 
 def _ptr(a):
@@ -388,8 +390,14 @@ class Context:
         lib().fsgpu_kmer_last_counts(self.h, _ptr(out))
         return out
 
+    def kmer_segments(self):
+        """last batch's partition: segments resolved by one wave / in LDS / through global scratch, segments with candidates, all segments, bins"""
+        out = np.zeros(7, np.uint32)
+        lib().fsgpu_kmer_last_segments(self.h, _ptr(out))
+        return out
+
     def kmer_stage_ms(self):
-        """ms of the last k-mer batch: device total, count, lists, emit, sort, dupflags, score, walk, select; [9] host tail; [10] k_kmer_lists kernel alone"""
+        """ms of the last k-mer batch: device total, count, lists, emit, partition, double-diagonal detection, score, walk, select; [9] host tail; [10] k_kmer_lists kernel alone"""
         return [lib().fsgpu_last_kernel_ms(self.h, 2 + i) for i in range(11)]
 
     def gapless_scores_multi(self, query_index):

@@ -29,12 +29,62 @@ struct KmerIndex {
     uint64_t nEntries = 0;
     int16_t *s3 = nullptr;                // extended 3-mer matrix, rows sorted descending
     uint16_t *i3 = nullptr;
-    ~KmerIndex() { (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(bitmap); (void) hipFree(entries); (void) hipFree(s3); (void) hipFree(i3); }
+    // target bins of the hit-stream partition (k_kmer.hpp, stage 2): contiguous id ranges with at most tcap targets and at most
+    // resCap residues, several granularities; a batch picks the coarsest level whose expected segment still fits the LDS path
+    struct BinLevel { uint64_t resCap = 0; uint32_t nBins = 0, nBlk = 0, nCoarse = 0; uint32_t *blk = nullptr; uint16_t *blkCoarse = nullptr; uint32_t *coarseFirst = nullptr, *binFirst = nullptr; };   // k_kmer.hpp KmerBins
+    std::vector<BinLevel> levels;
+    uint64_t residues = 0;
+    ~KmerIndex() {
+        (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(bitmap); (void) hipFree(entries); (void) hipFree(s3); (void) hipFree(i3);
+        for (BinLevel &l : levels) { (void) hipFree(l.blk); (void) hipFree(l.blkCoarse); (void) hipFree(l.coarseFirst); (void) hipFree(l.binFirst); }
+    }
 };
+
+// bins of one level (KmerBins): every block of 1024 target ids is cut into 2^k equal id ranges, k the smallest value that keeps a bin's share
+// of the block's residues at or below resCap (k <= 10: a bin holds at least one id).  Target databases are sorted by length or in random
+// order, so the residues of a block spread evenly over its ids.  Host-only, tested without a GPU through fsgpu_kmer_plan_bins.
+static void planBins(const int32_t *lengths, uint64_t n, uint64_t resCap, std::vector<uint32_t> &blk, std::vector<uint32_t> &binFirst) {
+    const uint64_t nBlk = (n + 1023) / 1024;
+    blk.assign(nBlk, 0); binFirst.clear();
+    for (uint64_t k = 0; k < nBlk; k++) {
+        const uint64_t t0 = k * 1024, t1 = std::min<uint64_t>(n, t0 + 1024);
+        uint64_t res = 0;
+        for (uint64_t i = t0; i < t1; i++) res += (uint64_t) std::max(lengths[i], 0);
+        uint32_t shift = 10;
+        while (shift > 3 && (res >> (10 - shift)) > resCap) shift--;           // 2^(10 - shift) <= kCoarseKeys bins in this block
+        blk[k] = ((uint32_t) binFirst.size() << 8) | shift;
+        for (uint64_t i = t0; i < t1; i += (1ull << shift)) binFirst.push_back((uint32_t) i);
+    }
+    if (binFirst.empty()) binFirst.push_back(0);
+    binFirst.push_back((uint32_t) n);
+}
+// coarse bins of the two-level scatter: runs of 1024-id blocks holding at most kCoarseKeys bins, never across a multiple of 65536 ids
+static void planCoarse(const std::vector<uint32_t> &blk, uint32_t nBins, std::vector<uint16_t> &blkCoarse, std::vector<uint32_t> &coarseFirst) {
+    blkCoarse.assign(blk.size(), 0); coarseFirst.clear();
+    uint32_t inCoarse = 0;
+    for (size_t k = 0; k < blk.size(); k++) {
+        const uint32_t first = blk[k] >> 8, next = k + 1 < blk.size() ? blk[k + 1] >> 8 : nBins, cnt = next - first;
+        if (coarseFirst.empty() || (k & 63) == 0 || inCoarse + cnt > (uint32_t) kCoarseKeys) { coarseFirst.push_back(first); inCoarse = 0; }
+        blkCoarse[k] = (uint16_t) (coarseFirst.size() - 1);
+        inCoarse += cnt;
+    }
+    if (coarseFirst.empty()) coarseFirst.push_back(0);
+    coarseFirst.push_back(nBins);
+}
+
+extern "C" int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t resCap, uint32_t *blk /*[ceil(n / 1024)]*/, uint32_t *binFirst /*[cap]*/, uint32_t cap) {
+    if (!lengths || resCap == 0) return FSGPU_E_ARG;
+    std::vector<uint32_t> bk, bf;
+    planBins(lengths, n, resCap, bk, bf);
+    if (bf.size() > cap) return FSGPU_E_ARG;
+    if (blk) std::copy(bk.begin(), bk.end(), blk);
+    if (binFirst) std::copy(bf.begin(), bf.end(), binFirst);
+    return (int) bf.size() - 1;
+}
 
 struct KmerScratch {
     DevBuf qs, posQuery, seqs, thrs, profiles, K, Kbase, listStart, listSize, listPos, listP, chunks,
-           keys0, keys1, vals0, vals1, flags, scan, ckeys, cvals, kept, score, scrA, scrB, best,
+           rec, part, tmpA, binCount, segStart, cursor, segCand, candBase, segLast, candFlags, segLists, ckeys, cvals, kept, score, scrA, scrB, best,
            ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand;
     PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc;
     hipEvent_t ev[14] = {};
@@ -44,7 +94,8 @@ struct KmerScratch {
 void fsgpu_kmer_free_scratch(KmerScratch *s) {
     if (!s) return;
     DevBuf *d[] = {&s->qs, &s->posQuery, &s->seqs, &s->thrs, &s->profiles, &s->K, &s->Kbase, &s->listStart, &s->listSize, &s->listPos, &s->listP,
-                   &s->chunks, &s->keys0, &s->keys1, &s->vals0, &s->vals1, &s->flags, &s->scan, &s->ckeys, &s->cvals, &s->kept, &s->score,
+                   &s->chunks, &s->rec, &s->part, &s->tmpA, &s->binCount, &s->segStart, &s->cursor, &s->segCand, &s->candBase, &s->segLast, &s->candFlags, &s->segLists,
+                   &s->ckeys, &s->cvals, &s->kept, &s->score,
                    &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand};
     for (DevBuf *b : d) if (b->p) (void) hipFree(b->p);
     PinBuf *h[] = {&s->hQs, &s->hPosQuery, &s->hSeqs, &s->hThrs, &s->hProfiles, &s->hChunks, &s->hEc, &s->hRounds, &s->hResSize, &s->hThr,
@@ -199,6 +250,41 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     IXCHK(hipMalloc((void **) &ix->bitmap, (tableSize / 32) * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_kmer_bitmap, dim3(gridFor(tableSize / 32, 256)), dim3(256), 0, ctx->stream, ix->offsets, (uint32_t) (tableSize / 32), ix->bitmap);
     IXCHK(hipGetLastError());
+    // bin levels of the hit-stream partition
+    {
+        ix->residues = R;
+        if ((n + 1023) / 1024 > (uint64_t) kMaxBins) {
+            ctx->err = "k-mer prefilter: more than " + std::to_string((uint64_t) kMaxBins * 1024) + " targets are not supported by the device hit-stream partition";
+            cleanup(); return FSGPU_E_UNSUPPORTED;
+        }
+        std::vector<uint32_t> bk, bf;
+        uint64_t resCap0 = 16384;                              // levels that cannot fit kMaxBins bins are not worth planning
+        while (R / resCap0 > (uint64_t) kMaxBins / 2) resCap0 *= 2;
+        uint32_t prevNb = 0;
+        for (uint64_t resCap = resCap0; ; resCap *= 2) {
+            planBins(db.hLengths.data(), n, resCap, bk, bf);
+            const uint32_t nb = (uint32_t) bf.size() - 1;
+            if (nb == prevNb) break;                           // one bin per block everywhere: no coarser level exists
+            prevNb = nb;
+            std::vector<uint16_t> bc; std::vector<uint32_t> cf;
+            planCoarse(bk, nb, bc, cf);
+            if (nb <= (uint32_t) kMaxBins && cf.size() - 1 <= (size_t) kMaxCoarse) {
+                ix->levels.emplace_back();                     // owned by the index from here on (freed by its destructor)
+                KmerIndex::BinLevel &lv = ix->levels.back();
+                lv.resCap = resCap; lv.nBins = nb; lv.nBlk = (uint32_t) bk.size(); lv.nCoarse = (uint32_t) cf.size() - 1;
+                IXCHK(hipMalloc((void **) &lv.blk, std::max<size_t>(bk.size(), 1) * sizeof(uint32_t)));
+                IXCHK(hipMalloc((void **) &lv.blkCoarse, std::max<size_t>(bc.size(), 1) * sizeof(uint16_t)));
+                IXCHK(hipMalloc((void **) &lv.coarseFirst, cf.size() * sizeof(uint32_t)));
+                IXCHK(hipMalloc((void **) &lv.binFirst, (size_t) (nb + 1) * sizeof(uint32_t)));
+                IXCHK(hipMemcpy(lv.blk, bk.data(), bk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                IXCHK(hipMemcpy(lv.blkCoarse, bc.data(), bc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                IXCHK(hipMemcpy(lv.coarseFirst, cf.data(), cf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                IXCHK(hipMemcpy(lv.binFirst, bf.data(), (size_t) (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+            if (resCap >= (1ull << 40) || ix->levels.size() >= 8) break;
+        }
+        if (ix->levels.empty()) { ctx->err = "k-mer prefilter: no bin level fits the device partition"; cleanup(); return FSGPU_E_UNSUPPORTED; }
+    }
     IXCHK(hipStreamSynchronize(ctx->stream));
     cleanup();
 #undef IXCHK
@@ -215,6 +301,9 @@ int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets /*64e6+1*/, uint64_t
     if (entries && ix.nEntries) RPCHK(hipMemcpy(entries, ix.entries, ix.nEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (masked && ix.db->bytes) RPCHK(hipMemcpy(masked, ix.masked, ix.db->bytes, hipMemcpyDeviceToHost));
     return FSGPU_OK;
+}
+void fsgpu_kmer_last_segments(const fsgpu_ctx *ctx, uint32_t *out7) {
+    for (int i = 0; i < 7; i++) out7[i] = ctx ? ctx->kmerSegs[i] : 0;
 }
 void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4) {
     for (int i = 0; i < 4; i++) out4[i] = ctx ? ctx->kmerCounts[i] : 0;
@@ -395,6 +484,17 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     const uint32_t maxHits = (uint32_t) std::min<uint64_t>((uint64_t) sp.maxResListLen, n);
     int rc;
 #define CHK(x) do { rc = (x); if (rc != FSGPU_OK) return rc; } while (0)
+    // FSGPU_KMER_TRACE=1: host wall clock of the phases of a batch on stderr (where a feeder thread's time goes between the device stages)
+    static const bool trace = getenv("FSGPU_KMER_TRACE") != nullptr;
+    auto tPrev = std::chrono::steady_clock::now();
+    std::string traceLine;
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        char b[64];
+        snprintf(b, sizeof(b), " %s %.3f", what, std::chrono::duration<double, std::milli>(now - tPrev).count());
+        traceLine += b; tPrev = now;
+    };
 
     // ---- stage the batch ------------------------------------------------------------------------------------
     uint64_t nPos = 0, seqBytes = 0, profBytes = 0;
@@ -449,6 +549,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     CHK(ensurePinned(ctx, S.hResSize, (size_t) nq * sizeof(uint64_t)));
     CHK(ensurePinned(ctx, S.hThr, (size_t) nq * sizeof(uint32_t)));
     CHK(ensurePinned(ctx, S.hOutCount, (size_t) nq * sizeof(uint32_t)));
+    mark("stage");
     hipStream_t st = ctx->stream;
     RPCHK(hipEventRecord(S.ev[0], st));
     RPCHK(hipMemcpyAsync(S.qs.p, S.hQs.p, (size_t) nq * sizeof(KmerQ), hipMemcpyHostToDevice, st));
@@ -461,6 +562,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     RPCHK(hipMemsetAsync(S.resSize.p, 0, (size_t) nq * sizeof(uint64_t), st));
     RPCHK(hipMemsetAsync(S.hist.p, 0, (size_t) nq * 256 * sizeof(uint32_t), st));
     RPCHK(hipMemsetAsync(S.outCount.p, 0, (size_t) nq * sizeof(uint32_t), st));
+    RPCHK(hipMemsetAsync(S.nCand.p, 0, 64, st));                 // [0] candidates of the batch, [1] elements handed to the host
 
     uint64_t *misc = (uint64_t *) S.hMisc.p;
     uint64_t nLists = 0, nHits = 0;
@@ -476,6 +578,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     RPCHK(hipMemcpyAsync(&misc[0], (uint64_t *) S.Kbase.p + nPos, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     CHK(syncStream(ctx));
     nLists = misc[0];
+    mark("count+sync");
     RPCHK(hipEventRecord(S.ev[1], st));
     CHK(ensureK(ctx, S.listStart, (nLists + 1) * sizeof(uint32_t)));
     CHK(ensureK(ctx, S.listSize, (nLists + 1) * sizeof(uint32_t)));
@@ -499,40 +602,128 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     RPCHK(hipMemcpyAsync(S.hQs.p, S.qs.p, (size_t) nq * sizeof(KmerQ), hipMemcpyDeviceToHost, st));
     CHK(syncStream(ctx));
     nHits = misc[1];
+    mark("lists+sync");
     RPCHK(hipEventRecord(S.ev[2], st));
     if (nHits >= 0xFFFFFF00ull) {
         if (nq > 1) return 1;                                // caller halves the batch
         ctx->err = "k-mer search: a single query produces more than 2^32 index hits"; return FSGPU_E_UNSUPPORTED;
     }
     const KmerChunks *hck = (const KmerChunks *) S.hChunks.p;
-    const uint32_t cap = (uint32_t) std::max<uint64_t>(1, n);
-    // ---- stage 2: hit stream, stable sort by (query, target) ---------------------------------------------------
+    // ---- stage 2: hit stream -> (query, bin) segments -> double-diagonal candidates (k_kmer.hpp) ---------------------
+    KmerDupArgs da{};
+    uint32_t nSeg = 0;
+    KmerSegLists segLists{};
+    uint32_t *candList = nullptr;
     if (nHits) {
-        CHK(ensureK(ctx, S.keys0, nHits * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.keys1, nHits * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.vals0, nHits * sizeof(uint64_t)));
-        CHK(ensureK(ctx, S.vals1, nHits * sizeof(uint64_t)));
-        CHK(ensureK(ctx, S.scan, (nHits / kDupTile + 4) * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, kEmitTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p,
+        // coarsest bin level whose largest expected segment (hits of the heaviest query x the bin's share of the residues) stays well
+        // inside the LDS path; hit density per residue is what the batch just measured
+        // coarsest bin level whose AVERAGE segment (hits of a query x the bin's share of the residues) is about a third of what a 256-thread
+        // workgroup resolves in LDS -- heavier segments (long queries, bins of long targets) take the 1024-thread variant, so the heaviest
+        // query's expected segment should still fit that one
+        uint64_t maxQ = 0;
+        for (int q = 0; q < nq; q++) maxQ = std::max<uint64_t>(maxQ, (q + 1 < nq ? hq[q + 1].hitBase : nHits) - hq[q].hitBase);
+        const double perResMax = (double) maxQ / (double) std::max<uint64_t>(ix.residues, 1);
+        const double perResAvg = (double) nHits / (double) nq / (double) std::max<uint64_t>(ix.residues, 1);
+        // LDS of the group kernels: 16-bit per-target counters x 2, the query's chunk starts, 12 bytes per hit (+ the rank loop's slack records)
+        const size_t ldsCnt16 = (size_t) 2 * (kDupCounters + 4) * sizeof(uint16_t) + (kMaxChunks + 1) * sizeof(uint32_t) + 8 + 64;
+        const size_t ldsCnt32 = (size_t) 2 * (kDupCounters + 4) * sizeof(uint32_t) + (kMaxChunks + 1) * sizeof(uint32_t) + 8 + 64;
+        const size_t ldsDynMax = 160 * 1024 - 1024;            // the kernel's static LDS (wave sums) counts against the CU's 160 KB too
+        uint32_t capLarge = (uint32_t) std::min<size_t>(kDupCapLarge, ((ldsDynMax - ldsCnt16) / 12) & ~(size_t) 63);
+        if (const char *e = getenv("FSGPU_KMER_CAP_LARGE")) capLarge = (uint32_t) std::min<long>(capLarge, std::max<long>(kDupCap, atol(e)));   // tests: push groups into the global-scratch variant
+        // coarsest bin level whose AVERAGE segment is at most a third of a workgroup's capacity (segments are grouped up to about two thirds
+        // of it, k_kmer_groups) and whose heaviest query's expected segment still fits the 1024-thread variant
+        const KmerIndex::BinLevel *lv = &ix.levels.front();
+        for (const KmerIndex::BinLevel &l : ix.levels)
+            if (perResAvg * (double) l.resCap <= 0.35 * kDupCap && perResMax * (double) l.resCap <= 0.6 * capLarge) lv = &l;
+        if (const char *e = getenv("FSGPU_KMER_BIN_LEVEL")) lv = &ix.levels[std::min<size_t>(ix.levels.size() - 1, (size_t) std::max(0, atoi(e)))];   // tests: force a level
+        // hits per bincount / binscatter workgroup: about 16 per bin (128-byte runs per segment and tile, one reservation atomic per 16 hits),
+        // but no fewer than 4 tiles per CU
+        uint64_t hitTile = std::max<uint64_t>(16384, ((uint64_t) lv->nBins * 16 + 4095) / 4096 * 4096);
+        hitTile = std::max<uint64_t>(16384, std::min<uint64_t>(hitTile, (nHits / ((uint64_t) ctx->numCU * 4) + 4095) / 4096 * 4096));
+        const bool blkInLds = ((size_t) lv->nBins + lv->nBlk) * sizeof(uint32_t) <= 64 * 1024 - 256;
+        const KmerBins bins{lv->blk, lv->blkCoarse, lv->coarseFirst, lv->binFirst, lv->nBlk, lv->nBins, lv->nCoarse, (uint32_t) hitTile, blkInLds ? 1u : 0u};
+        const size_t ldsBins = ((size_t) lv->nBins + (blkInLds ? lv->nBlk : 0)) * sizeof(uint32_t);
+        const uint32_t nOwners = (uint32_t) nq * lv->nCoarse;
+        nSeg = (uint32_t) nq * lv->nBins;
+        CHK(ensureK(ctx, S.rec, nHits * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.part, nHits * sizeof(uint64_t)));
+        CHK(ensureK(ctx, S.tmpA, nHits * sizeof(uint64_t)));            // level-A output; afterwards the big groups' position / flag arrays
+        CHK(ensureK(ctx, S.binCount, ((size_t) nSeg + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.segStart, ((size_t) nSeg + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.cursor, ((size_t) nSeg + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.segCand, ((size_t) nSeg + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.candBase, ((size_t) nSeg + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.segLast, ((size_t) nOwners + 2) * 2 * sizeof(uint32_t)));       // coarse segment starts + level-A cursors
+        CHK(ensureK(ctx, S.candFlags, ((size_t) nSeg + 1) * 2 * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.segLists, (size_t) nSeg * (4 * sizeof(KmerGroup) + sizeof(uint32_t)) + 64));
+        segLists.small = (KmerGroup *) S.segLists.p; segLists.wg = segLists.small + nSeg; segLists.large = segLists.wg + nSeg; segLists.big = segLists.large + nSeg;
+        candList = (uint32_t *) (segLists.big + nSeg);
+        segLists.counts = candList + nSeg;
+        RPCHK(hipMemsetAsync(S.binCount.p, 0, ((size_t) nSeg + 1) * sizeof(uint32_t), st));
+        RPCHK(hipMemsetAsync(segLists.counts, 0, 16 * sizeof(uint32_t), st));
+        const unsigned nTiles = gridFor(nHits, hitTile);
+        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, kEmitTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p,
                            (const uint16_t *) S.posQuery.p, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
-                           (const uint32_t *) S.listPos.p, ix.entries, nHits, tbits, (uint32_t *) S.keys0.p, (uint64_t *) S.vals0.p);
+                           (const uint32_t *) S.listPos.p, ix.entries, nHits, (uint64_t *) S.rec.p);
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[3], st));
-        CHK(sortPairs(ctx, S.tmp, (const uint32_t *) S.keys0.p, (uint32_t *) S.keys1.p, (const uint64_t *) S.vals0.p, (uint64_t *) S.vals1.p, nHits,
-                      std::min(32, tbits + bitsFor(std::max(nq, 2)))));
-        RPCHK(hipEventRecord(S.ev[4], st));
-        // ---- stage 3: double-diagonal candidates: tile counts, scan ------------------------------------------------------
-        const uint64_t nTiles = (nHits + kDupTile - 1) / kDupTile;
-        const KmerDupPred pred{(const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p};
-        CHK(ensureK(ctx, S.flags, (nTiles + 1) * sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_kmer_dupcount, dim3((unsigned) nTiles), dim3(256), 0, st, pred, nHits, (uint32_t *) S.flags.p);
+        hipLaunchKernelGGL(k_kmer_bincount, dim3(nTiles), dim3(256), ldsBins, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.rec.p, nHits, bins,
+                           (uint32_t *) S.binCount.p);
         RPCHK(hipGetLastError());
-        RPCHK(hipMemsetAsync((uint32_t *) S.flags.p + nTiles, 0, sizeof(uint32_t), st));
-        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.flags.p, (uint32_t *) S.scan.p, nTiles + 1));
-        RPCHK(hipMemcpyAsync(S.nCand.p, (uint32_t *) S.scan.p + nTiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        RPCHK(hipMemcpyAsync(&misc[2], (uint32_t *) S.scan.p + nTiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.binCount.p, (uint32_t *) S.segStart.p, (size_t) nSeg + 1));
+        RPCHK(hipMemcpyAsync(S.cursor.p, S.segStart.p, (size_t) nSeg * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        uint32_t *coarseStart = (uint32_t *) S.segLast.p, *cursorA = coarseStart + nOwners + 2;
+        hipLaunchKernelGGL(k_kmer_coarse_starts, dim3(gridFor((uint64_t) nOwners + 1, 256)), dim3(256), 0, st, (const uint32_t *) S.segStart.p, (const uint32_t *) lv->coarseFirst,
+                           lv->nBins, lv->nCoarse, nOwners, coarseStart);
+        RPCHK(hipMemcpyAsync(cursorA, coarseStart, (size_t) nOwners * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        // two staged levels: stream order -> (query, coarse bin) in the gaux buffers' place (tmpA), -> (query, bin) in part
+        uint64_t *tmpA = (uint64_t *) S.tmpA.p;
+        hipLaunchKernelGGL(k_kmer_scatter_coarse, dim3(gridFor(nHits, kScTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.rec.p, nHits, bins, cursorA, tmpA);
+        hipLaunchKernelGGL(k_kmer_scatter_fine, dim3(gridFor(nHits, kScTile)), dim3(256), 0, st, (const uint32_t *) coarseStart, nOwners, (const uint64_t *) tmpA, nHits, bins,
+                           (uint32_t *) S.cursor.p, (uint64_t *) S.part.p);
+        RPCHK(hipGetLastError());
+        RPCHK(hipEventRecord(S.ev[4], st));
+        // ---- stage 3: per segment, the double-diagonal rule in arrival order ------------------------------------------------
+        da.qs = (const KmerQ *) S.qs.p; da.chunks = (const KmerChunks *) S.chunks.p; da.segStart = (const uint32_t *) S.segStart.p;
+        da.binFirst = lv->binFirst; da.nBins = lv->nBins; da.part = (uint64_t *) S.part.p; da.segCand = (uint32_t *) S.segCand.p;
+        da.gbucket = (uint64_t *) S.rec.p;         // the emit records are dead after the scatter: their buffer is the big groups' bucket array
+        da.gaux = (uint32_t *) S.tmpA.p; da.gaux2 = da.gaux + nHits;            // the level-A buffer is dead after the fine scatter
+        hipLaunchKernelGGL(k_kmer_groups, dim3(gridFor(nSeg, 256)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p, (const uint32_t *) S.segStart.p,
+                           (const uint32_t *) lv->binFirst, lv->nBins, nSeg, segLists, capLarge, (uint32_t *) S.segCand.p);
+        static_assert(kDupCap <= kDupCounters + 4 && sizeof(uint16_t) == 2, "the flag prefix of the 512-thread variant lives in the cursor array");
+        const size_t ldsWg = ldsCnt16 + (size_t) kDupCap * (sizeof(uint64_t) + sizeof(uint16_t));
+        const size_t ldsLarge = ldsCnt16 + (size_t) capLarge * (sizeof(uint64_t) + 2 * sizeof(uint16_t));
+        const unsigned gridSmall = (unsigned) std::min<uint64_t>(gridFor(nSeg, 4), (uint64_t) ctx->numCU * 16);
+        const unsigned gridWg = (unsigned) std::min<uint64_t>(nSeg, (uint64_t) ctx->numCU * 8);
+        const unsigned gridLarge = (unsigned) std::min<uint64_t>(nSeg, (uint64_t) ctx->numCU);
+        // heaviest groups first: the one-CU workgroups start while the small ones fill the rest of the device
+        {
+            static const hipError_t attr = hipFuncSetAttribute((const void *) k_kmer_dup_wg<false, 1024, kDupCapLarge / 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            if (attr != hipSuccess) { ctx->err = std::string("hipFuncSetAttribute(k_kmer_dup_wg): ") + hipGetErrorString(attr); return FSGPU_E_HIP; }
+            hipLaunchKernelGGL((k_kmer_dup_wg<false, 1024, kDupCapLarge / 1024>), dim3(gridLarge), dim3(1024), ldsLarge, st, da, (const KmerGroup *) segLists.large, (const uint32_t *) segLists.counts + 2, capLarge);
+        }
+        hipLaunchKernelGGL((k_kmer_dup_wg<true, 256, 1>), dim3(gridWg), dim3(256), ldsCnt32, st, da, (const KmerGroup *) segLists.big, (const uint32_t *) segLists.counts + 3, 0u);
+        hipLaunchKernelGGL((k_kmer_dup_wg<false, 512, kDupCap / 512>), dim3(gridWg), dim3(512), ldsWg, st, da, (const KmerGroup *) segLists.wg, (const uint32_t *) segLists.counts + 1, (uint32_t) kDupCap);
+        hipLaunchKernelGGL(k_kmer_dup_small, dim3(gridSmall), dim3(256), 0, st, da, (const KmerGroup *) segLists.small, (const uint32_t *) segLists.counts + 0);
+        RPCHK(hipGetLastError());
+        RPCHK(hipMemsetAsync((uint32_t *) S.segCand.p + nSeg, 0, sizeof(uint32_t), st));
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.segCand.p, (uint32_t *) S.candBase.p, (size_t) nSeg + 1));
+        uint32_t *candFlag = (uint32_t *) S.candFlags.p, *candFlagScan = candFlag + nSeg + 1;
+        hipLaunchKernelGGL(k_kmer_candflags, dim3(gridFor((uint64_t) nSeg + 1, 256)), dim3(256), 0, st, (const uint32_t *) S.segCand.p, nSeg, candFlag);
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) candFlag, candFlagScan, (size_t) nSeg + 1));
+        hipLaunchKernelGGL(k_kmer_candlist, dim3(gridFor((uint64_t) nSeg + 1, 256)), dim3(256), 0, st, (const uint32_t *) S.segCand.p, (const uint32_t *) candFlagScan, nSeg, candList, segLists.counts + 4);
+        RPCHK(hipGetLastError());
+        RPCHK(hipMemcpyAsync(S.nCand.p, (uint32_t *) S.candBase.p + nSeg, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        RPCHK(hipMemcpyAsync(&misc[2], (uint32_t *) S.candBase.p + nSeg, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RPCHK(hipMemcpyAsync(&misc[3], segLists.counts, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         CHK(syncStream(ctx));
         nCand = (uint32_t) misc[2];
+        mark("emit..dup+sync");
+        {   // [0] one wave, [1] LDS (256- and 1024-thread workgroups), [2] global scratch, [3] with candidates, [4] all, [5] bins
+            const uint32_t *c = (const uint32_t *) &misc[3];
+            ctx->kmerSegs[0] = c[0]; ctx->kmerSegs[1] = c[1] + c[2]; ctx->kmerSegs[2] = c[3]; ctx->kmerSegs[3] = c[4];
+            ctx->kmerSegs[4] = nSeg; ctx->kmerSegs[5] = lv->nBins; ctx->kmerSegs[6] = c[2];         // [0..3] count GROUPS of segments
+        }
     }
     if (!nHits) { RPCHK(hipEventRecord(S.ev[3], st)); RPCHK(hipEventRecord(S.ev[4], st)); }   // keep every stage event recorded
     RPCHK(hipEventRecord(S.ev[5], st));
@@ -544,11 +735,12 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(ensureK(ctx, S.scrA, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
-        CHK(ensureK(ctx, S.out, (size_t) nq * cap * sizeof(KmerOut)));
+        CHK(ensureK(ctx, S.out, (size_t) nCand * sizeof(KmerOut)));
         {
-            const KmerDupPred pred{(const uint32_t *) S.keys1.p, (const uint64_t *) S.vals1.p};
-            hipLaunchKernelGGL(k_kmer_dupscatter, dim3(gridFor(nHits, kDupTile)), dim3(256), 0, st, pred, nHits, (const uint32_t *) S.scan.p, tbits,
-                               (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
+            const uint32_t nCandSegs = ctx->kmerSegs[3];
+            const unsigned gridEx = (unsigned) std::min<uint64_t>(gridFor(nCandSegs, 64), (uint64_t) ctx->numCU * 16);
+            hipLaunchKernelGGL(k_kmer_expand, dim3(gridEx), dim3(256), 0, st, da, (const uint32_t *) S.candBase.p, (const uint32_t *) candList,
+                               (const uint32_t *) segLists.counts + 4, tbits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
         }
         RPCHK(hipGetLastError());
         int maxL = 0;
@@ -570,7 +762,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
                            (const uint32_t *) S.nCand.p, tbits, (uint32_t *) S.hist.p);
         hipLaunchKernelGGL(k_kmer_cut, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const uint32_t *) S.hist.p, nq, maxHits, (uint32_t) sp.minDiagScoreThr, (uint32_t *) S.thr.p);
         hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
-                           (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, cap, (uint32_t *) S.outCount.p, (KmerOut *) S.out.p);
+                           (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, nCand, (uint32_t *) S.outCount.p,
+                           (uint32_t *) S.nCand.p + 1, (KmerOut *) S.out.p);
         RPCHK(hipGetLastError());
     } else {
         for (int e = 6; e <= 7; e++) RPCHK(hipEventRecord(S.ev[e], st));
@@ -583,27 +776,39 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     RPCHK(hipMemcpyAsync(S.hOutCount.p, S.outCount.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RPCHK(hipEventRecord(S.ev[8], st));
     CHK(syncStream(ctx));
+    mark("score..out+sync");
     const uint32_t *hOutCount = (const uint32_t *) S.hOutCount.p;
     size_t totalOut = 0;
     std::vector<size_t> outOff(nq + 1, 0);
-    for (int q = 0; q < nq; q++) { outOff[q] = totalOut; totalOut += std::min(hOutCount[q], cap); }
+    for (int q = 0; q < nq; q++) { outOff[q] = totalOut; totalOut += hOutCount[q]; }
     outOff[nq] = totalOut;
-    CHK(ensurePinned(ctx, S.hOut, std::max<size_t>(1, totalOut) * sizeof(KmerOut)));
-    for (int q = 0; q < nq; q++) {
-        const size_t c = std::min(hOutCount[q], cap);
-        if (c) RPCHK(hipMemcpyAsync((KmerOut *) S.hOut.p + outOff[q], (KmerOut *) S.out.p + (size_t) q * cap, c * sizeof(KmerOut), hipMemcpyDeviceToHost, st));
-    }
+    if (totalOut > nCand) { ctx->err = "k-mer search: output count exceeds the candidate count"; return FSGPU_E_HIP; }
+    CHK(ensurePinned(ctx, S.hOut, std::max<size_t>(1, totalOut) * 2 * sizeof(KmerOut)));
+    if (totalOut) RPCHK(hipMemcpyAsync((KmerOut *) S.hOut.p + totalOut, S.out.p, totalOut * sizeof(KmerOut), hipMemcpyDeviceToHost, st));
     RPCHK(hipEventRecord(S.ev[9], st));
     CHK(syncStream(ctx));
+    {   // the device hands the elements over in no particular order: counting sort by query (query index in count >> 8)
+        const HostOut *src = (const HostOut *) S.hOut.p + totalOut;
+        HostOut *dst = (HostOut *) S.hOut.p;
+        std::vector<size_t> at(outOff.begin(), outOff.end() - 1);
+        for (size_t i = 0; i < totalOut; i++) {
+            const uint32_t q = src[i].count >> 8;
+            if (q >= (uint32_t) nq || at[q] >= outOff[q + 1]) { ctx->err = "k-mer search: inconsistent output element"; return FSGPU_E_HIP; }
+            dst[at[q]] = src[i];
+            dst[at[q]++].count &= 0xffu;
+        }
+    }
     {
         float ms = 0;
         static const int a[9] = {0, 0, 1, 2, 3, 4, 5, 6, 7}, b[9] = {9, 1, 2, 3, 4, 5, 6, 7, 8};
         // [0] total, [1] count+scan, [2] lists+chunks, [3] emit, [4] sort, [5] dup flags+scan, [6] compact+score, [7] walk, [8] hist/cut/out
-        for (int i = 0; i < 9; i++) ctx->kmerMs[i] = hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess ? (double) ms : -1.0;
-        ctx->kmerMs[10] = nLists && hipEventElapsedTime(&ms, S.ev[10], S.ev[11]) == hipSuccess ? (double) ms : -1.0;
+        // summed over the device batches of one fsgpu_kmer_search call (the caller resets them)
+        for (int i = 0; i < 9; i++) if (hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess) ctx->kmerMs[i] += (double) ms;
+        if (nLists && hipEventElapsedTime(&ms, S.ev[10], S.ev[11]) == hipSuccess) ctx->kmerMs[10] += (double) ms;
         (void) hipGetLastError();   // an elapsed-time query must never leave a sticky error behind
-        ctx->kmerCounts[0] = nLists; ctx->kmerCounts[1] = nHits; ctx->kmerCounts[2] = nCand; ctx->kmerCounts[3] = totalOut;
+        ctx->kmerCounts[0] += nLists; ctx->kmerCounts[1] += nHits; ctx->kmerCounts[2] += nCand; ctx->kmerCounts[3] += totalOut;
     }
+    mark("copy out+sync");
     // ---- host tail ---------------------------------------------------------------------------------------------
     const auto tTail = std::chrono::steady_clock::now();
     const KmerQ *hq2 = (const KmerQ *) S.hQs.p;
@@ -627,7 +832,9 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             stats[q * 4 + 3] = (double) pickBins(sp, n);
         }
     }
-    ctx->kmerMs[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTail).count();
+    ctx->kmerMs[9] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTail).count();
+    mark("host tail");
+    if (trace) fprintf(stderr, "kmer batch nq=%d hits=%llu cand=%u:%s\n", nq, (unsigned long long) nHits, nCand, traceLine.c_str());
 #undef CHK
     return FSGPU_OK;
 }
@@ -639,19 +846,28 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
     if (p->maxResListLen <= 0 || p->minDiagScoreThr < 1) { ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 1 required"; return FSGPU_E_UNSUPPORTED; }
     if (p->bins && (p->bins & (p->bins - 1))) { ctx->err = "k-mer search: bins must be a power of two"; return FSGPU_E_ARG; }
     RPCHK(hipSetDevice(ctx->device));
-    // queries per device batch: the stable sort runs over tbits + qbits key bits in 8-bit passes, so stay at or below
-    // 24 bits (3 passes) while at least 8 queries fit; never more than 32 (5 bits)
+    // queries per device batch: the candidate keys are (query << tbits | target) in 32 bits; beyond that the batch is sized by its hit
+    // stream (24 bytes of scratch per index hit, fewer than 2^32 hits): the hits per query of the previous batch of this context set the
+    // size of the next one, a batch that still comes out too large is halved and redone
     const int tb = ctx->kidx->tbits;
-    int qbits = std::min(5, 32 - tb);
-    if (tb + qbits > 24 && 24 - tb >= 3) qbits = 24 - tb;
-    const int maxBatch = std::max(1, 1 << std::max(0, qbits));
+    const int maxBatch = std::max(1, std::min(1 << std::min(12, 32 - tb), 1024));
+    const double hitBudget = 2.4e8;
+    for (int i = 0; i < 12; i++) ctx->kmerMs[i] = 0;
+    for (int i = 0; i < 4; i++) ctx->kmerCounts[i] = 0;
     int q0 = 0;
-    int batch = maxBatch;
     while (q0 < nq) {
-        const int m = std::min(batch, nq - q0);
+        int batch = maxBatch;
+        if (ctx->kmerHitsPerQuery > 0) batch = (int) std::max(8.0, std::min((double) maxBatch, hitBudget / ctx->kmerHitsPerQuery));
+        batch = std::min(batch, maxBatch);
+        if (ctx->kmerBatchCap > 0) batch = std::min(batch, ctx->kmerBatchCap);
+        // the rest of the call in device batches of equal size
+        const int left = nq - q0, parts = (left + batch - 1) / batch;
+        const int m = (left + parts - 1) / parts;
+        const uint64_t hitsBefore = ctx->kmerCounts[1];
         int rc = kmerBatch(ctx, *p, queries + q0, m, out + (size_t) q0 * p->maxResListLen, nout + q0, status + q0, stats ? stats + (size_t) q0 * 4 : nullptr);
-        if (rc == 1) { batch = std::max(1, m / 2); continue; }
+        if (rc == 1) { ctx->kmerBatchCap = std::max(1, m / 2); continue; }            // more than 2^32 hits: redo with half the queries
         if (rc != FSGPU_OK) return rc;
+        ctx->kmerHitsPerQuery = (double) (ctx->kmerCounts[1] - hitsBefore) / (double) std::max(1, m);
         q0 += m;
     }
     return FSGPU_OK;

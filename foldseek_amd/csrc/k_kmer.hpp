@@ -379,13 +379,70 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// search, stage 2: the hit stream.  Output-balanced gather: one thread per hit, list found by binary search.
+// search, stage 2: the hit stream -> double-diagonal candidates, without a global sort.
+//
+// The reference decides "is this hit a double-diagonal hit" with a byte per target that remembers the 8-bit diagonal of
+// the PREVIOUS hit of that target in arrival order (findDuplicates, CacheFriendlyOperations.cpp:188-283); to make that
+// byte array fit its L2 it first scatters the hits into bins by target id (hashElements, :285-311).  Same idea here, one
+// level up the memory hierarchy: the hit stream is scattered into (query, bin) segments, a bin being a contiguous range
+// of target ids with a bounded number of targets AND of residues (so a segment's hits fit a workgroup's LDS), and every
+// segment is then resolved inside LDS:
+//   k_kmer_emit        output-balanced gather of the index entries; one 8-byte record (bin, target-in-bin, diagonal)
+//                      per hit at its stream position o, (query, bin) histogram in LDS -> binCount
+//   (exclusive scan)   segStart[query][bin]
+//   k_kmer_binscatter  record o -> its segment (order inside a segment is arbitrary: the record carries o)
+//   k_kmer_dup_*       per segment: group the hits by target (LDS counting sort on the target-in-bin), find every hit's
+//                      predecessor = the hit of the same target with the largest smaller o (rank scan inside the target's
+//                      bucket), flag it when the 8-bit diagonals agree (same databaseHits chunk, else the byte array was
+//                      reset: compare with 0), and write the flagged hits back IN (target, o) ORDER
+//   k_kmer_expand      candidates of all segments -> (key = query|target, value = g|diag16|chunk) arrays, in (query,
+//                      target, arrival) order: exactly what the stable sort used to deliver, for 2-3 % of the hits only.
+// Bytes per hit: 8 written by emit, 8 read + 8 written by the scatter, 8 read by the segment kernels (the global radix
+// sort moved 24 B four times).  Nothing here depends on the order in which atomics are served.
 // --------------------------------------------------------------------------------------------------------------
-constexpr int kEmitTile = 2048;               // outputs per workgroup
-constexpr int kEmitStage = 6144;              // list prefixes staged in LDS (24 KB -> 6 workgroups per CU)
-__global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerChunks *chunks, const uint16_t *posQuery, uint64_t nLists, const uint64_t *listP,
+constexpr int kEmitTile = 2048;               // hits per workgroup of k_kmer_emit
+constexpr int kEmitStage = 6144;              // list prefixes of an emit tile staged in LDS (24 KB -> 6 workgroups per CU)
+constexpr int kDupCap = 2560;                 // hits of a segment group resolved in LDS by a 512-thread workgroup (four of them per CU)
+constexpr int kDupCapLarge = 12288;           // ... by a 1024-thread workgroup that owns the CU's LDS; beyond: global scratch
+constexpr int kDupSmall = 64;                 // ... at most this many: one wave, all-pairs in registers (k_kmer_dup_small)
+constexpr int kDupWindow = 2048;              // a group's bins start inside one window of this many target ids ...
+constexpr int kBinTargets = 1024;             // ... and a bin holds at most this many targets: a group spans fewer than kDupWindow + kBinTargets targets
+constexpr int kDupCounters = kDupWindow + kBinTargets;
+constexpr int kMaxBins = 16000;               // LDS counters of bincount / binscatter: 4 B per bin, under 64 KB
+
+// Bins are power-of-two aligned id ranges inside blocks of 1024 target ids: bin(t) = base[t >> 10] + ((t & 1023) >> shift[t >> 10]), the shift
+// chosen per block from its residue count (fsgpu_kmer_plan_bins) -- a table of n / 1024 words that lives in LDS, so the per-hit bin
+// look-up costs no memory request (a per-target table did: one 64-byte L2 request per hit and pass, the scatter's limit).
+struct KmerBins {
+    const uint32_t *blk;          // [ceil(n / 1024)] first bin of the block << 8 | shift
+    const uint16_t *blkCoarse;    // [ceil(n / 1024)] coarse bin of the block: runs of blocks with at most kCoarseKeys bins, inside one 65536-id block
+    const uint32_t *coarseFirst;  // [nCoarse + 1] first (fine) bin of a coarse bin
+    const uint32_t *binFirst;     // [nBins + 1] first target id of a bin
+    uint32_t nBlk, nBins, nCoarse;
+    uint32_t hitTile;             // hits per workgroup of k_kmer_bincount (about 16 per bin: one flush atomic per 16 hits)
+    uint32_t blkInLds;            // bincount: the block table is staged behind the bin counters
+};
+__device__ __forceinline__ uint32_t kmerBinOf(const uint32_t *blk, uint32_t t) {
+    const uint32_t e = blk[t >> 10];
+    return (e >> 8) + ((t & 1023u) >> (e & 0xffu));
+}
+constexpr int kCoarseKeys = 128;              // fine bins per coarse bin (a block of 1024 ids has at most 128 bins: shift >= 3) and coarse bins per query
+constexpr int kMaxCoarse = 512;               // coarse bins per query (LDS counters of the staged scatter)
+constexpr int kScTile = 2048;                 // hits per workgroup pass of the staged scatters (16 KB of LDS staging)
+
+// hit record at stream position o (k_kmer_emit -> k_kmer_bincount / k_kmer_binscatter): target << 16 | 16-bit diagonal
+__host__ __device__ inline uint64_t recPack(uint32_t t, uint32_t d16) { return ((uint64_t) t << 16) | (d16 & 0xffffu); }
+// hit record inside a segment: ordered as a u64 by (target id & 0xffff, o)
+__host__ __device__ inline uint64_t partPack(uint32_t tloc, uint32_t o, uint32_t d16) { return ((uint64_t) tloc << 48) | ((uint64_t) o << 16) | (d16 & 0xffffu); }
+__host__ __device__ inline uint32_t partTloc(uint64_t r) { return (uint32_t) (r >> 48); }
+__host__ __device__ inline uint32_t partO(uint64_t r) { return (uint32_t) (r >> 16); }
+__host__ __device__ inline uint32_t partD16(uint64_t r) { return (uint32_t) r & 0xffffu; }
+__host__ __device__ inline uint32_t partD8(uint64_t r) { return (uint32_t) r & 0xffu; }
+
+// Output-balanced gather: one thread per hit, list found by binary search over the staged list prefixes.
+__global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const uint16_t *posQuery, uint64_t nLists, const uint64_t *listP,
                                                    const uint32_t *listStart, const uint32_t *listPos, const uint64_t *entries,
-                                                   uint64_t nHits, int tbits, uint32_t *keys, uint64_t *vals) {
+                                                   uint64_t nHits, uint64_t *rec) {
     __shared__ uint64_t range[2];
     __shared__ uint32_t rel[kEmitStage + 1];  // list prefix relative to the block's first list
     const uint64_t o0 = (uint64_t) blockIdx.x * kEmitTile;
@@ -438,97 +495,498 @@ __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const KmerCh
         e[u] = o < o1 ? entries[(uint64_t) st[u] + (o - lp[u])] : 0;
         qi[u] = posQuery[p[u]];
     }
+    uint32_t pb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) pb[u] = qs[qi[u]].posBase;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint64_t o = o0 + threadIdx.x + 256 * u;
         if (o >= o1) continue;
-        const KmerQ &q = qs[qi[u]];
-        const uint32_t seqId = (uint32_t) (e[u] >> 16), posj = (uint32_t) e[u] & 0xffffu;
-        const uint32_t i = p[u] - q.posBase;
-        const uint64_t g = o - q.hitBase;
-        const KmerChunks &ck = chunks[qi[u]];
-        uint32_t c = 0;
-        while (c + 1 < ck.nChunks && ck.start[c + 1] <= g) c++;
-        keys[o] = (qi[u] << tbits) | seqId;
-        vals[o] = hitPack(g, (i - posj) & 0xffffu, c);
+        const uint32_t posj = (uint32_t) e[u] & 0xffffu;
+        rec[o] = recPack((uint32_t) (e[u] >> 16), (p[u] - pb[u] - posj) & 0xffffu);
     }
 }
 
-// --------------------------------------------------------------------------------------------------------------
-// search, stage 3 (after the stable sort by (query, target)): double-diagonal detection
-// --------------------------------------------------------------------------------------------------------------
-// findDuplicates pass 1: a hit is a candidate iff its 8-bit diagonal equals that of the previous hit of the same
-// target in the same chunk (the byte array starts at 0, so a first hit on diagonal 0 also counts).  Predicate of the
-// ordered candidate compaction below.
-struct KmerDupPred {
-    const uint32_t *keys;
-    const uint64_t *vals;
-    __device__ bool operator()(uint32_t i) const {
-        const uint32_t k = keys[i];
-        const uint64_t v = vals[i];
-        uint32_t prev = 0;
-        if (i > 0 && keys[i - 1] == k) { const uint64_t pv = vals[i - 1]; if (hitChunk(pv) == hitChunk(v)) prev = hitD8(pv); }
-        return hitD8(v) == prev;
+__device__ __forceinline__ bool o_valid(uint64_t ob, int u, uint64_t t1) { return ob + threadIdx.x + 256 * u < t1; }
+
+// the query that owns hit t0 (the last one whose hitBase is <= t0) and where its hits end
+__device__ inline void kmerTileQuery(const KmerQ *qs, int nq, uint64_t t0, uint64_t nHits, uint32_t &q0, uint64_t &end0) {
+    int lo = 0, hi = nq;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qs[mid].hitBase <= t0) lo = mid; else hi = mid; }
+    q0 = (uint32_t) lo;
+    end0 = lo + 1 < nq ? qs[lo + 1].hitBase : nHits;
+}
+
+// hits per (query, bin): LDS counters for the tile's first query, one fire-and-forget global atomic per (tile, non-empty bin)
+__global__ __launch_bounds__(256) void k_kmer_bincount(const KmerQ *qs, int nq, const uint64_t *rec, uint64_t nHits, KmerBins bins, uint32_t *binCount /*[nq][nBins]*/) {
+    extern __shared__ uint32_t shCnt[];       // [nBins]
+    __shared__ uint32_t q0s;
+    __shared__ uint64_t end0s;
+    const uint64_t t0 = (uint64_t) blockIdx.x * bins.hitTile;
+    if (t0 >= nHits) return;
+    const uint64_t t1 = min(nHits, t0 + bins.hitTile);
+    if (threadIdx.x == 0) { uint32_t q; uint64_t e; kmerTileQuery(qs, nq, t0, nHits, q, e); q0s = q; end0s = e; }
+    for (uint32_t i = threadIdx.x; i < bins.nBins; i += 256) shCnt[i] = 0;
+    const uint32_t *blk = bins.blk;
+    if (bins.blkInLds) { uint32_t *sb = shCnt + bins.nBins; for (uint32_t i = threadIdx.x; i < bins.nBlk; i += 256) sb[i] = bins.blk[i]; blk = sb; }
+    __syncthreads();
+    const uint32_t q0 = q0s;
+    const uint64_t end0 = end0s;
+    constexpr int U = 16;                     // loads in flight per thread
+    for (uint64_t ob = t0; ob < t1; ob += 256 * U) {
+        uint64_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const uint64_t o = ob + threadIdx.x + 256 * u; r[u] = o < t1 ? rec[o] : 0; }
+        uint32_t bn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) bn[u] = o_valid(ob, u, t1) ? kmerBinOf(blk, (uint32_t) (r[u] >> 16)) : 0u;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t o = ob + threadIdx.x + 256 * u;
+            if (o >= t1) continue;
+            if (o < end0) atomicAdd(&shCnt[bn[u]], 1u);
+            else {                            // the tile runs into the next queries
+                uint32_t q = q0 + 1;
+                while (q + 1 < (uint32_t) nq && qs[q + 1].hitBase <= o) q++;
+                atomicAdd(&binCount[(size_t) q * bins.nBins + bn[u]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins.nBins; i += 256) { const uint32_t c = shCnt[i]; if (c) atomicAdd(&binCount[(size_t) q0 * bins.nBins + i], c); }
+}
+
+// block-wide in-place scan (NT threads) over an array in LDS or global memory: every thread owns a contiguous run (one block scan over the
+// run sums instead of one per NT elements)
+template <class T, bool INCLUSIVE, int NT>
+__device__ inline uint32_t kmerBlockScan(T *v, uint32_t n, uint32_t *wsum /*[NT / 64]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per = (n + NT - 1) / NT, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+    uint32_t x = 0;
+    for (uint32_t i = i0; i < i1; i++) x += (uint32_t) v[i];
+    uint32_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - x, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) { const uint32_t ws = wsum[w]; if (w < wave) before += ws; total += ws; }
+    for (uint32_t i = i0; i < i1; i++) { const uint32_t y = (uint32_t) v[i]; before += INCLUSIVE ? y : 0u; v[i] = (T) before; before += INCLUSIVE ? 0u : y; }
+    __syncthreads();
+    return total;
+}
+
+// Staged scatter, the building block of both levels: up to kScTile records of ONE owner (a query for level A, a (query, coarse bin)
+// segment for level B) are counted per key in LDS, every key reserves its run in the owner's output with one global atomic, the records
+// are ordered by key inside LDS and written out run by run -- consecutive lanes write consecutive addresses, every global write is a full
+// line (an 8-byte store per hit into thousands of open segments costs a read-modify-write of its line once the lines fall out of L2).
+struct KmerStage {
+    uint64_t rec[kScTile];
+    uint16_t key[kScTile];
+    uint32_t hist[kMaxCoarse], lbase[kMaxCoarse], gbase[kMaxCoarse];
+    uint32_t wsum[4];
+};
+template <class KeyOf, class Conv>
+__device__ inline void kmerStagedScatter(KmerStage &S, const uint64_t *in, uint64_t a, uint32_t n, uint32_t nKeys, uint32_t *cursorRow, uint64_t *out, KeyOf keyOf, Conv conv) {
+    constexpr int U = kScTile / 256;
+    for (uint32_t i = threadIdx.x; i < nKeys; i += 256) S.hist[i] = 0;
+    __syncthreads();
+    uint64_t r[U];
+    uint32_t k[U], rk[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t e = threadIdx.x + 256 * u; r[u] = e < n ? in[a + e] : 0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t e = threadIdx.x + 256 * u; k[u] = e < n ? keyOf(r[u]) : 0u; r[u] = conv(r[u], a + e); }
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t e = threadIdx.x + 256 * u; rk[u] = e < n ? atomicAdd(&S.hist[k[u]], 1u) : 0u; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nKeys; i += 256) {
+        const uint32_t c = S.hist[i];
+        S.lbase[i] = c;
+        S.gbase[i] = c ? atomicAdd(&cursorRow[i], c) : 0u;
+    }
+    __syncthreads();
+    kmerBlockScan<uint32_t, false, 256>(S.lbase, nKeys, S.wsum);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t e = threadIdx.x + 256 * u;
+        if (e < n) { const uint32_t p = S.lbase[k[u]] + rk[u]; S.rec[p] = r[u]; S.key[p] = (uint16_t) k[u]; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t kk = S.key[i];
+        out[S.gbase[kk] + (i - S.lbase[kk])] = S.rec[i];
+    }
+    __syncthreads();
+}
+
+// level A: hit records at their stream positions -> the (query, coarse bin) segments, as segment records (target id & 0xffff, o, diagonal)
+__global__ __launch_bounds__(256) void k_kmer_scatter_coarse(const KmerQ *qs, int nq, const uint64_t *rec, uint64_t nHits, KmerBins bins,
+                                                             uint32_t *cursorA /*[nq][nCoarse]*/, uint64_t *tmpA) {
+    __shared__ KmerStage S;
+    __shared__ uint32_t q0s;
+    __shared__ uint64_t end0s;
+    const uint64_t t0 = (uint64_t) blockIdx.x * kScTile;
+    if (t0 >= nHits) return;
+    const uint64_t t1 = min(nHits, t0 + kScTile);
+    const uint16_t *blkCoarse = bins.blkCoarse;
+    uint64_t pos = t0;
+    while (pos < t1) {                        // one pass per query the tile touches (almost always one)
+        if (threadIdx.x == 0) { uint32_t q; uint64_t e; kmerTileQuery(qs, nq, pos, nHits, q, e); q0s = q; end0s = e; }
+        __syncthreads();
+        const uint32_t q = q0s;
+        const uint64_t end = min(t1, end0s);
+        kmerStagedScatter(S, rec, pos, (uint32_t) (end - pos), bins.nCoarse, cursorA + (size_t) q * bins.nCoarse, tmpA,
+                          [&](uint64_t raw) { return (uint32_t) blkCoarse[(uint32_t) (raw >> 26)]; },                      // raw = target << 16 | diagonal: block = target >> 10
+                          [&](uint64_t raw, uint64_t o) { return partPack((uint32_t) (raw >> 16) & 0xffffu, (uint32_t) o, (uint32_t) raw & 0xffffu); });
+        pos = end;                            // (the helper ends with a barrier: q0s / end0s can be rewritten)
+    }
+}
+
+// level B: inside every (query, coarse bin) segment, records -> their (query, bin) segments.  coarseStart[query][coarse] (+ the total at
+// the end) delimits the owners; a tile that runs over several of them makes one pass per owner.
+__global__ __launch_bounds__(256) void k_kmer_scatter_fine(const uint32_t *coarseStart /*[nq * nCoarse + 1]*/, uint32_t nOwners, const uint64_t *tmpA, uint64_t nHits, KmerBins bins,
+                                                           uint32_t *cursor /*[nq][nBins]*/, uint64_t *part) {
+    __shared__ KmerStage S;
+    __shared__ uint32_t own, ownEnd;
+    const uint64_t t0 = (uint64_t) blockIdx.x * kScTile;
+    if (t0 >= nHits) return;
+    const uint64_t t1 = min(nHits, t0 + kScTile);
+    const uint32_t *blk = bins.blk;
+    uint64_t pos = t0;
+    while (pos < t1) {
+        if (threadIdx.x == 0) {
+            uint32_t lo = 0, hi = nOwners;    // last owner whose start is <= pos: it is non-empty and contains pos
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coarseStart[mid] <= pos) lo = mid; else hi = mid; }
+            own = lo; ownEnd = coarseStart[lo + 1];
+        }
+        __syncthreads();
+        const uint32_t o = own;
+        const uint64_t end = min<uint64_t>(t1, ownEnd);
+        const uint32_t q = o / bins.nCoarse, A = o - q * bins.nCoarse;
+        const uint32_t fine0 = bins.coarseFirst[A], nKeys = bins.coarseFirst[A + 1] - fine0;
+        const uint32_t idBlock = bins.binFirst[fine0] & ~0xffffu;          // a coarse bin lies inside one block of 65536 ids
+        kmerStagedScatter(S, tmpA, pos, (uint32_t) (end - pos), nKeys, cursor + (size_t) q * bins.nBins + fine0, part,
+                          [&](uint64_t r) { return kmerBinOf(blk, idBlock + partTloc(r)) - fine0; },
+                          [&](uint64_t r, uint64_t) { return r; });
+        pos = end;
+    }
+}
+
+// coarseStart[query][coarse] = segStart[query][first bin of the coarse bin] (+ the batch total at the end)
+__global__ void k_kmer_coarse_starts(const uint32_t *segStart, const uint32_t *coarseFirst, uint32_t nBins, uint32_t nCoarse, uint32_t nOwners, uint32_t *coarseStart) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nOwners) return;
+    if (i == nOwners) { coarseStart[i] = segStart[(size_t) (nOwners / nCoarse) * nBins]; return; }
+    const uint32_t q = i / nCoarse, A = i - q * nCoarse;
+    coarseStart[i] = segStart[(size_t) q * nBins + coarseFirst[A]];
+}
+
+// Segments -> groups.  A (query, bin) segment of average size fills a third of a workgroup's LDS capacity (the spread over bins and queries
+// is wide), and a workgroup pays ~10 latency-bound phases per pass whatever the fill.  So consecutive segments of one query are resolved
+// TOGETHER: a group = the run of (small) segments whose first hit falls into the same window of kDupCap / 2 stream positions of the query and whose
+// bins start inside the same window of kDupWindow target ids (so the group spans fewer than kDupCounters targets and, bins never
+// straddling a 65536-id block, one block).  Both keys are functions of the segment alone: heads are found independently, the head's thread
+// walks to the group's last segment.  A group is to the kernels below what a segment is -- a contiguous range of `part` holding ALL hits of
+// its targets -- with a wider target range; it is classed by its hit count.
+struct KmerGroup {
+    uint32_t s0, m;               // the group's hits: part[s0 .. s0 + m)
+    uint32_t seg;                 // head segment (query * nBins + bin): where the group's candidate count goes
+    uint32_t tBase, T;            // first target id & 0xffff, number of targets spanned
+    uint32_t q, hb, nCh;          // query, its first stream position, its databaseHits chunks
+};
+struct KmerSegLists { KmerGroup *small, *wg, *large, *big; uint32_t *counts; /* [5]: small, wg, large, big groups, (expand: groups with candidates) */ };
+__global__ void k_kmer_groups(const KmerQ *qs, const KmerChunks *chunks, const uint32_t *segStart, const uint32_t *binFirst, uint32_t nBins, uint32_t nSeg,
+                              KmerSegLists L, uint32_t capLarge, uint32_t *segCand) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nSeg) return;
+    segCand[s] = 0;                           // heads with candidates overwrite theirs (stream order: the dup kernels run after this one)
+    const uint32_t q = s / nBins, b = s - q * nBins;
+    const uint32_t qBase = segStart[q * nBins];
+    constexpr uint32_t C = kDupCap / 2;
+    // hit-window key of a segment; a segment of more than C / 2 hits stands alone (its key is its own), so a merged group holds at most
+    // C + C / 2 hits and never spills into the 1024-thread variant because of its last member
+    auto keyOf = [&](uint32_t seg) { const uint32_t st = segStart[seg], mm = segStart[seg + 1] - st; return mm > C / 2 ? 0x80000000u | seg : (st - qBase) / C; };
+    const uint32_t start = segStart[s];
+    const uint32_t keyH = keyOf(s), keyT = binFirst[b] / (uint32_t) kDupWindow;
+    if (b > 0 && keyOf(s - 1) == keyH && binFirst[b - 1] / (uint32_t) kDupWindow == keyT) return;      // not a head
+    uint32_t last = s;
+    while (last + 1 < (q + 1) * nBins && keyOf(last + 1) == keyH && binFirst[b + (last + 1 - s)] / (uint32_t) kDupWindow == keyT) last++;
+    const uint32_t m = segStart[last + 1] - start;
+    if (m == 0) return;
+    KmerGroup g;
+    g.s0 = start; g.m = m; g.seg = s; g.tBase = binFirst[b] & 0xffffu; g.T = binFirst[b + (last + 1 - s)] - binFirst[b];
+    g.q = q; g.hb = (uint32_t) qs[q].hitBase; g.nCh = chunks[q].nChunks;
+    const int cls = m <= (uint32_t) kDupSmall ? 0 : m <= (uint32_t) kDupCap ? 1 : m <= capLarge ? 2 : 3;
+    // one atomic per (wave, class): a hundred thousand single appends to one counter serialise in L2
+    const int lane = (int) (threadIdx.x & 63);
+    for (int c = 0; c < 4; c++) {
+        const unsigned long long mk = __ballot(cls == c);             // only the lanes that got here take part
+        if (cls != c || !mk) continue;
+        const int leader = __ffsll((long long) mk) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&L.counts[c], (uint32_t) __popcll(mk));
+        base = (uint32_t) __shfl((int) base, leader);
+        KmerGroup *dst = c == 0 ? L.small : c == 1 ? L.wg : c == 2 ? L.large : L.big;
+        dst[base + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))] = g;
+    }
+}
+
+struct KmerDupArgs {
+    const KmerQ *qs;
+    const KmerChunks *chunks;
+    const uint32_t *segStart;     // [nSeg + 1]
+    const uint32_t *binFirst;
+    uint32_t nBins;
+    uint64_t *part;               // in: the group's hits in any order; out: its candidates in (target, o) order at the group's start
+    uint32_t *segCand;            // [nSeg] candidates per group, at its head segment
+    uint64_t *gbucket;            // big groups: bucket array (same indexing as part)
+    uint32_t *gaux, *gaux2;       // big groups: sorted position | flag, flag prefix
+};
+
+// chunk (databaseHits refill round) of stream position g: start[] ascending, start[0] = 0; binary search (LDS or registers' worth of loads)
+template <class T>
+__device__ inline uint32_t kmerChunkOf(const T *start, uint32_t nChunks, uint32_t g) {
+    uint32_t lo = 0, hi = nChunks;            // last c with start[c] <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t) start[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// per-wave LDS copy of a query's chunk starts (stream positions relative to the query's first hit fit 32 bits: a batch has < 2^32 hits)
+__device__ inline void kmerStageChunks(uint32_t *cst, const KmerChunks &ck, uint32_t nCh, int lane) {
+    for (uint32_t i = (uint32_t) lane; i <= nCh; i += 64) cst[i] = (uint32_t) ck.start[i];
+}
+
+// groups of at most 64 hits: one wave, every hit looks at every other one through v_readlane
+__global__ __launch_bounds__(256) void k_kmer_dup_small(KmerDupArgs a, const KmerGroup *list, const uint32_t *countPtr) {
+    __shared__ uint32_t cstAll[4][kMaxChunks + 1];
+    const uint32_t n = *countPtr;
+    const int lane = threadIdx.x & 63;
+    uint32_t *cst = cstAll[threadIdx.x >> 6];
+    // everything that identifies the group is wave-uniform: keep it in SGPRs (scalar loop control, v_readlane indices)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nWaves = gridDim.x * 4u;
+    uint32_t qStaged = 0xffffffffu;
+    for (uint32_t it = wave; it < n; it += nWaves) {
+        const KmerGroup &g = list[it];
+        const uint32_t seg = __builtin_amdgcn_readfirstlane(g.seg), s0 = __builtin_amdgcn_readfirstlane(g.s0), m = __builtin_amdgcn_readfirstlane(g.m);
+        const uint32_t q = __builtin_amdgcn_readfirstlane(g.q), hb = __builtin_amdgcn_readfirstlane(g.hb), nCh = __builtin_amdgcn_readfirstlane(g.nCh);
+        const KmerChunks &ck = a.chunks[q];
+        if (nCh > 1 && q != qStaged) { kmerStageChunks(cst, ck, nCh, lane); qStaged = q; }     // same wave writes and reads: no barrier needed
+        const bool live = (uint32_t) lane < m;
+        const uint64_t r = live ? a.part[s0 + lane] : ~0ull;
+        uint64_t pred = 0;
+        bool has = false;
+        for (uint32_t j = 0; j < m; j++) {
+            const uint64_t x = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (r >> 32), (int) j) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) r, (int) j);
+            if (live && x < r && (x >> 48) == (r >> 48)) { has = true; pred = x > pred ? x : pred; }
+        }
+        uint32_t prevD8 = 0;
+        if (has) {
+            bool same = true;
+            if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, partO(r) - hb); same = partO(pred) - hb >= cst[c]; }
+            if (same) prevD8 = partD8(pred);
+        }
+        const bool flag = live && partD8(r) == prevD8;
+        unsigned long long fm = __ballot(flag);
+        const uint32_t nc = (uint32_t) __popcll(fm);
+        uint32_t slot = 0;
+        while (fm) {
+            const int j = __ffsll((long long) fm) - 1;
+            fm &= fm - 1;
+            const uint64_t x = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (r >> 32), j) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) r, j);
+            slot += x < r ? 1u : 0u;
+        }
+        if (flag) a.part[s0 + slot] = r;      // every lane holds its record in a register: the group's range can be overwritten
+        if (lane == 0) a.segCand[seg] = nc;
+    }
+}
+
+// per-target counters of a group.  In LDS as 16-bit halves (a group resolved in LDS has fewer than 65536 hits; two counters per dword, the
+// atomic adds 1 << 16 for the odd one -- no carry can reach the neighbour), 32-bit for the global-scratch variant whose groups can be larger.
+template <bool WIDE> struct KmerCnt;
+template <> struct KmerCnt<false> {
+    typedef uint16_t T;
+    static __device__ __forceinline__ uint32_t add(T *a, uint32_t i) {        // returns the counter's value before the add
+        const uint32_t sh = (i & 1u) * 16u;
+        return (atomicAdd(reinterpret_cast<uint32_t *>(a) + (i >> 1), 1u << sh) >> sh) & 0xffffu;
     }
 };
-// Ordered compaction of the candidates in two coalesced passes over the sorted hit stream (24 B per hit in total):
-// pass 1 counts the candidates of every 2048-hit tile, a scan over the tile counts gives the tile bases, pass 2
-// re-evaluates the predicate, ranks the candidates inside the tile with wave ballots and writes them in order.
-constexpr int kDupTile = 2048;
-__global__ __launch_bounds__(256) void k_kmer_dupcount(KmerDupPred pred, uint64_t n, uint32_t *tileCount) {
-    __shared__ uint32_t wsum[4];
-    const uint64_t base = (uint64_t) blockIdx.x * kDupTile;
-    uint32_t c = 0;
+template <> struct KmerCnt<true> {
+    typedef uint32_t T;
+    static __device__ __forceinline__ uint32_t add(T *a, uint32_t i) { return atomicAdd(a + i, 1u); }
+};
+
+// one workgroup (NT threads) per group.  BIG = false: up to `cap` = NT * PER hits, each thread keeps its PER records in registers from the
+// one global load to the scatter, bucket / position arrays in LDS; BIG = true: any size, arrays in global scratch, records re-read (same
+// code, the per-target counters stay in LDS).  The next group's descriptor is fetched while the current one is being resolved.
+template <bool BIG, int NT, int PER>
+__global__ __launch_bounds__(NT) void k_kmer_dup_wg(KmerDupArgs a, const KmerGroup *list, const uint32_t *countPtr, uint32_t cap) {
+    typedef KmerCnt<BIG> Cnt;
+    typedef typename Cnt::T CT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char shDup[];
+    __shared__ uint32_t wsum[NT / 64];
+    // byte offsets into the dynamic LDS block (plain pointer arithmetic on shDup: an integer round trip would turn every access below into
+    // a flat_* instruction -- address-space inference stops at ptrtoint -- and flat accesses to LDS go through the vector memory pipe)
+    constexpr uint32_t kCntBytes = (uint32_t) ((kDupCounters + 4) * sizeof(CT));
+    constexpr uint32_t kCstOff = 2 * kCntBytes, kBucketOff = (kCstOff + (kMaxChunks + 1) * 4 + 7) & ~7u;
+    CT *off = (CT *) shDup;                              // [kDupCounters + 4] bucket starts (off[t] .. off[t + 1])
+    CT *cur = (CT *) (shDup + kCntBytes);                // [kDupCounters + 4] scatter cursors
+    uint32_t *cst = (uint32_t *) (shDup + kCstOff);      // [kMaxChunks + 1] chunk starts of the query, stream positions relative to its first hit
+    uint64_t *lbucket = (uint64_t *) (shDup + kBucketOff);
+    uint16_t *lspos = (uint16_t *) (shDup + kBucketOff + (cap + 8) * 8);   // [cap] sorted position | flag << 15   (8 slack records: the rank loop reads in eights)
+    // [cap] flag at sorted position -> exclusive prefix.  The 256- / 512-thread variant keeps it in the scatter cursors' place (dead once the
+    // buckets are filled, and cap <= kDupCounters there): 40 KB per workgroup, four of them per CU
+    uint16_t *lpfx = (!BIG && NT <= 512) ? (uint16_t *) cur : lspos + cap;
+    const uint32_t n = *countPtr;
+    if (blockIdx.x >= n) return;
+    KmerGroup g = list[blockIdx.x];
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const uint32_t seg = g.seg, s0 = g.s0, m = g.m, tBase = g.tBase, T = g.T, nCh = g.nCh, hb = g.hb;
+        const KmerChunks &ck = a.chunks[g.q];
+        uint64_t *gb = a.gbucket + s0;       // BIG only; the two variants index different address spaces, so no common pointer
+        // every global load of this group is issued here, before anything waits: records, chunk starts, the next descriptor
+        uint64_t r[PER];
+        if (!BIG) {
 #pragma unroll
-    for (int u = 0; u < kDupTile / 256; u++) {
-        const uint64_t i = base + u * 256 + threadIdx.x;
-        const bool f = i < n && pred((uint32_t) i);
-        c += (uint32_t) __popcll(__ballot(f));
-    }
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tileCount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-__global__ __launch_bounds__(256) void k_kmer_dupscatter(KmerDupPred pred, uint64_t n, const uint32_t *tileBase, int tbits,
-                                                         uint32_t *ckeys, uint64_t *cvals, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
-    constexpr int U = kDupTile / 256;
-    __shared__ uint32_t wcnt[U][4];
-    __shared__ uint32_t h[kMaxChunks];        // per-chunk candidate counts of the block's first query
-    __shared__ uint32_t q0;
-    const uint64_t base = (uint64_t) blockIdx.x * kDupTile;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    h[threadIdx.x] = 0;
-    if (threadIdx.x == 0) q0 = pred.keys[base] >> tbits;
-    uint32_t mine = 0, rank[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const uint64_t i = base + u * 256 + threadIdx.x;
-        const bool f = i < n && pred((uint32_t) i);
-        const unsigned long long m = __ballot(f);
-        rank[u] = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-        if (f) mine |= 1u << u;
-        if (lane == 0) wcnt[u][wave] = (uint32_t) __popcll(m);
-    }
-    __syncthreads();
-    uint32_t run = tileBase[blockIdx.x];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        uint32_t before = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) before += w < wave ? wcnt[u][w] : 0;
-        if ((mine >> u) & 1u) {
-            const uint64_t i = base + u * 256 + threadIdx.x;
-            const uint32_t j = run + before + rank[u];
-            const uint32_t k = pred.keys[i];
-            const uint64_t v = pred.vals[i];
-            ckeys[j] = k; cvals[j] = v;
-            if ((k >> tbits) == q0) atomicAdd(&h[hitChunk(v)], 1u);
-            else atomicAdd(&ecCount[(size_t) (k >> tbits) * kMaxChunks + hitChunk(v)], 1u);
+            for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; r[u] = e < m ? a.part[s0 + e] : 0; }
         }
-        run += wcnt[u][0] + wcnt[u][1] + wcnt[u][2] + wcnt[u][3];
+        uint32_t cstv[(kMaxChunks + NT) / NT];
+#pragma unroll
+        for (int u = 0; u < (kMaxChunks + NT) / NT; u++) { const uint32_t i = threadIdx.x + NT * u; cstv[u] = i <= nCh ? (uint32_t) ck.start[i] : 0u; }
+        if (it + gridDim.x < n) g = list[it + gridDim.x];
+        for (uint32_t i = threadIdx.x; i < (T + 2) / 2 + 1; i += NT) {       // zero as dwords (both counter widths)
+            if (BIG) { off[2 * i] = 0; off[2 * i + 1] = 0; } else reinterpret_cast<uint32_t *>(off)[i] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < (kMaxChunks + NT) / NT; u++) { const uint32_t i = threadIdx.x + NT * u; if (i <= nCh) cst[i] = cstv[u]; }
+        __syncthreads();
+        if (BIG) {
+            for (uint32_t e = threadIdx.x; e < m; e += NT) Cnt::add(off, partTloc(a.part[s0 + e]) - tBase + 1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PER; u++) if (threadIdx.x + NT * u < m) Cnt::add(off, partTloc(r[u]) - tBase + 1);
+        }
+        __syncthreads();
+        kmerBlockScan<CT, true, NT>(off + 1, T, wsum);            // off[t + 1] = end of target t's bucket, off[0] = 0
+        for (uint32_t i = threadIdx.x; i < T; i += NT) cur[i] = off[i];
+        __syncthreads();
+        if (BIG) {
+            for (uint32_t e = threadIdx.x; e < m; e += NT) { const uint64_t x = a.part[s0 + e]; gb[Cnt::add(cur, partTloc(x) - tBase)] = x; }
+        } else {
+            uint32_t pos[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) pos[u] = threadIdx.x + NT * u < m ? Cnt::add(cur, partTloc(r[u]) - tBase) : 0u;
+#pragma unroll
+            for (int u = 0; u < PER; u++) if (threadIdx.x + NT * u < m) lbucket[pos[u]] = r[u];
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < m; p += NT) {
+            const uint64_t x0 = BIG ? gb[p] : lbucket[p];
+            const uint32_t t = partTloc(x0) - tBase, lo = off[t], hi = off[t + 1];
+            uint64_t pred = 0;
+            uint32_t rank = 0;
+            if (BIG) {
+                for (uint32_t j = lo; j < hi; j++) { const uint64_t x = gb[j]; if (x < x0) { rank++; pred = x > pred ? x : pred; } }
+            } else {
+                for (uint32_t j = lo; j < hi; j += 8) {       // eight bucket entries per round trip; entries past the bucket's end are masked out
+                    uint64_t x[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[k] = lbucket[j + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if (j + k < hi && x[k] < x0) { rank++; pred = x[k] > pred ? x[k] : pred; }
+                }
+            }
+            uint32_t prevD8 = 0;
+            if (rank) {
+                bool same = true;
+                if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, partO(x0) - hb); same = partO(pred) - hb >= cst[c]; }
+                if (same) prevD8 = partD8(pred);
+            }
+            const uint32_t flag = partD8(x0) == prevD8 ? 1u : 0u, sp = lo + rank;
+            if (BIG) { a.gaux[s0 + p] = sp | (flag << 31); a.gaux2[s0 + sp] = flag; }
+            else { lspos[p] = (uint16_t) (sp | (flag << 15)); lpfx[sp] = (uint16_t) flag; }
+        }
+        __syncthreads();
+        uint32_t nc;
+        if (BIG) nc = kmerBlockScan<uint32_t, false, NT>(a.gaux2 + s0, m, wsum);
+        else nc = kmerBlockScan<uint16_t, false, NT>(lpfx, m, wsum);
+        for (uint32_t p = threadIdx.x; p < m; p += NT) {
+            if (BIG) { const uint32_t sx = a.gaux[s0 + p]; if (sx >> 31) a.part[s0 + a.gaux2[s0 + (sx & 0x7fffffffu)]] = gb[p]; }
+            else { const uint32_t sx = lspos[p]; if (sx >> 15) a.part[s0 + lpfx[sx & 0x7fffu]] = lbucket[p]; }
+        }
+        if (threadIdx.x == 0) a.segCand[seg] = nc;
+        __syncthreads();                      // LDS arrays are reused by the next group
     }
-    __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&ecCount[(size_t) q0 * kMaxChunks + threadIdx.x], h[threadIdx.x]);
+}
+
+// groups that produced candidates, in segment order (flag -> exclusive scan -> list), so that neighbouring list entries belong to one query
+__global__ void k_kmer_candflags(const uint32_t *segCand, uint32_t nSeg, uint32_t *flags) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= nSeg) flags[s] = s < nSeg && segCand[s] ? 1u : 0u;
+}
+__global__ void k_kmer_candlist(const uint32_t *segCand, const uint32_t *flagScan, uint32_t nSeg, uint32_t *list, uint32_t *count) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nSeg && segCand[s]) list[flagScan[s]] = s;
+    if (s == nSeg) *count = flagScan[nSeg];
+}
+
+// candidates of a group (already in (target, o) order) -> the candidate arrays of the scoring / replay stages at candBase[head segment]:
+// key = query << tbits | target, value = (g, 16-bit diagonal, chunk); per-(query, chunk) candidate counts for the host's
+// findDuplicates capacity test, collected in LDS for the workgroup's first query (64 consecutive list entries per workgroup).
+__global__ __launch_bounds__(256) void k_kmer_expand(KmerDupArgs a, const uint32_t *candBase, const uint32_t *list, const uint32_t *countPtr, int tbits,
+                                                     uint32_t *ckeys, uint64_t *cvals, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
+    __shared__ uint32_t cstAll[4][kMaxChunks + 1];
+    __shared__ uint32_t h[kMaxChunks];
+    __shared__ uint32_t q0s;
+    const uint32_t n = *countPtr;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *cst = cstAll[wv];
+    for (uint32_t blk = blockIdx.x; blk * 64u < n; blk += gridDim.x) {
+        const uint32_t i0 = blk * 64u, i1 = min(n, i0 + 64u);
+        h[threadIdx.x] = 0;
+        if (threadIdx.x == 0) q0s = list[i0] / a.nBins;
+        __syncthreads();
+        const uint32_t q0 = q0s;
+        uint32_t qStaged = 0xffffffffu;
+        for (uint32_t it = i0 + wv; it < i1; it += 4) {
+            const uint32_t seg = __builtin_amdgcn_readfirstlane(list[it]);
+            const uint32_t s0 = __builtin_amdgcn_readfirstlane(a.segStart[seg]), nc = __builtin_amdgcn_readfirstlane(a.segCand[seg]), cb = __builtin_amdgcn_readfirstlane(candBase[seg]);
+            const uint32_t q = seg / a.nBins, b = seg - q * a.nBins;
+            const uint32_t tBlock = a.binFirst[b] & ~0xffffu;
+            const KmerChunks &ck = a.chunks[q];
+            const uint32_t nCh = __builtin_amdgcn_readfirstlane(ck.nChunks);
+            const uint32_t hb = (uint32_t) a.qs[q].hitBase;
+            if (nCh > 1 && q != qStaged) { kmerStageChunks(cst, ck, nCh, lane); qStaged = q; }
+            for (uint32_t k0 = 0; k0 < nc; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const bool live = k < nc;
+                uint32_t c = 0;
+                if (live) {
+                    const uint64_t r = a.part[s0 + k];
+                    const uint32_t g = partO(r) - hb;
+                    c = nCh > 1 ? kmerChunkOf(cst, nCh, g) : 0u;
+                    ckeys[cb + k] = (q << tbits) | (tBlock + partTloc(r));
+                    cvals[cb + k] = hitPack(g, partD16(r), c);
+                }
+                // one atomic per (wave, chunk): same-address atomics serialise
+                unsigned long long pending = __ballot(live);
+                while (pending) {
+                    const int leader = __ffsll((long long) pending) - 1;
+                    const uint32_t cl = (uint32_t) __shfl((int) c, leader);
+                    const unsigned long long grp = __ballot(live && c == cl);
+                    if (lane == leader) {
+                        if (q == q0) atomicAdd(&h[cl], (uint32_t) __popcll(grp));
+                        else atomicAdd(&ecCount[(size_t) q * kMaxChunks + cl], (uint32_t) __popcll(grp));
+                    }
+                    pending &= ~grp;
+                }
+            }
+        }
+        __syncthreads();
+        if (h[threadIdx.x]) atomicAdd(&ecCount[(size_t) q0 * kMaxChunks + threadIdx.x], h[threadIdx.x]);
+        __syncthreads();
+    }
 }
 
 // findDuplicates pass 2 (collapse runs of equal 8-bit diagonals among the candidates of one target and chunk) fused
@@ -744,9 +1202,11 @@ __global__ void k_kmer_cut(const uint32_t *hist, int nq, uint32_t maxHits, uint3
     for (t = 255; t > 0; t--) { found += h[t]; if (found >= maxHits) break; }
     thr[q] = t < minDiag ? minDiag : t;
 }
-struct KmerOut { uint32_t id; uint32_t count; uint32_t diag; int32_t score; uint64_t g; };
+struct KmerOut { uint32_t id; uint32_t count /* 8-bit score | query << 8 */; uint32_t diag; int32_t score; uint64_t g; };
+// elements at or above their query's cut go to ONE output array shared by the batch (a place per wave-group from a single counter; the
+// host tail sorts by query anyway), per-query counts alongside
 __global__ __launch_bounds__(256) void k_kmer_out(const uint32_t *ckeys, const uint64_t *cvals, const int32_t *score, const KmerBest *best, const uint32_t *nCandPtr, int tbits,
-                                                  const uint32_t *thr, uint32_t cap, uint32_t *outCount /*[nq]*/, KmerOut *out /*[nq][cap]*/) {
+                                                  const uint32_t *thr, uint32_t outCap, uint32_t *outCount /*[nq]*/, uint32_t *outTotal, KmerOut *out) {
     const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     bool take = false;
     uint32_t qi = 0;
@@ -758,25 +1218,27 @@ __global__ __launch_bounds__(256) void k_kmer_out(const uint32_t *ckeys, const u
             take = b.count >= thr[qi] && b.count != 0;
         }
     }
-    // one atomic per (wave, query) instead of one per element: same-address atomics serialise in L2
-    uint32_t slot = 0;
     const int lane = (int) (threadIdx.x & 63);
-    unsigned long long pending = __ballot(take);
+    const unsigned long long all = __ballot(take);
+    if (!all) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(outTotal, (uint32_t) __popcll(all));
+    base = (uint32_t) __shfl((int) base, 0);
+    const uint32_t slot = base + (uint32_t) __popcll(all & ((1ull << lane) - 1ull));
+    // one atomic per (wave, query) instead of one per element: same-address atomics serialise in L2
+    unsigned long long pending = all;
     while (pending) {
         const int leader = __ffsll((long long) pending) - 1;
         const uint32_t q = (uint32_t) __shfl((int) qi, leader);
         const unsigned long long grp = __ballot(take && qi == q);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&outCount[q], (uint32_t) __popcll(grp));
-        base = (uint32_t) __shfl((int) base, leader);
-        if (take && qi == q) slot = base + (uint32_t) __popcll(grp & ((1ull << lane) - 1ull));
+        if (lane == leader) atomicAdd(&outCount[q], (uint32_t) __popcll(grp));
         pending &= ~grp;
     }
-    if (!take || slot >= cap) return;
+    if (!take || slot >= outCap) return;
     const uint64_t v = cvals[b.cand];
     KmerOut o;
-    o.id = ckeys[s] & ((1u << tbits) - 1u); o.count = b.count; o.diag = hitDiag(v); o.score = score[b.cand]; o.g = hitG(v);
-    out[(size_t) qi * cap + slot] = o;
+    o.id = ckeys[s] & ((1u << tbits) - 1u); o.count = b.count | (qi << 8); o.diag = hitDiag(v); o.score = score[b.cand]; o.g = hitG(v);
+    out[slot] = o;
 }
 
 } // namespace fs

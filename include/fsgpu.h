@@ -286,12 +286,20 @@ int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params *p, const f
 /* Work counters of the last fsgpu_kmer_search batch: [0] similar k-mers probed in the index table, [1] index hits,
  * [2] double-diagonal candidates, [3] elements handed to the host tail. */
 void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4);
+/* Segment accounting of the last batch's hit-stream partition: [0] (query, bin) segments resolved by one wave (<= 64 hits), [1] in a
+ * workgroup's LDS, [2] through global scratch (larger than the LDS capacity), [3] groups with candidates, [4] all segments, [5] bins,
+ * [6] of [1]: those that needed the 1024-thread variant.  [0..3] count GROUPS of consecutive segments (k_kmer_groups). */
+void fsgpu_kmer_last_segments(const fsgpu_ctx *ctx, uint32_t *out7);
+/* The target bins of that partition (host-only planning, also used by the index build): every block of 1024 target ids is cut into 2^k equal
+ * id ranges so that a bin's share of the block's residues stays at or below resCap; bin(t) = (blk[t >> 10] >> 8) + ((t & 1023) >> (blk[t >> 10] & 255)).
+ * Fills blk[ceil(n / 1024)] / binFirst[bins + 1] (either may be NULL) and returns the number of bins, or FSGPU_E_ARG when cap is too small. */
+int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t resCap, uint32_t *blk, uint32_t *binFirst, uint32_t cap);
 
 /* ---- instrumentation -------------------------------------------------------------------------------------- */
 /* Device time (ms, HIP events on the context stream) of the dominant kernel of the last _finish()ed call:
  * which = 0 gapless scan kernel, 1 SW kernel, 2 whole device part of the last fsgpu_kmer_search batch,
- * 3..10 its stages (similar-k-mer count, index probes, hit gather, sort, double-diagonal flags, scoring, replay,
- * selection), 11 host tail, 12 the index-probe kernel (k_kmer_lists) alone.
+ * 3..10 its stages (similar-k-mer count, index probes, hit gather, partition into (query, bin) segments, double-diagonal
+ * detection per segment, scoring, replay, selection), 11 host tail, 12 the index-probe kernel (k_kmer_lists) alone.
  * Returns < 0 if nothing was recorded. */
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which);
 /* out[2][4], per direction (0 forward, 1 reversed query) of the last fsgpu_sw_multi_dir calls of this context: device ms of that pass's
