@@ -91,6 +91,7 @@ def lib():
         "fsgpu_kmer_row_copy": (i32, [vp, i32, vp, vp]),
         "fsgpu_kmer_last_counts": (None, [vp, vp]),
         "fsgpu_kmer_last_segments": (None, [vp, vp]),
+        "fsgpu_kmer_batch_hint": (i32, [vp]),
         "fsgpu_kmer_plan_bins": (i32, [vp, u64, u64, vp, vp, C.c_uint32]),
         "fshost_kmer_query_prepare": (i32, [vp, vp, vp, i32, i32, f32, i32, i32, i32, vp, vp]),
         "fshost_kmer_threshold": (i32, [f32, i32]),
@@ -153,7 +154,7 @@ def exported_symbols():
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_db_broadcast", "fsgpu_device_count", "fsgpu_gapless_plan_items",
             "fsgpu_last_kernel_ms", "fsgpu_sw_last_passes", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
-            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_bins"]
+            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_bins", "fsgpu_kmer_batch_hint"]
 
 
 def _ptr(a):

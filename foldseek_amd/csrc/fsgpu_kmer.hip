@@ -302,6 +302,14 @@ int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets /*64e6+1*/, uint64_t
     if (masked && ix.db->bytes) RPCHK(hipMemcpy(masked, ix.masked, ix.db->bytes, hipMemcpyDeviceToHost));
     return FSGPU_OK;
 }
+int fsgpu_kmer_batch_hint(const fsgpu_ctx *ctx) {
+    if (!ctx || !ctx->kidx || ctx->kmerHitsPerQuery <= 0) return 32;
+    const int tb = ctx->kidx->tbits;
+    const int maxBatch = std::max(1, std::min(1 << std::min(12, 32 - tb), 1024));
+    int b = (int) std::min<double>(maxBatch, 2.4e8 / ctx->kmerHitsPerQuery);
+    if (ctx->kmerBatchCap > 0) b = std::min(b, ctx->kmerBatchCap);
+    return std::max(32, b / 32 * 32);
+}
 void fsgpu_kmer_last_segments(const fsgpu_ctx *ctx, uint32_t *out7) {
     for (int i = 0; i < 7; i++) out7[i] = ctx ? ctx->kmerSegs[i] : 0;
 }

@@ -752,7 +752,7 @@ int fsmod_prefilter(int argc, const char **argv) {
     DbWriter w;
     if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();
-    const size_t batch = 32;
+    const size_t batch = 512;            // capacity of a thread's staging; a call takes fsgpu_kmer_batch_hint() queries (32 until the first call has measured the hit rate)
     std::vector<std::string> results(q.size());
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0), unstable(0);
@@ -769,9 +769,13 @@ int fsmod_prefilter(int argc, const char **argv) {
         std::vector<int32_t> nout(batch), status(batch);
         char line[128];
         for (;;) {
-            const size_t b0 = next.fetch_add(batch);
+            // device batches as large as the hit rate allows, but the tail of the query set is shared out evenly over the threads
+            const size_t seen = next.load();
+            const size_t fair = std::max<size_t>(32, (q.size() > seen ? q.size() - seen : 0) / ((size_t) nthreads * 2));
+            const size_t take = std::min<size_t>(std::min<size_t>(batch, (size_t) fsgpu_kmer_batch_hint(ctx)), fair);
+            const size_t b0 = next.fetch_add(take);
             if (b0 >= q.size() || bad) break;
-            const size_t nb = std::min(batch, q.size() - b0);
+            const size_t nb = std::min(take, q.size() - b0);
             for (size_t k = 0; k < nb; k++) {
                 const size_t id = b0 + k;
                 const uint32_t L = q.seqLen(id);
@@ -868,7 +872,7 @@ int fsmod_search(int argc, const char **argv) {
     const bool writePref = o.pos.size() == 4;
     if (writePref && !wp.open(o.pos[3], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();
-    const size_t batch = prefMode == 0 ? 32 : 16;
+    const size_t batch = prefMode == 0 ? 512 : 16;       // k-mer prefilter: capacity of a thread's staging, a round takes fsgpu_kmer_batch_hint() queries
     std::vector<std::string> results(q3.size()), prefs(writePref ? q3.size() : 0);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
@@ -898,9 +902,15 @@ int fsmod_search(int argc, const char **argv) {
         std::vector<char> line(1024 + 2 * 65536 * 2);
         char pl[128];
         for (;;) {
-            const size_t b0 = next.fetch_add(batch);
+            size_t take = batch;
+            if (prefMode == 0) {
+                const size_t seen = next.load();
+                const size_t fair = std::max<size_t>(32, (q3.size() > seen ? q3.size() - seen : 0) / ((size_t) nthreads * 2));
+                take = std::min<size_t>(std::min<size_t>(batch, (size_t) fsgpu_kmer_batch_hint(ctx)), fair);
+            }
+            const size_t b0 = next.fetch_add(take);
             if (b0 >= q3.size() || bad) break;
-            const size_t nb = std::min(batch, q3.size() - b0);
+            const size_t nb = std::min(take, q3.size() - b0);
             for (size_t k = 0; k < nb; k++) {
                 const size_t id = order[b0 + k];
                 qid[k] = id;

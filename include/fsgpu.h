@@ -286,6 +286,10 @@ int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params *p, const f
 /* Work counters of the last fsgpu_kmer_search batch: [0] similar k-mers probed in the index table, [1] index hits,
  * [2] double-diagonal candidates, [3] elements handed to the host tail. */
 void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4);
+/* Queries worth handing to the next fsgpu_kmer_search call of this context (a multiple of 32, 32..1024): as many as one device batch takes at
+ * the index hits per query the previous call saw.  A low-sensitivity prefilter (clustering: ~10^4 hits per query) needs hundreds of queries
+ * per batch to fill the device, the sensitive search default (~10^7 hits per query at 1M targets) fills it with 32. */
+int fsgpu_kmer_batch_hint(const fsgpu_ctx *ctx);
 /* Segment accounting of the last batch's hit-stream partition: [0] (query, bin) segments resolved by one wave (<= 64 hits), [1] in a
  * workgroup's LDS, [2] through global scratch (larger than the LDS capacity), [3] groups with candidates, [4] all segments, [5] bins,
  * [6] of [1]: those that needed the 1024-thread variant.  [0..3] count GROUPS of consecutive segments (k_kmer_groups). */
