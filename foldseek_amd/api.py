@@ -97,6 +97,7 @@ def lib():
         "fshost_kmer_threshold": (i32, [f32, i32]),
         "fshost_matrix_create": (vp, [i32, f32, f32]),
         "fshost_matrix_from_text": (vp, [C.c_char_p, f32, f32]),
+        "fshost_matrix_from_scores": (vp, [vp, i32, vp]),
         "fshost_matrix_free": (None, [vp]),
         "fshost_matrix_size": (i32, [vp]),
         "fshost_matrix_scores": (C.POINTER(C.c_int16), [vp]),

@@ -237,6 +237,19 @@ fshost_matrix *fshost_matrix_from_text(const char *text, float bitFactor, float 
     if (!h->m.parse(text, bitFactor, scoreBias)) { delete h; return nullptr; }
     return h;
 }
+fshost_matrix *fshost_matrix_from_scores(const int16_t *scores, int n, const double *pBack) {
+    if (!scores || !pBack || n < 1 || n > 32) return nullptr;
+    fshost_matrix *h = new fshost_matrix();
+    fsh::Matrix &m = h->m;
+    m.n = n;
+    m.sub.assign(scores, scores + (size_t) n * n);
+    m.tiny.resize((size_t) n * n);
+    for (size_t i = 0; i < (size_t) n * n; i++) m.tiny[i] = (int8_t) scores[i];
+    m.pBack.assign(pBack, pBack + n);
+    m.letters.assign((size_t) n, '?');
+    for (int i = 0; i < 256; i++) m.aa2num[i] = (uint8_t) (n - 1);           // no alphabet: callers of this variant pass numeric codes
+    return h;
+}
 void fshost_matrix_free(fshost_matrix *m) { delete m; }
 int fshost_matrix_size(const fshost_matrix *m) { return m ? m->m.n : 0; }
 const int16_t *fshost_matrix_scores(const fshost_matrix *m) { return m ? m->m.sub.data() : nullptr; }

@@ -37,6 +37,9 @@ enum { FSHOST_MAT_3DI = 0, FSHOST_MAT_BLOSUM62 = 1 };
 fshost_matrix *fshost_matrix_create(int which, float bitFactor, float scoreBias);
 /* user matrix in the .out text format (--sub-mat); NULL on parse error */
 fshost_matrix *fshost_matrix_from_text(const char *text, float bitFactor, float scoreBias);
+/* from an already scaled matrix: scores[n * n] (row-major, BaseMatrix::subMatrix) and background[n] (BaseMatrix::pBack) as the reference's
+ * SubstitutionMatrix object holds them -- what an adapter inside the reference has at hand.  No letters: numeric codes only. */
+fshost_matrix *fshost_matrix_from_scores(const int16_t *scores, int n, const double *pBack);
 void fshost_matrix_free(fshost_matrix *m);
 int fshost_matrix_size(const fshost_matrix *m);                 /* alphabet size incl. X (21) */
 const int16_t *fshost_matrix_scores(const fshost_matrix *m);    /* [n*n] bit-scaled substitution scores */

@@ -11,7 +11,8 @@
 #                            libfsgpu.so: the reference's own ungappedprefilter.cpp / gpuserver.cpp / GpuUtil.cpp
 #                            compiled and linked against this repository's Marv class with zero source hunks
 #   oracle/_ref_full/bin/foldseek        the reference, CPU path      (travels to the GPU box: CPU baseline + checker)
-#   oracle/_ref_full/bin/foldseek-fsgpu  the reference + our Marv      (travels to the GPU box: drop-in test)
+#   oracle/_ref_full/bin/foldseek-fsgpu  the reference + our Marv + the INTEGRATION.md 2 / 2b adapters (structurealign / prefilter
+#                                        --gpu 1 call libfsgpu.so; hunks in oracle/_ref_full/adapter_hunks.diff)  (travels to the GPU box: drop-in tests)
 #
 # The stock build cannot run here: M/CMakeLists.txt:210-251 imports the Rust crate lib/block-aligner through
 # corrosion and no cargo/rustc exists in this image.  The patch (oracle/patch_ref_full.py) replaces exactly that
@@ -28,11 +29,11 @@ WHAT="${1:-all}"          # cpu | gpu | all
 
 [ -d "$REF/src" ] || { echo "no reference tree at $REF" >&2; exit 2; }
 mkdir -p "$OUT/bin"
-if [ ! -f "$OUT/src/.patched" ]; then
+if [ ! -f "$OUT/src/.patched_v2" ]; then
     rm -rf "$OUT/src"
     cp -a "$REF" "$OUT/src"
     python3 "$HERE/patch_ref_full.py" "$OUT/src" "$REPO"
-    touch "$OUT/src/.patched"
+    touch "$OUT/src/.patched_v2"
 fi
 
 COMMON=(-G Ninja -DCMAKE_BUILD_TYPE=Release -DHAVE_AVX2=1 -DENABLE_PROSTT5=0 -DENABLE_STRUCTTY=0
