@@ -275,3 +275,203 @@ def _walk(bt, i, j):
             i += 1
         else:
             j += 1
+
+
+# ---- the crate's tie rules, stated independently, against the restatement on tie-rich inputs ---------------------------------------
+# When the block covers the whole DP matrix (block size >= both lengths, global variant) the crate computes ONE `right` block
+# (scan_block.rs:268-330: the first Grow step places a block of the full width with right = true), so the adaptive trajectory plays no role
+# and the backtrace is a function of the recurrences and of three documented tie rules (scan_block.rs:1492-1576, 1870-1925):
+#   C (gap consuming the reference, op D) = max(C[i][j-1] + ext, D[i][j-1] + open); "gap beginning" bit = (C == open candidate): ties -> open
+#   R (gap consuming the query, op I)     = max(R[i-1][j] + ext, D'[i-1][j] + open) (inclusive prefix scan); bit likewise: ties -> open
+#   D = max(D[i-1][j-1] + s, C, R); trace bits (D == C), (D == R); OP_LUT for right blocks: C before R before the diagonal.
+# _rule_model below is a scalar statement of exactly that, written from the crate's source and sharing no code with block_aligner.cpp.  It is
+# first held against the crate's OWN known answers (test_trace: "3M1D", "2M6I16M3D", the two "9=2I4=1I"), then the restatement is held
+# against it on homopolymers, tandem repeats and equal-score substitution / gap alternatives -- inputs where co-optimal paths abound.
+def _rule_model(q, r, score, go, ge, first_down=None):
+    """global alignment of q vs r with the crate's tie rules; returns (score, cigar with M/I/D runs).  Cells of DP rows >= first_down lie in
+    `down` blocks (right = false), where OP_LUT mirrors the precedence: R (op I) before C (op D) before the diagonal"""
+    n, m = len(q), len(r)
+    NEG = -10 ** 6
+    D = [[NEG] * (m + 1) for _ in range(n + 1)]
+    Cm = [[NEG] * (m + 1) for _ in range(n + 1)]
+    Rm = [[NEG] * (m + 1) for _ in range(n + 1)]
+    c_open = [[False] * (m + 1) for _ in range(n + 1)]
+    r_open = [[False] * (m + 1) for _ in range(n + 1)]
+    t_c = [[False] * (m + 1) for _ in range(n + 1)]
+    t_r = [[False] * (m + 1) for _ in range(n + 1)]
+    for j in range(m + 1):
+        pre_above = NEG                       # D' (before the max with R) of the cell above in this column
+        for i in range(n + 1):
+            if i == 0 and j == 0:
+                D[0][0] = 0
+                pre_above = 0
+                continue
+            c = NEG
+            if j > 0:
+                oc, ec = D[i][j - 1] + go, Cm[i][j - 1] + ge
+                c = max(oc, ec)
+                c_open[i][j] = c == oc
+            Cm[i][j] = c
+            diag = D[i - 1][j - 1] + score(q[i - 1], r[j - 1]) if i > 0 and j > 0 else NEG
+            pre = max(diag, c)
+            rr = NEG
+            if i > 0:
+                orr, er = pre_above + go, Rm[i - 1][j] + ge
+                rr = max(orr, er)
+                r_open[i][j] = rr == orr
+            Rm[i][j] = rr
+            D[i][j] = max(pre, rr)
+            t_c[i][j] = D[i][j] == c
+            t_r[i][j] = D[i][j] == rr
+            pre_above = pre
+    ops, i, j, table = [], n, m, "D"
+    while i > 0 or j > 0:
+        if table == "D":
+            down = first_down is not None and i >= first_down
+            first, second = (("R", t_r), ("C", t_c)) if down else (("C", t_c), ("R", t_r))
+            take = first[0] if first[1][i][j] else (second[0] if second[1][i][j] else "M")
+            if take == "C":
+                ops.append("D"); table = "D" if c_open[i][j] else "C"; j -= 1
+            elif take == "R":
+                ops.append("I"); table = "D" if r_open[i][j] else "R"; i -= 1
+            else:
+                ops.append("M"); i -= 1; j -= 1
+        elif table == "C":
+            ops.append("D"); table = "D" if c_open[i][j] else "C"; j -= 1
+        else:
+            ops.append("I"); table = "D" if r_open[i][j] else "R"; i -= 1
+    ops.reverse()
+    out, k = "", 0
+    while k < len(ops):
+        e = k
+        while e < len(ops) and ops[e] == ops[k]:
+            e += 1
+        out += f"{e - k}{ops[k]}"
+        k = e
+    return D[n][m], out
+
+
+def _simple(match, mismatch):
+    return lambda a, b: match if a == b else mismatch
+
+
+def _blosum_ar_score(a, b):
+    return {("A", "A"): 4, ("R", "R"): 5}.get((a, b), -1)
+
+
+def test_rule_model_reproduces_the_crates_own_known_answers():
+    """the independent statement of the tie rules is itself pinned: scan_block.rs:2366-2412 (test_trace)"""
+    assert _rule_model("AAA", "AAAA", _blosum_ar_score, -11, -1) == (1, "3M1D")
+    assert _rule_model("TTTTTTTTAAAAAAATTTTTTTTT", "TTAAAAAAATTTTTTTTTTTT", _simple(1, -1), -2, -1) == (7, "2M6I16M3D")
+    assert _rule_model("AAAAAAAAATTGCGCT", "AAAAAAAAAGCGC", _simple(1, -1), -2, -1)[0] == 8
+    assert _rule_model("AAAAAAAAATTGCGCT", "AAAAAAAAAGCGC", _simple(1, -1), -2, -1)[1].replace("M", "=") == "9=2I4=1I"
+    assert _rule_model("AAAAAAAAATTGCGCT", "AAAAAAAAAGCGC", _simple(2, -1), -5, -2) == (14, "9M2I4M1I")
+    assert _rule_model("AAAAAA", "AAARRA", _blosum_ar_score, -11, -1) == (14, "6M")
+
+
+def _tie_rich_cases():
+    rng = np.random.default_rng(7)
+    cases = [("AAAA", "AAA"), ("AAA", "AAAA"), ("AAAAAAAA", "AAAAA"), ("ATATATAT", "ATATAT"), ("ATATAT", "ATATATATAT"), ("AATTAATT", "AATT"),
+             ("ACGTACGTACGT", "ACGTACGT"), ("A", "AAAA"), ("AAAA", "A"), ("AT", "TA"), ("ATAT", "TATA"), ("AAAT", "TAAA"), ("GATTACA", "GCATGCT"),
+             ("AAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", "AAAAAAAAAAAAAAAAAAAAAAAA"), ("ACACACACACACACAC", "CACACACACACACA"), ("AGAGAGAG", "GAGAGAGAGAGA")]
+    for _ in range(160):
+        unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+        a = unit * int(rng.integers(1, 12)) + "".join(rng.choice(list("AC"), size=int(rng.integers(0, 4))))
+        b = unit * int(rng.integers(1, 12)) + "".join(rng.choice(list("AC"), size=int(rng.integers(0, 4))))
+        if rng.random() < 0.5:
+            a, b = a[::-1], b[::-1]
+        if 0 < len(a) <= 60 and 0 < len(b) <= 60:
+            cases.append((a, b))
+    return cases
+
+
+@pytest.mark.parametrize("scheme", [(1, -1, -2, -1), (2, -1, -5, -2), (1, -1, -3, -1), (3, -2, -4, -2), (1, -3, -2, -1)])
+def test_restatement_follows_the_crates_tie_rules_on_tie_rich_inputs(ba, scheme):
+    """homopolymers, tandem repeats, shifted repeats: every co-optimal choice (which gap, where it opens, gap vs substitution) must come out
+    the way the crate's rules decide it"""
+    L = ba
+    match, mismatch, go, ge = scheme
+    m = L.block_new_simple_aamatrix(match, mismatch)
+    g = Gaps(go, ge)
+    cg = L.block_new_cigar(128, 128)
+    a = L.block_new_aa_trace(128, 128, 64)
+    checked = gapped = 0
+    for q, r in _tie_rich_cases():
+        pq, pr = padded(L, q.encode(), 64), padded(L, r.encode(), 64)
+        L.block_align_aa_trace(a, pq, pr, m, g, SizeRange(64, 64), 0)
+        res = L.block_res_aa_trace(a)
+        L.block_cigar_aa_trace(a, res.query_idx, res.reference_idx, cg)
+        want_score, want_cigar = _rule_model(q, r, _simple(match, mismatch), go, ge)
+        assert (res.score, res.query_idx, res.reference_idx) == (want_score, len(q), len(r)), (q, r, scheme)
+        assert cigar_str(L, cg) == want_cigar, (q, r, scheme, cigar_str(L, cg), want_cigar)
+        checked += 1
+        gapped += ("I" in want_cigar) or ("D" in want_cigar)
+    assert checked >= 150 and gapped >= 100
+
+
+@pytest.mark.parametrize("scheme", [(1, -1, -2, -1), (2, -1, -5, -2), (1, -3, -2, -1)])
+def test_restatement_follows_the_mirrored_rules_in_down_blocks(ba, scheme):
+    """block size 16 and a reference of at most 15 residues: the first block spans every column, so every later step is forced DOWN
+    (scan_block.rs:412-421) -- DP rows from 16 on lie in `down` blocks, whose OP_LUT half prefers R (op I) to C (op D)"""
+    L = ba
+    match, mismatch, go, ge = scheme
+    m = L.block_new_simple_aamatrix(match, mismatch)
+    g = Gaps(go, ge)
+    cg = L.block_new_cigar(128, 128)
+    a = L.block_new_aa_trace(128, 128, 16)
+    rng = np.random.default_rng(11)
+    checked = differs = 0
+    for k in range(4000):
+        if k % 12 == 0:         # repeats
+            unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4))))
+            r = (unit * 8)[: int(rng.integers(3, 16))]
+            q = (unit * 30)[: int(rng.integers(17, 60))]
+        else:                   # three-letter strings: equal-score gap / substitution alternatives in every region of the matrix
+            r = "".join(rng.choice(list("ATC"), size=int(rng.integers(3, 16))))
+            q = "".join(rng.choice(list("ATC"), size=int(rng.integers(17, 40))))
+        want_score, want_cigar = _rule_model(q, r, _simple(match, mismatch), go, ge, first_down=16)
+        decisive = want_cigar != _rule_model(q, r, _simple(match, mismatch), go, ge)[1]
+        if not decisive and k % 8:
+            continue            # the aligner runs on every case the mirrored rule decides and on a sample of the others
+        pq, pr = padded(L, q.encode(), 16), padded(L, r.encode(), 16)
+        L.block_align_aa_trace(a, pq, pr, m, g, SizeRange(16, 16), 0)
+        res = L.block_res_aa_trace(a)
+        L.block_cigar_aa_trace(a, res.query_idx, res.reference_idx, cg)
+        assert res.score == want_score, (q, r, scheme)
+        assert cigar_str(L, cg) == want_cigar, (q, r, scheme, cigar_str(L, cg), want_cigar)
+        differs += decisive
+        checked += 1
+    assert checked >= 450 and differs >= 15          # the mirrored rule decides the path on these inputs
+
+
+# ---- oracle/ba_kat: the C-ABI harness that runs on the restatement here and on the Rust crate wherever cargo exists -----------------
+def test_ba_kat_harness_and_crate_answers_when_present(tmp_path):
+    """oracle/ba_kat/ba_kat.cpp (block aligner C ABI only) over the 697 committed cases (397 align_3di call sequences of
+    alignStartPosBacktraceBlock on homolog pairs incl. homopolymer / tandem-repeat / low-complexity families, 300 single-matrix tie-rich
+    strings over four block-size ranges with and without x-drop): the restatement reaches the target score in every 3di case and
+    reproduces its frozen answers (ours_v1.txt); and when somebody with a Rust toolchain has run `make -C oracle/ba_kat crate.txt
+    CRATE=.../lib/block-aligner` and committed crate.txt, every line (score, end cell, CIGAR, block sizes tried) must equal the crate's.
+    Without crate.txt the co-optimal-path choices of the ADAPTIVE trajectory stay unpinned against the crate -- said here, in
+    DESIGN.md 2 and in the test's skip message, not hidden."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kat = os.path.join(root, "oracle", "ba_kat")
+    exe = str(tmp_path / "ba_kat_ours")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mavx2", "-mfma", "-I" + os.path.join(root, "foldseek_amd", "csrc", "host"), "-o", exe,
+                           os.path.join(kat, "ba_kat.cpp"), os.path.join(root, "foldseek_amd", "csrc", "host", "block_aligner.cpp")])
+    ours = subprocess.run([exe, kat], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    assert len(ours) == 697
+    for ln in ours:
+        name, score = ln.split("\t")[:2]
+        if "@" in name:
+            assert int(score) == int(name.split("@")[1]), ln
+    assert ours == open(os.path.join(kat, "ours_v1.txt")).read().splitlines()
+    crate = os.path.join(kat, "crate.txt")
+    if not os.path.exists(crate):
+        pytest.skip("oracle/ba_kat/crate.txt absent (no Rust toolchain in this image): CIGAR tie-breaks of the adaptive block trajectory are NOT pinned "
+                    "against the crate; run `make -C oracle/ba_kat crate.txt CRATE=<reference>/lib/mmseqs/lib/block-aligner` where cargo exists")
+    want = open(crate).read().splitlines()
+    assert len(want) == len(ours)
+    bad = [(a, b) for a, b in zip(ours, want) if a != b]
+    assert not bad, bad[:5]
