@@ -231,33 +231,49 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
         c.close()
     if rank != 0:
         return None
-    probes = float(solo_cnt[0])
-    lists_s = solo_ms[10] * 1e-3
-    alg = probes * 8.0                                         # two uint32 offsets per similar k-mer
-    reg_ms = float(np.mean(stat["lists"]))
-    reg_probes = float(np.mean([c[0] for c in stat["counts"]]))
-    reg_alg = reg_probes * 8.0
+    # Roofline of the device part of ONE prefilter batch (32 queries, every k_kmer_* kernel from the similar-k-mer lists to the selected
+    # results, HIP events on the library's stream).  Algorithmic bytes: 8 per similar k-mer (the two u32 offsets of its probe)
+    # + 8 per index hit (the entry gathered) + the target residues under every scored diagonal.  "traffic": FETCH_SIZE + WRITE_SIZE of all
+    # k_kmer_* kernels of such a batch from a committed --pmc pass, per index hit, times this batch's hits.
+    qlen = float(np.mean([len(q) for q in q3]))
+
+    def alg_of(cnt):
+        return 8.0 * float(cnt[0]) + 8.0 * float(cnt[1]) + float(cnt[2]) * qlen
+
+    reg_ms = float(np.mean(stat["dev"]))
+    reg_cnt = np.mean(np.asarray(stat["counts"], dtype=np.float64), axis=0)
+    reg_alg, alg = alg_of(reg_cnt), alg_of(solo_cnt)
     e, traffic_src = pmc_traffic_entry(os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json"), args.targets)
-    traffic = None if e is None else e["k_kmer_lists_bytes_per_probe"] * probes
+    per_hit = None if e is None else e.get("k_kmer_all_bytes_per_index_hit")
+    lists_per_probe = None if e is None else e.get("k_kmer_lists_bytes_per_probe")
+    probes, lists_s = float(solo_cnt[0]), solo_ms[10] * 1e-3
     out = {"workload": f"{nqk} queries in batches of 32 vs the same {db.n}-structure DB: k-mer prefilter (-s 9.5, k=6 spaced, "
                        f"--max-seqs 1000, double-diagonal + ungapped scoring) + fwd/rev structure SW on its hits (one multi-query SW launch per register class)",
            "value": world * nqk * db.residues / dt, "unit": "residues/s", "queries_per_s": world * nqk / dt,
            "ms_per_query": 1e3 * dt / nqk, "prefilter_ms_per_query_host_wall": 1e3 * stat["t_pref"] / nqk,
            "align_ms_per_query_host_wall": 1e3 * stat["t_aln"] / nqk, "sw_kernels_ms_per_batch32": float(np.mean(stat["sw"])), "prefilter_device_ms_per_query": float(np.sum(stat["dev"])) / nqk,
+           "prefilter_device_ms_per_query_solo": solo_ms[0] / 32,
            "host_threads": KT, "index_build_s": t_index, "index_entries": int(ctx0.kmer_index_entries), "kmer_threshold": thr,
-           "similar_kmers_per_query": float(np.mean([c[0] for c in stat["counts"]])) / 32, "index_hits_per_query": float(np.mean([c[1] for c in stat["counts"]])) / 32,
-           "candidates_per_query": float(np.mean([c[2] for c in stat["counts"]])) / 32,
+           "similar_kmers_per_query": float(reg_cnt[0]) / 32, "index_hits_per_query": float(reg_cnt[1]) / 32,
+           "candidates_per_query": float(reg_cnt[2]) / 32,
            "hits_per_query": stat["hits"] / nqk, "alignments_per_query": stat["aln"] / nqk, "unsupported_queries": stat.get("bad", 0),
            "stage_ms_per_batch32_solo": {k: solo_ms[i] for i, k in enumerate(["device_total", "count", "lists", "emit", "partition", "dup", "score", "replay", "select", "host_tail", "k_kmer_lists"])},
-           # k_kmer_lists per-launch duration: HIP events on the library's stream, mean over the batches of the timed region
-           # (the host threads overlap their batches); "solo" = the same launch alone on the device
-           "roofline": {"bound": "hbm", "kernel": "k_kmer_lists", "kernel_ms": reg_ms, "achieved": reg_alg / (reg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": reg_alg / (reg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None if traffic is None else traffic * reg_probes / probes, "traffic_source": traffic_src,
-                        "algorithmic_bytes": reg_alg, "probes_per_launch": reg_probes, "probes_per_s": reg_probes / (reg_ms * 1e-3),
-                        "solo": {"kernel_ms": solo_ms[10], "achieved": alg / lists_s / 1e9, "frac": alg / lists_s / 1e9 / 8000.0, "probes_per_launch": probes,
-                                 "traffic": traffic},
-                        "note": "random 8-byte probes of the 256 MB k-mer offset table (algorithmic bytes = 8 per similar k-mer); the hardware "
-                                "moves a sector per probe of a non-empty list, see DESIGN.md 4.5"}}
+           "segments_solo": {k: int(v) for k, v in zip(["groups_one_wave", "groups_lds", "groups_global_scratch", "segments_with_candidates", "segments", "bins", "groups_lds_1024_threads"], kctx[0].kmer_segments())},
+           # kernel_ms: mean over the batches of the timed region (the host threads overlap their batches and the SW launches);
+           # "solo" = the same batch alone on the device
+           "roofline": {"bound": "hbm", "kernel": "k_kmer_* (the device part of one prefilter batch of 32 queries, all kernels)", "kernel_ms": reg_ms,
+                        "achieved": reg_alg / (reg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": reg_alg / (reg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None if per_hit is None else per_hit * float(reg_cnt[1]), "traffic_source": traffic_src,
+                        "algorithmic_bytes": reg_alg, "index_hits_per_launch": float(reg_cnt[1]), "index_hits_per_s": float(reg_cnt[1]) / (reg_ms * 1e-3),
+                        "solo": {"kernel_ms": solo_ms[0], "achieved": alg / (solo_ms[0] * 1e-3) / 1e9, "frac": alg / (solo_ms[0] * 1e-3) / 1e9 / 8000.0,
+                                 "algorithmic_bytes": alg, "index_hits_per_launch": float(solo_cnt[1]), "index_hits_per_s": float(solo_cnt[1]) / (solo_ms[0] * 1e-3),
+                                 "traffic": None if per_hit is None else per_hit * float(solo_cnt[1])},
+                        "k_kmer_lists_solo": {"kernel_ms": solo_ms[10], "algorithmic_bytes": probes * 8.0, "achieved": probes * 8.0 / max(lists_s, 1e-12) / 1e9,
+                                              "frac": probes * 8.0 / max(lists_s, 1e-12) / 1e9 / 8000.0, "probes_per_s": probes / max(lists_s, 1e-12),
+                                              "traffic": None if lists_per_probe is None else lists_per_probe * probes},
+                        "note": "bytes = 8 per similar k-mer + 8 per index hit + diagonal residues; the hit stream itself (8-byte records: written by the emit, "
+                                "moved twice by the two-level partition, read by the duplicate-diagonal kernels) is pipeline traffic, not algorithmic, "
+                                "so frac is bounded by about 8 / (8 + 5 * 8) even at HBM speed, see DESIGN.md 4.5"}}
     return out
 
 

@@ -670,8 +670,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         RPCHK(hipMemsetAsync(S.binCount.p, 0, ((size_t) nSeg + 1) * sizeof(uint32_t), st));
         RPCHK(hipMemsetAsync(segLists.counts, 0, 16 * sizeof(uint32_t), st));
         const unsigned nTiles = gridFor(nHits, hitTile);
-        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, kEmitTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p,
-                           (const uint16_t *) S.posQuery.p, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
+        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, kEmitTile)), dim3(256), 0, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
                            (const uint32_t *) S.listPos.p, ix.entries, nHits, (uint64_t *) S.rec.p);
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[3], st));

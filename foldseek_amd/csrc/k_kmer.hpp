@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     if (threadIdx.x == 0) runOx[nV] = carry;
     __syncthreads();
     const uint64_t base = Kbase[p];
+    const uint32_t qpos = ((uint32_t) posQuery[p] << 16) | (p - q.posBase);     // what k_kmer_emit needs of a list: its query and the k-mer's position in it
     for (uint32_t r0 = threadIdx.x; r0 < Kp; r0 += 4 * kKmerBlock) {
         uint32_t kmer[4], st[4], en[4];
 #pragma unroll
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t r = r0 + u * kKmerBlock;
-            if (r < Kp) { listStart[base + r] = st[u]; listSize[base + r] = en[u] - st[u]; listPos[base + r] = p; }
+            if (r < Kp) { listStart[base + r] = st[u]; listSize[base + r] = en[u] - st[u]; listPos[base + r] = qpos; }
         }
     }
 }
@@ -368,7 +369,7 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
         while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid + 1] >= want) hi = mid; else lo = mid + 1; }
         if (lo >= le) break;
         const uint64_t G2 = listP[lo] - base;
-        if (listP[lo + 1] - listP[lo] >= maxDbMatches) { c.aborted = 1; c.abortKmers = Kbase[listPos[lo] + 1] - lb; }
+        if (listP[lo + 1] - listP[lo] >= maxDbMatches) { c.aborted = 1; c.abortKmers = Kbase[qs[q].posBase + (listPos[lo] & 0xffffu) + 1] - lb; }
         if (nc >= (uint32_t) kMaxChunks) { c.aborted = 2; break; }
         c.start[nc++] = G2;
         if (c.aborted) break;
@@ -402,6 +403,7 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
 // --------------------------------------------------------------------------------------------------------------
 constexpr int kEmitTile = 2048;               // hits per workgroup of k_kmer_emit
 constexpr int kEmitStage = 6144;              // list prefixes of an emit tile staged in LDS (24 KB -> 6 workgroups per CU)
+static_assert(kEmitStage < 8192, "k_kmer_emit searches the staged prefixes with 13 halving steps");
 constexpr int kDupCap = 2560;                 // hits of a segment group resolved in LDS by a 512-thread workgroup (four of them per CU)
 constexpr int kDupCapLarge = 12288;           // ... by a 1024-thread workgroup that owns the CU's LDS; beyond: global scratch
 constexpr int kDupSmall = 64;                 // ... at most this many: one wave, all-pairs in registers (k_kmer_dup_small)
@@ -440,9 +442,8 @@ __host__ __device__ inline uint32_t partD16(uint64_t r) { return (uint32_t) r & 
 __host__ __device__ inline uint32_t partD8(uint64_t r) { return (uint32_t) r & 0xffu; }
 
 // Output-balanced gather: one thread per hit, list found by binary search over the staged list prefixes.
-__global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const uint16_t *posQuery, uint64_t nLists, const uint64_t *listP,
-                                                   const uint32_t *listStart, const uint32_t *listPos, const uint64_t *entries,
-                                                   uint64_t nHits, uint64_t *rec) {
+__global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64_t *listP, const uint32_t *listStart, const uint32_t *listPos /* query << 16 | position */,
+                                                   const uint64_t *entries, uint64_t nHits, uint64_t *rec) {
     __shared__ uint64_t range[2];
     __shared__ uint32_t rel[kEmitStage + 1];  // list prefix relative to the block's first list
     const uint64_t o0 = (uint64_t) blockIdx.x * kEmitTile;
@@ -466,44 +467,47 @@ __global__ __launch_bounds__(256) void k_kmer_emit(const KmerQ *qs, const uint16
     // 8 outputs per thread, handled phase by phase so that the dependent loads of all 8 are in flight together
     constexpr int U = kEmitTile / 256;
     uint64_t l[U];
+    if (staged) {
+        // the 8 searches of a thread advance in lockstep (fixed 13 halving steps, no data-dependent branch): 8 independent LDS reads per
+        // step instead of 8 x 13 dependent ones
+        uint32_t lo[U], ro[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const uint64_t o = o0 + threadIdx.x + 256 * u;
-        l[u] = l0;
-        if (o < o1) {
-            if (staged) {
-                const uint32_t ro = (uint32_t) (o - p0);
-                int lo = 0, hi = nl;
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rel[mid] <= ro) lo = mid; else hi = mid; }
-                l[u] = l0 + lo;
-            } else {
-                uint64_t lo = l0, hi = l1 + 1;
-                while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
-                l[u] = lo;
+        for (int u = 0; u < U; u++) { lo[u] = 0; ro[u] = (uint32_t) (min<uint64_t>(o0 + threadIdx.x + 256 * u, o1 - 1) - p0); }
+        for (uint32_t step = 4096; step >= 1; step >>= 1) {          // kEmitStage < 8192: last index with rel[index] <= ro
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t cand = lo[u] + step;
+                if (cand < (uint32_t) nl && rel[cand] <= ro[u]) lo[u] = cand;
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = l0 + lo[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t o = min<uint64_t>(o0 + threadIdx.x + 256 * u, o1 - 1);
+            uint64_t lo = l0, hi = l1 + 1;
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
+            l[u] = lo;
+        }
     }
+    // two dependent global round trips per hit: (list record) -> (index entry); the list's first stream position comes from the staged prefixes
     uint32_t p[U], st[U];
     uint64_t lp[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) { p[u] = listPos[l[u]]; st[u] = listStart[l[u]]; lp[u] = listP[l[u]]; }
+    for (int u = 0; u < U; u++) { p[u] = listPos[l[u]]; st[u] = listStart[l[u]]; lp[u] = staged ? p0 + rel[(uint32_t) (l[u] - l0)] : listP[l[u]]; }
     uint64_t e[U];
-    uint32_t qi[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint64_t o = o0 + threadIdx.x + 256 * u;
         e[u] = o < o1 ? entries[(uint64_t) st[u] + (o - lp[u])] : 0;
-        qi[u] = posQuery[p[u]];
     }
-    uint32_t pb[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) pb[u] = qs[qi[u]].posBase;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint64_t o = o0 + threadIdx.x + 256 * u;
         if (o >= o1) continue;
         const uint32_t posj = (uint32_t) e[u] & 0xffffu;
-        rec[o] = recPack((uint32_t) (e[u] >> 16), (p[u] - pb[u] - posj) & 0xffffu);
+        rec[o] = recPack((uint32_t) (e[u] >> 16), ((p[u] & 0xffffu) - posj) & 0xffffu);
     }
 }
 
@@ -1000,8 +1004,10 @@ __device__ inline int kmerDiagScore(const int8_t *prof, const uint8_t *db, int l
     // head: up to the first 8-byte boundary of the target
     const int head = min(len, (int) ((8 - ((uintptr_t) db & 7)) & 7));
     for (; pos < head; pos++) { s += prof[pos * 21 + db[pos]]; s = s < 0 ? 0 : s; mx = s > mx ? s : mx; }
+    uint64_t wNext = pos + 8 <= len ? *reinterpret_cast<const uint64_t *>(db + pos) : 0;
     for (; pos + 8 <= len; pos += 8) {
-        const uint64_t w = *reinterpret_cast<const uint64_t *>(db + pos);
+        const uint64_t w = wNext;
+        if (pos + 16 <= len) wNext = *reinterpret_cast<const uint64_t *>(db + pos + 8);      // in flight while these 8 cells are scored
         const int8_t *p = prof + pos * 21;
         int v[8];
 #pragma unroll

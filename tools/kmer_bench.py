@@ -12,12 +12,14 @@ m8 = api.Matrix(0, 8.0, -0.2); m2 = api.Matrix(0, 2.0, -0.2)
 t = time.time(); ctx.kmer_index_build(m8, kmer_thr=78); print("index build %.3fs entries=%d" % (time.time() - t, ctx.kmer_index_entries), flush=True)
 t = time.time(); prep = [api.kmer_query_prepare(m8, m2, q) for q in q3]; print("host prepare %.3f ms/query" % ((time.time() - t) / NQ * 1e3))
 for rep in range(REPS):
-    stages = np.zeros(11); t = time.time(); hits = 0
+    stages = np.zeros(11); t = time.time(); hits = 0; counts = np.zeros(4)
     for b in range(0, NQ, 32):
         res, status, stats = ctx.kmer_search(prep[b:b + 32], max_res=1000, want_stats=True)
-        stages += np.array(ctx.kmer_stage_ms()); hits += stats[:, 1].sum()
+        stages += np.array(ctx.kmer_stage_ms()); hits += stats[:, 1].sum(); counts += np.array(ctx.kmer_counts(), dtype=np.float64)
         assert (status >= 0).all()
     dt = time.time() - t
     print("segments of the last batch [wave, LDS, global, with candidates, all, bins, of LDS: 1024-thread]:", ctx.kmer_segments() if hasattr(ctx, "kmer_segments") else None)
     print("rep %d: %.3f ms/query wall, device %.3f ms/query; stage ms/query %s; hits/query %.0f; prefilter residues/s %.3e" % (
         rep, dt / NQ * 1e3, stages[0] / NQ, ["%.3f" % (x / NQ) for x in stages[1:]], hits / NQ, NQ * db.residues / dt), flush=True)
+    print("COUNTS " + __import__("json").dumps({"targets": N, "queries": NQ, "similar_kmers": counts[0], "index_hits": counts[1], "candidates": counts[2],
+                                                   "mean_query_len": float(np.mean([len(q) for q in q3])), "device_ms": stages[0]}), flush=True)

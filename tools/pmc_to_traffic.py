@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Turn the --pmc summaries of tools/r03_profile.sh (gpurun_out/r03_prof/TAG_*) into the per-unit HBM bytes bench.py reports as
+`roofline.traffic` (profiles/pmc_traffic.json, profiles/pmc_traffic_kmer.json), stamped with the hash of the kernel sources they were
+collected on (tools/csrc_hash.py; bench.py drops an entry whose hash is not the running one).
+usage: pmc_to_traffic.py gpurun_out/r03_prof TAG profiles/<name of the committed summary files' prefix>"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import ROOT, csrc_hash
+
+d, tag, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
+GAPLESS_FILES, KMER_FILES = ["k_gapless.hpp", "fs_kernels.h"], ["k_kmer.hpp", "fsgpu_kmer.hip", "fs_kernels.h"]
+hash_g = open(os.path.join(d, f"{tag}_csrc_hash_gapless.txt")).read().strip()
+hash_k = open(os.path.join(d, f"{tag}_csrc_hash_kmer.txt")).read().strip()
+for name, box, files in (("scan", hash_g, GAPLESS_FILES), ("k-mer", hash_k, KMER_FILES)):
+    if box != csrc_hash(files):
+        print(f"WARNING: the {name} kernel sources changed since the pass was collected ({box} on the box, {csrc_hash(files)} here): bench.py will report traffic null", file=sys.stderr)
+
+# --- main path: k_gapless per query slot
+b = json.load(open(os.path.join(d, f"{tag}_pmc_bench_1M.json")))
+g = b["fs::k_gapless"]["counters"]
+pt = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+t = json.load(open(pt))
+e = t["1000000"]
+e.update({"fetch_size_kb": g["FETCH_SIZE"]["per_query"], "write_size_kb": g["WRITE_SIZE"]["per_query"], "fetch_correction": 2.0,
+          "workload": f"1M-target synthetic DB (seed 20260923, 50 homologs per query), bench.py --steps 3 --warmup 1 --no-kmer --type2-steps 0 --allvsall-steps 0: "
+                      f"{g['FETCH_SIZE']['dispatches']} launches covering {g['FETCH_SIZE']['queries']:.0f} query slots",
+          "source": f"{prefix}_pmc_bench_1M_steps3.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per-query = counter total / (grid / (512 workgroups x 256 threads)); NOT collected in the run that prints it)",
+          "csrc_hash": hash_g, "csrc_files": GAPLESS_FILES})
+json.dump(t, open(pt, "w"), indent=1)
+valu = g["SQ_INSTS_VALU"]["per_query"]
+print(f"k_gapless: FETCH {e['fetch_size_kb']:.1f} KB x2 + WRITE {e['write_size_kb']:.1f} KB per query slot; SQ_INSTS_VALU per query slot {valu:.4e}")
+
+# --- k-mer prefilter: every kernel of one 32-query batch, per index hit
+k = json.load(open(os.path.join(d, f"{tag}_pmc_kmer_1M.json")))
+cnt = None
+for line in open(os.path.join(d, f"{tag}_pmc_kmer_1M_counts.txt")):
+    if line.startswith("COUNTS "):
+        cnt = json.loads(line[7:])
+hits, probes = cnt["index_hits"], cnt["similar_kmers"]
+fam = {n: (v["counters"].get("FETCH_SIZE", {}).get("total", 0.0), v["counters"].get("WRITE_SIZE", {}).get("total", 0.0)) for n, v in k.items()}
+# calibration on known byte counts in this access pattern (8 bytes per lane): k_kmer_bincount reads the hit records once (8 B per hit) and
+# writes only counters; k_kmer_scatter_coarse writes every record once (8 B per hit)
+fcal = 8.0 * hits / (fam["fs::k_kmer_bincount"][0] * 1024.0)
+wcal = 8.0 * hits / (fam["fs::k_kmer_scatter_coarse"][1] * 1024.0)
+rows, tot_raw, tot_cal = {}, 0.0, 0.0
+for n, (f, w) in sorted(fam.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
+    stream = not any(x in n for x in ("k_kmer_lists", "k_kmer_count"))          # those two are random 4-8 byte probes: raw counter
+    cal = (f * (fcal if stream else 1.0) + w * wcal) * 1024.0
+    rows[n.replace("fs::", "")] = {"fetch_kb": f, "write_kb": w, "bytes_calibrated": cal, "bytes_per_index_hit": cal / hits}
+    tot_raw += (f + w) * 1024.0
+    tot_cal += cal
+pk = os.path.join(ROOT, "profiles", "pmc_traffic_kmer.json")
+tk = json.load(open(pk))
+lists = rows["k_kmer_lists"]
+tk["1000000"] = {
+    "kernel": "k_kmer_* + the scans of one prefilter batch",
+    "workload": f"1M-target synthetic DB (seed 20260923), ONE batch of 32 queries (tools/kmer_bench.py 1000000 32 1): {probes:.0f} similar k-mers probed, {hits:.0f} index hits, {cnt['candidates']:.0f} double-diagonal candidates",
+    "index_hits": hits, "probes": probes,
+    "fetch_calibration": fcal, "write_calibration": wcal,
+    "k_kmer_all_bytes_per_index_hit": tot_cal / hits, "k_kmer_all_bytes_per_index_hit_raw_counters": tot_raw / hits,
+    "k_kmer_lists_bytes_per_probe": (lists["fetch_kb"] + lists["write_kb"] * wcal) * 1024.0 / probes,
+    "per_kernel": rows,
+    "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes. The counters are calibrated on known byte counts in this pipeline's own access pattern "
+            "(8-byte records, one per lane): k_kmer_bincount fetches exactly 8 B per hit, k_kmer_scatter_coarse writes exactly 8 B per hit; fetch_calibration / "
+            "write_calibration are bytes per reported byte (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a wide streaming read, other widths "
+            "to be calibrated). The random 4-8 byte probes of k_kmer_count / k_kmer_lists keep the raw fetch counter.",
+    "source": f"{prefix}_pmc_kmer_batch32_1M.txt (rocprofv3 --pmc passes of tools/kmer_bench.py 1000000 32 1; NOT collected in the run that prints it)",
+    "csrc_hash": hash_k, "csrc_files": KMER_FILES}
+json.dump(tk, open(pk, "w"), indent=1)
+print(f"k-mer batch: {hits:.3e} hits, calibrations fetch {fcal:.3f} write {wcal:.3f}; {tot_cal / hits:.1f} B per index hit (raw counters {tot_raw / hits:.1f})")
+for n, r in rows.items():
+    if r["bytes_per_index_hit"] > 0.05:
+        print(f"   {n:32s} {r['bytes_per_index_hit']:7.2f} B/hit  (fetch {r['fetch_kb']:.0f} KB, write {r['write_kb']:.0f} KB)")
