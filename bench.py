@@ -311,14 +311,18 @@ def sw_roofline(passes, has_aa, solo=None):
     out = {"bound": "valu-issue", "kernel": "k_sw2", "unit": "Gcell/s", "peak": peak, "achieved": cells / max(ms, 1e-9) / 1e6,
            "frac": cells / max(ms, 1e-9) / 1e6 / peak, "cells_per_pass_pair": cells / max(1, len(passes)), "kernel_ms_per_pass_pair": ms / max(1, len(passes)),
            "traffic": None,
-           # the same passes priced in what the waves really issue (two targets per wave run max(LtA, LtB) + lanes - 1 steps of `per` x R rows):
-           # the gap to `frac` is lane padding, wavefront fill / drain and the shorter target of a wave
-           "issued_dp_instr_frac": instr / max(ms, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3),
+           # the same passes priced in what the waves really issue: two targets per wave run max(LtA, LtB) + lanes - 1 steps of 14 R + 26 VALU
+           # instructions (16 R + 34 with the AA table; counted in the kernel's ISA), 4.3 cycles each.  frac / issued_valu_frac = the share of the
+           # issued stream that is the 14 (16) DP instructions of real cells: the rest is the step overhead, lane padding, wavefront fill / drain
+           # and the shorter target of a wave
+           "issued_valu_frac": instr / max(ms, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3),
            "note": "co-running with the other feeder threads' scans; DP cells = query rows x target columns of every pair of both passes"}
     if solo is not None:
         c = sum(float(solo[d][1]) for d in (0, 1) if solo[d][0] >= 0)
         m = sum(float(solo[d][0]) for d in (0, 1) if solo[d][0] >= 0)
-        out["solo"] = {"note": "one batch alone on the device", "kernel_ms": m, "achieved": c / max(m, 1e-9) / 1e6, "frac": c / max(m, 1e-9) / 1e6 / peak}
+        si = sum(float(solo[d][3]) for d in (0, 1) if solo[d][0] >= 0)
+        out["solo"] = {"note": "one batch alone on the device", "kernel_ms": m, "achieved": c / max(m, 1e-9) / 1e6, "frac": c / max(m, 1e-9) / 1e6 / peak,
+                       "issued_valu_frac": si / max(m, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3)}
     return out
 
 

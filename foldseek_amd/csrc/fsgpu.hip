@@ -920,7 +920,7 @@ static int launchSw(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nPa
 
 // k_sw2: two targets per wave, one direction (image with the extra "past the end" row)
 template <int R, bool HAS_AA>
-static int launchSwBlocks2T(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipStream_t stream) {
+static int launchSwBlocks2T(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, int pairsPerBlock, hipStream_t stream) {
     const int lds = (HAS_AA ? 2 : 1) * kSw2Rows * swRowDwords(R) * 4;
     static thread_local uint64_t attrDevs = 0;       // devices on which this thread has set the attribute (it is per device)
     const uint64_t devBit = 1ull << (ctx->device & 63);
@@ -928,12 +928,21 @@ static int launchSwBlocks2T(fsgpu_ctx *ctx, const SwArgs &sa, int nBlocks, hipSt
         HIPCHK(hipFuncSetAttribute((const void *) k_sw2<R, HAS_AA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attrDevs |= devBit;
     }
-    hipLaunchKernelGGL((k_sw2<R, HAS_AA>), dim3(nBlocks), dim3(256), lds, stream, sa);
+    hipLaunchKernelGGL((k_sw2<R, HAS_AA>), dim3(nBlocks), dim3(32 * pairsPerBlock), lds, stream, sa);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
-static int launchSwBlocks2(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks, hipStream_t stream) {
-#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocks2T<RR, true>(ctx, sa, nBlocks, stream) : launchSwBlocks2T<RR, false>(ctx, sa, nBlocks, stream);
+// Pairs of one query that share a workgroup (and one copy of the query's LDS image): two per wave.  8 pairs = 4 waves per image gives
+// 4 waves per SIMD (3Di, 33 KB image at R = 6) / 2 per SIMD (3Di + AA).  More waves per image (16 / 32 pairs: 8 waves per SIMD) is SLOWER:
+// the kernel is VALU-issue bound already at 4 waves per SIMD and a workgroup lasts as long as its longest pair (32 queries x 1000 targets,
+// forward pass, alone on the device: 1.69 / 1.87 / 2.08 ms at 8 / 16 / 32 pairs for 3Di, 2.44 / 2.60 / 2.71 ms for 3Di + AA;
+// tools/sw2_probe.py).  FSGPU_SW2_PAIRS = 8 | 16 | 32 overrides it for such measurements.
+static int sw2PairsPerBlock() {
+    static const int env = [] { const char *e = getenv("FSGPU_SW2_PAIRS"); const int v = e ? atoi(e) : 0; return (v == 8 || v == 16 || v == 32) ? v : 0; }();
+    return env ? env : 8;
+}
+static int launchSwBlocks2(fsgpu_ctx *ctx, int R, bool hasAA, const SwArgs &sa, int nBlocks, int pairsPerBlock, hipStream_t stream) {
+#define FS_SW_CASE(RR) case RR: return hasAA ? launchSwBlocks2T<RR, true>(ctx, sa, nBlocks, pairsPerBlock, stream) : launchSwBlocks2T<RR, false>(ctx, sa, nBlocks, pairsPerBlock, stream);
     switch (R) {
         FS_SW_CASE(1) FS_SW_CASE(2) FS_SW_CASE(3) FS_SW_CASE(4) FS_SW_CASE(6) FS_SW_CASE(8)
         default: ctx->err = "internal: bad SW R"; return FSGPU_E_ARG;
@@ -1395,7 +1404,8 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
     std::vector<int> cls(nq, -1);
     for (int i = 0; i < nq; i++) if (q[i].L <= 64 * kSwMaxR && nSel(i) > 0) cls[i] = swPickR(q[i].L);
     size_t imgDwTotal = 0, nBlocks = 0;
-    for (int i = 0; i < nq; i++) if (cls[i] > 0) { imgDwTotal += (size_t) kSw2Rows * swRowDwords(cls[i]) * (hasAA ? 2 : 1); nBlocks += ((size_t) nSel(i) + 7) / 8; }
+    const int ppb = sw2PairsPerBlock();
+    for (int i = 0; i < nq; i++) if (cls[i] > 0) { imgDwTotal += (size_t) kSw2Rows * swRowDwords(cls[i]) * (hasAA ? 2 : 1); nBlocks += ((size_t) nSel(i) + ppb - 1) / ppb; }
     if (total) {
         if ((rc = ensure(ctx, ctx->tids, total * 4)) != FSGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->res0, total * 16)) != FSGPU_OK) return rc;
@@ -1423,7 +1433,9 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
     if (dir == 0) ctx->swDirValid[1] = false;
     {
         // work of this pass in the units of the kernel's roofline: DP cells (query rows x target columns of every single-tile pair) and
-        // wave-steps (a wave carries two targets of one query and runs max(LtA, LtB) + lanes - 1 steps)
+        // VALU wave-instructions (a wave carries two targets of one query and runs max(LtA, LtB) + lanes - 1 steps; a step is 14 packed
+        // instructions per register row + 26 around them -- lane shifts, LDS addresses, loop and maximum bookkeeping; counted in the ISA
+        // of k_sw2<6, false>: 110 VALU instructions per step -- and 2 per row + 8 more with the AA table)
         double cells = 0, pairs = 0, wsteps = 0;
         const std::vector<int32_t> &len = ctx->db->hLengths;
         for (int i = 0; i < nq; i++) {
@@ -1433,7 +1445,7 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
             for (int k = 0; k < ns; k++) {
                 const int lt = len[q[i].targetIds[p[k]]];
                 cells += (double) q[i].L * lt;
-                if ((k & 1) == 0 && lt > 0) wsteps += (double) (lt + lanes - 1) * (14.0 * R + (hasAA ? 2.0 * R : 0.0));   // pairs are longest first: the even one sets the wave's length
+                if ((k & 1) == 0 && lt > 0) wsteps += (double) (lt + lanes - 1) * (14.0 * R + 26.0 + (hasAA ? 2.0 * R + 8.0 : 0.0));   // pairs are longest first: the even one sets the wave's length
             }
             pairs += ns;
         }
@@ -1475,9 +1487,9 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
                     for (int x = 0; x < rowDw; x++) dst[(size_t) kAlphabet * rowDw + x] = dead;
                 }
                 const int ns = nSel(i);
-                for (int p0 = 0; p0 < ns; p0 += 8) {
+                for (int p0 = 0; p0 < ns; p0 += ppb) {
                     SwBlockDesc &d = hb[blkPos++];
-                    d.imgOff = (uint32_t) imgPos; d.firstPair = (uint32_t) (sbase[i] + p0); d.nPairs = (uint16_t) std::min(8, ns - p0);
+                    d.imgOff = (uint32_t) imgPos; d.firstPair = (uint32_t) (sbase[i] + p0); d.nPairs = (uint16_t) std::min(ppb, ns - p0);
                     d.rowsInTile = (uint16_t) L; d.segLen = (uint32_t) ((L + 15) / 16);
                     g.nblk++;
                 }
@@ -1514,7 +1526,7 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
             sa.res0 = (int32_t *) ctx->res0.p; sa.res1 = nullptr;
             sa.blocks = (const SwBlockDesc *) ((const unsigned char *) ctx->img.p + descOff) + g.blk0;
             sa.dir = dir;
-            rc = launchSwBlocks2(ctx, g.R, hasAA, sa, (int) g.nblk, gs);
+            rc = launchSwBlocks2(ctx, g.R, hasAA, sa, (int) g.nblk, ppb, gs);
             if (rc != FSGPU_OK) return rc;
             if (gi > 0) { HIPCHK(hipEventRecord(ctx->swAuxEv[gi], gs)); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[gi], 0)); }
             gi++;

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
 constexpr int kSw2Rows = kAlphabet + 1;
 
 template <int R, bool HAS_AA>
-__global__ __launch_bounds__(256) void k_sw2(SwArgs a) {
+__global__ __launch_bounds__(1024) void k_sw2(SwArgs a) {
     using A = Pk16;
     constexpr int ROWB = swRowDwords(R) * 4;
     constexpr int TBL = kSw2Rows * ROWB;

@@ -308,7 +308,7 @@ int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t resCap, ui
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which);
 /* out[2][4], per direction (0 forward, 1 reversed query) of the last fsgpu_sw_multi_dir calls of this context: device ms of that pass's
  * k_sw2 launches (HIP events on the context stream; -1 when the pass did not run), DP cells (query rows x target columns over the
- * single-tile pairs), pairs, and the packed VALU wave-instructions of the DP rows its waves issue (the issue-rate roofline's unit). */
+ * single-tile pairs), pairs, and the VALU wave-instructions its waves issue (DP rows + per-step overhead; the issue-rate roofline's unit). */
 void fsgpu_sw_last_passes(const fsgpu_ctx *ctx, double *out);
 
 #ifdef __cplusplus
