@@ -410,10 +410,13 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
     lock = threading.Lock()
 
     def run(t, b, count):
+        tw = [time.perf_counter()]
         q3 = [db.seq(int(i), "3di") for i in b]
         qa = [db.seq(int(i), "aa") for i in b]
         prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in q3]
+        tw.append(time.perf_counter())
         res, status = ctxs[t].kmer_search(prep, identity=b, max_res=200)
+        tw.append(time.perf_counter())
         ms, cnt = ctxs[t].kmer_stage_ms(), ctxs[t].kmer_counts()
         # Prefiltering.cpp:880-887: canBeCovered at -c 0.8, cov-mode 0
         keep = []
@@ -421,7 +424,9 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
             lt = db.lengths[r["id"]].astype(np.float32)
             lq = np.float32(len(q))
             keep.append(r["id"][(lq / lt >= 0.8) & (lt / lq >= 0.8)])
+        tw.append(time.perf_counter())
         aln = searches[t].align_batch(qa, q3, keep, identity=b)
+        tw.append(time.perf_counter())
         swp = ctxs[t].sw_last_passes()
         if count:
             with lock:
@@ -429,6 +434,7 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
                 stat["res"] += int(sum(len(q) for q in q3)); stat["dev"] += ms[0]; stat["bad"] += int((status < 0).sum())
                 stat["stage"] += np.array(ms[:11]); stat["cnt"] += np.array(cnt, float); stat["nb"] += 1; stat["swp"].append(swp)
                 stat["diag_bytes"] += float(cnt[2]) * float(np.mean([len(q) for q in q3]))
+                stat["wall"] = [a + (y - x) for a, x, y in zip(stat.get("wall", [0.0] * 4), tw[:-1], tw[1:])]
 
     for t in range(KT):
         for b in warm[t::KT] or warm[:1]:
@@ -482,6 +488,9 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
                "unsupported_queries": sum(x["bad"] for x in tot), "index_build_s": t_index, "db_generation_s": t_gen,
                "projected_full_all_vs_all_s": db.n / max(1e-9, nq / dt),
                "queries_per_batch": AB, "stage_ms_per_batch": {k: s0["stage"][i] / nb0 for i, k in enumerate(names)},
+               # wall time of one feeder thread per batch (KT threads run their batches concurrently): harness-side query extraction + profile
+               # preparation (Python + fshost_kmer_query_prepare), the fsgpu_kmer_search call, the coverage pre-filter (numpy), the align call
+               "host_wall_ms_per_batch": {k: 1e3 * v / nb0 for k, v in zip(["prepare", "kmer_search_call", "coverage_filter", "align_call"], s0.get("wall", [0.0] * 4))},
                "similar_kmers_per_query": s0["cnt"][0] / max(1, s0["q"]), "index_hits_per_query": s0["cnt"][1] / max(1, s0["q"]),
                "candidates_per_query": s0["cnt"][2] / max(1, s0["q"]),
                "roofline": {"bound": "hbm", "kernel": f"k_kmer_* (the device part of one prefilter batch of {AB} queries, all kernels)", "unit": "GB/s", "peak": 8000.0,
@@ -496,6 +505,17 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
     for c in ctxs[1:]:
         c.close()
     ctx0.close()
+    if out is not None and world == 1 and with_cpu:
+        # the same configuration through the product's own host code: the C++ module `fsgpu-modules search` on the same DB written to disk,
+        # ALL its entries as queries, wall time of the whole process (start, DB read, index build, every query, result write).  The leg above
+        # feeds the C ABI from Python threads (sequence extraction, ctypes marshalling and the coverage pre-filter run under the interpreter
+        # lock: `host_wall_ms_per_batch`), this is what a user of the module gets.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import allvsall_modules
+            out["native_module_end_to_end"] = allvsall_modules.run(threads=usable_cores(), db=db)
+        except Exception as e:                                             # noqa: BLE001 -- the leg's own numbers stand without it
+            out["native_module_end_to_end"] = {"error": str(e)[-500:]}
     return out
 
 

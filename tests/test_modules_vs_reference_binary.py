@@ -5,7 +5,17 @@ workflow's complete parameter strings, `fsgpu-modules` gets the same argument ve
 byte-identical: k-mer prefilter, ungapped prefilter (plain and reference-padded target), structurealign on both (3Di+AA and 3Di
 only, with backtraces), structurerescorediagonal on the defined lines.  The padded target is written by the REFERENCE's
 makepaddedseqdb from the ASCII DB.  scop_v1 covers real structures at 30 entries; this covers length classes, masking, row tiles
-(queries > 512 residues), score ties at the --max-seqs cut and thousands of alignments."""
+(queries > 512 residues), score ties at the --max-seqs cut and thousands of alignments.
+WHAT "byte-identical to the reference" covers here.  The reference binary these result DBs come from (oracle/_ref_full, and oracle/_ref for
+the library-level tests) cannot link the upstream Rust block-aligner (no cargo in this image): oracle/patch_ref_full.py links this
+repository's own foldseek_amd/csrc/host/block_aligner.cpp for the `block_*` symbols.  So in structurealign records the
+BACKTRACE-DERIVED columns -- qStart, dbStart, the CIGAR / backtrace string, seqId, alnLen -- compare this repository's restatement of
+the block aligner with ITSELF (run once by the reference's caller, once by ours): they pin the caller-side logic (which rectangle is
+aligned, block sizes, the acceptance rule, reversal and offsets), not the crate's tie-breaking.  The prefilter DBs and the SW columns
+(score, qEnd, dbEnd, e-value, coverage gates, result order) are independent of this repository.  What pins the aligner itself:
+tests/test_block_aligner.py (the crate's own known answers, an independent model of its tie rules, optimality by re-scoring) and
+oracle/ba_kat (vectors to run against the crate wherever cargo exists).
+"""
 import json
 import os
 import subprocess

@@ -4,6 +4,16 @@ the reference's own `createdb` / `makepaddedseqdb` wrote the sequence DBs from F
 its `prefilter` / `ungappedprefilter` / `structurealign` wrote the result DBs -- here `fsgpu-modules` runs with the SAME
 positional arguments and the SAME complete parameter strings (what F/data/structuresearch.sh hands the modules) on those
 DBs and every entry of every result DB must be byte-identical.  Nothing in these tests is written by foldseek_amd/dbio.py.
+
+WHAT "byte-identical to the reference" covers here.  The reference binary these result DBs come from (oracle/_ref_full, and oracle/_ref for
+the library-level tests) cannot link the upstream Rust block-aligner (no cargo in this image): oracle/patch_ref_full.py links this
+repository's own foldseek_amd/csrc/host/block_aligner.cpp for the `block_*` symbols.  So in structurealign records the
+BACKTRACE-DERIVED columns -- qStart, dbStart, the CIGAR / backtrace string, seqId, alnLen -- compare this repository's restatement of
+the block aligner with ITSELF (run once by the reference's caller, once by ours): they pin the caller-side logic (which rectangle is
+aligned, block sizes, the acceptance rule, reversal and offsets), not the crate's tie-breaking.  The prefilter DBs and the SW columns
+(score, qEnd, dbEnd, e-value, coverage gates, result order) are independent of this repository.  What pins the aligner itself:
+tests/test_block_aligner.py (the crate's own known answers, an independent model of its tie rules, optimality by re-scoring) and
+oracle/ba_kat (vectors to run against the crate wherever cargo exists).
 """
 import json
 import os
