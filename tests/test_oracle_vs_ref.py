@@ -2,6 +2,8 @@
 (oracle/_ref/libfsref.so, built in-container from /root/reference by oracle/Makefile).  Skipped where _ref was not built.
 The same comparisons are frozen as committed fixtures in tests/golden/ (test_golden.py) so they also run without _ref."""
 import ctypes as C
+import os
+
 import numpy as np
 import pytest
 
@@ -59,6 +61,45 @@ def test_sw_matches_reference(atype):
             for (pA, p3, ref) in ((pAf, p3f, fw[i]), (pAr, p3r, rv[i])):
                 w = helpers.o_sw(pA, p3, L, ta, tt)
                 assert (w["score"], w["qEnd"], w["dbEnd"], w["word"]) == (ref["score"], ref["qEnd"], ref["dbEnd"], ref["word"])
+
+
+@pytest.mark.parametrize("go,ge", [(5, 5), (3, 7), (1, 1)])
+def test_gap_open_not_above_gap_extend_scores_equal_and_the_reference_aborts_on_the_backtrace(go, ge):
+    """gapOpen <= gapExtend: the score / end-position half of the reference (striped SW, lazy-F loop leaving early) equals the oracle's literal
+    emulation; as soon as a hit is accepted the reference goes through the block aligner, whose assertion `gaps.open < gaps.extend`
+    (scan_block.rs:864-867) ends the process -- so there is no reference answer for the device path to reproduce"""
+    import subprocess
+    import sys
+    q3, qa = synth.make_queries(1, seed=15)
+    db = synth.make_db(120, (q3, qa), seed=17, homologs_per_query=20)
+    t3 = np.where(db.data3di >= 32, db.data3di - 32, db.data3di).astype(np.uint8)
+    L = len(q3[0])
+    fw = np.zeros(db.n, REFSW_DT)
+    rv = np.zeros(db.n, REFSW_DT)
+    R.ref_structure_align(qa[0], q3[0], L, 2, 1, 0.5, go, ge, db.dataaa, t3, db.offsets[:-1].copy(), db.lengths, db.n,
+                          db.residues, 10.0, 0, 1, fw.ctypes.data, rv.ctypes.data, None, None, 0)
+    pAf, p3f, _, _ = helpers.o_align_profiles(qa[0], q3[0], 2)
+    for i in range(db.n):
+        ta, tt = helpers.target_seqs(db, i)
+        w = helpers.o_sw(pAf, p3f, L, ta, tt, go, ge)
+        assert (w["score"], w["qEnd"], w["dbEnd"], w["word"]) == (fw[i]["score"], fw[i]["qEnd"], fw[i]["dbEnd"], fw[i]["word"])
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import numpy as np, oracle_lib
+from foldseek_amd import synth
+R = oracle_lib.load_ref()
+q3, qa = synth.make_queries(1, seed=15)
+db = synth.make_db(120, (q3, qa), seed=17, homologs_per_query=20)
+t3 = np.where(db.data3di >= 32, db.data3di - 32, db.data3di).astype(np.uint8)
+n = db.n
+aln = np.zeros(n, oracle_lib.REFALN_DT); cig = np.zeros(1 << 20, np.uint8)
+R.ref_structure_align(qa[0], q3[0], len(q3[0]), 2, 1, 0.5, {go}, {ge}, db.dataaa, t3, db.offsets[:-1].copy(), db.lengths, n,
+                      db.residues, 10.0, 1, 1, None, None, aln.ctypes.data, cig.ctypes.data, cig.size)
+print("survived")
+"""
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0 and "survived" not in p.stdout and "open" in p.stderr
 
 
 def test_rowmajor_recurrence_equals_striped_emulation():
