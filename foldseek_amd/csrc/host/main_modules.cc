@@ -5,7 +5,7 @@
 #include <cstring>
 int main(int argc, const char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <search|prefilter|ungappedprefilter|structurealign|structurerescorediagonal|makepaddedseqdb|gpuserver|convertalis> <args...>\n", argv[0]);
+        fprintf(stderr, "usage: %s <search|prefilter|ungappedprefilter|structurealign|structurerescorediagonal|makepaddedseqdb|gpuserver|convertalis|indexdb|createindex> <args...>\n", argv[0]);
         return EXIT_FAILURE;
     }
     if (!strcmp(argv[1], "ungappedprefilter")) return fsmod_ungappedprefilter(argc - 2, argv + 2);
@@ -16,6 +16,8 @@ int main(int argc, const char **argv) {
     if (!strcmp(argv[1], "structurerescorediagonal") || !strcmp(argv[1], "structureungappedalign")) return fsmod_structurerescorediagonal(argc - 2, argv + 2);
     if (!strcmp(argv[1], "makepaddedseqdb")) return fsmod_makepaddedseqdb(argc - 2, argv + 2);
     if (!strcmp(argv[1], "convertalis")) return fsmod_convertalis(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "indexdb")) return fsmod_indexdb(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "createindex")) return fsmod_createindex(argc - 2, argv + 2);
     fprintf(stderr, "unknown module %s\n", argv[1]);
     return EXIT_FAILURE;
 }

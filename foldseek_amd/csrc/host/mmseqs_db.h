@@ -33,6 +33,7 @@ public:
     uint64_t offset(size_t id) const { return entries[id].offset; }
     int64_t idOf(uint32_t key) const;                                         // DBReader::getId, -1 if absent
     int dbtype() const { return type & 0xffff; }
+    int rawDbtype() const { return type; }                                   // the int32 of <db>.dbtype, extended bits included
     int extended() const { return (int) ((uint32_t) type >> 16); }
     const char *dataBase() const { return base; }
     uint64_t dataSize() const { return bytes; }

@@ -16,8 +16,12 @@
 #include "mmseqs_db.h"
 #include "gpu_shm.h"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -132,6 +136,16 @@ const FlagSpec kConvertFlags[] = {             // LocalParameters::convertalignm
     {"--format-output", false, USE, nullptr}, {"--translation-table", false, IGNORE, nullptr}, {"--gap-open", false, IGNORE, nullptr},
     {"--gap-extend", false, IGNORE, nullptr}, {"--db-output", true, USE, "0"}, {"--search-type", false, IGNORE, nullptr},
     {"--exact-tmscore", false, IGNORE, nullptr}, {nullptr, false, USE, nullptr}};
+
+const FlagSpec kIndexdbFlags[] = {             // Parameters::indexdb (Parameters.cpp:850-872)
+    {"--seed-sub-mat", false, ONLY, "3di.out"}, {"-k", false, ONLY, "0|6"}, {"--alph-size", false, ONLY, "21"},
+    {"--comp-bias-corr", false, USE, nullptr}, {"--comp-bias-corr-scale", false, IGNORE, nullptr}, {"--max-seq-len", false, USE, nullptr},
+    {"--max-seqs", false, IGNORE, nullptr}, {"--index-dbsuffix", false, USE, nullptr}, {"--mask", false, ONLY, "0"},
+    {"--mask-prob", false, IGNORE, nullptr}, {"--mask-lower-case", false, USE, nullptr}, {"--mask-n-repeat", false, USE, nullptr},
+    {"--spaced-kmer-mode", false, USE, nullptr}, {"--spaced-kmer-pattern", false, ONLY, ""}, {"-s", false, USE, nullptr},
+    {"--k-score", false, USE, nullptr}, {"--check-compatible", false, ONLY, "0"}, {"--search-type", false, IGNORE, nullptr},
+    {"--split", false, ONLY, "0|1"}, {"--split-memory-limit", false, IGNORE, nullptr}, {"--index-subset", false, USE, nullptr},
+    {nullptr, false, USE, nullptr}};
 
 const FlagSpec kServerFlags[] = {              // Parameters::gpuserver (Parameters.cpp:1638-1640)
     {"--max-seqs", false, USE, nullptr}, {"--prefilter-mode", false, ONLY, "0|1"}, {"--max-seq-len", false, USE, nullptr},
@@ -371,6 +385,8 @@ struct DeviceSet {
             int usedRccl = 0;
             if (fsgpu_db_broadcast(c0, root.data() + 1, want - 1, &usedRccl) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(c0); return false; }
             fprintf(stderr, "target DB replicated to %d GPUs (%s)\n", want, usedRccl ? "RCCL broadcast" : "peer copies");
+            // FSGPU_REQUIRE_RCCL=1: a multi-GPU run whose replication silently fell back to peer copies is an error (scaling runs set it)
+            { const char *e = getenv("FSGPU_REQUIRE_RCCL"); if (!usedRccl && e && *e && *e != '0' && !getenv("FSGPU_NO_RCCL")) { err = "GPU: the RCCL broadcast of the target DB was not used (FSGPU_REQUIRE_RCCL=1)"; return false; } }
         }
         perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 16));
         return true;
@@ -1246,6 +1262,321 @@ int fsmod_structurerescorediagonal(int argc, const char **argv) {
     return EXIT_SUCCESS;
 }
 
+
+// ---- indexdb / createindex: the precomputed index the search workflow hands to its modules ----------------
+// File format = PrefilteringIndexReader::createIndexFile (M/src/prefiltering/PrefilteringIndexReader.cpp:53-307): an MMseqs DB of type
+// DBTYPE_INDEX_DB (9) whose entries are keyed by the constants below, every entry padded to the page size.  The k-mer table (ENTRIES /
+// ENTRIESOFFSETS), the sequence lookup and the extended 3-mer matrix are what IndexBuilder::fillDatabase / ExtendedSubstitutionMatrix
+// leave in memory; here they come from the index this library builds ON THE DEVICE (fsgpu_kmer_index_build), renumbered from the
+// device's first-3-mer-major k-mer order to the reference's (first3 + 8000 * last3).  Consumers: the reference's CPU prefilter /
+// structurealign (`prefilter q db_ss.idx`), and this repository's modules, which read the sequence DBs out of it (DbReader::open).
+namespace {
+enum { IDX_VERSION = 0, IDX_META = 1, IDX_SCOREMATRIXNAME = 2, IDX_SCOREMATRIX2MER = 3, IDX_SCOREMATRIX3MER = 4, IDX_DBR1INDEX = 5, IDX_DBR1DATA = 6,
+       IDX_DBR2INDEX = 7, IDX_DBR2DATA = 8, IDX_ENTRIES = 9, IDX_ENTRIESOFFSETS = 10, IDX_ENTRIESNUM = 12, IDX_SEQCOUNT = 13, IDX_SEQINDEXDATA = 14,
+       IDX_SEQINDEXDATASIZE = 15, IDX_SEQINDEXSEQOFFSET = 16, IDX_HDR1INDEX = 18, IDX_HDR1DATA = 19, IDX_HDR2INDEX = 20, IDX_HDR2DATA = 21,
+       IDX_GENERATOR = 22, IDX_SPACEDPATTERN = 23 };
+enum { IDX_SUBSET_NO_HEADERS = 1, IDX_SUBSET_NO_PREFILTER = 2, IDX_SUBSET_NO_ALIGNMENT = 4, IDX_SUBSET_NO_SEQUENCE_LOOKUP = 8 };
+const int DBTYPE_INDEX_DB = 9;
+
+// DBWriter in the mode createIndexFile uses it: one data file, entry = bytes + '\0', then zero padding to the next page
+// (DBWriter::writeData / alignToPageSize, DBWriter.cpp:412-443), index sorted by key at close
+struct IdxWriter {
+    FILE *f = nullptr;
+    uint64_t off = 0;
+    bool failed = false;
+    std::vector<DbReader::Entry> entries;
+    void raw(const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) failed = true; off += n; }
+    uint64_t begin() const { return off; }
+    void end(uint32_t key, uint64_t start) {
+        const char z = 0;
+        raw(&z, 1);
+        if (off - start > 0xffffffffull) failed = true;                     // the index line carries a 32-bit length (DBWriter.cpp:489)
+        entries.push_back({key, start, (uint32_t) (off - start)});
+        static const char zeros[4096] = {0};
+        raw(zeros, (size_t) ((4096 - (off & 4095)) & 4095));
+    }
+    void put(uint32_t key, const void *p, size_t n) { const uint64_t s0 = begin(); raw(p, n); end(key, s0); }
+    void alias(uint32_t key, uint64_t o, uint64_t len) { entries.push_back({key, o, (uint32_t) len}); }
+};
+
+// DBReader::serialize (DBReader.cpp:812-840): size, dataSize (sum of the entry lengths), lastKey, dbtype, maxSeqLen (largest entry length),
+// then the 24-byte index records {u32 key, u64 offset, u32 length} with their struct padding (zeroed here, uninitialised in the reference)
+void serializeReader(const DbReader &r, std::vector<char> &out) {
+    const uint64_t n = r.size();
+    uint64_t dataSize = 0;
+    uint32_t lastKey = 0, maxLen = 0;
+    for (size_t i = 0; i < n; i++) { dataSize += r.entryLen(i); lastKey = std::max(lastKey, r.key(i)); maxLen = std::max(maxLen, r.entryLen(i)); }
+    out.assign(28 + 24 * n, 0);
+    char *p = out.data();
+    memcpy(p, &n, 8); memcpy(p + 8, &dataSize, 8); memcpy(p + 16, &lastKey, 4);
+    const int32_t type = r.rawDbtype();
+    memcpy(p + 20, &type, 4); memcpy(p + 24, &maxLen, 4);
+    p += 28;
+    for (size_t i = 0; i < n; i++, p += 24) {
+        const uint32_t key = r.key(i), len = r.entryLen(i);
+        const uint64_t o = r.offset(i);
+        memcpy(p, &key, 4); memcpy(p + 8, &o, 8); memcpy(p + 16, &len, 4);
+    }
+}
+
+// Masker::maskSequence with tantan off (Masker.cpp:15-56): runs of more than `nRepeats` equal codes -> X, then lower-case letters -> X
+void maskedCodes(const Matrix &m, const char *letters, int L, int nRepeats, bool lowerCase, uint8_t *out) {
+    const uint8_t X = m.aa2num[(unsigned char) 'X'];
+    for (int i = 0; i < L; i++) out[i] = m.aa2num[(unsigned char) letters[i]];
+    if (nRepeats > 0) {
+        int run = 0, start = 0;
+        for (int i = 0; i <= L; i++) {
+            if (i < L && i > 0 && out[i] == out[i - 1]) { run++; continue; }
+            if (i > 0 && run > nRepeats) for (int k = start; k < i; k++) out[k] = X;
+            run = 1; start = i;
+        }
+    }
+    if (lowerCase) for (int i = 0; i < L; i++) if (islower((unsigned char) letters[i])) out[i] = X;
+}
+
+// ExtendedSubstitutionMatrix::calcScoreMatrix for k = 2 (ExtendedSubstitutionMatrix.cpp:20-69): row of 2-mer a = all 400 2-mers sorted by score
+// descending, ties in the permutation order (first position most significant), rows padded to a multiple of 64 (+64) with (-255, 0)
+void scoreMatrix2mer(const int16_t *sub /*21x21*/, std::vector<int16_t> &score, std::vector<uint32_t> &index, size_t &rowSize) {
+    const size_t size = 400;
+    rowSize = (size / 64 + 1) * 64;
+    score.assign(size * rowSize, (int16_t) -255); index.assign(size * rowSize, 0);
+    std::vector<std::pair<int16_t, uint32_t>> tmp(size);
+    for (int a1 = 0; a1 < 20; a1++)
+        for (int a0 = 0; a0 < 20; a0++) {
+            const size_t row = (size_t) a0 + 20 * (size_t) a1;
+            for (int b0 = 0; b0 < 20; b0++)
+                for (int b1 = 0; b1 < 20; b1++)
+                    tmp[(size_t) b0 * 20 + b1] = {(int16_t) (sub[a0 * 21 + b0] + sub[a1 * 21 + b1]), (uint32_t) (b0 + 20 * b1)};
+            std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int16_t, uint32_t> &x, const std::pair<int16_t, uint32_t> &y) { return x.first > y.first; });
+            for (size_t z = 0; z < size; z++) { score[row * rowSize + z] = tmp[z].first; index[row * rowSize + z] = tmp[z].second; }
+        }
+}
+} // namespace
+
+int fsmod_indexdb(int argc, const char **argv) {
+    Options o;
+    {
+        std::string perr;
+        if (!parseArgs(argc, argv, "indexdb", {kIndexdbFlags, kCommonFlags}, o, perr)) return fail(perr);
+    }
+    if (o.pos.size() != 2) return fail("usage: indexdb <sequenceDB> <sequenceDB> [--index-subset N] [--index-dbsuffix S] [-s S] [--k-score T] [--mask-lower-case 0|1] "
+                                       "[--mask-n-repeat N] [--spaced-kmer-mode 0|1] [--comp-bias-corr 0|1] [--max-seq-len N]");
+    if (o.pos[0] != o.pos[1]) return fail("indexdb: a separate source database (<db1> != <db2>) is not implemented");
+    const std::string db = o.pos[0];
+    std::string err;
+    // profile / cluster databases (<db>_aln or <db>_clu next to <db>_seq, indexdb.cpp:49-75) index a different pair of readers: not covered
+    {
+        std::string base = db;
+        const std::string suffix = o.gets("--index-dbsuffix", "");
+        if (!suffix.empty()) { const size_t pos = base.find(suffix); if (pos != std::string::npos) base = base.substr(0, pos); }
+        auto exists = [](const std::string &f) { struct stat st; return stat(f.c_str(), &st) == 0; };
+        if ((exists(db + "_aln.dbtype") || exists(db + "_clu.dbtype")) && exists(base + "_seq" + suffix + ".dbtype"))
+            return fail("indexdb: cluster / profile databases (<db>_aln | <db>_clu with <db>_seq) are not implemented");
+    }
+    DbReader r;
+    if (!r.open(db, err)) return fail(err);
+    if (r.dbtype() != DBTYPE_AMINO_ACIDS) return fail("indexdb: only amino-acid typed sequence databases (AA or 3Di letters) are implemented");
+    if ((r.extended() & DBTYPE_EXTENDED_GPU) != 0) return fail("indexdb: padded GPU databases carry no k-mer index in the reference either");
+    if (!checkMaxSeqLen(o, r, "database", err)) return fail(err);
+    const int subset = o.geti("--index-subset", 0);
+    const bool needKmerIndex = (subset & IDX_SUBSET_NO_PREFILTER) == 0;
+    const bool needLookup = (subset & IDX_SUBSET_NO_SEQUENCE_LOOKUP) == 0;
+    const bool noHeaders = (subset & IDX_SUBSET_NO_HEADERS) != 0;
+    const int kmerSize = needKmerIndex ? 6 : 0;                                  // indexdb.cpp:128-135: no k-mer index -> k = 0, score 0
+    if (needKmerIndex && r.residues() >= 3350000000ull) return fail("indexdb: database needs k = 7, which is not implemented on the device path");
+    const float sens = (float) o.getd("-s", 5.7);                               // setIndexDbDefaults (indexdb.cpp:13-15)
+    const int kmerThr = !needKmerIndex ? 0 : (o.geti("--k-score", INT_MAX) != INT_MAX ? o.geti("--k-score", 0) : fshost_kmer_threshold(sens, 6));
+    const int spaced = o.geti("--spaced-kmer-mode", 1);
+    const int maskLower = o.geti("--mask-lower-case", 0), maskNrepeats = o.geti("--mask-n-repeat", 0);
+    fshost_matrix *m8 = fshost_matrix_create(FSHOST_MAT_3DI, 8.0f, -0.2f);
+    Matrix m3;
+    if (!m8 || !m3.builtin(FSHOST_MAT_3DI, 8.0f, -0.2f)) return fail("matrix construction failed");
+    DbReader hdr;
+    if (!noHeaders && !hdr.open(db + "_h", err)) return fail("Database " + db + " needs header information (" + err + ")");
+
+    const std::string out = db + ".idx";
+    for (const char *ext : {"", ".index", ".dbtype"}) remove((out + ext).c_str());
+    IdxWriter w;
+    w.f = fopen(out.c_str(), "wb");
+    if (!w.f) return fail("cannot write " + out);
+    w.put(IDX_VERSION, "fs1", 3);                                                // index_version_compatible of the Foldseek binary (F/src/foldseek.cpp:11)
+    {
+        const int32_t meta[12] = {o.geti("--max-seq-len", 65535), kmerSize, o.geti("--comp-bias-corr", 1) ? 1 : 0, 21, 0 /* --mask 0 */, spaced ? 1 : 0, kmerThr,
+                                  r.rawDbtype(), r.rawDbtype(), noHeaders ? 0 : 1, 0, 1};
+        w.put(IDX_META, meta, sizeof(meta));
+    }
+    {
+        size_t len = 0;
+        const char *text = fshost_matrix_text(FSHOST_MAT_3DI, &len);
+        std::string sm = std::string("3di.out:") + std::string(text, len);       // BaseMatrix::serialize: name ':' file text
+        w.put(IDX_SCOREMATRIXNAME, sm.data(), sm.size());
+    }
+    w.put(IDX_SPACEDPATTERN, "", 0);                                             // written exactly when the user pattern is EMPTY (:103, sic)
+    {
+        const std::string gen = "fsgpu-modules indexdb (foldseek_amd)";
+        w.put(IDX_GENERATOR, gen.data(), gen.size());
+    }
+    std::vector<char> ser;
+    auto putReader = [&](const DbReader &x, uint32_t keyIndex, uint32_t keyData, uint32_t aliasIndex, uint32_t aliasData) {
+        serializeReader(x, ser);
+        const uint64_t oi = w.begin();
+        w.put(keyIndex, ser.data(), ser.size());
+        const uint64_t od = w.begin();
+        w.put(keyData, x.dataBase(), x.dataSize());
+        w.alias(aliasIndex, oi, ser.size() + 1);                                 // dbr2 == NULL: the second reader is the first (:128-131)
+        w.alias(aliasData, od, x.dataSize() + 1);
+    };
+    putReader(r, IDX_DBR1INDEX, IDX_DBR1DATA, IDX_DBR2INDEX, IDX_DBR2DATA);
+    if (!noHeaders) putReader(hdr, IDX_HDR1INDEX, IDX_HDR1DATA, IDX_HDR2INDEX, IDX_HDR2DATA);
+
+    // the sequence lookup: numeric codes with the masking baked in (IndexBuilder.cpp:134-160), offsets = running sequence lengths
+    const size_t n = r.size();
+    std::vector<uint64_t> seqOff(n + 1, 0);
+    for (size_t i = 0; i < n; i++) seqOff[i + 1] = seqOff[i] + r.seqLen(i);
+    std::vector<uint8_t> lookup(seqOff[n] + 1, 0);
+    parallelRanges(n, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) maskedCodes(m3, r.data(i), (int) r.seqLen(i), maskNrepeats, maskLower != 0, lookup.data() + seqOff[i]);
+    });
+
+    if (needKmerIndex) {
+        PaddedTarget pt;
+        if (!loadPadded(r, nullptr, m3, nullptr, pt, err)) { fclose(w.f); return fail(err); }
+        DeviceSet ds;
+        if (!ds.open(o, pt, false, 1, err)) { ds.close(); fclose(w.f); return fail(err); }
+        fsgpu_ctx *ctx = ds.root[0];
+        fsgpu_kmer_index_params ip;
+        ip.kmerSize = 6; ip.spaced = spaced; ip.kmerThr = kmerThr; ip.maskLowerCase = maskLower; ip.maskNrepeats = maskNrepeats;
+        auto gpuFail = [&](const std::string &what) { const std::string m = what + ": " + fsgpu_last_error(ctx); ds.close(); fclose(w.f); return fail(m); };
+        if (fsgpu_kmer_index_build(ctx, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) return gpuFail("GPU k-mer index build");
+        // SCOREMATRIX3MER (:220-228): 8000 rows of 8064 (score int16 | index uint32), the rows this library sorts on the device (k_kmer_rows3)
+        {
+            const size_t size = 8000, rowSize = (size / 64 + 1) * 64;
+            std::vector<int16_t> sc(size * rowSize, (int16_t) -255);
+            std::vector<uint32_t> ix(size * rowSize, 0);
+            std::vector<uint16_t> row16(size);
+            for (size_t a = 0; a < size; a++) {
+                if (fsgpu_kmer_row_copy(ctx, (int) a, sc.data() + a * rowSize, row16.data()) != FSGPU_OK) return gpuFail("GPU 3-mer rows");
+                for (size_t z = 0; z < size; z++) ix[a * rowSize + z] = row16[z];
+            }
+            const uint64_t s0 = w.begin();
+            w.raw(sc.data(), sc.size() * sizeof(int16_t)); w.raw(ix.data(), ix.size() * sizeof(uint32_t));
+            w.end(IDX_SCOREMATRIX3MER, s0);
+        }
+        {
+            std::vector<int16_t> sc; std::vector<uint32_t> ix; size_t rowSize = 0;
+            scoreMatrix2mer(fshost_matrix_scores(m8), sc, ix, rowSize);
+            const uint64_t s0 = w.begin();
+            w.raw(sc.data(), sc.size() * sizeof(int16_t)); w.raw(ix.data(), ix.size() * sizeof(uint32_t));
+            w.end(IDX_SCOREMATRIX2MER, s0);
+        }
+        // ENTRIES / ENTRIESOFFSETS / ENTRIESNUM (:261-283): lists of {uint32 seqId, uint16 first position} per k-mer, sorted by (seqId, position)
+        const uint64_t table = 64000000ull, nE = fsgpu_kmer_index_entries(ctx);
+        std::vector<uint32_t> devOff(table + 1);
+        std::vector<uint64_t> devEnt(std::max<uint64_t>(nE, 1));
+        std::vector<uint8_t> devMasked(std::max<uint64_t>(pt.bytes, 1));
+        if (fsgpu_kmer_index_copy(ctx, devOff.data(), devEnt.data(), devMasked.data()) != FSGPU_OK) return gpuFail("GPU k-mer index copy");
+        ds.close();
+        // the lookup written below is the host's; the device masked the same letters with its own kernel: they must agree
+        for (size_t i = 0; i < n; i++)
+            if (memcmp(devMasked.data() + pt.offsets[i], lookup.data() + seqOff[i], r.seqLen(i)) != 0) { fclose(w.f); return fail("indexdb: internal error: device and host masking differ at entry " + std::to_string(r.key(i))); }
+        std::vector<uint64_t> refOff(table + 1, 0);
+        parallelRanges(8000, [&](size_t l0, size_t l1) {                          // reference k-mer number = first3 + 8000 * last3, device = first3 * 8000 + last3
+            for (size_t last3 = l0; last3 < l1; last3++)
+                for (size_t first3 = 0; first3 < 8000; first3++) { const size_t p = first3 * 8000 + last3; refOff[first3 + 8000 * last3 + 1] = devOff[p + 1] - devOff[p]; }
+        });
+        for (uint64_t k = 0; k < table; k++) refOff[k + 1] += refOff[k];
+        if (refOff[table] != nE) { fclose(w.f); return fail("indexdb: internal error: k-mer table sizes differ"); }
+        std::vector<uint8_t> ent((size_t) nE * 6 + 1);
+        parallelRanges(8000, [&](size_t l0, size_t l1) {
+            for (size_t last3 = l0; last3 < l1; last3++)
+                for (size_t first3 = 0; first3 < 8000; first3++) {
+                    const size_t p = first3 * 8000 + last3;
+                    uint8_t *dst = ent.data() + refOff[first3 + 8000 * last3] * 6;
+                    for (uint32_t e = devOff[p]; e < devOff[p + 1]; e++, dst += 6) {
+                        const uint32_t seqId = (uint32_t) (devEnt[e] >> 16);
+                        const uint16_t pos = (uint16_t) (devEnt[e] & 0xffffu);
+                        memcpy(dst, &seqId, 4); memcpy(dst + 4, &pos, 2);           // IndexEntryLocal, packed (IndexTable.h:25-41)
+                    }
+                }
+        });
+        w.put(IDX_ENTRIES, ent.data(), (size_t) nE * 6);
+        w.put(IDX_ENTRIESOFFSETS, refOff.data(), (table + 1) * sizeof(uint64_t));
+        w.put(IDX_ENTRIESNUM, &nE, sizeof(nE));
+    }
+    if (needLookup) {
+        const uint64_t cnt = n;
+        const int64_t dataSize = (int64_t) seqOff[n];
+        w.put(IDX_SEQCOUNT, &cnt, sizeof(cnt));
+        w.put(IDX_SEQINDEXDATASIZE, &dataSize, sizeof(dataSize));
+        w.put(IDX_SEQINDEXSEQOFFSET, seqOff.data(), (n + 1) * sizeof(uint64_t));
+        w.put(IDX_SEQINDEXDATA, lookup.data(), seqOff[n] + 1);                   // dataSize + 1 bytes (:300; the last one is uninitialised in the reference)
+    }
+    fshost_matrix_free(m8);
+    if (fclose(w.f) != 0 || w.failed) return fail("write error on " + out);
+    std::sort(w.entries.begin(), w.entries.end(), [](const DbReader::Entry &a, const DbReader::Entry &b) { return a.key < b.key; });
+    FILE *fi = fopen((out + ".index").c_str(), "w");
+    if (!fi) return fail("cannot write " + out + ".index");
+    for (const DbReader::Entry &e : w.entries) fprintf(fi, "%u\t%llu\t%u\n", e.key, (unsigned long long) e.offset, e.length);
+    if (fclose(fi) != 0) return fail("write error on " + out + ".index");
+    FILE *ft = fopen((out + ".dbtype").c_str(), "wb");
+    const int32_t t = DBTYPE_INDEX_DB;
+    if (!ft || fwrite(&t, 4, 1, ft) != 1 || fclose(ft) != 0) return fail("cannot write " + out + ".dbtype");
+    return EXIT_SUCCESS;
+}
+
+// createindex <db> <tmpDir>: F/data/structureindex.sh -- the AA database without k-mer table (--index-subset 2), header links for <db>_ss,
+// the 3Di database with the k-mer table (--index-subset 5, --index-dbsuffix _ss), then the C-alpha database appended to <db>.idx under the
+// keys 500 / 501 (appenddbtoindex, M/src/util/appenddbtoindex.cpp:9-150) when <db>_ca exists.
+int fsmod_createindex(int argc, const char **argv) {
+    std::vector<std::string> pos, rest;
+    for (int i = 0; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a.size() > 1 && a[0] == '-' && !isdigit((unsigned char) a[1])) {
+            if (a == "--index-subset" || a == "--index-dbsuffix" || a == "--index-exclude" || a == "--remove-tmp-files") { i++; continue; }   // set per call below / workflow housekeeping
+            rest.push_back(a);
+            if (i + 1 < argc) rest.push_back(argv[++i]);
+        } else pos.push_back(a);
+    }
+    if (pos.size() != 2) return fail("usage: createindex <sequenceDB> <tmpDir> [indexdb options]");
+    const std::string db = pos[0];
+    auto call = [&](const std::string &d, const char *subset, const char *suffix) {
+        std::vector<const char *> av = {d.c_str(), d.c_str()};
+        for (const std::string &x : rest) av.push_back(x.c_str());
+        av.push_back("--index-subset"); av.push_back(subset);
+        if (suffix) { av.push_back("--index-dbsuffix"); av.push_back(suffix); }
+        return fsmod_indexdb((int) av.size(), av.data());
+    };
+    if (call(db, "2", nullptr) != EXIT_SUCCESS) return EXIT_FAILURE;
+    struct stat st;
+    if (stat((db + "_ss_h.dbtype").c_str(), &st) != 0)                           // lndb <db>_h <db>_ss_h
+        for (const char *ext : {"", ".index", ".dbtype"}) {
+            const std::string from = db + "_h" + ext, to = db + "_ss_h" + ext;
+            const size_t slash = from.rfind('/');
+            if (symlink((slash == std::string::npos ? from : from.substr(slash + 1)).c_str(), to.c_str()) != 0 && errno != EEXIST) return fail("cannot link " + to);
+        }
+    if (call(db + "_ss", "5", "_ss") != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (stat((db + "_ca.dbtype").c_str(), &st) == 0) {
+        DbReader idx, ca;
+        std::string err;
+        if (!ca.open(db + "_ca", err)) return fail(err);
+        // append: serialised reader under key 500, the data under 501, offsets continue at the end of <db>.idx
+        FILE *f = fopen((db + ".idx").c_str(), "ab");
+        FILE *fi = fopen((db + ".idx.index").c_str(), "a");
+        if (!f || !fi) return fail("cannot append to " + db + ".idx");
+        fseek(f, 0, SEEK_END);
+        uint64_t off = (uint64_t) ftell(f);
+        std::vector<char> ser;
+        serializeReader(ca, ser);
+        const char z = 0;
+        bool ok = fwrite(ser.data(), 1, ser.size(), f) == ser.size() && fwrite(&z, 1, 1, f) == 1;
+        fprintf(fi, "%u\t%llu\t%llu\n", 500u, (unsigned long long) off, (unsigned long long) ser.size() + 1);
+        off += ser.size() + 1;
+        ok = ok && fwrite(ca.dataBase(), 1, ca.dataSize(), f) == ca.dataSize() && fwrite(&z, 1, 1, f) == 1;
+        fprintf(fi, "%u\t%llu\t%llu\n", 501u, (unsigned long long) off, (unsigned long long) ca.dataSize() + 1);
+        if (fclose(f) != 0 || fclose(fi) != 0 || !ok) return fail("write error on " + db + ".idx");
+    }
+    return EXIT_SUCCESS;
+}
 
 // gpuserver: load the target DB once, then answer gapless scans until SIGINT/SIGTERM (gpuserver.cpp:24-101).  The scan
 // is this library's (scores capped at 255 - bias like the CPU path, result order = score desc, id asc); the cap is

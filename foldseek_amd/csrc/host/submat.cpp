@@ -253,6 +253,11 @@ fshost_matrix *fshost_matrix_from_scores(const int16_t *scores, int n, const dou
 void fshost_matrix_free(fshost_matrix *m) { delete m; }
 int fshost_matrix_size(const fshost_matrix *m) { return m ? m->m.n : 0; }
 const int16_t *fshost_matrix_scores(const fshost_matrix *m) { return m ? m->m.sub.data() : nullptr; }
+const char *fshost_matrix_text(int which, size_t *len) {
+    if (which != FSHOST_MAT_3DI) { if (len) *len = 0; return nullptr; }
+    if (len) *len = sizeof(FS_MAT3DI_TEXT) - 1;
+    return FS_MAT3DI_TEXT;
+}
 const double *fshost_matrix_background(const fshost_matrix *m) { return m ? m->m.pBack.data() : nullptr; }
 void fshost_matrix_encode(const fshost_matrix *m, const char *ascii, int len, uint8_t *codes) {
     for (int i = 0; i < len; i++) codes[i] = m->m.aa2num[(unsigned char) ascii[i]];

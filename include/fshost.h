@@ -42,6 +42,9 @@ fshost_matrix *fshost_matrix_from_text(const char *text, float bitFactor, float 
 fshost_matrix *fshost_matrix_from_scores(const int16_t *scores, int n, const double *pBack);
 void fshost_matrix_free(fshost_matrix *m);
 int fshost_matrix_size(const fshost_matrix *m);                 /* alphabet size incl. X (21) */
+/* the parameter file of a built-in matrix as text (what a precomputed index stores next to the matrix name, BaseMatrix::serialize,
+ * M/src/commons/BaseMatrix.cpp:170-187); NULL for matrices without one.  *len = bytes without terminator. */
+const char *fshost_matrix_text(int which, size_t *len);
 const int16_t *fshost_matrix_scores(const fshost_matrix *m);    /* [n*n] bit-scaled substitution scores */
 const double *fshost_matrix_background(const fshost_matrix *m); /* [n] BaseMatrix::pBack */
 /* ASCII -> numeric codes with the reference's letter mapping (lower case = same letter; J->L, U/O->X, Z->E, B->D) */
@@ -216,6 +219,14 @@ int fsmod_convertalis(int argc, const char **argv);
  * shared-memory protocol until SIGINT/SIGTERM (M/src/util/gpuserver.cpp:24-101, M/src/commons/GpuUtil.h:9-49);
  * `ungappedprefilter ... --gpu-server 1` is the client (M/src/prefiltering/ungappedprefilter.cpp:71-122,208-257). */
 int fsmod_gpuserver(int argc, const char **argv);
+/* indexdb <seqDB> <seqDB> [--index-subset N] [--index-dbsuffix S] ...: writes <seqDB>.idx, the precomputed index of
+ * PrefilteringIndexReader::createIndexFile (M/src/prefiltering/PrefilteringIndexReader.cpp:53-307; module M/src/util/indexdb.cpp:43-215): sequence and
+ * header databases, sequence lookup and -- unless --index-subset has bit 2 -- the k-mer table and the extended 2-/3-mer matrices, taken from the index
+ * this library builds on the device and renumbered to the reference's k-mer order.  Read by the reference's CPU prefilter / structurealign and by the
+ * modules above.  createindex <seqDB> <tmpDir> = F/data/structureindex.sh: indexdb on <seqDB> (no k-mer table) and <seqDB>_ss (with it), header links,
+ * C-alpha database appended when present. */
+int fsmod_indexdb(int argc, const char **argv);
+int fsmod_createindex(int argc, const char **argv);
 /* protocol constants, exported so that tests (and a reference build) can check them:
  * name of the block for a database (Util::hash of realpath + visible devices + version, GpuUtil.cpp:18-34),
  * its size (GpuUtil.h:34-39) and the header layout: out = {sizeof, offsets of maxSeqLen, maxResListLen, state, serverExit,

@@ -108,3 +108,39 @@ def test_convertalis_hand_written_records_equal_the_reference_binary(tmp_path):
     par = ["--format-output", "query,target,qaln", "--threads", "1", "-v", "1"]
     assert subprocess.run([FS, "convertalis", "db", "db", "aln", "ref.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode != 0
     assert subprocess.run([BIN, "convertalis", "db", "db", "aln", "mine.m8"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode != 0
+
+
+def test_indexdb_without_kmer_table_equals_the_reference_binary(tmp_path):
+    """`indexdb <db> <db> --index-subset 2` (the first call of F/data/structureindex.sh: sequence + header DBs and the masked sequence lookup, no
+    k-mer table -> no device needed) on a database with empty / one-residue entries, X, lower-case stretches and homopolymer runs around the
+    --mask-n-repeat limit: entry by entry the reference binary's index (tests/idx_compare.py says which bytes the reference leaves undefined)"""
+    from idx_compare import compare
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 2, 6, 7, 8, 17, 300, 1, 0, 64, 65, 1500, 33, 7, 8]
+    seqs = [rng.integers(0, 21, L).astype(np.uint8) for L in lens]
+    seqs[7][10:16] = 3; seqs[7][30:37] = 4; seqs[7][100:120] = 20; seqs[12][0:9] = 1; seqs[12][-7:] = 2     # runs of 6 (kept), 7+ (masked), X, at both ends
+    masks = [rng.random(L) < 0.15 for L in lens]
+    keys = [5, 9, 2, 100, 7, 8, 1, 50, 51, 52, 3, 4, 6, 77, 1000000, 12]
+    par = ["--seed-sub-mat", "aa:3di.out,nucl:3di.out", "-k", "0", "--alph-size", "aa:21,nucl:5", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "1",
+           "--max-seq-len", "65535", "--max-seqs", "1000", "--mask", "0", "--mask-prob", "0.999995", "--mask-lower-case", "1", "--mask-n-repeat", "6",
+           "--spaced-kmer-mode", "1", "-s", "9.5", "--k-score", "seq:2147483647,prof:2147483647", "--check-compatible", "0", "--search-type", "0",
+           "--split", "0", "--split-memory-limit", "0", "-v", "1", "--threads", "1", "--index-subset", "2"]
+    for side, exe in (("ref", FS), ("mine", BIN)):
+        w = os.path.join(str(tmp_path), side)
+        os.makedirs(w)
+        dbio.write_seq_db(os.path.join(w, "t"), seqs, keys, masks)
+        with open(os.path.join(w, "t_h"), "wb") as f, open(os.path.join(w, "t_h.index"), "w") as fi:
+            off = 0
+            for k in sorted(keys):
+                b = f"entry {k}".encode() + b"\n\0"
+                f.write(b); fi.write(f"{k}\t{off}\t{len(b)}\n"); off += len(b)
+        np.array([12], np.int32).tofile(os.path.join(w, "t_h.dbtype"))
+        r = subprocess.run([exe, "indexdb", "t", "t"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+    assert compare(os.path.join(str(tmp_path), "ref", "t.idx"), os.path.join(str(tmp_path), "mine", "t.idx")) == []
+    # without the header database both stop (the reference: "needs header information")
+    for exe in (FS, BIN):
+        w = os.path.join(str(tmp_path), "nohdr_" + os.path.basename(exe))
+        os.makedirs(w)
+        dbio.write_seq_db(os.path.join(w, "t"), seqs, keys, masks)
+        assert subprocess.run([exe, "indexdb", "t", "t"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode != 0
