@@ -311,8 +311,8 @@ def sw_roofline(passes, has_aa, solo=None):
     out = {"bound": "valu-issue", "kernel": "k_sw2", "unit": "Gcell/s", "peak": peak, "achieved": cells / max(ms, 1e-9) / 1e6,
            "frac": cells / max(ms, 1e-9) / 1e6 / peak, "cells_per_pass_pair": cells / max(1, len(passes)), "kernel_ms_per_pass_pair": ms / max(1, len(passes)),
            "traffic": None,
-           # the same passes priced in what the waves really issue: two targets per wave run max(LtA, LtB) + lanes - 1 steps of 14 R + 26 VALU
-           # instructions (16 R + 34 with the AA table; counted in the kernel's ISA), 4.3 cycles each.  frac / issued_valu_frac = the share of the
+           # the same passes priced in what the waves really issue: two targets per wave run max(LtA, LtB) + lanes - 1 steps of 14 R + 14 VALU
+           # instructions (16 R + 23 with the AA table; counted in the kernel's ISA), 4.3 cycles each.  frac / issued_valu_frac = the share of the
            # issued stream that is the 14 (16) DP instructions of real cells: the rest is the step overhead, lane padding, wavefront fill / drain
            # and the shorter target of a wave
            "issued_valu_frac": instr / max(ms, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3),

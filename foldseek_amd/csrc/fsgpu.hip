@@ -1434,8 +1434,8 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
     {
         // work of this pass in the units of the kernel's roofline: DP cells (query rows x target columns of every single-tile pair) and
         // VALU wave-instructions (a wave carries two targets of one query and runs max(LtA, LtB) + lanes - 1 steps; a step is 14 packed
-        // instructions per register row + 26 around them -- lane shifts, LDS addresses, loop and maximum bookkeeping; counted in the ISA
-        // of k_sw2<6, false>: 110 VALU instructions per step -- and 2 per row + 8 more with the AA table)
+        // instructions per register row + 14 around them -- lane shifts, LDS addresses, column and maximum bookkeeping; counted in the ISA
+        // of k_sw2<6, false>: 98 VALU instructions per step outside the new-maximum block -- and 2 per row + 9 more with the AA table: 119)
         double cells = 0, pairs = 0, wsteps = 0;
         const std::vector<int32_t> &len = ctx->db->hLengths;
         for (int i = 0; i < nq; i++) {
@@ -1445,7 +1445,7 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
             for (int k = 0; k < ns; k++) {
                 const int lt = len[q[i].targetIds[p[k]]];
                 cells += (double) q[i].L * lt;
-                if ((k & 1) == 0 && lt > 0) wsteps += (double) (lt + lanes - 1) * (14.0 * R + 26.0 + (hasAA ? 2.0 * R + 8.0 : 0.0));   // pairs are longest first: the even one sets the wave's length
+                if ((k & 1) == 0 && lt > 0) wsteps += (double) (lt + lanes - 1) * (14.0 * R + 14.0 + (hasAA ? 2.0 * R + 9.0 : 0.0));   // pairs are longest first: the even one sets the wave's length
             }
             pairs += ns;
         }

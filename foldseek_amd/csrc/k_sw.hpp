@@ -112,21 +112,32 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {
     return __builtin_amdgcn_update_dpp(0u, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
 
+// One profile row of the LDS image (layout: swDwordIndex): 16-byte chunks at lane * 16, then the 8-byte / 4-byte remainders at their own lane
+// strides.  `rowOff` is the byte offset of the row (target code * row bytes, possibly wave-varying); the lane-dependent parts of the addresses
+// are loop invariants the caller keeps in registers (SwLaneBase), so every chunk costs ONE add (row offset + lane base) instead of
+// base + row + lane.  (A layout with a single lane stride for all chunks -- planes of 8 bytes at R = 6 -- needs fewer adds still, but the
+// compiler fuses its reads into ds_read2st64_b64, whose two halves hit the same banks: measured 9 % slower, dropped.)
 template <int R>
-__device__ __forceinline__ void swLoadRow(const unsigned char *rowBase, int lane, uint32_t (&P)[R]) {
+struct SwLaneBase {
+    const unsigned char *b16, *b8, *b4;
+    __device__ __forceinline__ SwLaneBase(const unsigned char *table, int lane)
+        : b16(table + lane * 16), b8(table + (R / 4) * 1024 + lane * 8), b4(table + (R / 4) * 1024 + (R % 4 == 3 ? 512 : 0) + lane * 4) {}
+};
+template <int R>
+__device__ __forceinline__ void swLoadRow(const SwLaneBase<R> &lb, uint32_t rowOff, uint32_t (&P)[R]) {
     constexpr int full = (R / 4) * 4;
 #pragma unroll
     for (int k = 0; k < R / 4; k++) {
-        const uint4 v = *(const uint4 *) (rowBase + (k * 256 + lane * 4) * 4);
+        const uint4 v = *(const uint4 *) (lb.b16 + rowOff + k * 1024);
         P[4 * k] = v.x; P[4 * k + 1] = v.y; P[4 * k + 2] = v.z; P[4 * k + 3] = v.w;
     }
     constexpr int rem = R % 4;
     if constexpr (rem >= 2) {
-        const uint2 v = *(const uint2 *) (rowBase + ((R / 4) * 256 + lane * 2) * 4);
+        const uint2 v = *(const uint2 *) (lb.b8 + rowOff);
         P[full] = v.x; P[full + 1] = v.y;
-        if constexpr (rem == 3) P[full + 2] = *(const uint32_t *) (rowBase + ((R / 4) * 256 + 128 + lane) * 4);
+        if constexpr (rem == 3) P[full + 2] = *(const uint32_t *) (lb.b4 + rowOff);
     } else if constexpr (rem == 1) {
-        P[full] = *(const uint32_t *) (rowBase + ((R / 4) * 256 + lane) * 4);
+        P[full] = *(const uint32_t *) (lb.b4 + rowOff);
     }
 }
 
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
     uint32_t bh = 0, bfs = 0, bff = 0, bhN = 0, bfsN = 0, bffN = 0;   // border-in chunks
     uint32_t oh = 0, ofs = 0, off_ = 0;                                // border-out accumulators
     const size_t bBase = a.tblocks ? (size_t) __builtin_amdgcn_readfirstlane(a.borderBase[pair]) : (size_t) pair * a.borderStride;
+    const SwLaneBase<R> lb3(smem, lane), lbA(smem + TBL, lane);
 
     auto loadChunk = [&](int s0) -> uint32_t {
         int col = s0 + lane;
@@ -250,8 +262,8 @@ __global__ __launch_bounds__(512) void k_sw(SwArgs a) {
         const int col = s - lane;
         if (laneActive && col >= 0 && col < Lt) {
             uint32_t P3[R], PA[R];
-            swLoadRow<R>(smem + (tval & 0xffffu), lane, P3);
-            if constexpr (HAS_AA) swLoadRow<R>(smem + TBL + (tval >> 16), lane, PA);
+            swLoadRow<R>(lb3, tval & 0xffffu, P3);
+            if constexpr (HAS_AA) swLoadRow<R>(lbA, tval >> 16, PA);
             uint32_t diag = hUpPrev, fseg = fsegIn, ffull = ffullIn, cm = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -386,7 +398,6 @@ __global__ __launch_bounds__(1024) void k_sw2(SwArgs a) {
     const int Lt = LtA > LtB ? LtA : LtB;          // the caller orders pairs longest first: normally LtA
     const int nLanes = (rowsInTile + R - 1) / R;
     const int steps = Lt > 0 ? Lt + nLanes - 1 : 0;
-    const bool laneActive = lane < nLanes;
     // merge selector: {S0 = target B's dword (bytes 4..7), S1 = target A's dword (bytes 0..3)} -> (A.dir, B.dir)
     const uint32_t sel = a.dir ? 0x07060302u : 0x05040100u;
 
@@ -397,9 +408,9 @@ __global__ __launch_bounds__(1024) void k_sw2(SwArgs a) {
 #pragma unroll
     for (int r = 0; r < R; r++) { E[r] = 0; Hp[r] = 0; snap[r] = 0; }
     uint32_t best = 0, bestcol = 0;
-    uint32_t hOut = 0, fsegOut = 0, ffullOut = 0, hUpPrev = 0, tval = 0, tvalAA = 0;
-    uint32_t chunkCur = 0, chunkNxt = 0, chunkAACur = 0, chunkAANxt = 0;
     constexpr uint32_t kDeadOff = (uint32_t) kAlphabet * (uint32_t) ROWB;
+    uint32_t hOut = 0, fsegOut = 0, ffullOut = 0, hUpPrev = 0, tval = kDeadOff | (kDeadOff << 16), tvalAA = kDeadOff | (kDeadOff << 16);
+    uint32_t chunkCur = 0, chunkNxt = 0, chunkAACur = 0, chunkAANxt = 0;
 
     auto loadChunk = [&](int s0, uint32_t &vAA) -> uint32_t {
         const int col = s0 + lane;
@@ -417,7 +428,10 @@ __global__ __launch_bounds__(1024) void k_sw2(SwArgs a) {
     };
     chunkNxt = loadChunk(0, chunkAANxt);
 
-    for (int s = 0; s < steps; s++) {
+    // two steps per loop iteration, each an inlined copy of the body: the diagonal registers (old H of a row = diag of the next) then
+    // alternate between two register sets instead of being moved back into place at every step (5 v_mov per step at R = 6)
+    const SwLaneBase<R> lb3(smem, lane), lbA(smem + TBL, lane);
+    auto step = [&](const int s) {
         if ((s & 63) == 0) {
             chunkCur = chunkNxt; chunkAACur = chunkAANxt;
             chunkNxt = loadChunk(s + 64, chunkAANxt);
@@ -436,14 +450,19 @@ __global__ __launch_bounds__(1024) void k_sw2(SwArgs a) {
             if (lane == 0) tvalAA = tv;
         }
         const int col = s - lane;
-        if (laneActive && col >= 0 && col < Lt) {
+        // No lane is masked off.  A lane that has not reached its first column yet still holds the "past the end" code it was initialised
+        // with (score INT16_MIN: H, E, F stay 0), columns beyond a target's end read the same row (values can only decay), and rows beyond
+        // the query -- inside the last lane or in whole lanes -- score 0 against everything: such a cell repeats the value of its diagonal
+        // neighbour, which was computed a step earlier, so it never sets a NEW maximum.  Without the exec mask the new H of a row is
+        // written in place instead of being merged into the persistent registers by a move per row.
+        {
             uint32_t PA[R], PB[R];
-            swLoadRow<R>(smem + (tval & 0xffffu), lane, PA);
-            swLoadRow<R>(smem + (tval >> 16), lane, PB);
+            swLoadRow<R>(lb3, tval & 0xffffu, PA);
+            swLoadRow<R>(lb3, tval >> 16, PB);
             if constexpr (HAS_AA) {
                 uint32_t QA[R], QB[R];
-                swLoadRow<R>(smem + TBL + (tvalAA & 0xffffu), lane, QA);
-                swLoadRow<R>(smem + TBL + (tvalAA >> 16), lane, QB);
+                swLoadRow<R>(lbA, tvalAA & 0xffffu, QA);
+                swLoadRow<R>(lbA, tvalAA >> 16, QB);
 #pragma unroll
                 for (int r = 0; r < R; r++) { PA[r] = A::add(QA[r], PA[r]); PB[r] = A::add(QB[r], PB[r]); }
             }
@@ -477,6 +496,11 @@ __global__ __launch_bounds__(1024) void k_sw2(SwArgs a) {
             }
         }
         hUpPrev = hUpNew;
+    };
+    {
+        int s = 0;
+        for (; s + 1 < steps; s += 2) { step(s); step(s + 1); }
+        if (s < steps) step(s);
     }
 
 #pragma unroll
