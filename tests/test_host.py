@@ -207,3 +207,41 @@ def test_bench_usable_cores():
     assert 1 <= n <= (os.cpu_count() or 1)
     if hasattr(os, "sched_getaffinity"):
         assert n <= len(os.sched_getaffinity(0))
+
+
+def test_kmer_bin_table_planner():
+    """fsgpu_kmer_plan_bins (host only): the arithmetic target-bin table of the k-mer hit-stream partition.  Invariants: bin(t) =
+    (blk[t >> 10] >> 8) + ((t & 1023) >> (blk[t >> 10] & 255)) is monotone in t, maps every target into [0, bins), binFirst is its inverse,
+    every block of 1024 ids is cut into equal power-of-two id ranges of at least 8 ids, and a block is only cut finer while a bin's
+    share of the block's residues exceeds resCap"""
+    L = api.lib()
+    rng = np.random.default_rng(21)
+    for trial in range(30):
+        n = int(rng.integers(1, 40000))
+        kind = trial % 3
+        if kind == 0:
+            lens = np.clip(np.rint(rng.gamma(2.0, 175.0, size=n)), 1, 3000).astype(np.int32)
+        elif kind == 1:
+            lens = np.sort(np.clip(np.rint(rng.gamma(2.0, 175.0, size=n)), 1, 3000).astype(np.int32))[::-1].copy()      # length-sorted DB
+        else:
+            lens = np.full(n, int(rng.integers(1, 2000)), np.int32)
+        res_cap = int(rng.choice([500, 5000, 40000, 10**7]))
+        nblk = (n + 1023) // 1024
+        blk = np.zeros(nblk, np.uint32)
+        cap = nblk * 128 + 2
+        first = np.zeros(cap, np.uint32)
+        bins = L.fsgpu_kmer_plan_bins(lens.ctypes.data, n, res_cap, blk.ctypes.data, first.ctypes.data, cap)
+        assert bins >= nblk and bins <= nblk * 128
+        assert L.fsgpu_kmer_plan_bins(lens.ctypes.data, n, res_cap, None, None, cap) == bins           # sizes only
+        assert L.fsgpu_kmer_plan_bins(lens.ctypes.data, n, res_cap, blk.ctypes.data, first.ctypes.data, bins) < 0   # cap too small: bins + 1 needed
+        t = np.arange(n, dtype=np.int64)
+        shift = (blk[t >> 10] & 255).astype(np.int64)
+        b = (blk[t >> 10] >> 8).astype(np.int64) + ((t & 1023) >> shift)
+        assert b[0] == 0 and (np.diff(b) >= 0).all() and (np.diff(b) <= 1).all() and b[-1] == bins - 1
+        assert first[bins] == n and (first[b] <= t).all() and (t < first[b + 1]).all()
+        assert ((blk & 255) >= 3).all() and ((blk & 255) <= 10).all()
+        for k in range(nblk):
+            sh = int(blk[k] & 255)
+            res = int(lens[k * 1024:(k + 1) * 1024].sum())
+            assert sh == 3 or (res >> (10 - sh)) <= res_cap                       # fine enough, or at the finest cut
+            assert sh == 10 or (res >> (10 - (sh + 1))) > res_cap                 # not finer than needed
