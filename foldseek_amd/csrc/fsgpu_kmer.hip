@@ -632,7 +632,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         for (int q = 0; q < nq; q++) maxQ = std::max<uint64_t>(maxQ, (q + 1 < nq ? hq[q + 1].hitBase : nHits) - hq[q].hitBase);
         const double perResMax = (double) maxQ / (double) std::max<uint64_t>(ix.residues, 1);
         const double perResAvg = (double) nHits / (double) nq / (double) std::max<uint64_t>(ix.residues, 1);
-        // LDS of the group kernels: 16-bit per-target counters x 2, the query's chunk starts, 12 bytes per hit (+ the rank loop's slack records)
+        // LDS of the group kernels: 16-bit per-target counters x 2, the query's chunk starts, 9 bytes per hit (two 32-bit stream-position arrays and the
+        // sorted 8-bit diagonals; + 2 for the flag prefix where it cannot live in the cursor array) + the rank loop's slack entries
         const size_t ldsCnt16 = (size_t) 2 * (kDupCounters + 4) * sizeof(uint16_t) + (kMaxChunks + 1) * sizeof(uint32_t) + 8 + 64;
         const size_t ldsCnt32 = (size_t) 2 * (kDupCounters + 4) * sizeof(uint32_t) + (kMaxChunks + 1) * sizeof(uint32_t) + 8 + 64;
         const size_t ldsDynMax = 160 * 1024 - 1024;            // the kernel's static LDS (wave sums) counts against the CU's 160 KB too
@@ -698,8 +699,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         hipLaunchKernelGGL(k_kmer_groups, dim3(gridFor(nSeg, 256)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p, (const uint32_t *) S.segStart.p,
                            (const uint32_t *) lv->binFirst, lv->nBins, nSeg, segLists, capLarge, (uint32_t *) S.segCand.p);
         static_assert(kDupCap <= kDupCounters + 4 && sizeof(uint16_t) == 2, "the flag prefix of the 512-thread variant lives in the cursor array");
-        const size_t ldsWg = ldsCnt16 + (size_t) kDupCap * (sizeof(uint64_t) + sizeof(uint16_t));
-        const size_t ldsLarge = ldsCnt16 + (size_t) capLarge * (sizeof(uint64_t) + 2 * sizeof(uint16_t));
+        const size_t ldsWg = ldsCnt16 + ((size_t) kDupCap + 8) * 9 + 16;
+        const size_t ldsLarge = ldsCnt16 + ((size_t) capLarge + 8) * 11 + 16;
         const unsigned gridSmall = (unsigned) std::min<uint64_t>(gridFor(nSeg, 4), (uint64_t) ctx->numCU * 16);
         const unsigned gridWg = (unsigned) std::min<uint64_t>(nSeg, (uint64_t) ctx->numCU * 8);
         const unsigned gridLarge = (unsigned) std::min<uint64_t>(nSeg, (uint64_t) ctx->numCU);
@@ -709,7 +710,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             if (attr != hipSuccess) { ctx->err = std::string("hipFuncSetAttribute(k_kmer_dup_wg): ") + hipGetErrorString(attr); return FSGPU_E_HIP; }
             hipLaunchKernelGGL((k_kmer_dup_wg<false, 1024, kDupCapLarge / 1024>), dim3(gridLarge), dim3(1024), ldsLarge, st, da, (const KmerGroup *) segLists.large, (const uint32_t *) segLists.counts + 2, capLarge);
         }
-        hipLaunchKernelGGL((k_kmer_dup_wg<true, 256, 1>), dim3(gridWg), dim3(256), ldsCnt32, st, da, (const KmerGroup *) segLists.big, (const uint32_t *) segLists.counts + 3, 0u);
+        hipLaunchKernelGGL((k_kmer_dup_wg<true, 1024, 1>), dim3(std::min<unsigned>(gridWg, (unsigned) ctx->numCU * 2)), dim3(1024), ldsCnt32, st, da, (const KmerGroup *) segLists.big, (const uint32_t *) segLists.counts + 3, 0u);
         hipLaunchKernelGGL((k_kmer_dup_wg<false, 512, kDupCap / 512>), dim3(gridWg), dim3(512), ldsWg, st, da, (const KmerGroup *) segLists.wg, (const uint32_t *) segLists.counts + 1, (uint32_t) kDupCap);
         hipLaunchKernelGGL(k_kmer_dup_small, dim3(gridSmall), dim3(256), 0, st, da, (const KmerGroup *) segLists.small, (const uint32_t *) segLists.counts + 0);
         RPCHK(hipGetLastError());

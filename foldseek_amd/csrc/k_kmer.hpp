@@ -821,11 +821,27 @@ template <> struct KmerCnt<true> {
     static __device__ __forceinline__ uint32_t add(T *a, uint32_t i) { return atomicAdd(a + i, 1u); }
 };
 
-// one workgroup (NT threads) per group.  BIG = false: up to `cap` = NT * PER hits, each thread keeps its PER records in registers from the
-// one global load to the scatter, bucket / position arrays in LDS; BIG = true: any size, arrays in global scratch, records re-read (same
-// code, the per-target counters stay in LDS).  The next group's descriptor is fetched while the current one is being resolved.
+// a group descriptor is the same for every lane: keep it in scalar registers
+__device__ __forceinline__ KmerGroup kmerLoadGroup(const KmerGroup *list, uint32_t i) {
+    const KmerGroup g = list[i];
+    KmerGroup s;
+    s.s0 = __builtin_amdgcn_readfirstlane(g.s0); s.m = __builtin_amdgcn_readfirstlane(g.m); s.seg = __builtin_amdgcn_readfirstlane(g.seg);
+    s.tBase = __builtin_amdgcn_readfirstlane(g.tBase); s.T = __builtin_amdgcn_readfirstlane(g.T); s.q = __builtin_amdgcn_readfirstlane(g.q);
+    s.hb = __builtin_amdgcn_readfirstlane(g.hb); s.nCh = __builtin_amdgcn_readfirstlane(g.nCh);
+    return s;
+}
+
+// one workgroup (NT threads) per group.  The hits are counted per target (LDS counters), the counters scanned into bucket starts, and
+// every hit gets its place in (target, stream position) order: bucket start + its rank among the bucket's stream positions.  The
+// predecessor of a hit (previous hit of the same target) is then the entry before it, and the double-diagonal rule one compare.
+// BIG = false: up to `cap` = NT * PER hits, read from global memory once.  LDS holds the entries grouped by target as two 32-bit arrays
+// (stream position; target | diagonal), filled through atomic cursors in any order inside a bucket; the rank loop reads the stream
+// positions only -- one 8-byte LDS read and two compare + add-with-carry per two bucket entries -- and the sorted stream positions
+// then replace the grouped ones.  The kernel is VALU-issue bound: what counts is instructions per hit.
+// BIG = true: any size, bucket / position arrays in global scratch, records re-read (the per-target counters stay in LDS).
+// The next group's descriptor is fetched while the current one is being resolved.
 template <bool BIG, int NT, int PER>
-__global__ __launch_bounds__(NT) void k_kmer_dup_wg(KmerDupArgs a, const KmerGroup *list, const uint32_t *countPtr, uint32_t cap) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 8 : 4))) void k_kmer_dup_wg(KmerDupArgs a, const KmerGroup *list, const uint32_t *countPtr, uint32_t cap) {
     typedef KmerCnt<BIG> Cnt;
     typedef typename Cnt::T CT;
     extern __shared__ __attribute__((aligned(16))) unsigned char shDup[];
@@ -837,28 +853,41 @@ __global__ __launch_bounds__(NT) void k_kmer_dup_wg(KmerDupArgs a, const KmerGro
     CT *off = (CT *) shDup;                              // [kDupCounters + 4] bucket starts (off[t] .. off[t + 1])
     CT *cur = (CT *) (shDup + kCntBytes);                // [kDupCounters + 4] scatter cursors
     uint32_t *cst = (uint32_t *) (shDup + kCstOff);      // [kMaxChunks + 1] chunk starts of the query, stream positions relative to its first hit
-    uint64_t *lbucket = (uint64_t *) (shDup + kBucketOff);
-    uint16_t *lspos = (uint16_t *) (shDup + kBucketOff + (cap + 8) * 8);   // [cap] sorted position | flag << 15   (8 slack records: the rank loop reads in eights)
+    uint32_t *ao = (uint32_t *) (shDup + kBucketOff);                        // [cap + 8] stream positions, grouped by target (any order inside a bucket)
+    uint32_t *so = ao;                                                       // ... and, once every rank is known, the same in sorted order
+    uint32_t *at = (uint32_t *) (shDup + kBucketOff + (cap + 8) * 4);        // [cap + 8] (target & 0xffff) << 16 | 16-bit diagonal of the grouped entry
+    uint8_t *sd = shDup + kBucketOff + (cap + 8) * 8;                        // [cap + 8] 8-bit diagonal at the sorted position
     // [cap] flag at sorted position -> exclusive prefix.  The 256- / 512-thread variant keeps it in the scatter cursors' place (dead once the
-    // buckets are filled, and cap <= kDupCounters there): 40 KB per workgroup, four of them per CU
-    uint16_t *lpfx = (!BIG && NT <= 512) ? (uint16_t *) cur : lspos + cap;
+    // buckets are filled, and cap <= kDupCounters there): 36 KB per workgroup, four of them per CU
+    uint16_t *lpfx = (!BIG && NT <= 512) ? (uint16_t *) cur : (uint16_t *) (shDup + kBucketOff + (cap + 8) * 9 + ((cap + 8) & 1u));
     const uint32_t n = *countPtr;
     if (blockIdx.x >= n) return;
-    KmerGroup g = list[blockIdx.x];
+    // software pipeline over the workgroup's groups: the descriptor is fetched two groups ahead and the records one group ahead, so the
+    // global round trips of group i + 1 run under the LDS phases of group i (a group is a dozen dependent LDS phases: latency, not issue,
+    // bounds the small variant)
+    KmerGroup g = kmerLoadGroup(list, blockIdx.x), gNext = g;
+    if (blockIdx.x + gridDim.x < n) gNext = kmerLoadGroup(list, blockIdx.x + gridDim.x);
+    uint64_t rNext[PER];
+    if (!BIG) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; rNext[u] = e < g.m ? a.part[g.s0 + e] : 0; }
+    }
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
         const uint32_t seg = g.seg, s0 = g.s0, m = g.m, tBase = g.tBase, T = g.T, nCh = g.nCh, hb = g.hb;
         const KmerChunks &ck = a.chunks[g.q];
         uint64_t *gb = a.gbucket + s0;       // BIG only; the two variants index different address spaces, so no common pointer
-        // every global load of this group is issued here, before anything waits: records, chunk starts, the next descriptor
         uint64_t r[PER];
-        if (!BIG) {
 #pragma unroll
-            for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; r[u] = e < m ? a.part[s0 + e] : 0; }
-        }
+        for (int u = 0; u < PER; u++) r[u] = BIG ? 0 : rNext[u];
         uint32_t cstv[(kMaxChunks + NT) / NT];
 #pragma unroll
         for (int u = 0; u < (kMaxChunks + NT) / NT; u++) { const uint32_t i = threadIdx.x + NT * u; cstv[u] = i <= nCh ? (uint32_t) ck.start[i] : 0u; }
-        if (it + gridDim.x < n) g = list[it + gridDim.x];
+        g = gNext;
+        if (!BIG && it + gridDim.x < n) {     // the next group's records (its range is disjoint from this group's: nothing below writes there)
+#pragma unroll
+            for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; rNext[u] = e < g.m ? a.part[g.s0 + e] : 0; }
+        }
+        if (it + 2 * gridDim.x < n) gNext = kmerLoadGroup(list, it + 2 * gridDim.x);
         for (uint32_t i = threadIdx.x; i < (T + 2) / 2 + 1; i += NT) {       // zero as dwords (both counter widths)
             if (BIG) { off[2 * i] = 0; off[2 * i + 1] = 0; } else reinterpret_cast<uint32_t *>(off)[i] = 0;
         }
@@ -875,49 +904,89 @@ __global__ __launch_bounds__(NT) void k_kmer_dup_wg(KmerDupArgs a, const KmerGro
         kmerBlockScan<CT, true, NT>(off + 1, T, wsum);            // off[t + 1] = end of target t's bucket, off[0] = 0
         for (uint32_t i = threadIdx.x; i < T; i += NT) cur[i] = off[i];
         __syncthreads();
-        if (BIG) {
+        uint32_t nc;
+        if constexpr (BIG) {
             for (uint32_t e = threadIdx.x; e < m; e += NT) { const uint64_t x = a.part[s0 + e]; gb[Cnt::add(cur, partTloc(x) - tBase)] = x; }
-        } else {
-            uint32_t pos[PER];
-#pragma unroll
-            for (int u = 0; u < PER; u++) pos[u] = threadIdx.x + NT * u < m ? Cnt::add(cur, partTloc(r[u]) - tBase) : 0u;
-#pragma unroll
-            for (int u = 0; u < PER; u++) if (threadIdx.x + NT * u < m) lbucket[pos[u]] = r[u];
-        }
-        __syncthreads();
-        for (uint32_t p = threadIdx.x; p < m; p += NT) {
-            const uint64_t x0 = BIG ? gb[p] : lbucket[p];
-            const uint32_t t = partTloc(x0) - tBase, lo = off[t], hi = off[t + 1];
-            uint64_t pred = 0;
-            uint32_t rank = 0;
-            if (BIG) {
+            __syncthreads();
+            for (uint32_t p = threadIdx.x; p < m; p += NT) {
+                const uint64_t x0 = gb[p];
+                const uint32_t t = partTloc(x0) - tBase, lo = off[t], hi = off[t + 1];
+                uint64_t pred = 0;
+                uint32_t rank = 0;
                 for (uint32_t j = lo; j < hi; j++) { const uint64_t x = gb[j]; if (x < x0) { rank++; pred = x > pred ? x : pred; } }
-            } else {
-                for (uint32_t j = lo; j < hi; j += 8) {       // eight bucket entries per round trip; entries past the bucket's end are masked out
-                    uint64_t x[8];
+                uint32_t prevD8 = 0;
+                if (rank) {
+                    bool same = true;
+                    if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, partO(x0) - hb); same = partO(pred) - hb >= cst[c]; }
+                    if (same) prevD8 = partD8(pred);
+                }
+                const uint32_t flag = partD8(x0) == prevD8 ? 1u : 0u, sp = lo + rank;
+                a.gaux[s0 + p] = sp | (flag << 31); a.gaux2[s0 + sp] = flag;
+            }
+            __syncthreads();
+            nc = kmerBlockScan<uint32_t, false, NT>(a.gaux2 + s0, m, wsum);
+            for (uint32_t p = threadIdx.x; p < m; p += NT) {
+                const uint32_t sx = a.gaux[s0 + p];
+                if (sx >> 31) a.part[s0 + a.gaux2[s0 + (sx & 0x7fffffffu)]] = gb[p];
+            }
+        } else {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) x[k] = lbucket[j + k];
+            for (int u = 0; u < PER; u++)
+                if (threadIdx.x + NT * u < m) {
+                    const uint32_t pos = Cnt::add(cur, partTloc(r[u]) - tBase);
+                    ao[pos] = partO(r[u]); at[pos] = (uint32_t) (r[u] >> 32 & 0xffff0000u) | partD16(r[u]);
+                }
+            __syncthreads();
+            // from here on a thread works on the entries at bucket positions threadIdx.x + NT * u: neighbouring lanes sit in the same bucket,
+            // so the rank loops of a wave have (nearly) the same trip count and their LDS reads are broadcasts
+            uint32_t o0[PER], td[PER], sp[PER], blo[PER];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) if (j + k < hi && x[k] < x0) { rank++; pred = x[k] > pred ? x[k] : pred; }
+            for (int u = 0; u < PER; u++) {
+                o0[u] = 0; td[u] = 0; sp[u] = 0; blo[u] = 0;
+                const uint32_t p = threadIdx.x + NT * u;
+                if (p < m) {
+                    o0[u] = ao[p]; td[u] = at[p];
+                    const uint32_t t = (td[u] >> 16) - tBase, lo = off[t], hi = off[t + 1], x = o0[u];
+                    // entries are read in aligned pairs from the even index at or below lo to the even index at or above hi; the (at most two)
+                    // entries outside [lo, hi) that this touches are taken out again afterwards
+                    const uint32_t hiE = (hi + 1) & ~1u;
+                    uint32_t j = lo & ~1u, rank = 0;
+                    for (; j + 8 <= hiE; j += 8) {
+                        const uint2 x0 = *reinterpret_cast<const uint2 *>(ao + j), x1 = *reinterpret_cast<const uint2 *>(ao + j + 2);
+                        const uint2 x2 = *reinterpret_cast<const uint2 *>(ao + j + 4), x3 = *reinterpret_cast<const uint2 *>(ao + j + 6);
+                        rank += (x0.x < x) + (x0.y < x) + (x1.x < x) + (x1.y < x) + (x2.x < x) + (x2.y < x) + (x3.x < x) + (x3.y < x);
+                    }
+                    for (; j < hiE; j += 2) { const uint2 y = *reinterpret_cast<const uint2 *>(ao + j); rank += (y.x < x) + (y.y < x); }
+                    if (lo & 1u) rank -= ao[lo - 1] < x ? 1u : 0u;
+                    if (hi & 1u) rank -= ao[hi] < x ? 1u : 0u;
+                    sp[u] = lo + rank; blo[u] = lo;
                 }
             }
-            uint32_t prevD8 = 0;
-            if (rank) {
-                bool same = true;
-                if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, partO(x0) - hb); same = partO(pred) - hb >= cst[c]; }
-                if (same) prevD8 = partD8(pred);
+            __syncthreads();                  // every rank is known: the grouped stream positions can be overwritten by the sorted ones
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (threadIdx.x + NT * u < m) { so[sp[u]] = o0[u]; sd[sp[u]] = (uint8_t) td[u]; }
+            __syncthreads();
+            uint32_t flags = 0;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                if (threadIdx.x + NT * u < m) {
+                    uint32_t prevD8 = 0;
+                    if (sp[u] > blo[u]) {
+                        bool same = true;
+                        if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, o0[u] - hb); same = so[sp[u] - 1] - hb >= cst[c]; }
+                        if (same) prevD8 = sd[sp[u] - 1];
+                    }
+                    const uint32_t f = (td[u] & 0xffu) == prevD8 ? 1u : 0u;
+                    flags |= f << u;
+                    lpfx[sp[u]] = (uint16_t) f;
+                }
             }
-            const uint32_t flag = partD8(x0) == prevD8 ? 1u : 0u, sp = lo + rank;
-            if (BIG) { a.gaux[s0 + p] = sp | (flag << 31); a.gaux2[s0 + sp] = flag; }
-            else { lspos[p] = (uint16_t) (sp | (flag << 15)); lpfx[sp] = (uint16_t) flag; }
-        }
-        __syncthreads();
-        uint32_t nc;
-        if (BIG) nc = kmerBlockScan<uint32_t, false, NT>(a.gaux2 + s0, m, wsum);
-        else nc = kmerBlockScan<uint16_t, false, NT>(lpfx, m, wsum);
-        for (uint32_t p = threadIdx.x; p < m; p += NT) {
-            if (BIG) { const uint32_t sx = a.gaux[s0 + p]; if (sx >> 31) a.part[s0 + a.gaux2[s0 + (sx & 0x7fffffffu)]] = gb[p]; }
-            else { const uint32_t sx = lspos[p]; if (sx >> 15) a.part[s0 + lpfx[sx & 0x7fffu]] = lbucket[p]; }
+            __syncthreads();
+            nc = kmerBlockScan<uint16_t, false, NT>(lpfx, m, wsum);
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if ((flags >> u) & 1u) a.part[s0 + lpfx[sp[u]]] = partPack(td[u] >> 16, o0[u], td[u] & 0xffffu);   // the group's range can be overwritten: it was read into registers
         }
         if (threadIdx.x == 0) a.segCand[seg] = nc;
         __syncthreads();                      // LDS arrays are reused by the next group
