@@ -191,8 +191,11 @@ static int buildDb(fsgpu_ctx *ctx, const uint8_t *dRaw3di, const uint8_t *dRawAA
         HIPCHK(hipMemcpy(ctx->db->stripeLen, sLen.data(), nStripes * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->db->stripeTargets, sTargets.data(), sTargets.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    HIPCHK(hipMemcpy(ctx->db->dOffsets, dOff, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy(ctx->db->dLengths, dLen, n * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    // stream-ordered copies: a device-to-device hipMemcpy runs on the null stream and is NOT synchronous with the host, and the context's
+    // stream is non-blocking, so the layout kernels below could otherwise start before their offsets / lengths have arrived (seen as an
+    // intermittent memory fault when two processes time-share one device)
+    HIPCHK(hipMemcpyAsync(ctx->db->dOffsets, dOff, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->db->dLengths, dLen, n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     if (nStripes) {
         hipLaunchKernelGGL(k_db_scan_layout, dim3(nStripes), dim3(256), 0, ctx->stream, dRaw3di, ctx->db->dOffsets, ctx->db->dLengths,
                            (uint32_t) n, ctx->db->stripeOff, ctx->db->stripeLen, ctx->db->stripeTargets, ctx->db->scan);
@@ -350,6 +353,11 @@ extern "C" int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *u
             if (!b.size) continue;
             for (int i = 0; i < n; i++)
                 if (hipMemcpyPeer(b.dstp[i], dst[i]->device, b.srcp, src->device, b.size) != hipSuccess) { freeAll(); src->err = "fsgpu_db_broadcast: peer copy failed"; return FSGPU_E_HIP; }
+        }
+        // peer copies are device-side work on the null streams: not synchronous with the host, not ordered against the contexts' non-blocking streams
+        for (int r = 0; r <= n; r++) {
+            fsgpu_ctx *c = r == 0 ? src : dst[r - 1];
+            if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { freeAll(); src->err = "fsgpu_db_broadcast: peer copy failed"; return FSGPU_E_HIP; }
         }
     }
     int rc = FSGPU_OK;
