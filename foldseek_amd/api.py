@@ -33,7 +33,7 @@ class KmerIndexParams(C.Structure):
 
 
 class KmerSearchParams(C.Structure):
-    _fields_ = [("maxResListLen", C.c_int32), ("minDiagScoreThr", C.c_int32), ("bins", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("maxResListLen", C.c_int32), ("minDiagScoreThr", C.c_int32), ("bins", C.c_int32), ("kmerScoreOnly", C.c_int32),
                 ("maxDbMatches", C.c_int64), ("foundDiagonalsSize", C.c_int64), ("l2CacheSize", C.c_uint64)]
 
 
@@ -365,10 +365,10 @@ class Context:
         return s, ix
 
     def kmer_search(self, prepared, identity=None, max_res=1000, min_diag=30, bins=0, max_db_matches=0,
-                    found_diagonals_size=0, l2_cache_size=0, want_stats=False):
+                    found_diagonals_size=0, l2_cache_size=0, want_stats=False, kmer_score_only=False):
         """prepared: list of (seq uint8[L], thr int16[nPos], profile int8[L,21]) from kmer_query_prepare."""
         nq = len(prepared)
-        sp = KmerSearchParams(max_res, min_diag, bins, 0, max_db_matches, found_diagonals_size, l2_cache_size)
+        sp = KmerSearchParams(max_res, min_diag, bins, 1 if kmer_score_only else 0, max_db_matches, found_diagonals_size, l2_cache_size)
         qs = (KmerQuery * max(nq, 1))()
         keep = []
         for i, (seq, thr, prof) in enumerate(prepared):

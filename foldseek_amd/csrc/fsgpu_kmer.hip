@@ -363,6 +363,9 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
     int status = FSGPU_KMER_OK;
     bool empty = false;
     if (ck.aborted == 2) status = FSGPU_KMER_E_CHUNKS;
+    // --diag-score 0: after a refill the reference sums the rounds' counts per target in mergeScoreDuplicates (CacheFriendlyOperations.cpp:150-180),
+    // whose leftover byte array makes later elements of a target reappear with the previous element's diagonal byte as "score": not replayed
+    if (sp.kmerScoreOnly && C >= 1 && status == FSGPU_KMER_OK) status = FSGPU_KMER_E_REFILL_COUNTS;
     if (ck.aborted == 1) empty = true;
     const bool lastEmpty = ck.start[ck.nChunks] == ck.start[ck.nChunks - 1];
     if (C >= 1 && lastEmpty) empty = true;
@@ -373,7 +376,8 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
         if ((uint64_t) ec[c] + before >= foundSize) status = FSGPU_KMER_E_OUTPUT;
     }
     size_t cur = 0;
-    if (q.identity >= 0 && maxHits > 0) { out[0].id = (uint32_t) q.identity; out[0].score = 65535; out[0].diagonal = 0; out[0].pad = 0; cur = 1; }
+    // getResult: the query's own entry first, with the top raw score of the mode (UCHAR_MAX for KMER_SCORE, USHRT_MAX otherwise; QueryMatcher.cpp:409-421)
+    if (q.identity >= 0 && maxHits > 0) { out[0].id = (uint32_t) q.identity; out[0].score = sp.kmerScoreOnly ? 255 : 65535; out[0].diagonal = 0; out[0].pad = 0; cur = 1; }
     if (status < 0) { *nout = 0; return status; }
     if (!empty && resultSize >= foundSize / 2) status = FSGPU_KMER_UNSTABLE;
     if (!empty && !el.empty()) {
@@ -400,7 +404,7 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
         };
         struct Key { uint32_t count; uint32_t bin; uint64_t ok; const HostOut *e; };
         auto arrayOrder = [](const Key &a, const Key &b) { return a.bin != b.bin ? a.bin < b.bin : a.ok < b.ok; };
-        const bool truncated = thr >= 255;
+        const bool truncated = thr >= 255 && !sp.kmerScoreOnly;      // rescoreHits belongs to the diagonal-score mode only
         if (status == FSGPU_KMER_UNSTABLE) {
             // resultSize >= foundDiagonalsSize/2 (QueryMatcher.cpp:205-215): the reference compacts the elements at or above
             // the cut in array order and orders them with std::sort(sortScore), which is not stable.  The same call on the
@@ -751,20 +755,29 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
                                (const uint32_t *) segLists.counts + 4, tbits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
         }
         RPCHK(hipGetLastError());
-        int maxL = 0;
-        for (int q = 0; q < nq; q++) maxL = std::max(maxL, queries[q].L);
-        const int ldsBytes = std::min(maxL * 21, 60 * 1024);
-        hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), (size_t) ldsBytes, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
-                           (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
-                           ldsBytes, (uint8_t *) S.kept.p, (int32_t *) S.score.p);
-        RPCHK(hipGetLastError());
-        RPCHK(hipEventRecord(S.ev[6], st));
-        // ---- stage 4: per-target replay ----------------------------------------------------------------------
-        hipLaunchKernelGGL(k_kmer_walk, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
-                           (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
-                           (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
-        RPCHK(hipGetLastError());
-        RPCHK(hipEventRecord(S.ev[7], st));
+        if (sp.kmerScoreOnly) {
+            // --diag-score 0: the score of a target is the number of its candidates, no diagonal is scored and nothing is replayed
+            hipLaunchKernelGGL(k_kmer_count_heads, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint32_t *) S.nCand.p, tbits,
+                               (uint8_t *) S.kept.p, (int32_t *) S.score.p, (KmerBest *) S.best.p, (unsigned long long *) S.resSize.p);
+            RPCHK(hipGetLastError());
+            RPCHK(hipEventRecord(S.ev[6], st));
+            RPCHK(hipEventRecord(S.ev[7], st));
+        } else {
+            int maxL = 0;
+            for (int q = 0; q < nq; q++) maxL = std::max(maxL, queries[q].L);
+            const int ldsBytes = std::min(maxL * 21, 60 * 1024);
+            hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), (size_t) ldsBytes, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                               (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
+                               ldsBytes, (uint8_t *) S.kept.p, (int32_t *) S.score.p);
+            RPCHK(hipGetLastError());
+            RPCHK(hipEventRecord(S.ev[6], st));
+            // ---- stage 4: per-target replay ----------------------------------------------------------------------
+            hipLaunchKernelGGL(k_kmer_walk, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                               (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
+                               (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
+            RPCHK(hipGetLastError());
+            RPCHK(hipEventRecord(S.ev[7], st));
+        }
         // ---- stage 5: histogram, cut, hand-over --------------------------------------------------------------
         hipLaunchKernelGGL(k_kmer_hist, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const KmerBest *) S.best.p,
                            (const uint32_t *) S.nCand.p, tbits, (uint32_t *) S.hist.p);
@@ -851,7 +864,9 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
                                  fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats) {
     if (!ctx || !p || (nq > 0 && (!queries || !out || !nout || !status))) return FSGPU_E_ARG;
     if (!ctx->kidx) { ctx->err = "k-mer index not built"; return FSGPU_E_NODB; }
-    if (p->maxResListLen <= 0 || p->minDiagScoreThr < 1) { ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 1 required"; return FSGPU_E_UNSUPPORTED; }
+    if (p->maxResListLen <= 0 || p->minDiagScoreThr < (p->kmerScoreOnly ? 0 : 1) || p->minDiagScoreThr > 255 * (p->kmerScoreOnly ? 1 : 1000)) {
+        ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 1 required (minDiagScoreThr 0 only with kmerScoreOnly = --diag-score 0)"; return FSGPU_E_UNSUPPORTED;
+    }
     if (p->bins && (p->bins & (p->bins - 1))) { ctx->err = "k-mer search: bins must be a power of two"; return FSGPU_E_ARG; }
     RPCHK(hipSetDevice(ctx->device));
     // queries per device batch: the candidate keys are (query << tbits | target) in 32 bits; beyond that the batch is sized by its hit

@@ -87,7 +87,7 @@ const FlagSpec kPrefilterFlags[] = {           // Parameters::prefilter (Paramet
     {"--split-mode", false, IGNORE, nullptr}, {"--split-memory-limit", false, IGNORE, nullptr},
     {"--disk-space-limit", false, IGNORE, nullptr}, {"-c", false, USE, nullptr}, {"--cov-mode", false, USE, nullptr},
     {"--comp-bias-corr", false, USE, nullptr}, {"--comp-bias-corr-scale", false, USE, nullptr},
-    {"--diag-score", true, ONLY, "1"}, {"--exact-kmer-matching", false, ONLY, "0"}, {"--mask", false, ONLY, "0"},
+    {"--diag-score", true, USE, "1"}, {"--exact-kmer-matching", false, ONLY, "0"}, {"--mask", false, ONLY, "0"},
     {"--mask-prob", false, IGNORE, nullptr}, {"--mask-lower-case", false, USE, nullptr}, {"--mask-n-repeat", false, USE, nullptr},
     {"--min-ungapped-score", false, USE, nullptr}, {"--add-self-matches", true, USE, "0"}, {"--spaced-kmer-mode", false, USE, nullptr},
     {"--spaced-kmer-pattern", false, ONLY, ""}, {"--local-tmp", false, IGNORE, nullptr}, {"--pca", false, IGNORE, nullptr},
@@ -739,8 +739,8 @@ int fsmod_prefilter(int argc, const char **argv) {
     const int kmerSize = o.geti("-k", 0) == 0 ? 6 : o.geti("-k", 6);     // k = 0: auto -> 6 below 3.35e9 residues (IndexTable.h:456-458)
     if (kmerSize != 6) return fail("prefilter: only -k 6 is implemented on the device path");
     if (t.residues() >= 3350000000ull && o.geti("-k", 0) == 0) return fail("prefilter: database needs k = 7, which is not implemented on the device path");
-    if (o.geti("--diag-score", 1) != 1 || o.geti("--exact-kmer-matching", 0) != 0 || o.geti("--mask", 0) != 0)
-        return fail("prefilter: --diag-score 0, --exact-kmer-matching 1 and --mask 1 are not implemented on the device path");
+    if (o.geti("--exact-kmer-matching", 0) != 0 || o.geti("--mask", 0) != 0)
+        return fail("prefilter: --exact-kmer-matching 1 and --mask 1 are not implemented on the device path");
     const float sens = (float) o.getd("-s", 9.5);
     // --k-score INT_MAX (the default the workflow passes) = derive the threshold from -s (Prefiltering.cpp:1036-1096)
     const int kmerThr = o.geti("--k-score", INT_MAX) != INT_MAX ? o.geti("--k-score", 0) : fshost_kmer_threshold(sens, kmerSize);
@@ -765,6 +765,7 @@ int fsmod_prefilter(int argc, const char **argv) {
     fsgpu_kmer_search_params sp;
     memset(&sp, 0, sizeof(sp));
     sp.maxResListLen = maxRes; sp.minDiagScoreThr = o.geti("--min-ungapped-score", 30);
+    sp.kmerScoreOnly = o.geti("--diag-score", 1) == 0 ? 1 : 0;        // the first step of easy-cluster's cascade: k-mer match counts instead of diagonal scores
     DbWriter w;
     if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();
@@ -883,6 +884,7 @@ int fsmod_search(int argc, const char **argv) {
     fsgpu_kmer_search_params sp;
     memset(&sp, 0, sizeof(sp));
     sp.maxResListLen = maxRes; sp.minDiagScoreThr = par.minDiagScoreThr;
+    sp.kmerScoreOnly = (prefMode == 0 && o.geti("--diag-score", 1) == 0) ? 1 : 0;
     DbWriter w, wp;
     if (!w.open(o.pos[2], DBTYPE_ALIGNMENT_RES, err)) { ds.close(); return fail(err); }
     const bool writePref = o.pos.size() == 4;

@@ -1241,6 +1241,29 @@ __global__ __launch_bounds__(128) void k_kmer_walk(const uint32_t *ckeys, const 
     if (threadIdx.x == 0 && rs) atomicAdd(&resultSize[q0], rs);
 }
 
+// --diag-score 0 (QueryMatcher with diagonalScoring == false): no diagonal scores and no replay -- findDuplicates runs with computeTotalScore
+// (CacheFriendlyOperations.cpp:217-241): a target's double-diagonal candidates are COUNTED (capped at 255) and it is handed on once, with the
+// diagonal of its first candidate.  One thread per candidate; the head of a (query, target) run counts the run (candidates are in (target,
+// stream position) order, so the head is the first arrival).  Queries that refilled databaseHits are answered with a status by the host.
+__global__ __launch_bounds__(256) void k_kmer_count_heads(const uint32_t *ckeys, const uint32_t *nCandPtr, int tbits, uint8_t *kept, int32_t *score, KmerBest *best,
+                                                          unsigned long long *resultSize /*[nq]*/) {
+    const uint64_t nCand = *nCandPtr;
+    const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nCand) return;
+    const uint32_t k = ckeys[j];
+    KmerBest b;
+    b.nElems = 0xFFFFFFFFu; b.cand = 0; b.count = 0; b.pad = 0;
+    kept[j] = 1;
+    if (j == 0 || ckeys[j - 1] != k) {
+        uint32_t c = 1;
+        while (c < 255 && j + c < nCand && ckeys[j + c] == k) c++;
+        b.nElems = 1; b.cand = (uint32_t) j; b.count = c;
+        atomicAdd(&resultSize[k >> tbits], 1ull);
+    }
+    score[j] = (int32_t) b.count;
+    best[j] = b;
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // search, stage 5: score histogram, cut (computeScoreThreshold) and hand-over of everything at or above the cut
 // --------------------------------------------------------------------------------------------------------------

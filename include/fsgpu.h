@@ -243,9 +243,12 @@ int fsgpu_kmer_row_copy(fsgpu_ctx *ctx, int row, int16_t *score, uint16_t *index
 
 typedef struct {
     int32_t maxResListLen;      /* --max-seqs */
-    int32_t minDiagScoreThr;    /* --min-ungapped-score, >= 1 */
+    int32_t minDiagScoreThr;    /* --min-ungapped-score, >= 1 (>= 0 with kmerScoreOnly) */
     int32_t bins;               /* BINSIZE of CacheFriendlyOperations; 0 = derive from l2CacheSize like initDiagonalMatcher */
-    int32_t reserved;
+    int32_t kmerScoreOnly;      /* 1 = --diag-score 0 (QueryMatcher with diagonalScoring == false, QueryMatcher.cpp:215-232): no ungapped diagonal scores,
+                                 * the score of a target is its number of double-diagonal k-mer matches (findDuplicates with computeTotalScore,
+                                 * CacheFriendlyOperations.cpp:217-241; capped at 255), the diagonal that of its first one; the first step of
+                                 * easy-cluster's cascaded prefilter runs like this (-s 1 --diag-score 0 --min-ungapped-score 0) */
     int64_t maxDbMatches;       /* 0 = 2*max(1e6,N) (QueryMatcher.cpp:45) */
     int64_t foundDiagonalsSize; /* 0 = max(1e6,N)   (QueryMatcher.cpp:44) */
     uint64_t l2CacheSize;       /* Util::getL2CacheSize() of the host whose tie order is to be reproduced; 0 = this host */
@@ -275,7 +278,8 @@ enum {
                                     unstable std::sort there (QueryMatcher.cpp:205-215); replayed with the same call on the same
                                     sequence, identical wherever both builds use libstdc++'s introsort (informational) */
     FSGPU_KMER_E_OUTPUT = -1,    /* the reference would have cut findDuplicates short (output array full); not replayed */
-    FSGPU_KMER_E_CHUNKS = -2     /* more than 255 databaseHits refills */
+    FSGPU_KMER_E_CHUNKS = -2,    /* more than 255 databaseHits refills */
+    FSGPU_KMER_E_REFILL_COUNTS = -3  /* kmerScoreOnly and the query refilled databaseHits: the reference's merge of the per-round counts is not replayed */
 };
 /* Runs nq queries (batched on the device), writes per query q up to maxResListLen hits to out[q*maxResListLen ..],
  * their number to nout[q] and a FSGPU_KMER_* code to status[q]; hits are bit-identical to QueryMatcher::matchQuery

@@ -53,6 +53,8 @@ struct RefKpfParams {
     int32_t bins;                 // 0: as the reference picks from Util::getL2CacheSize(); else force this BINSIZE
     int64_t maxDbMatches;         // 0: reference value 2*max(1e6,N); else override (to exercise the overflow path at test sizes)
     int64_t foundDiagonalsSize;   // 0: reference value max(1e6,N)
+    int32_t noDiagScore;          // 1: diagonalScoring = false (--diag-score 0): the per-target k-mer match count is the score
+    int32_t pad;
 };
 struct RefKpfHit { uint32_t id; int32_t score; uint16_t diag; uint16_t pad; };
 
@@ -64,7 +66,7 @@ namespace {
 struct KpfMatcher : QueryMatcher {
     KpfMatcher(IndexTable *it, SequenceLookup *sl, BaseMatrix *k, BaseMatrix *u, short thr, int ks, size_t dbSize, unsigned maxLen,
             size_t maxHits, bool cb, float cbs, unsigned minDiag, const RefKpfParams &p)
-        : QueryMatcher(it, sl, k, u, thr, ks, dbSize, maxLen, maxHits, cb, cbs, true, minDiag, false, false, NULL, Parameters::DBTYPE_AMINO_ACIDS) {
+        : QueryMatcher(it, sl, k, u, thr, ks, dbSize, maxLen, maxHits, cb, cbs, p.noDiagScore == 0, minDiag, false, false, NULL, Parameters::DBTYPE_AMINO_ACIDS) {
         if (p.bins != 0 && (unsigned) p.bins != activeCounter) {
             deleteDiagonalMatcher(activeCounter);
             // initDiagonalMatcher picks BINSIZE x as the first x with dbsize/x < L2 (QueryMatcher.cpp:460-488)

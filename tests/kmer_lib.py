@@ -11,15 +11,19 @@ _A = np.frombuffer(ALPHABET.encode(), np.uint8)
 HIT_DT = np.dtype([("id", np.uint32), ("score", np.int32), ("diag", np.uint16), ("pad", np.uint16)])
 
 
+_COMMON_FIELDS = [(n, C.c_int32) for n in
+                  "kmerSize spaced kmerThr maxResListLen compBias minDiagScoreThr maskLowerCase maskNrepeats".split()] + \
+                 [("compBiasScale", C.c_float), ("bins", C.c_int32), ("maxDbMatches", C.c_int64),
+                  ("foundDiagonalsSize", C.c_int64)]
+
+
 class RefParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in
-                "kmerSize spaced kmerThr maxResListLen compBias minDiagScoreThr maskLowerCase maskNrepeats".split()] + \
-               [("compBiasScale", C.c_float), ("bins", C.c_int32), ("maxDbMatches", C.c_int64),
-                ("foundDiagonalsSize", C.c_int64)]
+    # noDiagScore = 1: QueryMatcher built with diagonalScoring = false (--diag-score 0: the k-mer match count is the score)
+    _fields_ = _COMMON_FIELDS + [("noDiagScore", C.c_int32), ("pad", C.c_int32)]
 
 
 class OraParams(C.Structure):
-    _fields_ = RefParams._fields_ + [("l2CacheSize", C.c_uint64)]
+    _fields_ = _COMMON_FIELDS + [("l2CacheSize", C.c_uint64)]
 
 
 def default_params(cls=OraParams, **kw):
@@ -30,6 +34,8 @@ def default_params(cls=OraParams, **kw):
     d.update(kw)
     if cls is not OraParams:
         d.pop("l2CacheSize", None)
+    else:
+        d.pop("noDiagScore", None)
     return cls(**d)
 
 

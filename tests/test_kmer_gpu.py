@@ -306,3 +306,43 @@ def test_no_index_hits_then_next_call():
         res, status = ctx.kmer_search([api.kmer_query_prepare(m8, m2, q)], max_res=10)
         assert status[0] == 0 and len(res[0]) == 0
         ctx.close()
+
+
+@pytest.mark.parametrize("thr,kw", [(78, dict(maxResListLen=100, minDiagScoreThr=0, bins=2)), (78, dict(maxResListLen=7, minDiagScoreThr=0, bins=16)),
+                                    (78, dict(maxResListLen=1000, minDiagScoreThr=3, bins=4)), (123, dict(maxResListLen=100, minDiagScoreThr=0, bins=2)),
+                                    (154, dict(maxResListLen=100, minDiagScoreThr=0, bins=2))])
+def test_kmer_score_only_mode_equals_the_compiled_reference(thr, kw):
+    """--diag-score 0 (`kmerScoreOnly`: the first step of easy-cluster's cascaded prefilter runs with -s 1 --diag-score 0 --min-ungapped-score 0
+    --max-seqs 100): no ungapped diagonal scores -- a target's score is the number of its double-diagonal k-mer matches (capped at 255), its
+    diagonal that of the first one, the cut comes from the histogram of those counts.  Checked against the compiled reference's QueryMatcher
+    built with diagonalScoring = false (oracle/_ref, travels to the GPU box): ids, scores, diagonals, order, the truncation at --max-seqs,
+    identity hit with score 255; k-mer thresholds of -s 9.5 / 4.5 / 1."""
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    q3, qa = synth.make_queries(5, seed=3)
+    db = synth.make_db(2500, (q3, qa), seed=4, homologs_per_query=40, mask_frac=0.02)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    qs = list(q3) + [targets[11].copy()]
+    ident = np.array([-1, -1, 5, -1, -1, 11], np.int64)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=thr)
+    prep = [api.kmer_query_prepare(m8, m2, q, comp_bias=True, scale=0.15, kmer_thr=thr) for q in qs]
+    res, status = ctx.kmer_search(prep, identity=ident, max_res=kw["maxResListLen"], min_diag=kw["minDiagScoreThr"], bins=kw["bins"], kmer_score_only=True)
+    r = K.RefKpf(R, targets, threads=4, kmerThr=thr, noDiagScore=1, compBias=1, **kw)
+    rr, _, _ = r.run(qs, ident)
+    r.close()
+    total = 0
+    for q in range(len(qs)):
+        assert status[q] == 0, (q, status[q])
+        a, b = res[q], rr[q]
+        assert len(a) == len(b), (q, thr, kw, len(a), len(b))
+        assert (a["id"] == b["id"]).all() and (a["score"] == b["score"]).all() and (a["diag"] == b["diag"]).all(), (q, thr, kw)
+        total += len(a)
+    assert total > (20 if thr > 100 or kw["maxResListLen"] < 50 else 200) and res[5][0]["id"] == 11 and res[5][0]["score"] == 255
+    # a refill of databaseHits is answered with a status in this mode, not with different hits
+    res2, status2 = ctx.kmer_search(prep[:2], identity=ident[:2], max_res=50, min_diag=0, bins=2, max_db_matches=3000, kmer_score_only=True)
+    assert thr > 100 or (status2 == -3).all()
+    ctx.close()

@@ -218,3 +218,25 @@ def test_convertalis_equals_the_reference_binary_at_scale(world):
         _run([BIN, "convertalis", "q", "t", "ref_aln2", f"mine_{tag}.m8"] + par, w)
         a, b = open(w / f"ref_{tag}.m8", "rb").read(), open(w / f"mine_{tag}.m8", "rb").read()
         assert len(a) > 50000 and a == b, tag
+
+
+CASCADE = [("-s", "1", "--max-seqs", "100", "--diag-score", "0", "--min-ungapped-score", "0"),
+           ("-s", "4.5", "--max-seqs", "200", "--diag-score", "1", "--min-ungapped-score", "30"),
+           ("-s", "8", "--max-seqs", "1000", "--diag-score", "1", "--min-ungapped-score", "30")]
+
+
+@pytest.mark.parametrize("step", [0, 1, 2])
+def test_cluster_cascade_prefilter_steps_equal_the_reference_binary(world, step):
+    """the three prefilter calls of the cluster workflow's cascade (F/data/structurecluster.sh, parameter strings as `foldseek cluster -v 3` prints
+    them): all-vs-all of the 3000-target 3Di database at -s 1 (--diag-score 0: k-mer match counts as scores, cut 0), -s 4.5 and -s 8, -c 0.8,
+    no composition bias correction, self matches added -- both binaries, every entry byte-identical"""
+    w = world
+    par = ["--sub-mat", "aa:3di.out,nucl:3di.out", "--seed-sub-mat", "aa:3di.out,nucl:3di.out", "-k", "0", "--target-search-mode", "0",
+           "--k-score", "seq:2147483647,prof:2147483647", "--alph-size", "aa:21,nucl:5", "--max-seq-len", "65535", "--split", "0", "--split-mode", "2",
+           "--split-memory-limit", "0", "-c", "0.8", "--cov-mode", "0", "--comp-bias-corr", "0", "--comp-bias-corr-scale", "1", "--exact-kmer-matching", "0",
+           "--mask", "0", "--mask-prob", "0.999995", "--mask-lower-case", "1", "--mask-n-repeat", "6", "--add-self-matches", "1", "--spaced-kmer-mode", "1",
+           "--db-load-mode", "0", "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800", "--threads", "8", "--compressed", "0",
+           "-v", "1"] + list(CASCADE[step])
+    _run([FS, "prefilter", "t_ss", "t_ss", f"ref_casc{step}"] + par, w)
+    _run([BIN, "prefilter", "t_ss", "t_ss", f"mine_casc{step}"] + par, w)
+    assert _same(w, f"ref_casc{step}", f"mine_casc{step}") >= 3000          # at least every self match

@@ -85,6 +85,24 @@ def test_reference_prefilter_gpu1_equals_its_cpu_result(scop, run):
     assert read_db(out) == read_db(str(scop / run))
 
 
+def test_reference_prefilter_gpu1_cluster_cascade_step0(scop):
+    """the first prefilter call of the cluster workflow's cascade (`-s 1 --diag-score 0 --min-ungapped-score 0 --max-seqs 100 -c 0.8`, all-vs-all):
+    k-mer match counts as scores.  The reference module with --gpu 1 takes the device path for it too (no silent CPU fallback) and writes
+    what its own CPU path writes."""
+    spec = MANIFEST["runs"]["pref_kmer"]
+    par = _params(spec)
+    for k, v in (("-s", "1"), ("--max-seqs", "100"), ("--diag-score", "0"), ("--min-ungapped-score", "0"), ("-c", "0.8"), ("--comp-bias-corr", "0"), ("--add-self-matches", "1")):
+        par[par.index(k) + 1] = v
+    cpu = [x for x in par if x != "--gpu"]
+    cpu = cpu[:-1] if cpu[-1] == "1" and par[-2:] == ["--gpu", "1"] else cpu
+    ref, mine = str(scop / "casc0_cpu"), str(scop / "casc0_gpu")
+    _run([FS_CPU, "prefilter", str(scop / "db_ss"), str(scop / "db_ss"), ref] + cpu)
+    log = _run([FS_GPU, "prefilter", str(scop / "db_ss"), str(scop / "db_ss"), mine] + par)
+    assert "Index table (device)" in log, log[-1500:]
+    a, b = read_db(ref), read_db(mine)
+    assert a == b and sum(len(v) for v in a[1].values()) > 100
+
+
 @pytest.mark.parametrize("extra", [["--prefilter-mode", "1"], ["--prefilter-mode", "1", "--alignment-type", "0"], ["--prefilter-mode", "0"],
                                    ["--prefilter-mode", "0", "-s", "7.5", "--max-seqs", "5"], ["--prefilter-mode", "1", "--sort-by-structure-bits", "0", "-e", "0.001"]])
 def test_easy_search_from_a_structure_file_gpu1_equals_cpu_binary(padded_target, extra):
