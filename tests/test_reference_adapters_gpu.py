@@ -131,3 +131,18 @@ def test_easy_search_all_against_all_gpu1_equals_cpu_binary(padded_target):
     _run([FS_GPU, "easy-search", EXAMPLES, "target_pad", "gpu.m8", "tmp_gpu", "--threads", "1", "-v", "1", "--gpu", "1"] + cols, cwd=w)
     a, b = open(os.path.join(w, "cpu.m8"), "rb").read(), open(os.path.join(w, "gpu.m8"), "rb").read()
     assert a == b and a.count(b"\n") >= 60
+
+
+def test_easy_cluster_gpu1_equals_cpu_binary(tmp_path):
+    """`foldseek easy-cluster <structure files> out tmp` (BASELINE configs[4]'s workflow): linclust's kmermatcher + structurerescorediagonal + clust,
+    then the cascade of three prefilter / structurealign / clust steps.  With `--gpu 1` the patched reference runs all three prefilter calls
+    (the first with --diag-score 0) and its structurealign calls on this library; the cluster assignment must equal the CPU binary's."""
+    w = str(tmp_path)
+    _run([FS_CPU, "easy-cluster", EXAMPLES, "cpu", "tmp_cpu", "--threads", "1", "-v", "1"], cwd=w)
+    log = _run([FS_GPU, "easy-cluster", EXAMPLES, "gpu", "tmp_gpu", "--threads", "1", "-v", "3", "--gpu", "1"], cwd=w)
+    assert log.count("Index table (device)") == 3, log[-2000:]
+    assert sum(1 for l in log.splitlines() if l.startswith("structurealign ") and "--gpu 1" in l) >= 2
+    a, b = open(os.path.join(w, "cpu_cluster.tsv"), "rb").read(), open(os.path.join(w, "gpu_cluster.tsv"), "rb").read()
+    assert a == b and a.count(b"\n") == 12
+    for f in ("_rep_seq.fasta", "_all_seqs.fasta"):
+        assert open(os.path.join(w, "cpu" + f), "rb").read() == open(os.path.join(w, "gpu" + f), "rb").read()
