@@ -56,7 +56,7 @@ def parse(argv=None):
     ap.add_argument("--kmer-cpu-queries", type=int, default=64, help="queries the reference k-mer prefilter is timed on")
     ap.add_argument("--cpu-sample-targets", type=int, default=100000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
-    ap.add_argument("--type2-steps", type=int, default=6, help="configs[3] leg of the default run: that many extra steps with --alignment-type 2 (3Di+AA) on the same "
+    ap.add_argument("--type2-steps", type=int, default=12, help="configs[3] leg of the default run: that many extra steps with --alignment-type 2 (3Di+AA) on the same "
                     "resident DB, reported under `align_type2` (0 = skip; skipped when the main run already is type 2)")
     ap.add_argument("--allvsall-steps", type=int, default=48, help="configs[4] leg of the default run: that many batches of 32 DB entries as queries (k-mer prefilter "
                     "+ structurealign on a --allvsall-targets DB), reported under `allvsall` (0 = skip)")
