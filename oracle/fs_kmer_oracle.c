@@ -29,6 +29,8 @@ typedef struct {
     int64_t maxDbMatches;         /* 0 = 2*max(1e6,N)  (QueryMatcher.cpp:45) */
     int64_t foundDiagonalsSize;   /* 0 = max(1e6,N)    (QueryMatcher.cpp:44) */
     uint64_t l2CacheSize;         /* Util::getL2CacheSize() of the host being emulated */
+    int32_t noDiagScore;          /* 1 = diagonalScoring == false (--diag-score 0): k-mer match counts as scores (QueryMatcher.cpp:215-232) */
+    int32_t pad;
 } fko_params;
 
 typedef struct { uint32_t id; int32_t score; uint16_t diag; uint16_t pad; } fko_hit;
@@ -436,6 +438,36 @@ static size_t cfo_find_duplicates(Cfo *c, const Counter *hits, size_t nHits, Cou
     }
     return dbl;
 }
+/* findDuplicates with computeTotalScore == true (CacheFriendlyOperations.cpp:217-241): the candidates of a bin are counted per target
+ * (saturating at 255) and every target is handed on once -- at its first candidate, with that candidate's diagonal. */
+static size_t cfo_find_duplicates_total(Cfo *c, const Counter *hits, size_t nHits, Counter *output, size_t outputSize) {
+    cfo_hash(c, hits, nHits);
+    memset(c->dup, 0, c->dupSize);
+    size_t dbl = 0;
+    for (unsigned bin = 0; bin < c->B; bin++) {
+        const Counter *bs = c->frame + c->binStart[bin];
+        const size_t sz = c->binStart[bin + 1] - c->binStart[bin];
+        size_t ec = 0;
+        for (size_t n = 0; n < sz; n++) {
+            const size_t hb = bs[n].id >> c->shift;
+            const uint8_t cur = (uint8_t) bs[n].diagonal, prev = c->dup[hb];
+            c->tmp[ec].id = bs[n].id; c->tmp[ec].diagonal = bs[n].diagonal;
+            ec += (cur == prev) ? 1 : 0;
+            c->dup[hb] = cur;
+        }
+        if (dbl + ec >= outputSize) return dbl;
+        for (size_t n = 0; n < ec; n++) c->dup[c->tmp[n].id >> c->shift] = 0;
+        for (size_t n = 0; n < ec; n++) { uint8_t *d = &c->dup[c->tmp[n].id >> c->shift]; *d = (uint8_t) (*d + (*d < 255 ? 1 : 0)); }
+        for (size_t n = 0; n < ec; n++) {
+            const size_t hb = c->tmp[n].id >> c->shift;
+            output[dbl].id = c->tmp[n].id; output[dbl].count = c->dup[hb]; output[dbl].diagonal = c->tmp[n].diagonal;
+            dbl += (c->dup[hb] != 0) ? 1 : 0;
+            c->dup[hb] = 0;
+        }
+        for (size_t n = 0; n < sz; n++) c->dup[bs[n].id >> c->shift] = 0;
+    }
+    return dbl;
+}
 static size_t cfo_merge_diag(Cfo *c, Counter *io, size_t N) {              /* mergeDiagonalDuplicates */
     cfo_hash(c, io, N);
     size_t dbl = 0;
@@ -588,7 +620,7 @@ int fko_query(void *hv, const uint8_t *qcodes, int L, int64_t identity, fko_hit 
 
     /* ---- QueryMatcher::match -------------------------------------------------------------------------- */
     size_t kmerListLen = 0, numMatches = 0, overflowNumMatches = 0, overflowHitCount = 0, nh = 0, hitCount = 0;
-    int overflow = 0, aborted = 0;
+    int overflow = 0, aborted = 0, unsupported = 0;
     uint8_t kmer[16];
     for (int cur = 0; !aborted; cur++) {
         int r = kmer_at(h, q, L, cur, kmer);
@@ -605,6 +637,7 @@ int fko_query(void *hv, const uint8_t *qcodes, int L, int64_t identity, fko_hit 
         for (size_t kp = 0; kp < len; kp++) {
             const uint64_t o0 = h->offsets[list[kp]], sz = h->offsets[list[kp] + 1] - o0;
             if (nh + sz >= maxDbMatches) {
+                if (p->noDiagScore) { unsupported = 1; aborted = 1; break; }     /* the merge of per-round counts (mergeScoreDuplicates) is not restated */
                 overflow = 1;
                 const size_t hc = cfo_find_duplicates(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount);
                 if (overflowHitCount != 0) {
@@ -628,11 +661,43 @@ int fko_query(void *hv, const uint8_t *qcodes, int L, int64_t identity, fko_hit 
             numMatches += sz;
         }
     }
+    if (unsupported) { kmergen_free(&g); cfo_free(&cfo); free(hits); free(found); free(profile); free(bias); free(q); return -3; }
     if (numMatches > 0) {
-        hitCount = cfo_find_duplicates(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount);
+        hitCount = p->noDiagScore ? cfo_find_duplicates_total(&cfo, hits, nh, found, foundSize)
+                                  : cfo_find_duplicates(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount);
         if (overflowHitCount != 0) hitCount = cfo_merge_diag(&cfo, found, overflowHitCount + hitCount);
     }
     if (stats) { stats[0] = (double) kmerListLen / (double) L; stats[1] = (double) (overflowNumMatches + numMatches); stats[2] = overflow; stats[3] = cfo.B; }
+    if (p->noDiagScore) {
+        /* ---- matchQuery without diagonal scoring (QueryMatcher.cpp:215-232): histogram of the counts (match(), :344-348), cut, radix
+         * order by count, getResult<KMER_SCORE> (the query itself with UCHAR_MAX), final order by (score, id) ---- */
+        int nr = 0;
+        unsigned sz[256];
+        memset(sz, 0, sizeof(sz));
+        for (size_t i = 0; i < hitCount; i++) sz[found[i].count]++;
+        unsigned t;
+        { size_t fh = 0; for (t = 255; t > 0; t--) { fh += sz[t]; if (fh >= maxHits) break; } }
+        if (t < (unsigned) p->minDiagScoreThr) t = (unsigned) p->minDiagScoreThr;
+        if (hitCount >= foundSize / 2) nr = -1;               /* std::sort branch (:222-231): not modelled, like the diagonal-score mode */
+        else {
+            Counter *w2 = found + hitCount;
+            const size_t cnt = radix_by_score(sz, w2, t, found, hitCount);
+            size_t cur = 0;
+            if (identity >= 0) { out[0].id = (uint32_t) identity; out[0].score = 255; out[0].diag = 0; out[0].pad = 0; cur = 1; }
+            for (size_t i = 0; i < cnt && cur < maxHits; i++)
+                if (w2[i].count >= t && (identity < 0 || (uint32_t) identity != w2[i].id)) {
+                    out[cur].id = w2[i].id; out[cur].score = w2[i].count; out[cur].diag = w2[i].diagonal; out[cur].pad = 0;
+                    cur++;
+                }
+            if (cur > 1) {
+                if (identity >= 0) qsort(out + 1, cur - 1, sizeof(fko_hit), cmp_hit);
+                else qsort(out, cur, sizeof(fko_hit), cmp_hit);
+            }
+            nr = (int) cur;
+        }
+        kmergen_free(&g); cfo_free(&cfo); free(hits); free(found); free(profile); free(bias); free(q);
+        return nr;
+    }
 
     /* ---- matchQuery post-processing (diagonalScoring, amino acids) ------------------------------------- */
     int nres = 0;

@@ -23,7 +23,7 @@ class RefParams(C.Structure):
 
 
 class OraParams(C.Structure):
-    _fields_ = _COMMON_FIELDS + [("l2CacheSize", C.c_uint64)]
+    _fields_ = _COMMON_FIELDS + [("l2CacheSize", C.c_uint64), ("noDiagScore", C.c_int32), ("pad", C.c_int32)]
 
 
 def default_params(cls=OraParams, **kw):
@@ -34,8 +34,6 @@ def default_params(cls=OraParams, **kw):
     d.update(kw)
     if cls is not OraParams:
         d.pop("l2CacheSize", None)
-    else:
-        d.pop("noDiagScore", None)
     return cls(**d)
 
 
@@ -172,6 +170,7 @@ class OraKpf:
         stats = np.zeros(4)
         qq = np.ascontiguousarray(q, np.uint8)
         n = self.L.fko_query(self.h, _vp(qq), len(qq), C.c_int64(identity), _vp(out), _vp(stats))
+        self.last_rc = int(n)        # -1: the reference's std::sort branch (not modelled), -3: a refill without diagonal scoring (not restated)
         return (out[:max(n, 0)].copy() if n >= 0 else None), stats
 
     def run(self, queries, identity=None):

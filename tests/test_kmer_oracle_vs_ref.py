@@ -104,3 +104,23 @@ def test_hit_lists(world, kw):
     assert sum(len(x) for x in rr) > 0
     if "maxDbMatches" in kw:
         assert rs[:, 2].sum() > 0     # the overflow path was really taken
+
+
+@pytest.mark.parametrize("kw", [dict(maxResListLen=100, minDiagScoreThr=0), dict(maxResListLen=5, minDiagScoreThr=0, bins=16), dict(maxResListLen=1000, minDiagScoreThr=2, bins=4),
+                                dict(maxResListLen=100, minDiagScoreThr=0, compBias=0)])
+def test_hit_lists_without_diagonal_scoring(world, kw):
+    """--diag-score 0 (QueryMatcher with diagonalScoring == false, the first prefilter call of the cluster workflow's cascade): the oracle's
+    restatement of findDuplicates(computeTotalScore) + the KMER_SCORE result path == the compiled reference -- ids, counts as scores,
+    diagonals, order, truncation at --max-seqs, the query's own entry with score 255"""
+    r, o, q3 = world["r"], world["o"], world["q3"]
+    base = dict(maxResListLen=1000, bins=0, maxDbMatches=0, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=0, noDiagScore=1)
+    base.update(kw)
+    r.set(**base); o.set(**base)
+    ident = np.array([-1, 7, -1, 100, -1], np.int64)
+    rr, rs, _ = r.run(q3, ident)
+    orr, os_ = o.run(q3, ident)
+    for q in range(NQ):
+        assert orr[q] is not None
+        assert len(rr[q]) == len(orr[q]) and (rr[q] == orr[q]).all(), (q, kw)
+    assert sum(len(x) for x in rr) > min(50, 4 * base["maxResListLen"]) and rr[1][0]["id"] == 7 and rr[1][0]["score"] == 255
+    r.set(noDiagScore=0); o.set(noDiagScore=0)

@@ -24,6 +24,9 @@ for rd in range(rounds):
     kw = dict(kmerThr=thr, spaced=spaced, maxResListLen=int(rng.choice([1, 3, 30, 300, 1000, 5000])), bins=int(rng.choice([0, 2, 4, 16, 64])),
               maxDbMatches=int(rng.choice([0, 0, 500, 3000, 20000])), minDiagScoreThr=int(rng.choice([30, 30, 10, 60, 1])),
               compBias=int(rng.integers(0, 2)), maskLowerCase=int(rng.integers(0, 2)), maskNrepeats=int(rng.choice([6, 6, 0, 2])))
+    if rng.random() < 0.25:          # --diag-score 0: k-mer match counts as scores (cut 0 allowed)
+        kw["noDiagScore"] = 1
+        kw["minDiagScoreThr"] = int(rng.choice([0, 0, 1, 3]))
     qs = list(q3)
     if n > 3:
         qs.append(targets[int(rng.integers(n))].copy())            # a database member as query (identity path)
@@ -38,11 +41,13 @@ for rd in range(rounds):
         ctx.kmer_index_build(m8, kmer_thr=thr, spaced=spaced, mask_lower_case=kw["maskLowerCase"], mask_n_repeats=kw["maskNrepeats"])
         prep = [api.kmer_query_prepare(m8, m2, q, comp_bias=bool(kw["compBias"]), kmer_thr=thr, spaced=spaced) for q in qs]
         res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=kw["maxResListLen"], min_diag=kw["minDiagScoreThr"], bins=kw["bins"],
-                                             max_db_matches=kw["maxDbMatches"], l2_cache_size=2 << 20, want_stats=True)
+                                             max_db_matches=kw["maxDbMatches"], l2_cache_size=2 << 20, want_stats=True, kmer_score_only=bool(kw.get("noDiagScore", 0)))
         ok = True
         for i, q in enumerate(qs):
             b, st = o.query(q, int(ident[i]))
-            if b is None:
+            if b is None and o.last_rc == -3:
+                same = status[i] == -3         # a refill in the count mode: both sides answer with a status
+            elif b is None:
                 same = status[i] == 1          # the oracle does not model the std::sort branch
             elif status[i] == -2:
                 # FSGPU_KMER_E_OUTPUT: the conservative "findDuplicates would run out of output space" test fired (only with the
@@ -58,7 +63,7 @@ for rd in range(rounds):
                 print("  MISMATCH round", rd, "query", i, "L", len(q), "ident", ident[i], "status", status[i], "gpu n", len(res[i]), "ora n", None if b is None else len(b), kw, "n", n)
                 print("    gpu", res[i][:5].tolist(), "ora", None if b is None else b[:5].tolist(), "stats", stats[i].tolist(), None if b is None else st.tolist())
         bad += 0 if ok else 1
-        print("round %d n=%d nq=%d %s overflowed=%s %s" % (rd, n, len(qs), "ok" if ok else "BAD", stats[:, 2].tolist(), {k: kw[k] for k in ("kmerThr", "spaced", "maxResListLen", "bins", "maxDbMatches")}), flush=True)
+        print("round %d n=%d nq=%d %s overflowed=%s %s" % (rd, n, len(qs), "ok" if ok else "BAD", stats[:, 2].tolist(), {k: kw.get(k, 0) for k in ("kmerThr", "spaced", "maxResListLen", "bins", "maxDbMatches", "noDiagScore")}), flush=True)
         o.close(); ctx.close()
     except Exception as e:
         bad += 1
