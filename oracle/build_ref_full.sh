@@ -29,11 +29,11 @@ WHAT="${1:-all}"          # cpu | gpu | all
 
 [ -d "$REF/src" ] || { echo "no reference tree at $REF" >&2; exit 2; }
 mkdir -p "$OUT/bin"
-if [ ! -f "$OUT/src/.patched_v2" ]; then
+if [ ! -f "$OUT/src/.patched_v3" ]; then
     rm -rf "$OUT/src"
     cp -a "$REF" "$OUT/src"
     python3 "$HERE/patch_ref_full.py" "$OUT/src" "$REPO"
-    touch "$OUT/src/.patched_v2"
+    touch "$OUT/src/.patched_v3"
 fi
 
 COMMON=(-G Ninja -DCMAKE_BUILD_TYPE=Release -DHAVE_AVX2=1 -DENABLE_PROSTT5=0 -DENABLE_STRUCTTY=0

@@ -80,7 +80,8 @@ def edit(rel, pairs):
     hunks.extend(difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/" + rel, "b/" + rel, n=2))
 
 
-for name, dst in (("structurealign_fsgpu.inc", "src/strucclustutils"), ("prefiltering_fsgpu.inc", "lib/mmseqs/src/prefiltering")):
+for name, dst in (("structurealign_fsgpu.inc", "src/strucclustutils"), ("structurerescorediagonal_fsgpu.inc", "src/strucclustutils"),
+                  ("prefiltering_fsgpu.inc", "lib/mmseqs/src/prefiltering")):
     shutil.copy(os.path.join(repo, "foldseek_amd", "csrc", "host", "adapters", name), os.path.join(src, dst, name))
 
 edit("src/strucclustutils/structurealign.cpp", [
@@ -90,9 +91,18 @@ edit("src/strucclustutils/structurealign.cpp", [
      "    bool fsgpuDone = false;\n#ifdef HAVE_FSGPU\n    if (par.gpu == 1) {\n        fsgpuDone = fsgpuStructureAlign(par, tAADbr, t3DiDbr, qAADbr, q3DiDbr, qcadbr, tcadbr, resultReader, dbw, subMat3Di, subMatAA,\n                                        sameDB, needCalpha, needTMaligner, needLDDT);\n    }\n#endif\n    if (fsgpuDone == false)\n"
      "#pragma omp parallel\n    {\n        unsigned int thread_idx = 0;\n#ifdef OPENMP\n        thread_idx = static_cast<unsigned int>(omp_get_thread_num());\n#endif\n        EvalueNeuralNet evaluer(tAADbr"),
 ])
+edit("src/strucclustutils/structurerescorediagonal.cpp", [
+    ("int structureungappedalign(int argc, const char **argv, const Command& command) {",
+     "#ifdef HAVE_FSGPU\n#include \"structurerescorediagonal_fsgpu.inc\"\n#endif\n\nint structureungappedalign(int argc, const char **argv, const Command& command) {"),
+    ("#pragma omp parallel\n    {\n        unsigned int thread_idx = 0;\n#ifdef OPENMP\n        thread_idx = static_cast<unsigned int>(omp_get_thread_num());\n#endif\n        EvalueNeuralNet evaluer(tAADbr",
+     "    bool fsgpuDone = false;\n#ifdef HAVE_FSGPU\n    if (par.gpu == 1) {\n        fsgpuDone = fsgpuRescoreDiagonal(par, *tAADbr, *t3DiDbr, qdbrAA, qdbr3Di, resultReader, dbw, subMat3Di, subMatAA, sameDB, needTMaligner || needLDDT);\n    }\n#endif\n    if (fsgpuDone == false)\n"
+     "#pragma omp parallel\n    {\n        unsigned int thread_idx = 0;\n#ifdef OPENMP\n        thread_idx = static_cast<unsigned int>(omp_get_thread_num());\n#endif\n        EvalueNeuralNet evaluer(tAADbr"),
+])
 edit("src/commons/LocalParameters.cpp", [
     ("    structurealign = combineList(structurealign, align);\n",
      "    structurealign = combineList(structurealign, align);\n#ifdef HAVE_FSGPU\n    structurealign.push_back(&PARAM_GPU);\n#endif\n"),
+    ("    structurerescorediagonal = combineList(structurerescorediagonal, align);\n",
+     "    structurerescorediagonal = combineList(structurerescorediagonal, align);\n#ifdef HAVE_FSGPU\n    structurerescorediagonal.push_back(&PARAM_GPU);\n#endif\n"),
 ])
 edit("lib/mmseqs/src/commons/Parameters.cpp", [
     ("    prefilter.push_back(&PARAM_V);\n", "    prefilter.push_back(&PARAM_V);\n#ifdef HAVE_FSGPU\n    prefilter.push_back(&PARAM_GPU);\n#endif\n"),

@@ -85,6 +85,20 @@ def test_reference_prefilter_gpu1_equals_its_cpu_result(scop, run):
     assert read_db(out) == read_db(str(scop / run))
 
 
+RESC_RUNS = [k for k, v in MANIFEST["runs"].items() if v["module"] == "structurerescorediagonal"]
+
+
+@pytest.mark.parametrize("run", RESC_RUNS)
+def test_reference_structurerescorediagonal_gpu1_equals_its_cpu_result(scop, run):
+    """the frozen single-diagonal rescoring runs (linclust hand-off of easy-cluster; 3Di and 3Di+AA, with and without backtrace, the cluster
+    workflow's -e 0.01 -c 0.8): the reference module with --gpu 1 (k_diag_rescore behind the adapter) == the DB its CPU path wrote"""
+    spec = MANIFEST["runs"][run]
+    out = str(scop / ("adapter_" + run))
+    log = _run([FS_GPU, "structurerescorediagonal"] + [str(scop / x) for x in spec["positional"]] + [out] + _params(spec))
+    assert "Diagonal rescoring (device)" in log, log[-1500:]
+    assert read_db(out) == read_db(str(scop / run))
+
+
 def test_reference_prefilter_gpu1_cluster_cascade_step0(scop):
     """the first prefilter call of the cluster workflow's cascade (`-s 1 --diag-score 0 --min-ungapped-score 0 --max-seqs 100 -c 0.8`, all-vs-all):
     k-mer match counts as scores.  The reference module with --gpu 1 takes the device path for it too (no silent CPU fallback) and writes
@@ -141,6 +155,7 @@ def test_easy_cluster_gpu1_equals_cpu_binary(tmp_path):
     _run([FS_CPU, "easy-cluster", EXAMPLES, "cpu", "tmp_cpu", "--threads", "1", "-v", "1"], cwd=w)
     log = _run([FS_GPU, "easy-cluster", EXAMPLES, "gpu", "tmp_gpu", "--threads", "1", "-v", "3", "--gpu", "1"], cwd=w)
     assert log.count("Index table (device)") == 3, log[-2000:]
+    assert "Diagonal rescoring (device)" in log                       # linclust's kmermatcher hits rescored on the device
     assert sum(1 for l in log.splitlines() if l.startswith("structurealign ") and "--gpu 1" in l) >= 2
     a, b = open(os.path.join(w, "cpu_cluster.tsv"), "rb").read(), open(os.path.join(w, "gpu_cluster.tsv"), "rb").read()
     assert a == b and a.count(b"\n") == 12
