@@ -1501,6 +1501,9 @@ int fsmod_indexdb(int argc, const char **argv) {
                     }
                 }
         });
+        if ((uint64_t) nE * 6 + 1 > 0xffffffffull || (table + 1) * sizeof(uint64_t) + 1 > 0xffffffffull) {
+            fclose(w.f); return fail("indexdb: the k-mer table of this database exceeds the 32-bit entry length of the index DB format (DBWriter.cpp:489); split the database");
+        }
         w.put(IDX_ENTRIES, ent.data(), (size_t) nE * 6);
         w.put(IDX_ENTRIESOFFSETS, refOff.data(), (table + 1) * sizeof(uint64_t));
         w.put(IDX_ENTRIESNUM, &nE, sizeof(nE));
