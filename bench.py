@@ -859,33 +859,39 @@ def main():
 
     # ---- configs[3]: the same search with --alignment-type 2 (3Di + AA substitution scores, Gotoh affine gaps) on the resident DB ----
     if args.type2_steps > 0 and args.alignment_type != 2:
-        par2 = api.default_params()
-        par2.alignmentType = 2
-        searches2 = [api.Search(c, par2) for c in ctxs]
-        nb2 = min(len(batches), max(nthreads, args.type2_steps))
-        pick = np.linspace(0, len(batches) - 1, nb2 + nthreads).astype(np.int64)          # spread over the length-sorted batches
-        sel2 = [batches[i] for i in pick]
-        dt2, rec2, step2 = search_region(api, ctxs, searches2, q3, qa, sel2[:nthreads], sel2[nthreads:], world, dev, fdist, False, nq)
-        step2(0, sel2[nthreads + (len(sel2) - nthreads) // 2])
-        solo2 = ctxs[0].sw_last_passes()
-        n2 = sum(len(b) for b in sel2[nthreads:])
-        tot2 = fdist.gather_objects((rec2["counts"][0], rec2["counts"][1], n2))
-        if rank == 0:
-            n2t = sum(x[2] for x in tot2)
-            lq2 = [len(q3[i]) for b in sel2[nthreads:] for i in b]
-            leg = {"workload": f"configs[3]: {len(sel2) - nthreads} more steps of {G_eff} queries on the same resident {db.n}-structure DB with --alignment-type 2 "
-                               f"(3Di + AA scores at aaFactor 1.4, affine gaps 10/1): same gapless prefilter, k_sw2 with two LDS tables, host gates, backtraces",
-                   "value": n2t * db.residues / dt2, "unit": "residues/s", "steps": len(sel2) - nthreads, "ms_per_step": 1e3 * dt2 / max(1, len(sel2) - nthreads),
-                   "queries_per_s": n2t / dt2, "ms_per_query": 1e3 * dt2 / max(1, n2t / world), "mean_query_len": float(np.mean(lq2)),
-                   "hits_per_query": sum(x[0] for x in tot2) / max(1, n2t), "alignments_per_query": sum(x[1] for x in tot2) / max(1, n2t),
-                   "sw_kernels_ms_per_query": float(np.mean(rec2["sms"])),
-                   "roofline": gapless_roofline(rec2["kms"], lq2), "align_roofline": sw_roofline(rec2["swp"], True, solo2)}
-            if not args.no_cpu_baseline and world == 1:
-                hits, _ = step1(0, n_warm, searches2)
-                leg["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], 2, args.cpu_sample_targets, reuse_prefilter=t_pref_cpu)
-            out["align_type2"] = leg
-        for x in searches2:
-            x.close()
+        try:
+            par2 = api.default_params()
+            par2.alignmentType = 2
+            searches2 = [api.Search(c, par2) for c in ctxs]
+            nb2 = min(len(batches), max(nthreads, args.type2_steps))
+            pick = np.linspace(0, len(batches) - 1, nb2 + nthreads).astype(np.int64)          # spread over the length-sorted batches
+            sel2 = [batches[i] for i in pick]
+            dt2, rec2, step2 = search_region(api, ctxs, searches2, q3, qa, sel2[:nthreads], sel2[nthreads:], world, dev, fdist, False, nq)
+            step2(0, sel2[nthreads + (len(sel2) - nthreads) // 2])
+            solo2 = ctxs[0].sw_last_passes()
+            n2 = sum(len(b) for b in sel2[nthreads:])
+            tot2 = fdist.gather_objects((rec2["counts"][0], rec2["counts"][1], n2))
+            if rank == 0:
+                n2t = sum(x[2] for x in tot2)
+                lq2 = [len(q3[i]) for b in sel2[nthreads:] for i in b]
+                leg = {"workload": f"configs[3]: {len(sel2) - nthreads} more steps of {G_eff} queries on the same resident {db.n}-structure DB with --alignment-type 2 "
+                                   f"(3Di + AA scores at aaFactor 1.4, affine gaps 10/1): same gapless prefilter, k_sw2 with two LDS tables, host gates, backtraces",
+                       "value": n2t * db.residues / dt2, "unit": "residues/s", "steps": len(sel2) - nthreads, "ms_per_step": 1e3 * dt2 / max(1, len(sel2) - nthreads),
+                       "queries_per_s": n2t / dt2, "ms_per_query": 1e3 * dt2 / max(1, n2t / world), "mean_query_len": float(np.mean(lq2)),
+                       "hits_per_query": sum(x[0] for x in tot2) / max(1, n2t), "alignments_per_query": sum(x[1] for x in tot2) / max(1, n2t),
+                       "sw_kernels_ms_per_query": float(np.mean(rec2["sms"])),
+                       "roofline": gapless_roofline(rec2["kms"], lq2), "align_roofline": sw_roofline(rec2["swp"], True, solo2)}
+                if not args.no_cpu_baseline and world == 1:
+                    hits, _ = step1(0, n_warm, searches2)
+                    leg["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], 2, args.cpu_sample_targets, reuse_prefilter=t_pref_cpu)
+                out["align_type2"] = leg
+            for x in searches2:
+                x.close()
+        except Exception as e:                                             # noqa: BLE001 -- see the k-mer leg below
+            if world > 1:
+                raise
+            if rank == 0:
+                out["align_type2"] = {"error": repr(e)[:500]}
 
     for x in searches[1:]:
         x.close()
@@ -894,9 +900,16 @@ def main():
     searches, ctxs = searches[:1], ctxs[:1]
     kout = None
     if not args.no_kmer:
-        kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist, [q3[i] for i in timed], [qa[i] for i in timed])
+        # the legs after the main line are additional evidence: on one GPU a failure in one of them is recorded in its place instead of
+        # costing the whole line (with several ranks the others would wait in a collective: there the error propagates)
+        try:
+            kout = kmer_section(args, api, synth, ctx0, searches[0], par, db, rank, world, dev, fdist, [q3[i] for i in timed], [qa[i] for i in timed])
+        except Exception as e:                                             # noqa: BLE001
+            if world > 1:
+                raise
+            kout = {"error": repr(e)[:500]}
     if rank == 0 and kout is not None:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and "error" not in kout:
             kout["cpu_baseline"] = kmer_cpu_baseline(args, synth, db)
         out["kmer_prefilter"] = kout
     for x in searches:
@@ -906,8 +919,13 @@ def main():
     del db
     # ---- configs[4]: all-vs-all of a 200k-structure DB (easy-cluster's prefilter + align step), own DB, same process ----
     if args.allvsall_steps > 0:
-        av = allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, args.allvsall_targets, args.allvsall_steps, 8,
-                          with_cpu=(world == 1 and not args.no_cpu_baseline))
+        try:
+            av = allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, args.allvsall_targets, args.allvsall_steps, 8,
+                              with_cpu=(world == 1 and not args.no_cpu_baseline))
+        except Exception as e:                                             # noqa: BLE001
+            if world > 1:
+                raise
+            av = {"error": repr(e)[:500]}
         if rank == 0:
             for k in ("metric", "higher_is_better", "vs_baseline", "data"):
                 av.pop(k, None)
