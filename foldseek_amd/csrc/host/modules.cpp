@@ -1442,13 +1442,13 @@ int fsmod_indexdb(int argc, const char **argv) {
 
     if (needKmerIndex) {
         PaddedTarget pt;
-        if (!loadPadded(r, nullptr, m3, nullptr, pt, err)) { fclose(w.f); return fail(err); }
+        if (!loadPadded(r, nullptr, m3, nullptr, pt, err)) { fclose(w.f); remove(out.c_str()); return fail(err); }
         DeviceSet ds;
-        if (!ds.open(o, pt, false, 1, err)) { ds.close(); fclose(w.f); return fail(err); }
+        if (!ds.open(o, pt, false, 1, err)) { ds.close(); fclose(w.f); remove(out.c_str()); return fail(err); }
         fsgpu_ctx *ctx = ds.root[0];
         fsgpu_kmer_index_params ip;
         ip.kmerSize = 6; ip.spaced = spaced; ip.kmerThr = kmerThr; ip.maskLowerCase = maskLower; ip.maskNrepeats = maskNrepeats;
-        auto gpuFail = [&](const std::string &what) { const std::string m = what + ": " + fsgpu_last_error(ctx); ds.close(); fclose(w.f); return fail(m); };
+        auto gpuFail = [&](const std::string &what) { const std::string m = what + ": " + fsgpu_last_error(ctx); ds.close(); fclose(w.f); remove(out.c_str()); return fail(m); };
         if (fsgpu_kmer_index_build(ctx, &ip, fshost_matrix_scores(m8)) != FSGPU_OK) return gpuFail("GPU k-mer index build");
         // SCOREMATRIX3MER (:220-228): 8000 rows of 8064 (score int16 | index uint32), the rows this library sorts on the device (k_kmer_rows3)
         {
@@ -1480,14 +1480,14 @@ int fsmod_indexdb(int argc, const char **argv) {
         ds.close();
         // the lookup written below is the host's; the device masked the same letters with its own kernel: they must agree
         for (size_t i = 0; i < n; i++)
-            if (memcmp(devMasked.data() + pt.offsets[i], lookup.data() + seqOff[i], r.seqLen(i)) != 0) { fclose(w.f); return fail("indexdb: internal error: device and host masking differ at entry " + std::to_string(r.key(i))); }
+            if (memcmp(devMasked.data() + pt.offsets[i], lookup.data() + seqOff[i], r.seqLen(i)) != 0) { fclose(w.f); remove(out.c_str()); return fail("indexdb: internal error: device and host masking differ at entry " + std::to_string(r.key(i))); }
         std::vector<uint64_t> refOff(table + 1, 0);
         parallelRanges(8000, [&](size_t l0, size_t l1) {                          // reference k-mer number = first3 + 8000 * last3, device = first3 * 8000 + last3
             for (size_t last3 = l0; last3 < l1; last3++)
                 for (size_t first3 = 0; first3 < 8000; first3++) { const size_t p = first3 * 8000 + last3; refOff[first3 + 8000 * last3 + 1] = devOff[p + 1] - devOff[p]; }
         });
         for (uint64_t k = 0; k < table; k++) refOff[k + 1] += refOff[k];
-        if (refOff[table] != nE) { fclose(w.f); return fail("indexdb: internal error: k-mer table sizes differ"); }
+        if (refOff[table] != nE) { fclose(w.f); remove(out.c_str()); return fail("indexdb: internal error: k-mer table sizes differ"); }
         std::vector<uint8_t> ent((size_t) nE * 6 + 1);
         parallelRanges(8000, [&](size_t l0, size_t l1) {
             for (size_t last3 = l0; last3 < l1; last3++)
@@ -1502,7 +1502,7 @@ int fsmod_indexdb(int argc, const char **argv) {
                 }
         });
         if ((uint64_t) nE * 6 + 1 > 0xffffffffull || (table + 1) * sizeof(uint64_t) + 1 > 0xffffffffull) {
-            fclose(w.f); return fail("indexdb: the k-mer table of this database exceeds the 32-bit entry length of the index DB format (DBWriter.cpp:489); split the database");
+            fclose(w.f); remove(out.c_str()); return fail("indexdb: the k-mer table of this database exceeds the 32-bit entry length of the index DB format (DBWriter.cpp:489); split the database");
         }
         w.put(IDX_ENTRIES, ent.data(), (size_t) nE * 6);
         w.put(IDX_ENTRIESOFFSETS, refOff.data(), (table + 1) * sizeof(uint64_t));

@@ -173,3 +173,37 @@ def test_gpuserver_and_client_fail_loudly(tmp_path):
     r = subprocess.run([exe, "ungappedprefilter", src, src, str(tmp_path / "out"), "--gpu-server", "1", "--gpu-server-wait-timeout", "0",
                         "--shm-name", "fsgpu_test_absent_%d" % os.getpid()], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "gpuserver" in r.stderr and "not found" in r.stderr
+
+
+def test_indexdb_needs_the_device_only_for_the_kmer_table(tmp_path):
+    """`indexdb --index-subset 2` (sequence / header DBs + masked lookup) is file assembly and runs anywhere; with the k-mer table
+    (`--index-subset 5`) the table comes from the device build -- without a GPU the module stops with the device error and writes no
+    index (no CPU fallback); argument errors are reported before anything is opened"""
+    import subprocess
+    import torch
+    rng = np.random.default_rng(8)
+    seqs = [rng.integers(0, 20, size=int(L)).astype(np.uint8) for L in rng.integers(20, 90, size=12)]
+    keys = list(range(3, 3 + 12))
+    for name in ("t", "t_ss"):
+        dbio.write_seq_db(str(tmp_path / name), seqs, keys)
+        with open(tmp_path / f"{name}_h", "wb") as f, open(tmp_path / f"{name}_h.index", "w") as fi:
+            off = 0
+            for k in keys:
+                b = f"h{k}".encode() + b"\n\0"
+                f.write(b); fi.write(f"{k}\t{off}\t{len(b)}\n"); off += len(b)
+        np.array([12], np.int32).tofile(str(tmp_path / f"{name}_h.dbtype"))
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    r = subprocess.run([exe, "indexdb", "t", "t", "--index-subset", "2", "--mask-lower-case", "1", "--mask-n-repeat", "6"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    idx = {int(l.split()[0]): (int(l.split()[1]), int(l.split()[2])) for l in open(tmp_path / "t.idx.index")}
+    assert set(idx) == {0, 1, 2, 5, 6, 7, 8, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23} and all(o % 4096 == 0 for o, _ in idx.values())
+    data = open(tmp_path / "t.idx", "rb").read()
+    assert data[idx[0][0]:idx[0][0] + 4] == b"fs1\0" and np.frombuffer(data, np.int32, 12, idx[1][0]).tolist()[:4] == [65535, 0, 1, 21]
+    assert np.frombuffer(data, np.uint64, 1, idx[13][0])[0] == 12 and int(np.frombuffer(data, np.int64, 1, idx[15][0])[0]) == sum(len(s) for s in seqs)
+    r = subprocess.run([exe, "indexdb", "t", "other"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "not implemented" in r.stderr
+    r = subprocess.run([exe, "indexdb", "t_ss", "t_ss", "--index-subset", "5", "--index-dbsuffix", "_ss"], cwd=tmp_path, capture_output=True, text=True)
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "GPU" in r.stderr and not os.path.exists(tmp_path / "t_ss.idx.index") and not os.path.exists(tmp_path / "t_ss.idx")
+    else:
+        assert r.returncode == 0 and os.path.exists(tmp_path / "t_ss.idx.index")
