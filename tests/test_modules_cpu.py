@@ -53,7 +53,7 @@ def test_prefilter_module_argument_errors(tmp_path):
     dbio.write_seq_db(src, seqs, [1, 2, 3, 4])
     out = str(tmp_path / "out")
     assert _call("fsmod_prefilter", [src, src, out, "-k", "7"]) != 0                    # only k = 6 on the device path
-    assert _call("fsmod_prefilter", [src, src, out, "--diag-score", "0"]) != 0
+    assert _call("fsmod_prefilter", [src, src, out, "--mask", "1"]) != 0                  # tantan masking is not on the device path
     assert _call("fsmod_prefilter", [src, src, out, "--exact-kmer-matching", "1"]) != 0
     assert _call("fsmod_prefilter", [str(tmp_path / "missing"), src, out]) != 0
     assert not os.path.exists(out + ".index")
