@@ -468,6 +468,32 @@ static size_t cfo_find_duplicates_total(Cfo *c, const Counter *hits, size_t nHit
     }
     return dbl;
 }
+/* mergeElementsByScore -> mergeScoreDuplicates (CacheFriendlyOperations.cpp:52-58, :150-180), the merge of the per-refill lists without
+ * diagonal scoring.  Restated as the reference executes it, not as its comments describe it: per bin the counts of a target are summed
+ * (saturating at 255) into its byte, every element of the bin is handed on with the byte's CURRENT value, and the byte is then left at
+ * that element's diagonal byte (not zero).  So a target present in both lists comes out twice -- first with the sum, then with the low
+ * byte of the first entry's diagonal as its "count" (dropped only when that byte is 0) -- and a byte left behind by one bin is the
+ * starting value of the targets of later bins that share id >> shift. */
+static size_t cfo_merge_score(Cfo *c, Counter *io, size_t N) {
+    cfo_hash(c, io, N);
+    size_t dbl = 0;
+    for (unsigned bin = 0; bin < c->B; bin++) {
+        const Counter *bs = c->frame + c->binStart[bin];
+        const size_t sz = c->binStart[bin + 1] - c->binStart[bin];
+        for (size_t n = 0; n < sz; n++) {
+            uint8_t *d = &c->dup[bs[n].id >> c->shift];
+            const uint8_t cur = bs[n].count, db = *d;
+            *d = (cur > 0xFF - db) ? 0xFF : (uint8_t) (db + cur);
+        }
+        for (size_t n = 0; n < sz; n++) {
+            uint8_t *d = &c->dup[bs[n].id >> c->shift];
+            io[dbl].id = bs[n].id; io[dbl].count = *d; io[dbl].diagonal = bs[n].diagonal;
+            dbl += (*d != 0) ? 1 : 0;
+            *d = (uint8_t) bs[n].diagonal;
+        }
+    }
+    return dbl;
+}
 static size_t cfo_merge_diag(Cfo *c, Counter *io, size_t N) {              /* mergeDiagonalDuplicates */
     cfo_hash(c, io, N);
     size_t dbl = 0;
@@ -637,10 +663,12 @@ int fko_query(void *hv, const uint8_t *qcodes, int L, int64_t identity, fko_hit 
         for (size_t kp = 0; kp < len; kp++) {
             const uint64_t o0 = h->offsets[list[kp]], sz = h->offsets[list[kp] + 1] - o0;
             if (nh + sz >= maxDbMatches) {
-                if (p->noDiagScore) { unsupported = 1; aborted = 1; break; }     /* the merge of per-round counts (mergeScoreDuplicates) is not restated */
                 overflow = 1;
-                const size_t hc = cfo_find_duplicates(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount);
-                if (overflowHitCount != 0) {
+                const size_t hc = p->noDiagScore ? cfo_find_duplicates_total(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount)
+                                                 : cfo_find_duplicates(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount);
+                if (overflowHitCount != 0 && p->noDiagScore) {
+                    overflowHitCount = cfo_merge_score(&cfo, found, hc + overflowHitCount);      /* QueryMatcher.cpp:328-332 */
+                } else if (overflowHitCount != 0) {
                     overflowHitCount = cfo_merge_diag_keep_scored(&cfo, found, hc + overflowHitCount);
                     align_counters(h, profile, (unsigned) L, found, overflowHitCount);
                     overflowHitCount = cfo_keep_max(&cfo, found, overflowHitCount);
@@ -663,9 +691,10 @@ int fko_query(void *hv, const uint8_t *qcodes, int L, int64_t identity, fko_hit 
     }
     if (unsupported) { kmergen_free(&g); cfo_free(&cfo); free(hits); free(found); free(profile); free(bias); free(q); return -3; }
     if (numMatches > 0) {
-        hitCount = p->noDiagScore ? cfo_find_duplicates_total(&cfo, hits, nh, found, foundSize)
+        hitCount = p->noDiagScore ? cfo_find_duplicates_total(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount)
                                   : cfo_find_duplicates(&cfo, hits, nh, found + overflowHitCount, foundSize - overflowHitCount);
-        if (overflowHitCount != 0) hitCount = cfo_merge_diag(&cfo, found, overflowHitCount + hitCount);
+        if (overflowHitCount != 0) hitCount = p->noDiagScore ? cfo_merge_score(&cfo, found, overflowHitCount + hitCount)
+                                                             : cfo_merge_diag(&cfo, found, overflowHitCount + hitCount);
     }
     if (stats) { stats[0] = (double) kmerListLen / (double) L; stats[1] = (double) (overflowNumMatches + numMatches); stats[2] = overflow; stats[3] = cfo.B; }
     if (p->noDiagScore) {

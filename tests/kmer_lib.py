@@ -170,7 +170,7 @@ class OraKpf:
         stats = np.zeros(4)
         qq = np.ascontiguousarray(q, np.uint8)
         n = self.L.fko_query(self.h, _vp(qq), len(qq), C.c_int64(identity), _vp(out), _vp(stats))
-        self.last_rc = int(n)        # -1: the reference's std::sort branch (not modelled), -3: a refill without diagonal scoring (not restated)
+        self.last_rc = int(n)        # -1: the reference's std::sort branch (not modelled)
         return (out[:max(n, 0)].copy() if n >= 0 else None), stats
 
     def run(self, queries, identity=None):

@@ -124,3 +124,42 @@ def test_hit_lists_without_diagonal_scoring(world, kw):
         assert len(rr[q]) == len(orr[q]) and (rr[q] == orr[q]).all(), (q, kw)
     assert sum(len(x) for x in rr) > min(50, 4 * base["maxResListLen"]) and rr[1][0]["id"] == 7 and rr[1][0]["score"] == 255
     r.set(noDiagScore=0); o.set(noDiagScore=0)
+
+
+@pytest.mark.parametrize("kw", [dict(maxResListLen=300, maxDbMatches=9000), dict(maxResListLen=60, maxDbMatches=4000, bins=8),
+                                dict(maxResListLen=1000, maxDbMatches=3000, bins=2), dict(maxResListLen=25, maxDbMatches=7000, compBias=0, minDiagScoreThr=3),
+                                dict(maxResListLen=2000, maxDbMatches=2500, bins=32)])
+def test_hit_lists_without_diagonal_scoring_with_refills(world, kw):
+    """--diag-score 0 with databaseHits refills: mergeElementsByScore as the reference EXECUTES it (CacheFriendlyOperations.cpp:150-180) --
+    a target present in two per-refill lists comes out twice (the sum, then the low byte of a diagonal as its "count") and bytes left by
+    one bin seed the sums of later bins.  The oracle restates exactly that; the device path answers such queries with
+    FSGPU_KMER_E_REFILL_COUNTS (tests/test_kmer_gpu.py) until it replays the merge.
+    Entries that share (score, id) -- possible only through that duplication -- compare equal under the reference's
+    compareHitsByScoreAndId, so their relative order is whatever its std::sort leaves: the lists are compared with such ties
+    put in diagonal order on both sides, and each side is checked to be ordered by (score desc, id asc)."""
+    def canon(a):
+        return a[np.lexsort((a["diag"], a["id"], -a["score"]))]
+
+    def _ordered(a):
+        s, i = a["score"].astype(np.int64), a["id"].astype(np.int64)
+        return bool(((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (i[:-1] <= i[1:]))).all())
+
+    r, o, q3 = world["r"], world["o"], world["q3"]
+    base = dict(maxResListLen=1000, bins=0, maxDbMatches=0, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=0, noDiagScore=1)
+    base.update(kw)
+    r.set(**base); o.set(**base)
+    ident = np.array([-1, 7, -1, 100, -1], np.int64)
+    rr, rs, _ = r.run(q3, ident)
+    orr, os_ = o.run(q3, ident)
+    dup = 0
+    try:
+        for q in range(NQ):
+            assert orr[q] is not None
+            assert len(rr[q]) == len(orr[q]) and _ordered(rr[q]) and _ordered(orr[q]), (q, kw)
+            assert (canon(rr[q]) == canon(orr[q])).all(), (q, kw)
+            assert np.allclose(rs[q], os_[q]), (q, rs[q], os_[q])
+            dup += len(rr[q]) - len(np.unique(rr[q]["id"]))
+        assert rs[:, 2].sum() > 0     # refills really happened
+        assert dup > 0 or base["maxResListLen"] < 100      # ... and the reference's duplicated targets are in the lists
+    finally:
+        r.set(noDiagScore=0, maxDbMatches=0, bins=0); o.set(noDiagScore=0, maxDbMatches=0, bins=0)
