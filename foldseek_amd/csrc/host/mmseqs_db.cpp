@@ -47,7 +47,7 @@ bool DbReader::openInsideIndex(const std::string &idxPath, std::string &err) {
     if (outer.entryLen((size_t) iIdx) < need) { err = idxPath + ": truncated DBR1INDEX"; return false; }
     uint64_t n, dataSize; int32_t dbt;
     memcpy(&n, p, 8); memcpy(&dataSize, p + 8, 8); memcpy(&dbt, p + 20, 4);
-    if (outer.entryLen((size_t) iIdx) < need + n * 24) { err = idxPath + ": truncated DBR1INDEX"; return false; }
+    if (n > (outer.entryLen((size_t) iIdx) - need) / 24) { err = idxPath + ": truncated DBR1INDEX"; return false; }
     const char *rec = p + 28;
     entries.resize(n);
     for (uint64_t i = 0; i < n; i++) {
@@ -65,7 +65,7 @@ bool DbReader::openInsideIndex(const std::string &idxPath, std::string &err) {
     if (!mapped) { base = owned.data() + (base - outer.base); }
     outer.mapped = false; outer.base = nullptr;
     for (const Entry &e : entries)
-        if (e.offset + e.length > bytes + 1) { err = idxPath + ": sequence entry beyond the data blob inside the index"; return false; }
+        if (e.offset > bytes || e.length > bytes + 1 - e.offset) { err = idxPath + ": sequence entry beyond the data blob inside the index"; return false; }
     return true;
 }
 
@@ -146,7 +146,7 @@ bool DbReader::open(const std::string &pathIn, std::string &err) {
     const bool gpuDb = (extended() & DBTYPE_EXTENDED_GPU) != 0;
     for (const Entry &e : entries) {
         const uint64_t need = gpuDb ? (e.length >= 2 ? e.length - 2 : 0) : e.length;
-        if (e.offset + need > bytes) { err = path + ": index entry beyond end of data file"; return false; }
+        if (e.offset > bytes || need > bytes - e.offset) { err = path + ": index entry beyond end of data file"; return false; }      // no sum: a damaged offset must not wrap
     }
     return true;
 }

@@ -512,9 +512,10 @@ int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbRead
 
 // Util::parseFastaHeader (M/src/commons/Util.cpp:147-229): the accession of a header line -- the field between the
 // database prefix ("sp|", "gi|x|y|" ...) and the next '|' or blank, else the first word
-std::string fastaHeaderName(const char *headerPtr) {
+// `avail`: bytes of the header entry (an entry that lost its terminator must not be read past its end)
+std::string fastaHeaderName(const char *headerPtr, size_t avail) {
     size_t len = 0;
-    while (headerPtr[len] != '\0' && !isspace((unsigned char) headerPtr[len])) len++;
+    while (len < avail && headerPtr[len] != '\0' && !isspace((unsigned char) headerPtr[len])) len++;
     const std::string header(headerPtr, len);
     if (header.empty()) return "";
     size_t offset = header.compare(0, 10, "consensus_") == 0 ? 10 : 0;
@@ -603,7 +604,7 @@ int fsmod_makepaddedseqdb(int argc, const char **argv) {
             ioOk = ioOk && fwrite(h, 1, hl, fh) == hl;                       // entry incl. its terminator, verbatim
             ioOk = ioOk && fprintf(fhi, "%zu\t%llu\t%u\n", k, (unsigned long long) hoff, hl) > 0;
             hoff += hl;
-            name = fastaHeaderName(h);
+            name = fastaHeaderName(h, hl);
         }
         // lookup: new key, entry name parsed from the header, ORIGINAL key in the file-number column (makepaddedseqdb.cpp:121-138)
         if (fl) ioOk = ioOk && fprintf(fl, "%zu\t%s\t%u\n", k, name.c_str(), r.key(id)) > 0;
@@ -1095,23 +1096,26 @@ int fsmod_structurealign(int argc, const char **argv) {
             size_t m = 0;
             for (size_t id = b0; id < std::min(pref.size(), b0 + group) && !bad; id++) {
                 const uint32_t queryKey = pref.key(id);
-                const char *data = pref.data(id);
-                if (*data == '\0') continue;
+                const char *data = pref.data(id), *const dataEnd = data + pref.entryLen(id);      // an entry that lost its terminator ends at its length
+                if (data == dataEnd || *data == '\0') continue;
                 const int64_t qid = q3.idOf(queryKey);
                 if (qid < 0 || qA.idOf(queryKey) < 0) { if (!bad++) firstErr = "query key missing in query database"; break; }
                 const uint32_t L = q3.seqLen((size_t) qid);
+                if (qA.seqLen((size_t) qA.idOf(queryKey)) != L) { if (!bad++) firstErr = "query AA / 3Di entries do not match"; break; }
                 cA[m].resize(L); c3[m].resize(L);
                 const char *sA = qA.data((size_t) qA.idOf(queryKey)), *s3 = q3.data((size_t) qid);
                 for (uint32_t i = 0; i < L; i++) { cA[m][i] = mA.aa2num[(unsigned char) sA[i]]; c3[m][i] = m3.aa2num[(unsigned char) s3[i]]; }
                 // prefilter entry: lines "targetKey \t score \t diagonal" (Util::parseKey, structurealign.cpp:351-355)
                 ids[m].clear();
-                while (*data != '\0') {
-                    const uint32_t dbKey = (uint32_t) strtoul(data, nullptr, 10);
+                while (data < dataEnd && *data != '\0') {
+                    const char *lineEnd = data;
+                    while (lineEnd < dataEnd && *lineEnd != '\n' && *lineEnd != '\0') lineEnd++;
+                    const std::string line(data, lineEnd);                  // a terminated copy: strtoul stops inside the entry
+                    const uint32_t dbKey = (uint32_t) strtoul(line.c_str(), nullptr, 10);
                     const int64_t tid = t3.idOf(dbKey);
                     if (tid < 0) { if (!bad++) firstErr = "target key missing in target database"; break; }
                     ids[m].push_back((uint32_t) tid);
-                    while (*data != '\n' && *data != '\0') data++;
-                    if (*data == '\n') data++;
+                    data = (lineEnd < dataEnd && *lineEnd == '\n') ? lineEnd + 1 : lineEnd;
                 }
                 if (bad) break;
                 res[m].resize(ids[m].size() * (size_t) (1 + par.altAlignment) + 1);
@@ -1205,27 +1209,31 @@ int fsmod_structurerescorediagonal(int argc, const char **argv) {
             size_t m = 0;
             for (size_t id = b0; id < std::min(pref.size(), b0 + group) && !bad; id++) {
                 const uint32_t queryKey = pref.key(id);
-                const char *data = pref.data(id);
-                if (*data == '\0') continue;
+                const char *data = pref.data(id), *const dataEnd = data + pref.entryLen(id);      // an entry that lost its terminator ends at its length
+                if (data == dataEnd || *data == '\0') continue;
                 const int64_t qid = q3.idOf(queryKey);
                 if (qid < 0 || qA.idOf(queryKey) < 0) { if (!bad++) firstErr = "query key missing in query database"; break; }
                 const uint32_t L = q3.seqLen((size_t) qid);
+                if (qA.seqLen((size_t) qA.idOf(queryKey)) != L) { if (!bad++) firstErr = "query AA / 3Di entries do not match"; break; }
                 cA[m].resize(L); c3[m].resize(L);
                 const char *sA = qA.data((size_t) qA.idOf(queryKey)), *s3 = q3.data((size_t) qid);
                 for (uint32_t i = 0; i < L; i++) { cA[m][i] = mA.aa2num[(unsigned char) sA[i]]; c3[m][i] = m3.aa2num[(unsigned char) s3[i]]; }
                 ids[m].clear(); diags[m].clear();
-                while (*data != '\0') {          // QueryMatcher::parsePrefilterHit: exactly three columns
+                while (data < dataEnd && *data != '\0') {          // QueryMatcher::parsePrefilterHit: exactly three columns
+                    const char *lineEnd = data;
+                    while (lineEnd < dataEnd && *lineEnd != '\n' && *lineEnd != '\0') lineEnd++;
+                    const std::string line(data, lineEnd);                  // a terminated copy: the number parsers stop inside the entry
+                    const char *l0 = line.c_str();
                     char *e1, *e2, *e3;
-                    const uint32_t dbKey = (uint32_t) strtoul(data, &e1, 10);
+                    const uint32_t dbKey = (uint32_t) strtoul(l0, &e1, 10);
                     (void) strtol(e1, &e2, 10);
                     const long dg = strtol(e2, &e3, 10);
-                    if (e1 == data || e2 == e1 || e3 == e2) { if (!bad++) firstErr = "Invalid prefilter input"; break; }
+                    if (e1 == l0 || e2 == e1 || e3 == e2) { if (!bad++) firstErr = "Invalid prefilter input"; break; }
                     const int64_t tid = t3.idOf(dbKey);
                     if (tid < 0) { if (!bad++) firstErr = "target key missing in target database"; break; }
                     ids[m].push_back((uint32_t) tid);
                     diags[m].push_back((int16_t) dg);
-                    while (*data != '\n' && *data != '\0') data++;
-                    if (*data == '\n') data++;
+                    data = (lineEnd < dataEnd && *lineEnd == '\n') ? lineEnd + 1 : lineEnd;
                 }
                 if (bad) break;
                 if (L == 0 || ids[m].empty()) continue;
@@ -1749,11 +1757,14 @@ bool parseAlnRecord(const char *line, const char *end, AlnRecord &r, std::string
     if (n < 10) { err = "Invalid alignment result record."; return false; }
     if (n != 10 && n != 11) { err = "alignment records with ORF columns are not produced on this path"; return false; }
     auto wordEnd = [&](size_t i) { const char *e = w[i]; while (e < end && *e != ' ' && *e != '\t' && *e != '\n') e++; return e; };
-    r.dbKey = (uint32_t) strtoul(w[0], nullptr, 10);
-    r.score = atoi(w[1]);
-    const double seqId = strtod(std::string(w[2], wordEnd(2)).c_str(), nullptr);
-    r.eval = strtod(std::string(w[3], wordEnd(3)).c_str(), nullptr);
-    r.qStart = atoi(w[4]); r.qEnd = atoi(w[5]); r.qLen = atoi(w[6]); r.dbStart = atoi(w[7]); r.dbEnd = atoi(w[8]); r.dbLen = atoi(w[9]);
+    // every field is parsed from a terminated copy: the record may be the last bytes of an entry that lost its terminator
+    auto field = [&](size_t i) { return std::string(w[i], wordEnd(i)); };
+    auto toInt = [&](size_t i) { return (int) strtol(field(i).c_str(), nullptr, 10); };
+    r.dbKey = (uint32_t) strtoul(field(0).c_str(), nullptr, 10);
+    r.score = toInt(1);
+    const double seqId = strtod(field(2).c_str(), nullptr);
+    r.eval = strtod(field(3).c_str(), nullptr);
+    r.qStart = toInt(4); r.qEnd = toInt(5); r.qLen = toInt(6); r.dbStart = toInt(7); r.dbEnd = toInt(8); r.dbLen = toInt(9);
     const int aq = r.qStart == -1 ? 0 : r.qStart, ad = r.dbStart == -1 ? 0 : r.dbStart;
     auto cov = [](unsigned int s, unsigned int e, unsigned int len) { return (std::min(len, std::max(s, e)) - std::min(s, e) + 1) / (float) len; };   // SmithWaterman::computeCov
     r.qcov = (float) (double) cov((unsigned) aq, (unsigned) r.qEnd, (unsigned) r.qLen);
@@ -1764,14 +1775,17 @@ bool parseAlnRecord(const char *line, const char *end, AlnRecord &r, std::string
     return true;
 }
 
-std::string expandBacktrace(const std::string &cbt) {          // Matcher::uncompressAlignment (Matcher.cpp:189-203)
-    std::string bt;
+// Matcher::uncompressAlignment (Matcher.cpp:189-203).  false: the run lengths add up to more than `limit` columns (a damaged record: no
+// alignment of two database entries is longer than their lengths together) -- the reference would expand it anyway and read past its
+// sequences, here the record is refused by the caller.
+bool expandBacktrace(const std::string &cbt, size_t limit, std::string &bt) {
+    bt.clear();
     size_t count = 0;
     for (char c : cbt) {
-        if (c >= '0' && c <= '9') count = count * 10 + (size_t) (c - '0');
-        else { bt.append(count == 0 ? 1 : count, c); count = 0; }
+        if (c >= '0' && c <= '9') { count = count * 10 + (size_t) (c - '0'); if (count > limit) return false; }
+        else { const size_t n = count == 0 ? 1 : count; if (bt.size() + n > limit) return false; bt.append(n, c); count = 0; }
     }
-    return bt;
+    return true;
 }
 
 // structurePrintSeqBasedOnAln (structureconvertalis.cpp:133-171) without the nucleotide branches; target = the `reverse` argument
@@ -1816,7 +1830,7 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
     const std::string outfmt = o.has("--format-output") ? o.kv["--format-output"] : "query,target,fident,alnlen,mismatch,gapopen,qstart,qend,tstart,tend,evalue,bits";
     std::vector<ConvCol> cols;
     std::vector<std::string> colNames;
-    bool needSeq = false, need3Di = false, needBt = false;
+    bool needSeq = false, need3Di = false, needBt = false, alignedCols = false;
     int needSets = 0;
     for (size_t b = 0; b <= outfmt.size();) {                      // Util::split(outfmt, ","): empty fields are skipped
         size_t e = outfmt.find(',', b);
@@ -1833,6 +1847,7 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
         }
         cols.push_back(spec->col); colNames.push_back(name);
         needSeq = needSeq || spec->needSeq; need3Di = need3Di || spec->need3Di; needBt = needBt || spec->needBt;
+        alignedCols = alignedCols || (spec->needBt && (spec->needSeq || spec->need3Di));
         needSets |= spec->needSets;
     }
     std::map<unsigned int, unsigned int> qKeyToSet, tKeyToSet;
@@ -1894,10 +1909,11 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
         if (qh < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " has no header entry");
         const char *qHeader = qHdr.data((size_t) qh);
         const size_t qHeaderLen = qHdr.seqLen((size_t) qh);
-        const std::string queryId = fastaHeaderName(qHeader);
+        const std::string queryId = fastaHeaderName(qHeader, qHdr.entryLen((size_t) qh));
         const char *qSeqData = nullptr, *q3Data = nullptr;
-        if (needSeq) { const int64_t id = qSeq.idOf(queryKey); if (id < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " is not in " + o.pos[0]); qSeqData = seqText(qSeq, (size_t) id, qSeqBuf); }
-        if (need3Di) { const int64_t id = q3.idOf(queryKey); if (id < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " is not in the query 3Di database"); q3Data = seqText(q3, (size_t) id, q3Buf); }
+        size_t qHave = SIZE_MAX;               // residues the loaded query entries really hold: what a record may address
+        if (needSeq) { const int64_t id = qSeq.idOf(queryKey); if (id < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " is not in " + o.pos[0]); qSeqData = seqText(qSeq, (size_t) id, qSeqBuf); qHave = std::min(qHave, (size_t) qSeq.seqLen((size_t) id)); }
+        if (need3Di) { const int64_t id = q3.idOf(queryKey); if (id < 0) return fail("convertalis: query key " + std::to_string(queryKey) + " is not in the query 3Di database"); q3Data = seqText(q3, (size_t) id, q3Buf); qHave = std::min(qHave, (size_t) q3.seqLen((size_t) id)); }
         result.clear();
         const char *data = aln.data(i), *dataEnd = data + aln.entryLen(i);
         while (data < dataEnd && *data != '\0') {
@@ -1912,7 +1928,7 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
             if (th < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " has no header entry");
             const char *tHeader = tHdr.data((size_t) th);
             const size_t tHeaderLen = tHdr.seqLen((size_t) th);
-            const std::string targetId = fastaHeaderName(tHeader);
+            const std::string targetId = fastaHeaderName(tHeader, tHdr.entryLen((size_t) th));
             // alignment length, gap opens, identities, mismatches (structureconvertalis.cpp:731-768)
             unsigned int gapOpenCount = 0, alnLen = res.alnLength, missMatchCount = 0, identical = 0;
             if (!res.backtrace.empty()) {
@@ -1921,9 +1937,9 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
                 const std::string &b = res.backtrace;
                 for (size_t pos = 0; pos < b.size(); pos++) {
                     int cnt = 0;
-                    if (isdigit((unsigned char) b[pos])) {
-                        cnt += atoi(b.c_str() + pos);
-                        while (pos < b.size() && isdigit((unsigned char) b[pos])) pos++;
+                    while (pos < b.size() && isdigit((unsigned char) b[pos])) {       // atoi there; saturating here (a damaged run length must not overflow)
+                        if (cnt < 100000000) cnt = cnt * 10 + (b[pos] - '0');
+                        pos++;
                     }
                     alnLen += (unsigned int) cnt;
                     if (pos >= b.size()) break;
@@ -1947,9 +1963,27 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
                 continue;
             }
             const char *tSeqData = nullptr, *t3Data = nullptr;
-            if (needSeq) { const int64_t id = tSeq.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in " + o.pos[1]); tSeqData = seqText(tSeq, (size_t) id, tSeqBuf); }
-            if (need3Di) { const int64_t id = t3.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in the target 3Di database"); t3Data = seqText(t3, (size_t) id, t3Buf); }
-            if (needBt) bt = expandBacktrace(res.backtrace);
+            size_t tHave = SIZE_MAX;
+            if (needSeq) { const int64_t id = tSeq.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in " + o.pos[1]); tSeqData = seqText(tSeq, (size_t) id, tSeqBuf); tHave = std::min(tHave, (size_t) tSeq.seqLen((size_t) id)); }
+            if (need3Di) { const int64_t id = t3.idOf(res.dbKey); if (id < 0) return fail("convertalis: target key " + std::to_string(res.dbKey) + " is not in the target 3Di database"); t3Data = seqText(t3, (size_t) id, t3Buf); tHave = std::min(tHave, (size_t) t3.seqLen((size_t) id)); }
+            // A record that addresses residues its entries do not have (lengths / start positions / backtrace that do not belong to these
+            // databases): the reference prints whatever lies behind the entry; here it is an error naming the record.
+            const auto misfit = [&](const char *what) {
+                return fail("convertalis: the alignment of query " + std::to_string(queryKey) + " with target " + std::to_string(res.dbKey) + " does not fit the databases (" + what + ")");
+            };
+            if (needSeq || need3Di) {
+                if (res.qLen < 0 || (size_t) res.qLen > qHave) return misfit("query length");
+                if (res.dbLen < 0 || (size_t) res.dbLen > tHave) return misfit("target length");
+            }
+            if (needBt) {
+                if (!expandBacktrace(res.backtrace, (size_t) std::max(res.qLen, 0) + (size_t) std::max(res.dbLen, 0) + 1, bt)) return misfit("backtrace longer than both entries");
+                if (alignedCols) {
+                    size_t useQ = 0, useT = 0;
+                    for (char c : bt) { useQ += (c == 'M' || c == 'I'); useT += (c == 'M' || c == 'D'); }
+                    if (res.qStart < 0 || (size_t) res.qStart + useQ > qHave) return misfit("backtrace leaves the query");
+                    if (res.dbStart < 0 || (size_t) res.dbStart + useT > tHave) return misfit("backtrace leaves the target");
+                }
+            }
             if (cols.empty()) {                    // no column survived Util::split: the reference's fixed 12-column BLAST line (:776-800)
                 const int count = snprintf(buffer, sizeof(buffer), "%s\t%s\t%1.3f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%.2E\t%d\n", queryId.c_str(), targetId.c_str(),
                                            res.seqId, alnLen, missMatchCount, gapOpenCount, res.qStart + 1, res.qEnd + 1, res.dbStart + 1, res.dbEnd + 1, res.eval, res.score);

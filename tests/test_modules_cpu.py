@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import numpy as np
+import pytest
 from foldseek_amd import api, synth, dbio
 
 
@@ -207,3 +208,199 @@ def test_indexdb_needs_the_device_only_for_the_kmer_table(tmp_path):
         assert r.returncode != 0 and "GPU" in r.stderr and not os.path.exists(tmp_path / "t_ss.idx.index") and not os.path.exists(tmp_path / "t_ss.idx")
     else:
         assert r.returncode == 0 and os.path.exists(tmp_path / "t_ss.idx.index")
+
+
+def _golden_copy(w):
+    import shutil
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scop_v1")
+    for f in ("db", "db.index", "db.dbtype", "db_h", "db_h.index", "db_h.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype", "db.lookup", "db.source"):
+        shutil.copy(os.path.join(gold, f), os.path.join(w, f))
+    return sorted(int(l.split()[0]) for l in open(os.path.join(w, "db.index")))
+
+
+ALL_RECORD_COLUMNS = ("query,target,evalue,gapopen,pident,fident,nident,qstart,qend,qlen,tstart,tend,tlen,alnlen,bits,cigar,qseq,tseq,qheader,theader,"
+                      "qaln,taln,mismatch,qcov,tcov,qset,qsetid,tset,tsetid,q3di,t3di,q3dialn,t3dialn,prob,empty")
+
+
+@pytest.mark.parametrize("tag,rec,ok,msg", [
+    ("intact", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t{tl}\t10M\n", True, ""),
+    ("no trailing newline", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t{tl}\t10M", True, ""),
+    ("gaps only", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t{tl}\t10I10D\n", True, ""),
+    ("backtrace longer than both entries", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t{tl}\t5000M\n", False, "backtrace longer"),
+    ("run length that overflows", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t{tl}\t99999999999999999999M\n", False, "backtrace longer"),
+    ("start outside the query", "{t}\t100\t0.5\t1e-5\t100000\t200000\t{ql}\t0\t9\t{tl}\t10M\n", False, "leaves the query"),
+    ("start outside the target", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t70000\t90000\t{tl}\t10M\n", False, "leaves the target"),
+    ("backtrace runs off the end", "{t}\t100\t0.5\t1e-5\t{qlm5}\t9\t{ql}\t0\t9\t{tl}\t10M\n", False, "leaves the query"),
+    ("negative start", "{t}\t100\t0.5\t1e-5\t-5\t9\t{ql}\t0\t9\t{tl}\t10M\n", False, "leaves the query"),
+    ("lengths of other databases", "{t}\t100\t0.5\t1e-5\t0\t9\t100000\t0\t9\t{tl}\t10M\n", False, "query length"),
+    ("target length of another database", "{t}\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t100000\t10M\n", False, "target length"),
+    ("too few fields", "{t}\t100\t0.5\n", False, "Invalid alignment result record"),
+    ("unknown target", "987654321\t100\t0.5\t1e-5\t0\t9\t{ql}\t0\t9\t{tl}\t10M\n", False, "987654321"),
+    ("binary junk", "\x01\x02\xff\xfe\t\t\t\t\t\t\t\t\t\t\n", False, "Invalid alignment result record"),
+])
+def test_convertalis_refuses_records_that_do_not_fit_the_databases(tmp_path, tag, rec, ok, msg):
+    """alignment records whose lengths, start positions or backtrace address residues the database entries do not have (a result DB of
+    other databases, a damaged file): the reference's convertalis prints whatever lies behind the entry (structureconvertalis.cpp:133-171
+    walks the backtrace without looking at the lengths); this module names the record and stops -- checked under ASan + UBSan with
+    tools/sanitize_host.sh.  Records that do fit keep working, also without a final newline."""
+    import subprocess
+    w = str(tmp_path)
+    keys = _golden_copy(w)
+    lens = {int(l.split()[0]): int(l.split()[2]) - 2 for l in open(os.path.join(w, "db.index"))}
+    q, t = keys[0], keys[1]
+    assert lens[q] >= 20 and lens[t] >= 20
+    b = rec.format(t=t, ql=lens[q], tl=lens[t], qlm5=lens[q] - 5).encode("latin1") + b"\0"
+    open(os.path.join(w, "aln"), "wb").write(b)
+    open(os.path.join(w, "aln.index"), "w").write(f"{q}\t0\t{len(b)}\n")
+    np.array([5], np.int32).tofile(os.path.join(w, "aln.dbtype"))
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    r = subprocess.run([exe, "convertalis", "db", "db", "aln", "out.m8", "--threads", "1", "--format-output", ALL_RECORD_COLUMNS], cwd=w, capture_output=True, timeout=120)
+    err = r.stderr.decode("latin1")
+    assert r.returncode >= 0, (tag, err[-500:])          # never a signal
+    if ok:
+        assert r.returncode == 0, (tag, err[-500:])
+        line = open(os.path.join(w, "out.m8")).read().split("\t")
+        assert len(line) == len(ALL_RECORD_COLUMNS.split(",")) and line[9] == str(lens[q])
+    else:
+        assert r.returncode != 0 and msg in err, (tag, err[-500:])
+    # the default columns need no sequences: the same record is formatted without looking at them, as in the reference
+    r = subprocess.run([exe, "convertalis", "db", "db", "aln", "out0.m8", "--threads", "1"], cwd=w, capture_output=True, timeout=120)
+    assert r.returncode >= 0
+
+
+@pytest.mark.parametrize("tag", ["empty index", "data cut in half", "entry beyond the data", "non-numeric index line", "zero-length entry", "no dbtype", "short dbtype", "bytes outside the alphabet"])
+def test_makepaddedseqdb_on_damaged_databases(tmp_path, tag):
+    """damaged inputs end in an error message or a valid (possibly smaller) output, never in a signal"""
+    import subprocess
+    w = str(tmp_path)
+    _golden_copy(w)
+    p = os.path.join(w, "db_ss")
+    if tag == "empty index": open(p + ".index", "w").write("")
+    elif tag == "data cut in half": d = open(p, "rb").read(); open(p, "wb").write(d[:len(d) // 2])
+    elif tag == "entry beyond the data": open(p + ".index", "a").write("999999\t99999999999\t50\n")
+    elif tag == "non-numeric index line": open(p + ".index", "a").write("abc\tdef\tghi\n")
+    elif tag == "zero-length entry": open(p + ".index", "a").write("999999\t0\t0\n")
+    elif tag == "no dbtype": os.remove(p + ".dbtype")
+    elif tag == "short dbtype": open(p + ".dbtype", "wb").write(b"\x01")
+    else:
+        d = bytearray(open(p, "rb").read()); d[10:20] = bytes([200, 255, 0, 1, 2, 127, 128, 129, 10, 0]); open(p, "wb").write(d)
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    r = subprocess.run([exe, "makepaddedseqdb", "db_ss", "pad", "--threads", "1"], cwd=w, capture_output=True, text=True, timeout=120)
+    assert r.returncode >= 0, r.stderr[-500:]
+    if tag in ("data cut in half", "entry beyond the data", "no dbtype", "short dbtype"):
+        assert r.returncode != 0 and r.stderr.strip()
+    if r.returncode == 0:
+        idx = [l.split() for l in open(os.path.join(w, "pad.index"))]
+        size = os.path.getsize(os.path.join(w, "pad"))
+        assert all(int(o) + max(int(n) - 2, 0) <= size for _, o, n in idx)      # the padded layout keeps the source's length + 2 in the index
+
+
+def _write_one_alignment(w, q, t):
+    b = f"{t}\t100\t0.5\t1e-5\t0\t9\t50\t0\t9\t60\t10M\n".encode() + b"\0"
+    open(os.path.join(w, "aln"), "wb").write(b)
+    open(os.path.join(w, "aln.index"), "w").write(f"{q}\t0\t{len(b)}\n")
+    np.array([5], np.int32).tofile(os.path.join(w, "aln.dbtype"))
+
+
+SEQ_COLUMNS = "query,target,qseq,tseq,qheader,theader,qaln,taln,q3di,t3di,q3dialn,t3dialn"
+
+
+@pytest.mark.parametrize("tag,msg", [
+    ("offset 2^64-1 in db.index", "beyond end of data"),
+    ("offset near 2^64 in db_h.index", "beyond end of data"),
+    ("negative offset in db_ss.index", "beyond end of data"),
+    ("header entry without terminator at a page boundary", None),
+    ("sequence entry without terminator at a page boundary", None),
+    ("alignment entry without terminator, page multiple", "Invalid alignment result record"),
+])
+def test_database_readers_on_damaged_index_files(tmp_path, tag, msg):
+    """index offsets that would wrap the bounds check, and entries that lost their terminator exactly at the end of the mapping: an
+    error message or the correct output, never a read past the file (sanitizer run: tools/sanitize_host.sh)"""
+    import subprocess
+    w = str(tmp_path)
+    keys = _golden_copy(w)
+    q, t = keys[0], keys[1]
+    _write_one_alignment(w, q, t)
+
+    def unterminate(name):
+        p = os.path.join(w, name)
+        d = open(p, "rb").read()
+        lines = [l.split() for l in open(p + ".index")]
+        d2 = d + b"A" * ((-len(d)) % 4096 or 4096)
+        open(p, "wb").write(d2)
+        with open(p + ".index", "w") as f:
+            for k, o, n in lines:
+                f.write(f"{k}\t{len(d)}\t{len(d2) - len(d)}\n" if int(k) == q else f"{k}\t{o}\t{n}\n")
+        return len(d2) - len(d)
+    if tag.startswith("offset 2^64-1"): open(os.path.join(w, "db.index"), "a").write("5000\t18446744073709551615\t10\n")
+    elif tag.startswith("offset near"): open(os.path.join(w, "db_h.index"), "a").write("5001\t18446744073709551610\t100\n")
+    elif tag.startswith("negative"): open(os.path.join(w, "db_ss.index"), "a").write("5002\t-5\t100\n")
+    elif tag.startswith("header"): unterminate("db_h")
+    elif tag.startswith("sequence"): unterminate("db")
+    else:
+        rec = f"{t}\t100\t0.5\t1e-5\t0\t9\t50\t0\t9\t60\t10M\n".encode()
+        blob = rec * (4096 // len(rec))
+        blob += b"1" * (4096 - len(blob))
+        open(os.path.join(w, "aln"), "wb").write(blob)
+        open(os.path.join(w, "aln.index"), "w").write(f"{q}\t0\t4096\n")
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    r = subprocess.run([exe, "convertalis", "db", "db", "aln", "out.m8", "--threads", "1", "--format-output", SEQ_COLUMNS], cwd=w, capture_output=True, timeout=120)
+    assert r.returncode >= 0
+    if msg is None:
+        assert r.returncode in (0, 1)            # the grown entry may no longer fit the record's lengths: then it is named, not read
+        if r.returncode == 0:
+            assert len(open(os.path.join(w, "out.m8")).read().split("\t")) == len(SEQ_COLUMNS.split(","))
+    else:
+        assert r.returncode != 0 and msg in r.stderr.decode("latin1")
+
+
+@pytest.mark.parametrize("tag,msg", [
+    ("intact", None),
+    ("data cut in half", "beyond end of data"),
+    ("entry count 2^60", "truncated DBR1INDEX"),
+    ("entry count 2^64-1", "truncated DBR1INDEX"),
+    ("first offset 2^64-1", "beyond the data blob"),
+    ("first length 2^32-1", "beyond the data blob"),
+    ("index of the index names the wrong blobs", "truncated DBR1INDEX"),
+])
+def test_sequences_out_of_a_damaged_precomputed_index(tmp_path, tag, msg):
+    """`indexdb --index-subset 2` (host only) writes <db>.idx; with the plain sequence DBs gone the modules read the sequences out of it
+    (DbReader::openInsideIndex).  Damaged counts / offsets / lengths inside the serialised reader are refused by name."""
+    import struct
+    import subprocess
+    import shutil
+    w = str(tmp_path)
+    keys = _golden_copy(w)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scop_v1")
+    for e in ("", ".index", ".dbtype"):
+        shutil.copy(os.path.join(gold, "db_h" + e), os.path.join(w, "db_ss_h" + e))
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    for name in ("db", "db_ss"):
+        r = subprocess.run([exe, "indexdb", name, name, "--index-subset", "2"], cwd=w, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    expect = None
+    _write_one_alignment(w, keys[0], keys[1])
+    r = subprocess.run([exe, "convertalis", "db", "db", "aln", "plain.m8", "--threads", "1", "--format-output", SEQ_COLUMNS], cwd=w, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    expect = open(os.path.join(w, "plain.m8")).read()
+    for f in ("db", "db.index", "db.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype"):
+        os.remove(os.path.join(w, f))
+    for name in ("db", "db_ss"):
+        e = {int(l.split()[0]): (int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(w, name + ".idx.index"))}
+        p = os.path.join(w, name + ".idx")
+        d = open(p, "rb").read()
+        o5 = e[5][0]
+        if tag == "data cut in half": d = d[:len(d) // 2]
+        elif tag == "entry count 2^60": d = d[:o5] + struct.pack("<Q", 1 << 60) + d[o5 + 8:]
+        elif tag == "entry count 2^64-1": d = d[:o5] + struct.pack("<Q", (1 << 64) - 1) + d[o5 + 8:]
+        elif tag == "first offset 2^64-1": d = d[:o5 + 36] + struct.pack("<Q", (1 << 64) - 1) + d[o5 + 44:]
+        elif tag == "first length 2^32-1": d = d[:o5 + 44] + struct.pack("<I", (1 << 32) - 1) + d[o5 + 48:]
+        elif tag.startswith("index of the index"): open(p + ".index", "w").write("5\t0\t10\n6\t0\t10\n")
+        open(p, "wb").write(d)
+    r = subprocess.run([exe, "convertalis", "db.idx", "db.idx", "aln", "idx.m8", "--threads", "1", "--format-output", SEQ_COLUMNS], cwd=w, capture_output=True, text=True, timeout=120)
+    assert r.returncode >= 0
+    if msg is None:
+        assert r.returncode == 0, r.stderr
+        assert open(os.path.join(w, "idx.m8")).read() == expect          # same text from the index as from the plain databases
+    else:
+        assert r.returncode != 0 and msg in r.stderr, r.stderr
