@@ -36,18 +36,21 @@ std::string dbPathWithSuffix(const std::string &db, const std::string &suffix) {
 // sequence DB stored inside a precomputed index: DBR1INDEX (key 5) = DBReader::serialize (DBReader.cpp:824-840: size, dataSize,
 // lastKey, dbtype, maxSeqLen, then `size` records {u32 id; u64 offset; u32 length} with natural alignment = 24 bytes),
 // DBR1DATA (key 6) = the data file's bytes
-bool DbReader::openInsideIndex(const std::string &idxPath, std::string &err) {
+bool DbReader::openInsideIndex(const std::string &idxPath, std::string &err, uint32_t indexKey, uint32_t dataKey) {
     DbReader outer;
     // the index DB itself is an ordinary MMseqs DB (its .dbtype is INDEX_DB = 16: no sequence semantics needed here)
     if (!outer.open(idxPath + "\x01raw", err)) return false;
-    const int64_t iIdx = outer.idOf(5), iDat = outer.idOf(6);
-    if (iIdx < 0 || iDat < 0) { err = idxPath + ": no sequence database inside the index (DBR1INDEX / DBR1DATA missing)"; return false; }
+    const int64_t iIdx = outer.idOf(indexKey), iDat = outer.idOf(dataKey);
+    if (iIdx < 0 || iDat < 0) {
+        err = idxPath + (indexKey == 5 ? ": no sequence database inside the index (DBR1INDEX / DBR1DATA missing)" : ": no header database inside the index (HDR1INDEX / HDR1DATA missing)");
+        return false;
+    }
     const char *p = outer.data((size_t) iIdx);
     const uint64_t need = 8 + 8 + 4 + 4 + 4;
-    if (outer.entryLen((size_t) iIdx) < need) { err = idxPath + ": truncated DBR1INDEX"; return false; }
+    if (outer.entryLen((size_t) iIdx) < need) { err = idxPath + (indexKey == 5 ? ": truncated DBR1INDEX" : ": truncated HDR1INDEX"); return false; }
     uint64_t n, dataSize; int32_t dbt;
     memcpy(&n, p, 8); memcpy(&dataSize, p + 8, 8); memcpy(&dbt, p + 20, 4);
-    if (n > (outer.entryLen((size_t) iIdx) - need) / 24) { err = idxPath + ": truncated DBR1INDEX"; return false; }
+    if (n > (outer.entryLen((size_t) iIdx) - need) / 24) { err = idxPath + (indexKey == 5 ? ": truncated DBR1INDEX" : ": truncated HDR1INDEX"); return false; }
     const char *rec = p + 28;
     entries.resize(n);
     for (uint64_t i = 0; i < n; i++) {
@@ -67,6 +70,14 @@ bool DbReader::openInsideIndex(const std::string &idxPath, std::string &err) {
     for (const Entry &e : entries)
         if (e.offset > bytes || e.length > bytes + 1 - e.offset) { err = idxPath + ": sequence entry beyond the data blob inside the index"; return false; }
     return true;
+}
+
+bool DbReader::openHeaders(const std::string &db, std::string &err) {
+    const bool idx = endsWith(db, ".idx");
+    const std::string plain = (idx ? db.substr(0, db.size() - 4) : db) + "_h";
+    uint64_t sz;
+    if (!idx || (fileSize(plain + ".dbtype", sz) && fileSize(plain + ".index", sz))) return open(plain, err);
+    return openInsideIndex(db, err, 18, 19);
 }
 
 bool DbReader::open(const std::string &pathIn, std::string &err) {

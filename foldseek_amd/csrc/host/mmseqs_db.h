@@ -25,6 +25,9 @@ public:
     // M/src/prefiltering/PrefilteringIndexReader.cpp:15-18,116-128: a serialised DBReader index + the data blob).  The
     // persisted k-mer table itself is not read: the device rebuilds it from the sequences in 0.02-0.07 s.
     bool open(const std::string &path, std::string &err);
+    // the header database of `db` (which may name a precomputed index): <db>_h if it exists, else the copy inside <db>.idx (entries
+    // HDR1INDEX = 18 / HDR1DATA = 19, what the reference's IndexReader(..., SRC_HEADERS) reads, M/src/commons/IndexReader.h:55-75)
+    bool openHeaders(const std::string &db, std::string &err);
     size_t size() const { return entries.size(); }
     uint32_t key(size_t id) const { return entries[id].key; }
     const char *data(size_t id) const { return base + entries[id].offset; }
@@ -47,7 +50,7 @@ private:
     std::vector<char> owned;                                                  // multi-file DBs are read into memory
     const char *mapBase = nullptr;                                            // what to munmap (base may point into it)
     uint64_t mapBytes = 0;
-    bool openInsideIndex(const std::string &idxPath, std::string &err);
+    bool openInsideIndex(const std::string &idxPath, std::string &err, uint32_t indexKey = 5, uint32_t dataKey = 6);
 };
 
 // <db>[.idx] + suffix the way StructureUtil::getIndexWithSuffix does (F/src/commons/StructureUtil.h:9-21): "db.idx" + "_ss" ->

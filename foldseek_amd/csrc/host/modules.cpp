@@ -1860,8 +1860,8 @@ extern "C" int fsmod_convertalis(int argc, const char **argv) {
     const bool sameDB = o.pos[0] == o.pos[1];
     std::string err;
     DbReader qSeq, tSeqOwn, q3, t3Own, qHdr, tHdrOwn, aln;
-    if (!qHdr.open(dbPathWithSuffix(o.pos[0], "_h"), err)) return fail(err);
-    if (!sameDB && !tHdrOwn.open(dbPathWithSuffix(o.pos[1], "_h"), err)) return fail(err);
+    if (!qHdr.openHeaders(o.pos[0], err)) return fail(err);
+    if (!sameDB && !tHdrOwn.openHeaders(o.pos[1], err)) return fail(err);
     if (needSeq && (!qSeq.open(o.pos[0], err) || (!sameDB && !tSeqOwn.open(o.pos[1], err)))) return fail(err);
     if (need3Di && (!q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || (!sameDB && !t3Own.open(dbPathWithSuffix(o.pos[1], "_ss"), err)))) return fail(err);
     if (!aln.open(o.pos[2], err)) return fail(err);

@@ -144,3 +144,40 @@ def test_indexdb_without_kmer_table_equals_the_reference_binary(tmp_path):
         os.makedirs(w)
         dbio.write_seq_db(os.path.join(w, "t"), seqs, keys, masks)
         assert subprocess.run([exe, "indexdb", "t", "t"] + par, cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode != 0
+
+
+def test_convertalis_reads_sequences_and_headers_out_of_the_reference_written_index(tmp_path):
+    """the reference's `createindex` writes <db>.idx / <db>_ss.idx (sequences under DBR1*, headers under HDR1*); with the plain databases moved
+    away both binaries must print the same text from inside the index (DbReader::openInsideIndex / openHeaders against the reference's
+    IndexReader), equal to what the plain databases gave"""
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "scop_v1")
+    w = str(tmp_path)
+    for f in ("db", "db.index", "db.dbtype", "db_h", "db_h.index", "db_h.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype", "db.lookup", "db.source"):
+        shutil.copy(os.path.join(gold, f), os.path.join(w, f))
+    for e in ("", ".index", ".dbtype"):
+        shutil.copy(os.path.join(gold, "db_h" + e), os.path.join(w, "db_ss_h" + e))
+    keys = sorted(int(l.split()[0]) for l in open(os.path.join(w, "db.index")))
+    lens = {int(l.split()[0]): int(l.split()[2]) - 2 for l in open(os.path.join(w, "db.index"))}
+    blob, idx, off = b"", "", 0
+    for q, t in ((keys[0], keys[1]), (keys[3], keys[3]), (keys[7], keys[2])):
+        n = min(lens[q], lens[t]) - 2
+        b = f"{t}\t100\t0.5\t1e-5\t1\t{n}\t{lens[q]}\t2\t{n + 1}\t{lens[t]}\t{n}M\n".encode() + b"\0"
+        idx += f"{q}\t{off}\t{len(b)}\n"; blob += b; off += len(b)
+    open(os.path.join(w, "aln"), "wb").write(blob); open(os.path.join(w, "aln.index"), "w").write(idx)
+    np.array([5], np.int32).tofile(os.path.join(w, "aln.dbtype"))
+    cols = "query,target,qseq,tseq,qheader,theader,qaln,taln,q3di,t3di,q3dialn,t3dialn,qlen,tlen,cigar"
+    subprocess.run([FS, "createindex", "db", "tmp", "--threads", "1", "-v", "1"], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)   # no db_ca: stops after both indexes
+    assert os.path.exists(os.path.join(w, "db.idx.index")) and os.path.exists(os.path.join(w, "db_ss.idx.index"))
+    r = subprocess.run([FS, "convertalis", "db", "db", "aln", "ref_plain.m8", "--threads", "1", "-v", "1", "--format-output", cols], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    os.makedirs(os.path.join(w, "gone"))
+    for f in ("db", "db.index", "db.dbtype", "db_h", "db_h.index", "db_h.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype", "db_ss_h", "db_ss_h.index", "db_ss_h.dbtype"):
+        shutil.move(os.path.join(w, f), os.path.join(w, "gone", f))
+    r = subprocess.run([FS, "convertalis", "db.idx", "db.idx", "aln", "ref_idx.m8", "--threads", "1", "-v", "1", "--format-output", cols], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    m = subprocess.run([BIN, "convertalis", "db.idx", "db.idx", "aln", "mine_idx.m8", "--threads", "1", "--format-output", cols], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert m.returncode == 0, m.stdout[-2000:]
+    ref = open(os.path.join(w, "ref_idx.m8"), "rb").read()
+    assert ref == open(os.path.join(w, "ref_plain.m8"), "rb").read() and ref.count(b"\n") == 3
+    assert open(os.path.join(w, "mine_idx.m8"), "rb").read() == ref

@@ -383,8 +383,8 @@ def test_sequences_out_of_a_damaged_precomputed_index(tmp_path, tag, msg):
     r = subprocess.run([exe, "convertalis", "db", "db", "aln", "plain.m8", "--threads", "1", "--format-output", SEQ_COLUMNS], cwd=w, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     expect = open(os.path.join(w, "plain.m8")).read()
-    for f in ("db", "db.index", "db.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype"):
-        os.remove(os.path.join(w, f))
+    for f in ("db", "db.index", "db.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype") + (("db_h", "db_h.index", "db_h.dbtype") if tag == "intact" else ()):
+        os.remove(os.path.join(w, f))          # "intact": the headers, too, come out of the index (HDR1INDEX / HDR1DATA)
     for name in ("db", "db_ss"):
         e = {int(l.split()[0]): (int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(w, name + ".idx.index"))}
         p = os.path.join(w, name + ".idx")
