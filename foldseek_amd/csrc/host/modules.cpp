@@ -31,6 +31,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <regex.h>
 #include <thread>
 #include <vector>
 
@@ -157,6 +158,81 @@ const FlagSpec kServerFlags[] = {              // Parameters::gpuserver (Paramet
 static double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool moduleTiming() { const char *e = getenv("FSGPU_MODULE_TIMING"); return e && *e && *e != '0'; }
 
+// Value domains of the reference's parameters: the `regex` argument of their definitions (M/src/commons/Parameters.cpp:28-330,
+// F/src/commons/LocalParameters.cpp:9-130 with the overrides at :56,:78,:461), applied the way Parameters::parseParameters does
+// (Parameters.cpp:1820-1827,1905-2040: POSIX extended, REG_NEWLINE, regexec = a SEARCH, so an unanchored pattern accepts what it accepts
+// there).  A value outside its domain ends in the reference's "Error in argument <flag>" before anything is opened.
+//   V_REGEX       int / size_t / float / double parameters
+//   V_BYTES       ByteParser parameters: "Error in argument regex <flag>"
+//   V_NUCLAA_INT  MultiParam<NuclAA<int>>: "N" or "aa:N,nucl:M"; a component with trailing junk or out of range is "Error in value
+//                 parsing <flag>", a purely non-numeric one reads as 0 (MultiParam.h:210-219) -- as there
+enum ValueKind { V_REGEX, V_BYTES, V_NUCLAA_INT };
+struct FlagDomain { const char *name; ValueKind kind; const char *regex; };
+const FlagDomain kFlagDomains[] = {
+    {"--alignment-mode", V_REGEX, "^[0-3]{1}$"}, {"--alignment-output-mode", V_REGEX, "^[0-1]{1}$"}, {"--alignment-type", V_REGEX, "^[0-3]{1}$"},
+    {"--alph-size", V_NUCLAA_INT, nullptr}, {"--alt-ali", V_REGEX, "^[0-9]{1}[0-9]*$"}, {"--check-compatible", V_REGEX, "^[0-2]{1}$"},
+    {"--comp-bias-corr", V_REGEX, "^[0-1]{1}$"}, {"--comp-bias-corr-scale", V_REGEX, "^0(\\.[0-9]+)?|^1(\\.0+)?$"},
+    {"--compressed", V_REGEX, "^[0-1]{1}$"}, {"--corr-score-weight", V_REGEX, "^-?[0-9]*(\\.[0-9]+)?$"}, {"--cov-mode", V_REGEX, "^[0-5]{1}$"},
+    {"--db-load-mode", V_REGEX, "[0-3]{1}"}, {"--disk-space-limit", V_BYTES, "^(0|[1-9]{1}[0-9]*(B|K|M|G|T)?)$"},
+    {"--exact-kmer-matching", V_REGEX, "^[0-1]{1}$"}, {"--exact-tmscore", V_REGEX, "^[0-1]{1}$"}, {"--format-mode", V_REGEX, "^[0-5]{1}$"},
+    {"--gap-extend", V_NUCLAA_INT, nullptr}, {"--gap-open", V_NUCLAA_INT, nullptr}, {"--gpu", V_REGEX, "^[0-1]{1}$"},
+    {"--gpu-server", V_REGEX, "^[0-1]{1}$"}, {"--gpu-server-wait-timeout", V_REGEX, "^-?[0-9]+"}, {"--index-subset", V_REGEX, "^[0-9]{1}[0-9]*$"},
+    {"--lddt-threshold", V_REGEX, "^0(\\.[0-9]+)?|1(\\.0+)?$"}, {"--mask", V_REGEX, "^[0-1]{1}"}, {"--mask-lower-case", V_REGEX, "^[0-1]{1}"},
+    {"--mask-n-repeat", V_REGEX, "^[0-9]{1}[0-9]*$"}, {"--mask-prob", V_REGEX, "^0(\\.[0-9]+)?|^1(\\.0+)?$"},
+    {"--max-accept", V_REGEX, "^[1-9]{1}[0-9]*$"}, {"--max-rejected", V_REGEX, "^[1-9]{1}[0-9]*$"}, {"--max-seq-len", V_REGEX, "^[0-9]{1}[0-9]*"},
+    {"--max-seqs", V_REGEX, "^[1-9]{1}[0-9]*$"}, {"--min-aln-len", V_REGEX, "^[0-9]{1}[0-9]*$"},
+    {"--min-seq-id", V_REGEX, "^0(\\.[0-9]+)?|1(\\.0+)?$"}, {"--min-ungapped-score", V_REGEX, "^[0-9]{1}[0-9]*$"},
+    {"--prefilter-mode", V_REGEX, "^[0-3]{1}$"}, {"--realign-max-seqs", V_REGEX, "^[0-9]{1}[0-9]*$"},
+    {"--realign-score-bias", V_REGEX, "^-?[0-9]*(\\.[0-9]+)?$"}, {"--score-bias", V_REGEX, "^-?[0-9]*(\\.[0-9]+)?$"},
+    {"--search-type", V_REGEX, "^[0-4]{1}"}, {"--seq-id-mode", V_REGEX, "^[0-2]{1}$"}, {"--sort-by-structure-bits", V_REGEX, "^[0-1]{1}$"},
+    {"--spaced-kmer-mode", V_REGEX, "^[0-1]{1}"}, {"--split", V_REGEX, "^[0-9]{1}[0-9]*$"},
+    {"--split-memory-limit", V_BYTES, "^(0|[1-9]{1}[0-9]*(B|K|M|G|T)?)$"}, {"--split-mode", V_REGEX, "^[0-2]{1}$"},
+    {"--target-search-mode", V_REGEX, "^[0-1]{1}$"}, {"--threads", V_REGEX, "^[1-9]{1}[0-9]*$"},
+    {"--tmscore-threshold", V_REGEX, "^0(\\.[0-9]+)?|1(\\.0+)?$"}, {"--tmscore-threshold-mode", V_REGEX, "^[0-2]{1}$"},
+    {"--translation-table", V_REGEX, "^[1-9]{1}[0-9]*$"}, {"--write-lookup", V_REGEX, "^[0-1]{1}"}, {"-c", V_REGEX, "^0(\\.[0-9]+)?|^1(\\.0+)?$"},
+    {"-e", V_REGEX, "^([-+]?[0-9]*\\.?[0-9]+([eE][-+]?[0-9]+)?)|[0-9]*(\\.[0-9]+)?$"}, {"-k", V_REGEX, "^[0-9]{1}[0-9]*$"},
+    {"-s", V_REGEX, "^[0-9]*(\\.[0-9]+)?$"}, {"-v", V_REGEX, "^[0-4]{1}$"},
+    {nullptr, V_REGEX, nullptr}};
+
+// "" = inside the domain, else the reference's message
+std::string domainError(const std::string &flag, const std::string &value) {
+    const FlagDomain *d = kFlagDomains;
+    while (d->name && flag != d->name) d++;
+    if (!d->name) return "";
+    if (d->kind == V_NUCLAA_INT) {
+        auto component = [](const std::string &v) {          // MultiParam::assign(const std::string &, int &)
+            char *rest = nullptr;
+            errno = 0;
+            (void) strtol(v.c_str(), &rest, 10);
+            return !((rest != v.c_str() && *rest != '\0') || errno == ERANGE);
+        };
+        bool ok;
+        if (value.find(',') == std::string::npos) ok = component(value);
+        else {
+            // two components, "aa:" and "nucl:" in either order, each with exactly one ':' (MultiParam.cpp:15-33)
+            const size_t comma = value.find(',');
+            const std::string parts[2] = {value.substr(0, comma), value.substr(comma + 1)};
+            bool haveAA = false, haveNucl = false;
+            ok = parts[1].find(',') == std::string::npos && !parts[0].empty() && !parts[1].empty();
+            for (int i = 0; ok && i < 2; i++) {
+                const bool aa = parts[i].rfind("aa:", 0) == 0, nucl = parts[i].rfind("nucl:", 0) == 0;
+                if (!aa && !nucl) continue;
+                const std::string num = parts[i].substr(aa ? 3 : 5);
+                if (num.empty() || num.find(':') != std::string::npos || !component(num)) ok = false;
+                haveAA = haveAA || aa; haveNucl = haveNucl || nucl;
+            }
+            ok = ok && haveAA && haveNucl;
+        }
+        return ok ? "" : "Error in value parsing " + flag;
+    }
+    regex_t re;
+    if (regcomp(&re, d->regex, REG_EXTENDED | REG_NEWLINE) != 0) return std::string("Error in regex ") + d->regex;
+    const int nomatch = regexec(&re, value.c_str(), 0, nullptr, 0);
+    regfree(&re);
+    if (!nomatch) return "";
+    return (d->kind == V_BYTES ? "Error in argument regex " : "Error in argument ") + flag;
+}
+
 const FlagSpec *findFlag(const std::string &a, std::initializer_list<const FlagSpec *> tables) {
     for (const FlagSpec *t : tables)
         for (; t->name; t++)
@@ -201,6 +277,8 @@ bool parseArgs(int argc, const char **argv, const char *module, std::initializer
         } else {
             if (i + 1 >= argc) { err = "Missing argument " + a; return false; }
             v = argv[++i];
+            err = domainError(a, v);
+            if (!err.empty()) return false;
         }
         if (f->support == ONLY && !valueAllowed(Options::first(v), f->only)) {
             err = std::string(module) + ": " + a + " " + v + " is not implemented on the device path (supported: " +

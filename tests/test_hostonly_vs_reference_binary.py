@@ -181,3 +181,34 @@ def test_convertalis_reads_sequences_and_headers_out_of_the_reference_written_in
     ref = open(os.path.join(w, "ref_idx.m8"), "rb").read()
     assert ref == open(os.path.join(w, "ref_plain.m8"), "rb").read() and ref.count(b"\n") == 3
     assert open(os.path.join(w, "mine_idx.m8"), "rb").read() == ref
+
+
+@pytest.mark.parametrize("module,pos,flag,value", [
+    ("structurealign", ["db", "db", "pref", "out"], "--threads", "0"), ("structurealign", ["db", "db", "pref", "out"], "--threads", "abc"),
+    ("structurealign", ["db", "db", "pref", "out"], "-c", "1.5"), ("structurealign", ["db", "db", "pref", "out"], "-c", "0.5"),
+    ("structurealign", ["db", "db", "pref", "out"], "--cov-mode", "6"), ("structurealign", ["db", "db", "pref", "out"], "--alignment-type", "4"),
+    ("structurealign", ["db", "db", "pref", "out"], "--min-seq-id", "2"), ("structurealign", ["db", "db", "pref", "out"], "-e", "nan"),
+    ("structurealign", ["db", "db", "pref", "out"], "--gap-open", "12abc"), ("structurealign", ["db", "db", "pref", "out"], "--gap-open", "aa:3,nucl:1x"),
+    ("structurealign", ["db", "db", "pref", "out"], "--gap-open", "aa:3,prot:4"), ("structurealign", ["db", "db", "pref", "out"], "--gap-open", "aa:3"),
+    ("structurealign", ["db", "db", "pref", "out"], "--gap-open", "xyz"), ("structurealign", ["db", "db", "pref", "out"], "--gap-extend", "99999999999999999999"),
+    ("structurealign", ["db", "db", "pref", "out"], "--alt-ali", "-1"), ("structurealign", ["db", "db", "pref", "out"], "--comp-bias-corr", "2"),
+    ("prefilter", ["db_ss", "db_ss", "out"], "--max-seqs", "0"), ("prefilter", ["db_ss", "db_ss", "out"], "--max-seqs", "1.5"),
+    ("prefilter", ["db_ss", "db_ss", "out"], "-s", "-1"), ("prefilter", ["db_ss", "db_ss", "out"], "-k", "x"),
+    ("prefilter", ["db_ss", "db_ss", "out"], "--split-memory-limit", "12X"), ("prefilter", ["db_ss", "db_ss", "out"], "--mask-n-repeat", "-2"),
+    ("convertalis", ["db", "db", "aln", "out.m8"], "--format-mode", "7"), ("convertalis", ["db", "db", "aln", "out.m8"], "--translation-table", "0"),
+    ("makepaddedseqdb", ["db_ss", "pad"], "--write-lookup", "2"), ("makepaddedseqdb", ["db_ss", "pad"], "--threads", "1x"),
+])
+def test_argument_domain_errors_equal_the_reference_binary(tmp_path, module, pos, flag, value):
+    """a value outside (or inside) a parameter's pattern: both binaries say "Error in argument <flag>" / "Error in value parsing <flag>" or
+    neither does (what happens after a parse that passed -- missing prefilter DB, no device -- is not compared here)"""
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "scop_v1")
+    w = str(tmp_path)
+    for f in ("db", "db.index", "db.dbtype", "db_h", "db_h.index", "db_h.dbtype", "db_ss", "db_ss.index", "db_ss.dbtype"):
+        shutil.copy(os.path.join(gold, f), os.path.join(w, f))
+    ref = subprocess.run([FS, module] + pos + [flag, value, "-v", "1"], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    mine = subprocess.run([BIN, module] + pos + [flag, value], cwd=w, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    for msg in (f"Error in argument {flag}", f"Error in value parsing {flag}", f"Error in argument regex {flag}"):
+        assert (msg in ref.stdout) == (msg in mine.stdout), (msg, ref.stdout[-300:], mine.stdout[-300:])
+    if "Error in" in ref.stdout:
+        assert ref.returncode != 0 and mine.returncode != 0

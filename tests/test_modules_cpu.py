@@ -404,3 +404,72 @@ def test_sequences_out_of_a_damaged_precomputed_index(tmp_path, tag, msg):
         assert open(os.path.join(w, "idx.m8")).read() == expect          # same text from the index as from the plain databases
     else:
         assert r.returncode != 0 and msg in r.stderr, r.stderr
+
+
+def _manifest_vectors():
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scop_v1")
+    m = json.load(open(os.path.join(gold, "MANIFEST.json")))
+    out = []
+    for group in ("runs", "runs_with_index", "convert_runs"):
+        for name, r in m[group].items():
+            out.append((f"{group}:{name}", r["module"], list(r["positional"]), list(r["parameters"])))
+    for i, v in enumerate(m["indexdb"]):
+        out.append((f"indexdb:{i}", v[0], [], list(v[1:])))
+    return out
+
+
+def test_every_reference_parameter_vector_is_inside_the_value_domains(tmp_path):
+    """the complete parameter vectors the reference's workflows handed to its modules (tests/golden/scop_v1/MANIFEST.json, 60+ runs) and the
+    edge values of test_modules_vs_reference_binary.py must pass the argument parser -- incl. the reference's per-parameter value patterns
+    (`domainError`) -- so without a GPU every device module ends at the DEVICE error, not at an argument error"""
+    import subprocess
+    w = str(tmp_path)
+    _golden_copy(w)
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    vectors = _manifest_vectors()
+    edge = {"-e": ["0", "1e-300", "1e+30", "10", "0.001"], "--max-accept": ["1"], "-c": ["1.0", "0.8"], "--min-seq-id": ["1.0"], "--min-aln-len": ["100000"],
+            "--alt-ali": ["5"], "--gap-open": ["aa:2,nucl:2", "7"], "--max-seqs": ["1", "100000"], "-s": ["1", "9.5", "7.5"], "--k-score": ["seq:200,prof:200"],
+            "--min-ungapped-score": ["0", "255"], "--mask-n-repeat": ["2"], "--comp-bias-corr-scale": ["1.0", "0.15"], "--split-memory-limit": ["0", "12G"]}
+    base = next(v for v in vectors if v[1] == "structurealign")
+    pbase = next(v for v in vectors if v[1] == "prefilter")
+    for k, vals in edge.items():
+        for v in vals:
+            src = base if k in base[3] else pbase
+            par = list(src[3]); par[par.index(k) + 1] = v
+            vectors.append((f"edge:{k}={v}", src[1], src[2], par))
+    assert len(vectors) > 60
+    for tag, module, pos, par in vectors:
+        if module == "convertalis" or (module == "indexdb" and "--index-subset" in par and par[par.index("--index-subset") + 1] == "2"):
+            continue                                       # host-only: run for real by test_scop_golden / test_indexdb tests
+        pos = [p for p in pos] + ([f"out_{abs(hash(tag))}"] if module != "indexdb" else [])
+        r = subprocess.run([exe, module] + pos + par, cwd=w, capture_output=True, text=True, timeout=300)
+        bad = [m for m in ("Error in", "Unrecognized parameter", "Missing argument", "Invalid boolean", "Duplicate parameter") if m in r.stderr]
+        assert not bad, (tag, r.stderr[-400:])
+
+
+@pytest.mark.parametrize("flag,value,msg", [
+    ("--threads", "0", "Error in argument --threads"), ("--threads", "abc", "Error in argument --threads"), ("--threads", "-5", "Error in argument --threads"),
+    ("--max-seqs", "0", "Error in argument --max-seqs"), ("--max-seqs", "1.5", "Error in argument --max-seqs"),
+    ("-e", "", None), ("-e", "nan", None),                  # the reference's pattern for -e accepts an empty match: anything goes there, too
+    ("-c", "1.5", "Error in argument -c"), ("-c", "-0.1", "Error in argument -c"), ("--cov-mode", "6", "Error in argument --cov-mode"),
+    ("--alignment-type", "4", "Error in argument --alignment-type"), ("--min-seq-id", "2", "Error in argument --min-seq-id"),
+    ("--gap-open", "12abc", "Error in value parsing --gap-open"), ("--gap-open", "aa:3", None), ("--gap-open", "aa:3,nucl:x1", None),
+    ("--gap-open", "aa:3,nucl:1x", "Error in value parsing --gap-open"), ("--gap-open", "aa:3,prot:4", "Error in value parsing --gap-open"),
+    ("--gap-extend", "99999999999999999999", "Error in value parsing --gap-extend"),
+    ("--comp-bias-corr", "2", "Error in argument --comp-bias-corr"), ("--alt-ali", "-1", "Error in argument --alt-ali"),
+])
+def test_values_outside_the_reference_domains_get_the_reference_message(tmp_path, flag, value, msg):
+    """Parameters::parseParameters validates every value against the parameter's pattern before anything runs (Parameters.cpp:1905-2040)
+    and ends in "Error in argument <flag>" / "Error in value parsing <flag>"; same here, with the same patterns"""
+    import subprocess
+    w = str(tmp_path)
+    _golden_copy(w)
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    module = ["prefilter", "db", "db", "out"] if flag == "--max-seqs" else ["structurealign", "db", "db", "pref", "out"]
+    r = subprocess.run([exe] + module + [flag, value], cwd=w, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 or msg is None               # (a GPU box runs the prefilter; here: no such prefilter DB / no device at the latest)
+    if msg is None:
+        assert "Error in" not in r.stderr, r.stderr
+    else:
+        assert msg in r.stderr, r.stderr
