@@ -75,7 +75,16 @@ GpuShm *gpuShmOpen(const std::string &name, std::string &err) {
     ptr = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (ptr == MAP_FAILED) { err = "Failed to remap shared memory"; return nullptr; }
-    return reinterpret_cast<GpuShm *>(ptr);
+    // the three areas must lie inside the block (a block of another program / version under the same name is refused, not written into)
+    GpuShm *shm = reinterpret_cast<GpuShm *>(ptr);
+    const auto inside = [&](unsigned int off, size_t len) { return off >= sizeof(GpuShm) && off <= size && len <= size - off; };
+    if (!inside(shm->queryOffset, maxSeqLen) || !inside(shm->resultsOffset, sizeof(GpuShmResult) * (size_t) maxResListLen) ||
+        !inside(shm->profileOffset, (size_t) 21 * maxSeqLen) || shm->resultsOffset % alignof(GpuShmResult) != 0) {
+        munmap(ptr, size);
+        err = "shared memory block has an unexpected layout (not a gpuserver block of this database?)";
+        return nullptr;
+    }
+    return shm;
 }
 
 bool gpuShmExists(const std::string &name) {

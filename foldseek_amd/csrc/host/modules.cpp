@@ -526,7 +526,11 @@ int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbRead
     if (!w.open(o.pos[2], DBTYPE_PREFILTER_RES, err)) { gpuShmUnmap(shm); return fail(err); }
     std::vector<uint8_t> codes;
     std::vector<int8_t> pssm;
-    std::vector<GpuShmResult> results(shm->maxResListLen);
+    // geometry as validated by gpuShmOpen, read ONCE: the areas are addressed through these, not through header fields re-read later
+    const unsigned int shmMaxSeqLen = shm->maxSeqLen, shmMaxRes = shm->maxResListLen;
+    int8_t *const shmQuery = shm->query(), *const shmProfile = shm->profile();
+    const GpuShmResult *const shmResults = shm->results();
+    std::vector<GpuShmResult> results(shmMaxRes);
     std::vector<fsgpu_hit> hits;
     std::string out;
     char line[128];
@@ -535,7 +539,7 @@ int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbRead
         const uint32_t L = q.seqLen(id);
         out.clear();
         if (L > 0) {
-            if (L > shm->maxSeqLen) { rc = fail("query longer than the gpuserver's --max-seq-len"); break; }
+            if (L > shmMaxSeqLen) { rc = fail("query longer than the gpuserver's --max-seq-len"); break; }
             codes.resize(L);
             const char *sq = q.data(id);
             for (uint32_t i = 0; i < L; i++) codes[i] = m3.aa2num[(unsigned char) sq[i]];
@@ -549,8 +553,8 @@ int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbRead
                 int expected = GpuShm::IDLE;
                 if (!shm->state.compare_exchange_strong(expected, GpuShm::RESERVED, std::memory_order_acq_rel)) { std::this_thread::yield(); continue; }
                 claimed = true;
-                memcpy(shm->query(), codes.data(), L);
-                memcpy(shm->profile(), pssm.data(), (size_t) m3.n * L);
+                memcpy(shmQuery, codes.data(), L);
+                memcpy(shmProfile, pssm.data(), (size_t) m3.n * L);
                 shm->queryLen = L;
                 std::atomic_thread_fence(std::memory_order_release);
                 shm->state.store(GpuShm::READY, std::memory_order_release);
@@ -560,8 +564,8 @@ int ungappedPrefilterViaServer(const Options &o, const DbReader &q, const DbRead
                 }
                 if (rc != EXIT_SUCCESS) break;
                 std::atomic_thread_fence(std::memory_order_acquire);
-                nres = std::min(shm->resultLen, shm->maxResListLen);
-                memcpy(results.data(), shm->results(), nres * sizeof(GpuShmResult));
+                nres = std::min(shm->resultLen, shmMaxRes);
+                memcpy(results.data(), shmResults, nres * sizeof(GpuShmResult));
                 shm->state.store(GpuShm::IDLE, std::memory_order_release);
             }
             if (rc != EXIT_SUCCESS) break;

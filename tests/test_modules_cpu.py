@@ -473,3 +473,49 @@ def test_values_outside_the_reference_domains_get_the_reference_message(tmp_path
         assert "Error in" not in r.stderr, r.stderr
     else:
         assert msg in r.stderr, r.stderr
+
+
+@pytest.mark.parametrize("tag,msg", [
+    ("server already gone", "GPU server has unexpectedly shut down"),
+    ("block smaller than its header says", "smaller than its header"),
+    ("profile area outside the block", "unexpected layout"),
+    ("query area inside the header", "unexpected layout"),
+    ("results area wraps", "unexpected layout"),
+    ("garbage", None),
+])
+def test_gpuserver_client_checks_the_shared_memory_block(tmp_path, tag, msg):
+    """the client side of the gpuserver protocol (no GPU involved: `ungappedprefilter --gpu-server 1`) against hand-made blocks under the
+    server's name: a block whose areas do not lie inside it (another program / version under the same name) is refused before anything is
+    written into it; a well-formed block of a server that has exited ends with the reference's message"""
+    import struct
+    import subprocess
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, 20, size=50).astype(np.uint8) for _ in range(6)]
+    src = str(tmp_path / "db_ss")
+    dbio.write_seq_db(src, seqs, list(range(6)))
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    name = "fsgpu_test_fake_%d_%d" % (os.getpid(), abs(hash(tag)) % 100000)
+    max_len, max_res = 1000, 300
+    size = 36 + max_len + 16 * max_res + 21 * max_len
+    qoff, roff, poff = 36, 36 + max_len, 36 + max_len + 16 * max_res          # the reference's order: query, results, profile
+    assert roff % 4 == 0
+    state, server_exit = 0, 0
+    if tag == "server already gone": server_exit = 1
+    elif tag.startswith("profile"): poff = size - 100
+    elif tag.startswith("query"): qoff = 8
+    elif tag.startswith("results"): roff = 0xfffffff0
+    hdr = struct.pack("<IIiB3xIIIII", max_len, max_res, state, server_exit, qoff, 0, roff, 0, poff)
+    assert len(hdr) == 36
+    blob = hdr + bytes(size - 36)
+    if tag.startswith("block smaller"): blob = blob[:size // 2]
+    if tag == "garbage": blob = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+    path = "/dev/shm/" + name
+    open(path, "wb").write(blob)
+    try:
+        r = subprocess.run([exe, "ungappedprefilter", src, src, str(tmp_path / "out"), "--gpu-server", "1", "--gpu-server-wait-timeout", "0", "--shm-name", name],
+                           capture_output=True, text=True, timeout=60)
+    finally:
+        os.remove(path)
+    assert r.returncode > 0, r.stderr                  # an error exit, never a signal
+    if msg:
+        assert msg in r.stderr, r.stderr
