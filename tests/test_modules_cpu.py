@@ -477,6 +477,7 @@ def test_values_outside_the_reference_domains_get_the_reference_message(tmp_path
 
 @pytest.mark.parametrize("tag,msg", [
     ("server already gone", "GPU server has unexpectedly shut down"),
+    ("server already gone, default geometry", "GPU server has unexpectedly shut down"),
     ("block smaller than its header says", "smaller than its header"),
     ("profile area outside the block", "unexpected layout"),
     ("query area inside the header", "unexpected layout"),
@@ -495,12 +496,11 @@ def test_gpuserver_client_checks_the_shared_memory_block(tmp_path, tag, msg):
     dbio.write_seq_db(src, seqs, list(range(6)))
     exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
     name = "fsgpu_test_fake_%d_%d" % (os.getpid(), abs(hash(tag)) % 100000)
-    max_len, max_res = 1000, 300
+    max_len, max_res = (65535, 1000) if "default geometry" in tag else (1001, 300)      # odd: the result area is unaligned, as with the default 65535
     size = 36 + max_len + 16 * max_res + 21 * max_len
     qoff, roff, poff = 36, 36 + max_len, 36 + max_len + 16 * max_res          # the reference's order: query, results, profile
-    assert roff % 4 == 0
     state, server_exit = 0, 0
-    if tag == "server already gone": server_exit = 1
+    if tag.startswith("server already gone"): server_exit = 1
     elif tag.startswith("profile"): poff = size - 100
     elif tag.startswith("query"): qoff = 8
     elif tag.startswith("results"): roff = 0xfffffff0
