@@ -519,3 +519,79 @@ def test_gpuserver_client_checks_the_shared_memory_block(tmp_path, tag, msg):
     assert r.returncode > 0, r.stderr                  # an error exit, never a signal
     if msg:
         assert msg in r.stderr, r.stderr
+
+
+def test_gpuserver_client_round_trip_against_a_scripted_server(tmp_path):
+    """the client's half of the protocol end to end without a GPU: a scripted server (this test, through the same /dev/shm block layout the
+    reference's GPUSharedMemory has) answers every READY with a made-up result list; the client must hand over each query's residue codes and
+    21 x L profile, take the list, drop what is not above --min-ungapped-score, order by (score desc, key asc), cut at --max-seqs and write
+    the prefilter DB in the reference's text format"""
+    import mmap
+    import struct
+    import subprocess
+    import threading
+    import time
+    rng = np.random.default_rng(9)
+    lens = [50, 1, 333, 0, 77, 120]
+    seqs = [rng.integers(0, 20, size=L).astype(np.uint8) for L in lens]
+    keys = [3, 5, 8, 13, 21, 34]
+    src = str(tmp_path / "db_ss")
+    dbio.write_seq_db(src, seqs, keys)
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "bin", "fsgpu-modules")
+    name = "fsgpu_test_script_%d" % os.getpid()
+    max_len, max_res = 65535, 10
+    qoff, roff = 36, 36 + max_len
+    poff = roff + 16 * max_res
+    size = poff + 21 * max_len
+    path = "/dev/shm/" + name
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIiB3xIIIII", max_len, max_res, 0, 0, qoff, 0, roff, 0, poff) + bytes(size - 36))
+    fd = os.open(path, os.O_RDWR)
+    mm = mmap.mmap(fd, size)
+    seen, stop = [], threading.Event()
+
+    def made_up(codes):                  # (target id, score): ids of the 6 targets, two ties, one score at the threshold, one below
+        s = int(codes.sum()) % 50
+        return [(5, 100 + s), (0, 31), (2, 100 + s), (4, 30), (1, 255), (3, 12)]
+
+    def server():
+        while not stop.is_set():
+            if struct.unpack_from("<i", mm, 8)[0] != 2:          # READY
+                time.sleep(0.0005)
+                continue
+            L = struct.unpack_from("<I", mm, 20)[0]
+            codes = np.frombuffer(mm[qoff:qoff + L], np.uint8).copy()
+            prof = np.frombuffer(mm[poff:poff + 21 * L], np.int8).copy().reshape(21, L)
+            seen.append((codes, prof))
+            res = made_up(codes)
+            for i, (tid, sc) in enumerate(res):
+                struct.pack_into("<Iiii", mm, roff + 16 * i, tid, sc, 0, 0)
+            struct.pack_into("<I", mm, 28, len(res))               # resultLen
+            struct.pack_into("<i", mm, 8, 3)                       # DONE
+    th = threading.Thread(target=server, daemon=True)
+    th.start()
+    try:
+        r = subprocess.run([exe, "ungappedprefilter", src, src, str(tmp_path / "out"), "--gpu-server", "1", "--gpu-server-wait-timeout", "0", "--shm-name", name,
+                            "--max-seqs", "4", "--comp-bias-corr", "0"], capture_output=True, text=True, timeout=120)
+    finally:
+        stop.set(); th.join(timeout=5)
+        mm.close(); os.close(fd); os.remove(path)
+    assert r.returncode == 0, r.stderr
+    nonempty = [s for s in seqs if len(s)]
+    assert len(seen) == len(nonempty)
+    for (codes, prof), s in zip(seen, nonempty):
+        assert (codes == s).all()                                  # residue codes in the padded alphabet's numbering
+        assert prof.shape == (21, len(s)) and len(np.unique(prof[:20], axis=0)) > 1 if len(s) > 5 else True
+        for j in range(len(s)):                                    # no bias: a column of the profile is the matrix row of the query residue
+            assert (prof[:, j] == prof[:, int(np.flatnonzero(s == s[j])[0])]).all()
+    data = open(tmp_path / "out", "rb").read()
+    idx = {int(l.split()[0]): (int(l.split()[1]), int(l.split()[2])) for l in open(str(tmp_path / "out") + ".index")}
+    assert sorted(idx) == keys
+    for k, s in zip(keys, seqs):
+        entry = data[idx[k][0]:idx[k][0] + idx[k][1] - 1].decode()
+        if len(s) == 0:
+            assert entry == ""
+            continue
+        hits = [(keys[t], sc) for t, sc in made_up(s) if sc > 30 or keys[t] == k]        # identity (same DB) stays whatever its score
+        hits.sort(key=lambda h: (-h[1], h[0]))
+        assert entry == "".join(f"{t}\t{sc}\t0\n" for t, sc in hits[:4]), (k, entry)
