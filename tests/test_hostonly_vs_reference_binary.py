@@ -181,6 +181,9 @@ def test_convertalis_reads_sequences_and_headers_out_of_the_reference_written_in
     ref = open(os.path.join(w, "ref_idx.m8"), "rb").read()
     assert ref == open(os.path.join(w, "ref_plain.m8"), "rb").read() and ref.count(b"\n") == 3
     assert open(os.path.join(w, "mine_idx.m8"), "rb").read() == ref
+    for f in ("db.idx", "db_ss.idx"):                      # the reference's k-mer tables: 0.4 GB each, not worth keeping in pytest's tmp
+        os.remove(os.path.join(w, f))
+    shutil.rmtree(os.path.join(w, "tmp"), ignore_errors=True)
 
 
 @pytest.mark.parametrize("module,pos,flag,value", [
