@@ -14,6 +14,8 @@
 #include "k_select.hpp"
 #include "k_gapless.hpp"
 #include "k_sw.hpp"
+#include "k_sw3.hpp"
+#include "fsgpu_sw3.h"
 
 static thread_local std::string g_createError;
 
@@ -76,13 +78,14 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (ctx->kmer) fsgpu_kmer_free_scratch(ctx->kmer);
     DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
                       &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys, &ctx->lbuf, &ctx->lres,
-                      &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen,
+                      &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen, &ctx->s3img, &ctx->s3pass, &ctx->s3build, &ctx->s3res,
                       &ctx->mqPssm, &ctx->mqScores, &ctx->mqQueues, &ctx->mqRec, &ctx->mqHist, &ctx->mqBaseGt, &ctx->mqBaseTie, &ctx->mqMeta,
                       &ctx->mqOutId, &ctx->mqOutScore, &ctx->mqIdent};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
     hipFree(ctx->dMeta); hipFree(ctx->queue);
     hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId.p); hipHostFree(ctx->hOutScore.p);
     hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p); hipHostFree(ctx->hLbuf.p); hipHostFree(ctx->hLres.p);
+    hipHostFree(ctx->hS3pass.p); hipHostFree(ctx->hS3build.p); hipHostFree(ctx->hS3res.p);
     if (ctx->swLong) (void) hipStreamDestroy(ctx->swLong);
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
     hipHostFree(ctx->hMqPssm.p); hipHostFree(ctx->hMqRec.p); hipHostFree(ctx->hMqMeta.p); hipHostFree(ctx->hMqOutId.p); hipHostFree(ctx->hMqOutScore.p); hipHostFree(ctx->hMqIdent.p);
@@ -1571,6 +1574,288 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
         f2.resize(ids.size()); r2.resize(ids.size());
         rc = fsgpu_sw_batch(ctx, q[i].pAA_fwd, q[i].p3Di_fwd, q[i].pAA_rev, q[i].p3Di_rev, q[i].L, ids.data(), (int) ids.size(), gapOpen, gapExtend,
                             f2.data(), r2.data());
+        if (rc != FSGPU_OK) return rc;
+        for (size_t k = 0; k < ids.size(); k++) out[base[i] + where[k]] = dir == 0 ? f2[k] : r2[k];
+    }
+    return FSGPU_OK;
+}
+
+// ---- compact-query form of fsgpu_sw_multi_dir: k_sw3 over device-built images ---------------------------------------------------
+// A structurealign profile is matrix column + position bias (StructureSmithWaterman.cpp:1566-1640), so a query is given by its codes and
+// biases; the LDS images are built by k_sw3_image.  Queries of up to 32 * 16 rows run with 32 lanes per target pair (four targets per
+// wave), up to 64 * 16 rows with 64 lanes; longer ones and the int32 re-run of int16-saturated pairs go through the profile-based
+// entry points with profiles materialised here.
+static bool sw3Class(int L, int &R, int &HL) {
+    if (L <= 32 * kSw3MaxR) { HL = 32; R = (L + 31) / 32; return true; }
+    if (L <= 64 * kSw3MaxR) { HL = 64; R = (L + 63) / 64; return true; }
+    return false;
+}
+static int sw3Waves(int R, int HL, bool hasAA) {
+    static const int env = [] { const char *e = getenv("FSGPU_SW3_WAVES"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 8) ? v : 0; }();
+    if (env) return env;
+    return (160 * 1024) / sw3LdsBytes(R, HL, hasAA, 4) >= 3 ? 4 : 8;
+}
+static void sw3Materialize(const int8_t *mat, const uint8_t *codes, const int8_t *cb, int L, bool reversed, std::vector<int16_t> &out) {
+    out.resize((size_t) kAlphabet * L);
+    for (int a = 0; a < kAlphabet; a++)
+        for (int i = 0; i < L; i++)
+            out[(size_t) a * L + i] = (int16_t) ((int) mat[a * kAlphabet + codes[reversed ? L - 1 - i : i]] + (cb ? (int) cb[i] : 0));
+}
+
+int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend, int dir,
+                         const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out) {
+    if (!ctx || !mat3Di || nq < 0 || (nq > 0 && (!q || !out)) || (dir != 0 && dir != 1) || ((sel == nullptr) != (nsel == nullptr))) return FSGPU_E_ARG;
+    if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
+    if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
+        ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
+        return FSGPU_E_UNSUPPORTED;
+    }
+    if (ctx->sw.pending) { ctx->err = "previous SW batch not finished"; return FSGPU_E_ARG; }
+    if (nq > 65535) { ctx->err = "fsgpu_sw_multi_dir_c: more than 65535 queries in one call"; return FSGPU_E_ARG; }
+    const bool hasAA = matAA != nullptr;
+    if (hasAA && !ctx->db->hasAA) { ctx->err = "AA matrix given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<size_t> base(nq + 1, 0), sbase(nq + 1, 0);
+    for (int i = 0; i < nq; i++) {
+        if (!q[i].q3Di || (hasAA && !q[i].qAA) || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN || q[i].n < 0 || (q[i].n > 0 && !q[i].targetIds)) { ctx->err = "fsgpu_sw_multi_dir_c: bad query"; return FSGPU_E_ARG; }
+        for (int k = 0; k < q[i].L; k++) if (q[i].q3Di[k] >= kAlphabet || (hasAA && q[i].qAA[k] >= kAlphabet)) { ctx->err = "fsgpu_sw_multi_dir_c: residue code out of range"; return FSGPU_E_ARG; }
+        base[i + 1] = base[i] + (size_t) q[i].n;
+        const int ns = sel ? nsel[i] : q[i].n;
+        if (ns < 0 || ns > q[i].n || (sel && ns > 0 && !sel[i])) { ctx->err = "fsgpu_sw_multi_dir_c: bad selection"; return FSGPU_E_ARG; }
+        for (int k = 0; k < q[i].n; k++) if (q[i].targetIds[k] >= ctx->db->n) { ctx->err = "target id out of range"; return FSGPU_E_ARG; }
+        if (sel) for (int k = 0; k < ns; k++) if (sel[i][k] < 0 || sel[i][k] >= q[i].n) { ctx->err = "fsgpu_sw_multi_dir_c: selection index out of range"; return FSGPU_E_ARG; }
+    }
+    auto nSelAll = [&](int i) { return sel ? (int) nsel[i] : q[i].n; };
+    auto selIdx = [&](int i, int k) { return sel ? sel[i][k] : k; };
+    int rc;
+    // ---- queries outside k_sw3's classes: the profile-based path, all of them in one sub-call (the same set in both directions) ----
+    std::vector<int> cR(nq, 0), cHL(nq, 0);
+    std::vector<int> classic;
+    for (int i = 0; i < nq; i++) if (!sw3Class(q[i].L, cR[i], cHL[i])) { cR[i] = 0; classic.push_back(i); }
+    struct Prof { std::vector<int16_t> aF, sF, aR, sR; };
+    auto profilesOf = [&](int i, Prof &pr) {
+        sw3Materialize(mat3Di, q[i].q3Di, q[i].cb3Di_fwd, q[i].L, false, pr.sF);
+        sw3Materialize(mat3Di, q[i].q3Di, q[i].cb3Di_rev, q[i].L, true, pr.sR);
+        if (hasAA) { sw3Materialize(matAA, q[i].qAA, q[i].cbAA_fwd, q[i].L, false, pr.aF); sw3Materialize(matAA, q[i].qAA, q[i].cbAA_rev, q[i].L, true, pr.aR); }
+    };
+    if (!classic.empty()) {
+        std::vector<Prof> prof(classic.size());
+        std::vector<fsgpu_sw_query> cq(classic.size());
+        std::vector<const int32_t *> csel(classic.size());
+        std::vector<int32_t> cnsel(classic.size());
+        size_t ctotal = 0;
+        for (size_t c = 0; c < classic.size(); c++) {
+            const int i = classic[c];
+            profilesOf(i, prof[c]);
+            cq[c].pAA_fwd = hasAA ? prof[c].aF.data() : nullptr; cq[c].pAA_rev = hasAA ? prof[c].aR.data() : nullptr;
+            cq[c].p3Di_fwd = prof[c].sF.data(); cq[c].p3Di_rev = prof[c].sR.data();
+            cq[c].L = q[i].L; cq[c].n = q[i].n; cq[c].targetIds = q[i].targetIds;
+            csel[c] = sel ? sel[i] : nullptr; cnsel[c] = sel ? nsel[i] : 0;
+            ctotal += (size_t) q[i].n;
+        }
+        std::vector<fsgpu_swres> cout(std::max<size_t>(ctotal, 1));
+        rc = fsgpu_sw_multi_dir(ctx, cq.data(), (int) cq.size(), gapOpen, gapExtend, dir, sel ? csel.data() : nullptr, sel ? cnsel.data() : nullptr, cout.data());
+        if (rc != FSGPU_OK) return rc;
+        size_t cb = 0;
+        for (size_t c = 0; c < classic.size(); c++) {
+            const int i = classic[c];
+            for (int k = 0; k < nSelAll(i); k++) { const int j = selIdx(i, k); out[base[i] + j] = cout[cb + j]; }
+            cb += (size_t) q[i].n;
+        }
+    }
+    // ---- k_sw3 ----
+    auto nSel = [&](int i) { return cR[i] > 0 ? nSelAll(i) : 0; };
+    for (int i = 0; i < nq; i++) sbase[i + 1] = sbase[i] + (size_t) nSel(i);
+    const size_t total = sbase[nq];
+    if (!ctx->swDirEv[3]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->swDirEv[i]));
+    ctx->swDirValid[dir] = false;
+    if (dir == 0) ctx->swDirValid[1] = false;
+    ctx->swDirCells[dir] = 0; ctx->swDirPairs[dir] = 0; ctx->swDirWaveSteps[dir] = 0;
+    if (total == 0) return FSGPU_OK;
+    // images: built once per set of queries (the reversed call of a forward call finds them in place)
+    uint64_t sig = 0xcbf29ce484222325ull ^ (uint64_t) nq ^ ((uint64_t) hasAA << 40);
+    sig = hashWords(sig, mat3Di, kAlphabet * kAlphabet);
+    if (hasAA) sig = hashWords(sig, matAA, kAlphabet * kAlphabet);
+    for (int i = 0; i < nq; i++) {
+        if (cR[i] == 0) continue;
+        const size_t L = (size_t) q[i].L;
+        sig = hashWords(sig ^ (uint64_t) i * 0x9E3779B97F4A7C15ull ^ L, q[i].q3Di, L);
+        if (hasAA) sig = hashWords(sig, q[i].qAA, L);
+        const int8_t *cbs[4] = {q[i].cb3Di_fwd, q[i].cbAA_fwd, q[i].cb3Di_rev, q[i].cbAA_rev};
+        for (int c = 0; c < 4; c++) { if (cbs[c]) sig = hashWords(sig, cbs[c], L); else sig = (sig ^ 0x55) * 0x100000001B3ull; }
+    }
+    if (!sig) sig = 1;
+    const bool haveImages = ctx->s3Sig == sig && (int) ctx->s3ImgOff.size() == nq;
+    if (!haveImages) {
+        ctx->s3Sig = 0;
+        ctx->s3ImgOff.assign((size_t) nq, 0xffffffffu);
+        size_t imgDw = 0, dataBytes = 0;
+        int nImg = 0, maxDw = 0;
+        for (int i = 0; i < nq; i++) {
+            if (cR[i] == 0) continue;
+            const size_t one = (size_t) 2 * sw3ImageBytes(cR[i], cHL[i], hasAA) / 4;
+            if (imgDw + one >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: images of one call exceed 16 GiB"; return FSGPU_E_NOMEM; }
+            ctx->s3ImgOff[i] = (uint32_t) imgDw; imgDw += one; maxDw = std::max(maxDw, (int) one);
+            dataBytes += ((size_t) 6 * q[i].L + 15) / 16 * 16;
+            nImg++;
+        }
+        const size_t descBytes = ((size_t) nImg * sizeof(Sw3ImgQuery) + 15) / 16 * 16, matOff = descBytes, dataOff0 = matOff + 1024;
+        if ((rc = ensurePinned(ctx, ctx->hS3build, dataOff0 + dataBytes)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->s3build, dataOff0 + dataBytes)) != FSGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->s3img, imgDw * 4)) != FSGPU_OK) return rc;
+        unsigned char *hb = (unsigned char *) ctx->hS3build.p;
+        Sw3ImgQuery *hd = (Sw3ImgQuery *) hb;
+        memcpy(hb + matOff, mat3Di, kAlphabet * kAlphabet);
+        if (hasAA) memcpy(hb + matOff + 512, matAA, kAlphabet * kAlphabet);
+        size_t dpos = dataOff0;
+        int k = 0;
+        for (int i = 0; i < nq; i++) {
+            if (cR[i] == 0) continue;
+            const size_t L = (size_t) q[i].L;
+            hd[k].imgOff = ctx->s3ImgOff[i]; hd[k].dataOff = (uint32_t) (dpos - dataOff0); hd[k].L = (uint32_t) L; hd[k].R = (uint16_t) cR[i]; hd[k].HL = (uint16_t) cHL[i];
+            unsigned char *d = hb + dpos;
+            memcpy(d, q[i].q3Di, L);
+            if (hasAA) memcpy(d + L, q[i].qAA, L); else memset(d + L, 0, L);
+            const int8_t *cbs[4] = {q[i].cb3Di_fwd, q[i].cbAA_fwd, q[i].cb3Di_rev, q[i].cbAA_rev};
+            for (int c = 0; c < 4; c++) { if (cbs[c]) memcpy(d + (2 + c) * L, cbs[c], L); else memset(d + (2 + c) * L, 0, L); }
+            dpos += (6 * L + 15) / 16 * 16;
+            k++;
+        }
+        if (dpos - dataOff0 >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: query data of one call exceeds 4 GiB"; return FSGPU_E_NOMEM; }
+        HIPCHK(hipMemcpyAsync(ctx->s3build.p, hb, dpos, hipMemcpyHostToDevice, ctx->stream));
+        const unsigned char *db = (const unsigned char *) ctx->s3build.p;
+        rc = fsgpuLaunchSw3Image(ctx, (const Sw3ImgQuery *) db, nImg, maxDw, db + dataOff0, (const int8_t *) (db + matOff), (const int8_t *) (db + matOff + 512),
+                                 (uint32_t *) ctx->s3img.p, hasAA, ctx->stream);
+        if (rc != FSGPU_OK) return rc;
+        ctx->s3Sig = sig;
+    }
+    // ---- the pass: target ids (longest first inside a query: neighbours share a wave) and workgroup descriptors per (R, HL) class ----
+    struct Group { int R, HL, waves; size_t blk0, nblk; };
+    std::vector<Group> groups;
+    size_t nBlocks = 0;
+    {
+        std::vector<int> key(nq, -1);
+        std::vector<int> keys;
+        for (int i = 0; i < nq; i++) if (nSel(i) > 0) { key[i] = cHL[i] * 64 + cR[i]; keys.push_back(key[i]); }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        for (int kx : keys) {
+            Group g{kx % 64, kx / 64, 0, nBlocks, 0};
+            g.waves = sw3Waves(g.R, g.HL, hasAA);
+            const size_t ppb = (size_t) g.waves * 2 * (64 / g.HL);
+            for (int i = 0; i < nq; i++) if (key[i] == kx) g.nblk += ((size_t) nSel(i) + ppb - 1) / ppb;
+            nBlocks += g.nblk;
+            groups.push_back(g);
+        }
+    }
+    const size_t descOff = (total * 4 + 15) / 16 * 16;
+    if ((rc = ensurePinned(ctx, ctx->hS3pass, descOff + nBlocks * sizeof(SwBlockDesc))) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->s3pass, descOff + nBlocks * sizeof(SwBlockDesc))) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->s3res, total * 16)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hS3res, total * 16)) != FSGPU_OK) return rc;
+    std::vector<uint32_t> perm(total);
+    uint32_t *hTids = (uint32_t *) ctx->hS3pass.p;
+    SwBlockDesc *hBlk = (SwBlockDesc *) ((unsigned char *) ctx->hS3pass.p + descOff);
+    const std::vector<int32_t> &len = ctx->db->hLengths;
+    {
+        std::vector<uint64_t> lkey;
+        for (int i = 0; i < nq; i++) {
+            const int ns = nSel(i);
+            if (ns == 0) continue;
+            uint32_t *p = perm.data() + sbase[i];
+            const uint32_t *ids = q[i].targetIds;
+            lkey.resize(ns);
+            for (int k = 0; k < ns; k++) { const int j = selIdx(i, k); lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[j]]) << 32) | (uint32_t) j; }
+            std::sort(lkey.begin(), lkey.end());
+            uint32_t *dst = hTids + sbase[i];
+            for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; dst[k] = ids[p[k]]; }
+        }
+    }
+    {
+        double cells = 0, pairs = 0, winsts = 0;
+        for (Group &g : groups) {
+            const int ppb = g.waves * 2 * (64 / g.HL), ppw = 2 * (64 / g.HL);
+            size_t bp = g.blk0;
+            for (int i = 0; i < nq; i++) {
+                if (nSel(i) == 0 || cR[i] != g.R || cHL[i] != g.HL) continue;
+                const int ns = nSel(i), L = q[i].L, lanes = (L + g.R - 1) / g.R;
+                for (int p0 = 0; p0 < ns; p0 += ppb) {
+                    SwBlockDesc &d = hBlk[bp++];
+                    d.imgOff = ctx->s3ImgOff[i]; d.firstPair = (uint32_t) (sbase[i] + p0); d.nPairs = (uint16_t) std::min(ppb, ns - p0);
+                    d.rowsInTile = (uint16_t) L; d.segLen = (uint32_t) ((L + 15) / 16);
+                }
+                // accounting in the units of the kernel's roofline: DP cells and the VALU wave-instructions its waves issue (a wave runs
+                // (longest of its targets) + lanes - 1 steps of 14 packed instructions per register row + 16 around them [+ the AA adds])
+                const uint32_t *tp = hTids + sbase[i];
+                const double perStep = 14.0 * g.R + 16.0 + (hasAA ? 2.0 * sw3Dw(g.R) + 4.0 : 0.0);
+                for (int k = 0; k < ns; k++) {
+                    const int lt = len[tp[k]];
+                    cells += (double) L * lt;
+                    if (k % ppw == 0 && lt > 0) winsts += (double) (lt + lanes - 1) * perStep;
+                }
+                pairs += ns;
+            }
+            // first pair of a workgroup is its longest: longest workgroups first
+            std::stable_sort(hBlk + g.blk0, hBlk + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return len[hTids[x.firstPair]] > len[hTids[y.firstPair]]; });
+        }
+        ctx->swDirCells[dir] = cells; ctx->swDirPairs[dir] = pairs; ctx->swDirWaveSteps[dir] = winsts;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
+    if (dir == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir], ctx->stream));
+    // every class gets a stream (round robin over the side streams): their long-target tails overlap instead of queueing up
+    const size_t nStreams = std::min<size_t>(groups.size(), 6);
+    if (nStreams > 1) {
+        if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
+        for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking));
+        HIPCHK(hipEventRecord(ctx->swAuxEv[6], ctx->stream));
+        for (size_t k = 1; k < nStreams; k++) HIPCHK(hipStreamWaitEvent(ctx->swAux[k], ctx->swAuxEv[6], 0));
+    }
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        const Group &g = groups[gi];
+        const size_t k = gi % nStreams;
+        hipStream_t gs = k == 0 ? ctx->stream : ctx->swAux[k];
+        Sw3Args sa;
+        sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
+        sa.targetIds = (const uint32_t *) ctx->s3pass.p;
+        sa.img = (const uint32_t *) ctx->s3img.p;
+        sa.blocks = (const SwBlockDesc *) ((const unsigned char *) ctx->s3pass.p + descOff) + g.blk0;
+        sa.go = (uint32_t) gapOpen | ((uint32_t) gapOpen << 16);
+        sa.ge = (uint32_t) gapExtend | ((uint32_t) gapExtend << 16);
+        sa.dir = dir;
+        sa.res0 = (int32_t *) ctx->s3res.p;
+        rc = hasAA ? fsgpuLaunchSw3AA(ctx, g.R, g.HL, sa, (int) g.nblk, g.waves, gs) : fsgpuLaunchSw3NA(ctx, g.R, g.HL, sa, (int) g.nblk, g.waves, gs);
+        if (rc != FSGPU_OK) { for (size_t x = 1; x < nStreams; x++) (void) hipStreamSynchronize(ctx->swAux[x]); return rc; }
+    }
+    for (size_t k = 1; k < nStreams; k++) { HIPCHK(hipEventRecord(ctx->swAuxEv[k], ctx->swAux[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[k], 0)); }
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir + 1], ctx->stream));
+    ctx->swDirValid[dir] = true;
+    ctx->evValid[1] = true;
+    HIPCHK(hipMemcpyAsync(ctx->hS3res.p, ctx->s3res.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
+    {
+        const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hS3res.p;
+        for (int i = 0; i < nq; i++)
+            for (int k = 0; k < nSel(i); k++) out[base[i] + perm[sbase[i] + k]] = r0[sbase[i] + k];
+    }
+    // int16-saturated pairs: the single-query path re-runs them with the int32 kernel (computes both directions, keeps `dir`)
+    std::vector<fsgpu_swres> f2, r2;
+    for (int i = 0; i < nq; i++) {
+        const int ns = nSel(i);
+        if (ns == 0) continue;
+        std::vector<uint32_t> ids;
+        std::vector<int> where;
+        for (int k = 0; k < ns; k++) {
+            const int j = selIdx(i, k);
+            if (out[base[i] + j].score == 32767) { ids.push_back(q[i].targetIds[j]); where.push_back(j); }
+        }
+        if (ids.empty()) continue;
+        Prof pr;
+        profilesOf(i, pr);
+        f2.resize(ids.size()); r2.resize(ids.size());
+        rc = fsgpu_sw_batch(ctx, hasAA ? pr.aF.data() : nullptr, pr.sF.data(), hasAA ? pr.aR.data() : nullptr, pr.sR.data(), q[i].L, ids.data(), (int) ids.size(),
+                            gapOpen, gapExtend, f2.data(), r2.data());
         if (rc != FSGPU_OK) return rc;
         for (size_t k = 0; k < ids.size(); k++) out[base[i] + where[k]] = dir == 0 ? f2[k] : r2[k];
     }

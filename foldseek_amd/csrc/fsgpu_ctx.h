@@ -116,6 +116,12 @@ struct fsgpu_ctx {
     struct LongRev { uint64_t hash = 0; std::vector<int32_t> res; };   // reversed-query results of the forward call's k_sw launches (4 int32 per pair, word 0 = not computed)
     std::vector<LongRev> swLongRev;                // per query of the last dir-0 call
     DevBuf ovAA, ovSS, ovOff, ovLen;               // explicit target sequences of fsgpu_sw_batch_seqs (instead of database entries)
+    // fsgpu_sw_multi_dir_c (k_sw3): images built on the device from the compact query data; the images of a forward call are kept for the
+    // reversed call over the same queries (s3Sig = hash of what the images depend on)
+    DevBuf s3img, s3pass, s3build, s3res;          // images; [target ids | workgroup descriptors] of a pass; [image descriptors | matrices | query data]; results
+    PinBuf hS3pass, hS3build, hS3res;
+    uint64_t s3Sig = 0;
+    std::vector<uint32_t> s3ImgOff;                // per query of the call the images were built for: dword offset of its images
     PinBuf hRes0, hRes1;                           // pinned result staging
     struct {
         bool pending = false;

@@ -248,17 +248,33 @@ extern "C" {
 
 namespace {
 
-// per-query state of the alignment stage: profiles of the forward and the reversed query, biases, e-value parameters
+// per-query state of the alignment stage: position biases of the forward and the reversed query, e-value parameters; the int16 profiles
+// only where a profile-based device call needs them (single-query path, --alt-ali)
 struct AlignQuery {
     const uint8_t *qAA = nullptr, *q3di = nullptr;
     int L = 0;
     std::vector<int16_t> pAAf, p3f, pAAr, p3r;
-    std::vector<int8_t> cbAA, cbSS;
+    std::vector<int8_t> cbAA, cbSS, cbAAr, cbSSr;       // r: biases of the reversed query, indexed by reversed position
     double lambda = 0, mu = 0;
 };
 
-// structurealign.cpp:322-347: e-value network + forward / reversed-query profiles
-int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, std::vector<uint8_t> &r3Di) {
+// the four word profiles from codes + biases (StructureSmithWaterman.cpp:1566-1640: matrix column + position bias)
+void materializeProfiles(const fshost_search *s, AlignQuery &aq) {
+    if (!aq.p3f.empty()) return;
+    const int A = s->mat3Di.n, L = aq.L;
+    aq.pAAf.resize((size_t) A * L); aq.p3f.resize((size_t) A * L); aq.pAAr.resize((size_t) A * L); aq.p3r.resize((size_t) A * L);
+    for (int a = 0; a < A; a++)
+        for (int i = 0; i < L; i++) {
+            const int j = L - 1 - i;
+            aq.pAAf[(size_t) a * L + i] = (int16_t) (s->matAA.tiny[a * A + aq.qAA[i]] + aq.cbAA[i]);
+            aq.p3f[(size_t) a * L + i] = (int16_t) (s->mat3Di.tiny[a * A + aq.q3di[i]] + aq.cbSS[i]);
+            aq.pAAr[(size_t) a * L + i] = (int16_t) (s->matAA.tiny[a * A + aq.qAA[j]] + aq.cbAAr[i]);
+            aq.p3r[(size_t) a * L + i] = (int16_t) (s->mat3Di.tiny[a * A + aq.q3di[j]] + aq.cbSSr[i]);
+        }
+}
+
+// structurealign.cpp:322-347: e-value network + the biases of the forward / reversed-query profiles (+ the profiles themselves on request)
+int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, std::vector<uint8_t> &r3Di, bool withProfiles = true) {
     const fshost_params &par = s->par;
     // the block aligner takes NEGATIVE gap costs with open < extend (block-aligner scan_block.rs: "Gap costs must be negative!"; the
     // reference process dies in that assertion with --gap-extend 0) and the device SW reproduces the striped kernel for open > extend:
@@ -269,17 +285,18 @@ int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, st
     }
     const int A = s->mat3Di.n, L = aq.L;
     s->evaluer.predictMuLambda(aq.q3di, L, A, &aq.lambda, &aq.mu);
-    aq.pAAf.resize((size_t) A * L); aq.p3f.resize((size_t) A * L); aq.pAAr.resize((size_t) A * L); aq.p3r.resize((size_t) A * L);
-    aq.cbAA.resize(L); aq.cbSS.resize(L);
+    aq.cbAA.resize(L); aq.cbSS.resize(L); aq.cbAAr.resize(L); aq.cbSSr.resize(L);
+    aq.pAAf.clear(); aq.p3f.clear(); aq.pAAr.clear(); aq.p3r.clear();
     rAA.assign(aq.qAA, aq.qAA + L); r3Di.assign(aq.q3di, aq.q3di + L);
     std::reverse(rAA.begin(), rAA.end());
     std::reverse(r3Di.begin(), r3Di.end());
-    int rc = alignProfiles(s->matAA, s->mat3Di, aq.qAA, aq.q3di, L, par.compBiasCorrection != 0, par.alnCompBiasScale, aq.pAAf.data(), aq.p3f.data(),
+    int rc = alignProfiles(s->matAA, s->mat3Di, aq.qAA, aq.q3di, L, par.compBiasCorrection != 0, par.alnCompBiasScale, nullptr, nullptr,
                            aq.cbAA.data(), aq.cbSS.data());
     if (rc == FSGPU_OK)
         rc = alignProfiles(s->matAA, s->mat3Di, rAA.data(), r3Di.data(), L, par.compBiasCorrection != 0, par.alnCompBiasScale,
-                           aq.pAAr.data(), aq.p3r.data(), nullptr, nullptr);
-    if (rc != FSGPU_OK) s->err = "bad query residue code";
+                           nullptr, nullptr, aq.cbAAr.data(), aq.cbSSr.data());
+    if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
+    if (withProfiles) materializeProfiles(s, aq);
     return rc;
 }
 
@@ -559,22 +576,40 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
     const bool useAA = par.alignmentType == 2;
     const double t0 = nowSec();
     std::vector<AlignQuery> aq(nq);
-    std::vector<fsgpu_sw_query> dq(nq);
+    std::vector<fsgpu_sw_cquery> dq(nq);
     size_t total = 0;
     for (int i = 0; i < nq; i++) {
         if (!qAA[i] || !q3di[i] || L[i] <= 0 || n[i] < 0) return FSGPU_E_ARG;
         aq[i].qAA = qAA[i]; aq[i].q3di = q3di[i]; aq[i].L = L[i];
-        const int rc = prepareAlign(s, aq[i], s->rAA, s->r3Di);
+        const int rc = prepareAlign(s, aq[i], s->rAA, s->r3Di, par.altAlignment > 0);      // --alt-ali re-aligns through the profile-based call
         if (rc != FSGPU_OK) return rc;
-        dq[i].pAA_fwd = useAA ? aq[i].pAAf.data() : nullptr; dq[i].p3Di_fwd = aq[i].p3f.data();
-        dq[i].pAA_rev = useAA ? aq[i].pAAr.data() : nullptr; dq[i].p3Di_rev = aq[i].p3r.data();
+        dq[i].qAA = qAA[i]; dq[i].q3Di = q3di[i];
+        dq[i].cbAA_fwd = aq[i].cbAA.data(); dq[i].cb3Di_fwd = aq[i].cbSS.data(); dq[i].cbAA_rev = aq[i].cbAAr.data(); dq[i].cb3Di_rev = aq[i].cbSSr.data();
         dq[i].L = L[i]; dq[i].n = n[i]; dq[i].targetIds = targetIds[i];
         total += (size_t) n[i];
     }
+    const int8_t *m3 = s->mat3Di.tiny.data(), *mA = useAA ? s->matAA.tiny.data() : nullptr;
+    // FSGPU_SW_PROFILES=1: the profile-based device entry (word profiles built here, LDS images built on the host, k_sw2) instead of the
+    // compact one -- kept for A/B measurements of the two device paths (tools/sw2_probe.py)
+    static const bool viaProfiles = [] { const char *e = getenv("FSGPU_SW_PROFILES"); return e && *e && *e != '0'; }();
+    std::vector<fsgpu_sw_query> pq;
+    if (viaProfiles) {
+        pq.resize(nq);
+        for (int i = 0; i < nq; i++) {
+            materializeProfiles(s, aq[i]);
+            pq[i].pAA_fwd = useAA ? aq[i].pAAf.data() : nullptr; pq[i].p3Di_fwd = aq[i].p3f.data();
+            pq[i].pAA_rev = useAA ? aq[i].pAAr.data() : nullptr; pq[i].p3Di_rev = aq[i].p3r.data();
+            pq[i].L = L[i]; pq[i].n = n[i]; pq[i].targetIds = targetIds[i];
+        }
+    }
+    auto pass = [&](int dir, const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out) {
+        return viaProfiles ? fsgpu_sw_multi_dir(s->ctx, pq.data(), nq, par.gapOpen, par.gapExtend, dir, sel, nsel, out)
+                           : fsgpu_sw_multi_dir_c(s->ctx, m3, mA, dq.data(), nq, par.gapOpen, par.gapExtend, dir, sel, nsel, out);
+    };
     s->fwd.resize(total); s->rev.assign(total, fsgpu_swres{0, 0, 0, 0});
     const double t1 = nowSec();
     // forward pass over every pair; the reversed-query pass only over the pairs whose forward score passes the gates
-    int rc = fsgpu_sw_multi_dir(s->ctx, dq.data(), nq, par.gapOpen, par.gapExtend, 0, nullptr, nullptr, s->fwd.data());
+    int rc = pass(0, nullptr, nullptr, s->fwd.data());
     if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
     {
         std::vector<std::vector<int32_t>> sel(nq);
@@ -592,7 +627,7 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
         }
         s->stats[7] = (double) any;
         if (any) {
-            rc = fsgpu_sw_multi_dir(s->ctx, dq.data(), nq, par.gapOpen, par.gapExtend, 1, selp.data(), nsel.data(), s->rev.data());
+            rc = pass(1, selp.data(), nsel.data(), s->rev.data());
             if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
         }
     }

@@ -209,12 +209,13 @@ int alignProfiles(const Matrix &mAA, const Matrix &m3Di, const uint8_t *qAA, con
         compBias(mAA, q3Di, L, scale3Di, tmp.data());      // 3Di bias against the AA matrix (sic)
         roundBias(tmp.data(), L, cbSS.data());
     }
-    for (int a = 0; a < n; a++)
-        for (int i = 0; i < L; i++) {
-            if (qAA[i] >= n || q3Di[i] >= n) return FSGPU_E_ARG;
-            if (pAA) pAA[(size_t) a * L + i] = (int16_t) (mAA.tiny[a * n + qAA[i]] + cbAA[i]);
-            p3Di[(size_t) a * L + i] = (int16_t) (m3Di.tiny[a * n + q3Di[i]] + cbSS[i]);
-        }
+    for (int i = 0; i < L; i++) if (qAA[i] >= n || q3Di[i] >= n) return FSGPU_E_ARG;
+    if (p3Di)                                   // p3Di == NULL: the caller wants the biases only
+        for (int a = 0; a < n; a++)
+            for (int i = 0; i < L; i++) {
+                if (pAA) pAA[(size_t) a * L + i] = (int16_t) (mAA.tiny[a * n + qAA[i]] + cbAA[i]);
+                p3Di[(size_t) a * L + i] = (int16_t) (m3Di.tiny[a * n + q3Di[i]] + cbSS[i]);
+            }
     if (cbAAout) memcpy(cbAAout, cbAA.data(), L);
     if (cbSSout) memcpy(cbSSout, cbSS.data(), L);
     return FSGPU_OK;

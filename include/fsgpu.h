@@ -182,6 +182,23 @@ int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *queries, int nq, int ga
  * survivors.  Device side: two targets of one query share a wave (int16 halves), half the waves of fsgpu_sw_batch. */
 int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, int dir,
                        const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out);
+/* The same with COMPACT queries.  A structurealign profile is nothing but a matrix column plus a position bias
+ * (pAA[a*L+i] = matAA[a][qAA_i] + cbAA_i, StructureSmithWaterman.cpp:1566-1640), so a query is its codes (0..20) and its bias arrays --
+ * for the forward query and for the reversed query (cb*_rev[i] belongs to position i of the REVERSED sequence; NULL = all zero) --
+ * and the 21 x 21 int8 matrices are passed once: mat[a * 21 + b], matAA = NULL for --alignment-type 0 (then qAA / cbAA_* are not read).
+ * The device builds its profile images itself: 6 L bytes per query cross the bus instead of 4 x 21 x L int16 words.  Results, selection
+ * and the int16 -> int32 re-run are those of fsgpu_sw_multi_dir; a reversed call (dir 1) over the queries of the preceding forward call
+ * finds the images in place.  Device side: queries of up to 512 residues run four targets per wave (32 lanes per target pair), up to
+ * 1024 residues two per wave, longer ones row-tiled through the profile-based path. */
+typedef struct {
+    const uint8_t *qAA, *q3Di;
+    const int8_t *cbAA_fwd, *cb3Di_fwd, *cbAA_rev, *cb3Di_rev;
+    int32_t L;
+    int32_t n;
+    const uint32_t *targetIds;
+} fsgpu_sw_cquery;
+int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend,
+                         int dir, const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out);
 /* Asynchronous halves of fsgpu_sw_batch.  The four profile arrays and targetIds are BORROWED until fsgpu_sw_finish returns
  * (the int32 re-run of saturated pairs reads the profiles again); after a failed _launch nothing is pending. */
 int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,
