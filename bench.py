@@ -61,6 +61,10 @@ def parse(argv=None):
     ap.add_argument("--allvsall-steps", type=int, default=48, help="configs[4] leg of the default run: that many batches of 32 DB entries as queries (k-mer prefilter "
                     "+ structurealign on a --allvsall-targets DB), reported under `allvsall` (0 = skip)")
     ap.add_argument("--allvsall-targets", type=int, default=200000)
+    ap.add_argument("--allvsall-families", type=int, default=-1, help="configs[4] DB: that many seed structures, each with targets / families - 1 mutated relatives "
+                    "(the shape a clustering input has); -1: targets / 10, 0: unrelated structures (only the self match survives -e 0.01)")
+    ap.add_argument("--fullrange-steps", type=int, default=8, help="querylen_full_range leg of the default run: that many extra steps with query lengths drawn from the "
+                    "DB's own 30..2000 range (their homologs are planted too); 0 disables it")
     ap.add_argument("--allvsall-batch", type=int, default=256, help="queries per device batch of the all-vs-all leg")
     ap.add_argument("--emulate-rank-share", type=int, default=0, help="N: on ONE GPU, run what ONE rank of an N-rank node runs: CPU affinity cut to usable_cores / N, "
                     "backtrace pool sized for that, and with --scaling strong only 1/N of the queries (step size adapted like a real rank's)")
@@ -369,6 +373,17 @@ def allvsall_cpu_baseline(db, thr, sample_queries=64):
             "prefilter_s": secs, "align_s": t_aln, "index_build_s": t_build}
 
 
+def allvsall_db(synth, targets, families):
+    """configs[4] input: `families` seed structures + targets / families - 1 mutated relatives of each (substitution rate 20..60 %, indels:
+    synth._homologs), the shape a clustering input has; families == 0: unrelated structures."""
+    if families <= 0:
+        return synth.make_db_fast(targets, None, seed=20260923, homologs_per_query=0)
+    sd = synth.make_db_fast(families, None, seed=7, homologs_per_query=0, mask_frac=0, x_frac=0)
+    seeds = ([sd.data3di[sd.offsets[i]:sd.offsets[i] + sd.lengths[i]].copy() for i in range(families)],
+             [sd.dataaa[sd.offsets[i]:sd.offsets[i] + sd.lengths[i]].copy() for i in range(families)])
+    return synth.make_db_fast(targets, seeds, seed=20260923, homologs_per_query=max(targets // families - 1, 1))
+
+
 def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets, steps, warmup, with_cpu=False):
     """configs[4]: all-vs-all of a `targets`-structure DB, the shape of easy-cluster's cascaded steps (F/data/structurecluster.sh via
     `easy-cluster -v 3`): prefilter -s 4.5 --max-seqs 200 --min-ungapped-score 30 -c 0.8 --add-self-matches 1, then structurealign
@@ -379,7 +394,8 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
     import torch
     import torch.distributed as dist
     t_gen = time.perf_counter()
-    db = synth.make_db_fast(targets, None, seed=20260923, homologs_per_query=0) if rank == 0 else None
+    fam = args.allvsall_families if args.allvsall_families >= 0 else targets // 10
+    db = allvsall_db(synth, targets, fam) if rank == 0 else None
     t_gen = time.perf_counter() - t_gen
     tensors, db = fdist.broadcast_db(db, dev)
     torch.cuda.synchronize()
@@ -399,12 +415,21 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
     ctxs = [ctx0] + [ctx0.clone() for _ in range(KT - 1)]
     searches = [api.Search(c, par) for c in ctxs]
     AB = max(32, args.allvsall_batch // 32 * 32)        # queries per device batch: the low-sensitivity prefilter yields ~10^4 index hits per query, far too few to fill the device in 32s
-    lo, hi = fdist.shard_range(db.n, rank, world)
-    ids = np.arange(lo, hi)
-    nb_all = (len(ids) + AB - 1) // AB
-    nb = nb_all if steps <= 0 else min(nb_all, steps + warmup)
-    # a spread sample of the shard when only some batches are run: the DB is length sorted
-    pick = np.linspace(0, nb_all - 1, nb).astype(np.int64) if nb < nb_all else np.arange(nb_all)
+    strong = args.scaling == "strong" and steps > 0 and world > 1
+    if strong:
+        # the SAME `steps` timed batches whatever the number of ranks: picked over the whole DB, dealt out to the ranks round robin
+        ids = np.arange(db.n)
+        nb_all = (db.n + AB - 1) // AB
+        nb = min(nb_all, steps + warmup * world)
+        pick = np.linspace(0, nb_all - 1, nb).astype(np.int64) if nb < nb_all else np.arange(nb_all)
+        pick = pick[rank::world]
+    else:
+        lo, hi = fdist.shard_range(db.n, rank, world)
+        ids = np.arange(lo, hi)
+        nb_all = (len(ids) + AB - 1) // AB
+        nb = nb_all if steps <= 0 else min(nb_all, steps + warmup)
+        # a spread sample of the shard when only some batches are run: the DB is length sorted
+        pick = np.linspace(0, nb_all - 1, nb).astype(np.int64) if nb < nb_all else np.arange(nb_all)
     batches = [ids[b * AB:(b + 1) * AB] for b in pick]
     if steps > 0:            # warm-up batches spread over the length range as well, so every register class has been launched once
         wsel = set(np.linspace(0, len(batches) - 1, min(warmup, len(batches))).astype(np.int64).tolist()) if warmup > 0 else set()
@@ -485,10 +510,11 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         dev_s = s0["stage"][0] * 1e-3
         out = {"metric": "residues aligned/sec (prefilter+align)", "value": nq * db.residues / dt, "unit": "residues/s", "n_gpus": world,
                "steps": len(timed), "warmup": len(warm), "ms_per_step": 1e3 * dt / max(1, len(timed)), "higher_is_better": True,
-               "scaling": "strong" if steps <= 0 else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
+               "scaling": "strong" if (steps <= 0 or strong) else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
                "config": {"workload": f"all-vs-all (configs[4]): {nq} of the {db.n} DB entries as queries in batches of {AB} (1 step = 1 batch), k-mer prefilter -s 4.5 --max-seqs 200 "
                                       f"-c 0.8 + structurealign -e 0.01 -c 0.8 (3Di+AA) on its hits; queries shard over {world} rank(s), DB replicated by one broadcast",
-                          "targets": db.n, "db_residues": db.residues, "host_threads_per_gpu": KT, "kmer_threshold": thr},
+                          "targets": db.n, "db_residues": db.residues, "host_threads_per_gpu": KT, "kmer_threshold": thr, "families": fam,
+                          "family_size": (targets // fam) if fam > 0 else 1},
                "queries_per_s": nq / dt, "ms_per_query": 1e3 * dt / max(1, nq / world), "hits_per_query": sum(x["hits"] for x in tot) / max(1, nq),
                "alignments_per_query": sum(x["aln"] for x in tot) / max(1, nq), "prefilter_device_ms_per_query": s0["dev"] / max(1, s0["q"]),
                "unsupported_queries": sum(x["bad"] for x in tot), "index_build_s": t_index, "db_generation_s": t_gen,
@@ -519,7 +545,7 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import allvsall_modules
-            out["native_module_end_to_end"] = allvsall_modules.run(threads=usable_cores(), db=db)
+            out["native_module_end_to_end"] = allvsall_modules.run(threads=usable_cores(), db=db, fam=fam)
         except Exception as e:                                             # noqa: BLE001 -- the leg's own numbers stand without it
             out["native_module_end_to_end"] = {"error": str(e)[-500:]}
     return out

@@ -1629,9 +1629,9 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     auto selIdx = [&](int i, int k) { return sel ? sel[i][k] : k; };
     int rc;
     // ---- queries outside k_sw3's classes: the profile-based path, all of them in one sub-call (the same set in both directions) ----
-    std::vector<int> cR(nq, 0), cHL(nq, 0);
+    std::vector<int> cR(nq, 0);                       // > 0: the query runs through k_sw3
     std::vector<int> classic;
-    for (int i = 0; i < nq; i++) if (!sw3Class(q[i].L, cR[i], cHL[i])) { cR[i] = 0; classic.push_back(i); }
+    for (int i = 0; i < nq; i++) { int hl; if (!sw3Class(q[i].L, cR[i], hl)) { cR[i] = 0; classic.push_back(i); } }
     struct Prof { std::vector<int16_t> aF, sF, aR, sR; };
     auto profilesOf = [&](int i, Prof &pr) {
         sw3Materialize(mat3Di, q[i].q3Di, q[i].cb3Di_fwd, q[i].L, false, pr.sF);
@@ -1664,6 +1664,11 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         }
     }
     // ---- k_sw3 ----
+    // A query of up to 512 rows has two shapes: 32 lanes per target pair (R32 = ceil(L / 32) rows per lane, four targets per wave: fewest
+    // instructions per cell) and 64 lanes (R64 = ceil(L / 64), two targets per wave: half the instructions per target COLUMN).  A wave's
+    // run time is (columns + lanes - 1) steps of ~(14 R + 16) dependent-ish instructions, so the longest targets of a launch set its
+    // critical path: pairs whose target is longer than the threshold take the 64-lane shape, the others the 32-lane one.
+    static const int longT = [] { const char *e = getenv("FSGPU_SW3_LONG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 640; }();
     auto nSel = [&](int i) { return cR[i] > 0 ? nSelAll(i) : 0; };
     for (int i = 0; i < nq; i++) sbase[i + 1] = sbase[i] + (size_t) nSel(i);
     const size_t total = sbase[nq];
@@ -1672,6 +1677,28 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     if (dir == 0) ctx->swDirValid[1] = false;
     ctx->swDirCells[dir] = 0; ctx->swDirPairs[dir] = 0; ctx->swDirWaveSteps[dir] = 0;
     if (total == 0) return FSGPU_OK;
+    const std::vector<int32_t> &len = ctx->db->hLengths;
+    // target ids of the pass, longest first inside a query (neighbours share a wave), and the split into the two shapes
+    if ((rc = ensurePinned(ctx, ctx->hS3pass, total * 4 + 64)) != FSGPU_OK) return rc;      // grown below once the descriptors are counted
+    std::vector<uint32_t> perm(total);
+    std::vector<int> nLong(nq, 0);
+    {
+        std::vector<uint64_t> lkey;
+        for (int i = 0; i < nq; i++) {
+            const int ns = nSel(i);
+            if (ns == 0) continue;
+            uint32_t *p = perm.data() + sbase[i];
+            const uint32_t *ids = q[i].targetIds;
+            lkey.resize(ns);
+            for (int k = 0; k < ns; k++) { const int j = selIdx(i, k); lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[j]]) << 32) | (uint32_t) j; }
+            std::sort(lkey.begin(), lkey.end());
+            int nl = 0;
+            for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; if (len[ids[p[k]]] > longT) nl++; }
+            nLong[i] = q[i].L > 32 * kSw3MaxR ? ns : nl;
+        }
+    }
+    auto need64 = [&](int i) { return nLong[i] > 0; };
+    auto need32 = [&](int i) { return nSel(i) - nLong[i] > 0; };
     // images: built once per set of queries (the reversed call of a forward call finds them in place)
     uint64_t sig = 0xcbf29ce484222325ull ^ (uint64_t) nq ^ ((uint64_t) hasAA << 40);
     sig = hashWords(sig, mat3Di, kAlphabet * kAlphabet);
@@ -1685,19 +1712,25 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         for (int c = 0; c < 4; c++) { if (cbs[c]) sig = hashWords(sig, cbs[c], L); else sig = (sig ^ 0x55) * 0x100000001B3ull; }
     }
     if (!sig) sig = 1;
-    const bool haveImages = ctx->s3Sig == sig && (int) ctx->s3ImgOff.size() == nq;
+    bool haveImages = ctx->s3Sig == sig && (int) ctx->s3ImgOff.size() == 2 * nq;
+    for (int i = 0; i < nq && haveImages; i++)
+        if ((need32(i) && ctx->s3ImgOff[2 * i] == 0xffffffffu) || (need64(i) && ctx->s3ImgOff[2 * i + 1] == 0xffffffffu)) haveImages = false;
     if (!haveImages) {
         ctx->s3Sig = 0;
-        ctx->s3ImgOff.assign((size_t) nq, 0xffffffffu);
+        ctx->s3ImgOff.assign((size_t) 2 * nq, 0xffffffffu);       // [2 i]: 32-lane image of query i, [2 i + 1]: 64-lane image
         size_t imgDw = 0, dataBytes = 0;
         int nImg = 0, maxDw = 0;
         for (int i = 0; i < nq; i++) {
-            if (cR[i] == 0) continue;
-            const size_t one = (size_t) 2 * sw3ImageBytes(cR[i], cHL[i], hasAA) / 4;
-            if (imgDw + one >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: images of one call exceed 16 GiB"; return FSGPU_E_NOMEM; }
-            ctx->s3ImgOff[i] = (uint32_t) imgDw; imgDw += one; maxDw = std::max(maxDw, (int) one);
+            if (nSel(i) == 0) continue;
+            for (int shape = 0; shape < 2; shape++) {
+                if (!(shape == 0 ? need32(i) : need64(i))) continue;
+                const int HL = shape == 0 ? 32 : 64, R = (q[i].L + HL - 1) / HL;
+                const size_t one = (size_t) 2 * sw3ImageBytes(R, HL, hasAA) / 4;
+                if (imgDw + one >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: images of one call exceed 16 GiB"; return FSGPU_E_NOMEM; }
+                ctx->s3ImgOff[2 * i + shape] = (uint32_t) imgDw; imgDw += one; maxDw = std::max(maxDw, (int) one);
+                nImg++;
+            }
             dataBytes += ((size_t) 6 * q[i].L + 15) / 16 * 16;
-            nImg++;
         }
         const size_t descBytes = ((size_t) nImg * sizeof(Sw3ImgQuery) + 15) / 16 * 16, matOff = descBytes, dataOff0 = matOff + 1024;
         if ((rc = ensurePinned(ctx, ctx->hS3build, dataOff0 + dataBytes)) != FSGPU_OK) return rc;
@@ -1710,18 +1743,23 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         size_t dpos = dataOff0;
         int k = 0;
         for (int i = 0; i < nq; i++) {
-            if (cR[i] == 0) continue;
+            if (nSel(i) == 0) continue;
             const size_t L = (size_t) q[i].L;
-            hd[k].imgOff = ctx->s3ImgOff[i]; hd[k].dataOff = (uint32_t) (dpos - dataOff0); hd[k].L = (uint32_t) L; hd[k].R = (uint16_t) cR[i]; hd[k].HL = (uint16_t) cHL[i];
+            for (int shape = 0; shape < 2; shape++) {
+                if (ctx->s3ImgOff[2 * i + shape] == 0xffffffffu) continue;
+                const int HL = shape == 0 ? 32 : 64;
+                hd[k].imgOff = ctx->s3ImgOff[2 * i + shape]; hd[k].dataOff = (uint32_t) (dpos - dataOff0); hd[k].L = (uint32_t) L;
+                hd[k].R = (uint16_t) ((L + HL - 1) / HL); hd[k].HL = (uint16_t) HL;
+                k++;
+            }
             unsigned char *d = hb + dpos;
             memcpy(d, q[i].q3Di, L);
             if (hasAA) memcpy(d + L, q[i].qAA, L); else memset(d + L, 0, L);
             const int8_t *cbs[4] = {q[i].cb3Di_fwd, q[i].cbAA_fwd, q[i].cb3Di_rev, q[i].cbAA_rev};
             for (int c = 0; c < 4; c++) { if (cbs[c]) memcpy(d + (2 + c) * L, cbs[c], L); else memset(d + (2 + c) * L, 0, L); }
             dpos += (6 * L + 15) / 16 * 16;
-            k++;
+            if (dpos - dataOff0 >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: query data of one call exceeds 4 GiB"; return FSGPU_E_NOMEM; }
         }
-        if (dpos - dataOff0 >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: query data of one call exceeds 4 GiB"; return FSGPU_E_NOMEM; }
         HIPCHK(hipMemcpyAsync(ctx->s3build.p, hb, dpos, hipMemcpyHostToDevice, ctx->stream));
         const unsigned char *db = (const unsigned char *) ctx->s3build.p;
         rc = fsgpuLaunchSw3Image(ctx, (const Sw3ImgQuery *) db, nImg, maxDw, db + dataOff0, (const int8_t *) (db + matOff), (const int8_t *) (db + matOff + 512),
@@ -1729,21 +1767,28 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         if (rc != FSGPU_OK) return rc;
         ctx->s3Sig = sig;
     }
-    // ---- the pass: target ids (longest first inside a query: neighbours share a wave) and workgroup descriptors per (R, HL) class ----
+    // ---- workgroup descriptors per (HL, R) class ----
+    struct Part { int q, key, first, n; };          // pairs [first, first + n) of query q's sorted list run in class key = HL * 64 + R
+    std::vector<Part> parts;
+    for (int i = 0; i < nq; i++) {
+        const int ns = nSel(i);
+        if (ns == 0) continue;
+        if (nLong[i] > 0) parts.push_back({i, 64 * 64 + (q[i].L + 63) / 64, 0, nLong[i]});
+        if (ns - nLong[i] > 0) parts.push_back({i, 32 * 64 + (q[i].L + 31) / 32, nLong[i], ns - nLong[i]});
+    }
     struct Group { int R, HL, waves; size_t blk0, nblk; };
     std::vector<Group> groups;
     size_t nBlocks = 0;
     {
-        std::vector<int> key(nq, -1);
         std::vector<int> keys;
-        for (int i = 0; i < nq; i++) if (nSel(i) > 0) { key[i] = cHL[i] * 64 + cR[i]; keys.push_back(key[i]); }
+        for (const Part &pt : parts) keys.push_back(pt.key);
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         for (int kx : keys) {
             Group g{kx % 64, kx / 64, 0, nBlocks, 0};
             g.waves = sw3Waves(g.R, g.HL, hasAA);
             const size_t ppb = (size_t) g.waves * 2 * (64 / g.HL);
-            for (int i = 0; i < nq; i++) if (key[i] == kx) g.nblk += ((size_t) nSel(i) + ppb - 1) / ppb;
+            for (const Part &pt : parts) if (pt.key == kx) g.nblk += ((size_t) pt.n + ppb - 1) / ppb;
             nBlocks += g.nblk;
             groups.push_back(g);
         }
@@ -1753,47 +1798,35 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     if ((rc = ensure(ctx, ctx->s3pass, descOff + nBlocks * sizeof(SwBlockDesc))) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->s3res, total * 16)) != FSGPU_OK) return rc;
     if ((rc = ensurePinned(ctx, ctx->hS3res, total * 16)) != FSGPU_OK) return rc;
-    std::vector<uint32_t> perm(total);
     uint32_t *hTids = (uint32_t *) ctx->hS3pass.p;
     SwBlockDesc *hBlk = (SwBlockDesc *) ((unsigned char *) ctx->hS3pass.p + descOff);
-    const std::vector<int32_t> &len = ctx->db->hLengths;
-    {
-        std::vector<uint64_t> lkey;
-        for (int i = 0; i < nq; i++) {
-            const int ns = nSel(i);
-            if (ns == 0) continue;
-            uint32_t *p = perm.data() + sbase[i];
-            const uint32_t *ids = q[i].targetIds;
-            lkey.resize(ns);
-            for (int k = 0; k < ns; k++) { const int j = selIdx(i, k); lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[j]]) << 32) | (uint32_t) j; }
-            std::sort(lkey.begin(), lkey.end());
-            uint32_t *dst = hTids + sbase[i];
-            for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; dst[k] = ids[p[k]]; }
-        }
+    for (int i = 0; i < nq; i++) {
+        const uint32_t *p = perm.data() + sbase[i];
+        for (int k = 0; k < nSel(i); k++) hTids[sbase[i] + k] = q[i].targetIds[p[k]];
     }
     {
         double cells = 0, pairs = 0, winsts = 0;
         for (Group &g : groups) {
-            const int ppb = g.waves * 2 * (64 / g.HL), ppw = 2 * (64 / g.HL);
+            const int ppb = g.waves * 2 * (64 / g.HL), ppw = 2 * (64 / g.HL), key = g.HL * 64 + g.R;
             size_t bp = g.blk0;
-            for (int i = 0; i < nq; i++) {
-                if (nSel(i) == 0 || cR[i] != g.R || cHL[i] != g.HL) continue;
-                const int ns = nSel(i), L = q[i].L, lanes = (L + g.R - 1) / g.R;
-                for (int p0 = 0; p0 < ns; p0 += ppb) {
+            for (const Part &pt : parts) {
+                if (pt.key != key) continue;
+                const int i = pt.q, L = q[i].L, lanes = (L + g.R - 1) / g.R;
+                for (int p0 = 0; p0 < pt.n; p0 += ppb) {
                     SwBlockDesc &d = hBlk[bp++];
-                    d.imgOff = ctx->s3ImgOff[i]; d.firstPair = (uint32_t) (sbase[i] + p0); d.nPairs = (uint16_t) std::min(ppb, ns - p0);
+                    d.imgOff = ctx->s3ImgOff[2 * i + (g.HL == 64 ? 1 : 0)]; d.firstPair = (uint32_t) (sbase[i] + pt.first + p0); d.nPairs = (uint16_t) std::min(ppb, pt.n - p0);
                     d.rowsInTile = (uint16_t) L; d.segLen = (uint32_t) ((L + 15) / 16);
                 }
                 // accounting in the units of the kernel's roofline: DP cells and the VALU wave-instructions its waves issue (a wave runs
                 // (longest of its targets) + lanes - 1 steps of 14 packed instructions per register row + 16 around them [+ the AA adds])
-                const uint32_t *tp = hTids + sbase[i];
+                const uint32_t *tp = hTids + sbase[i] + pt.first;
                 const double perStep = 14.0 * g.R + 16.0 + (hasAA ? 2.0 * sw3Dw(g.R) + 4.0 : 0.0);
-                for (int k = 0; k < ns; k++) {
+                for (int k = 0; k < pt.n; k++) {
                     const int lt = len[tp[k]];
                     cells += (double) L * lt;
-                    if (k % ppw == 0 && lt > 0) winsts += (double) (lt + lanes - 1) * perStep;
+                    if ((k % ppb) % ppw == 0 && lt > 0) winsts += (double) (lt + lanes - 1) * perStep;
                 }
-                pairs += ns;
+                pairs += pt.n;
             }
             // first pair of a workgroup is its longest: longest workgroups first
             std::stable_sort(hBlk + g.blk0, hBlk + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return len[hTids[x.firstPair]] > len[hTids[y.firstPair]]; });
@@ -1803,7 +1836,9 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
     if (dir == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir], ctx->stream));
-    // every class gets a stream (round robin over the side streams): their long-target tails overlap instead of queueing up
+    // every class gets a stream (round robin over the side streams): their long-target tails overlap instead of queueing up; the 64-lane
+    // classes (the long targets) sort first and are launched first
+    std::sort(groups.begin(), groups.end(), [](const Group &x, const Group &y) { return x.HL != y.HL ? x.HL > y.HL : x.R > y.R; });
     const size_t nStreams = std::min<size_t>(groups.size(), 6);
     if (nStreams > 1) {
         if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));

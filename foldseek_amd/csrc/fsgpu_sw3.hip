@@ -46,6 +46,7 @@ int fsgpuLaunchSw3NA(fsgpu_ctx *ctx, int R, int HL, const Sw3Args &sa, int nBloc
         }
     } else if (HL == 64) {
         switch (R) {
+            FS_C64(1) FS_C64(2) FS_C64(3) FS_C64(4) FS_C64(5) FS_C64(6) FS_C64(7) FS_C64(8)
             FS_C64(9) FS_C64(10) FS_C64(11) FS_C64(12) FS_C64(13) FS_C64(14) FS_C64(15) FS_C64(16)
             default: break;
         }

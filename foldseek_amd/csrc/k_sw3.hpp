@@ -147,7 +147,6 @@ __global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
         else *(uint2 *) (smem + at) = make_uint2(kDeadOff, kDeadOff);
     }
     __syncthreads();
-    __builtin_amdgcn_s_setprio(3);
     const int pairsW = pairsHere - wave * 2 * GPW;     // pairs of this wave (scalar)
     if (pairsW <= 0) return;
     const int pA = pairBase + wave * 2 * GPW + 2 * grp;
@@ -158,6 +157,11 @@ __global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
     int LtW = LtA > LtB ? LtA : LtB;                   // longest target of the wave -> scalar loop bound
     if constexpr (GPW == 2) { const int o = __shfl_xor(LtW, 32); LtW = o > LtW ? o : LtW; }
     LtW = __builtin_amdgcn_readfirstlane(LtW);
+    // The wavefront is a long dependent chain: the waves with the longest targets are the critical path of the launch, they win the issue
+    // arbitration of their SIMD; every wave of this kernel stays above a co-running throughput kernel (the gapless scan of another query).
+    if (LtW > 1024) __builtin_amdgcn_s_setprio(3);
+    else if (LtW > 512) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
     const int nLanes = (rows + R - 1) / R;
     const int steps = LtW > 0 ? LtW + nLanes - 1 : 0;
     // merge selectors: {S0 = target B's dword (bytes 4..7), S1 = target A's dword (bytes 0..3)} -> (A | B << 16) of the even / odd row of a pair
