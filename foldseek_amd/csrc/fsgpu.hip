@@ -1767,31 +1767,30 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         if (rc != FSGPU_OK) return rc;
         ctx->s3Sig = sig;
     }
-    // ---- workgroup descriptors per (HL, R) class ----
-    struct Part { int q, key, first, n; };          // pairs [first, first + n) of query q's sorted list run in class key = HL * 64 + R
+    // ---- workgroup descriptors: one launch per (lanes per target pair, rows-per-lane range 1..8 / 9..16) ----
+    struct Part { int q, key, R, first, n; };       // pairs [first, first + n) of query q's sorted list run with R rows per lane in launch group `key`
     std::vector<Part> parts;
+    auto keyOf = [](int HL, int R) { return (HL == 64 ? 2 : 0) + (R > 8 ? 1 : 0); };
     for (int i = 0; i < nq; i++) {
         const int ns = nSel(i);
         if (ns == 0) continue;
-        if (nLong[i] > 0) parts.push_back({i, 64 * 64 + (q[i].L + 63) / 64, 0, nLong[i]});
-        if (ns - nLong[i] > 0) parts.push_back({i, 32 * 64 + (q[i].L + 31) / 32, nLong[i], ns - nLong[i]});
+        const int R64 = (q[i].L + 63) / 64, R32 = (q[i].L + 31) / 32;
+        if (nLong[i] > 0) parts.push_back({i, keyOf(64, R64), R64, 0, nLong[i]});
+        if (ns - nLong[i] > 0) parts.push_back({i, keyOf(32, R32), R32, nLong[i], ns - nLong[i]});
     }
-    struct Group { int R, HL, waves; size_t blk0, nblk; };
+    struct Group { int key, HL, rlo, maxR, waves, lds; size_t blk0, nblk; };
     std::vector<Group> groups;
     size_t nBlocks = 0;
-    {
-        std::vector<int> keys;
-        for (const Part &pt : parts) keys.push_back(pt.key);
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-        for (int kx : keys) {
-            Group g{kx % 64, kx / 64, 0, nBlocks, 0};
-            g.waves = sw3Waves(g.R, g.HL, hasAA);
-            const size_t ppb = (size_t) g.waves * 2 * (64 / g.HL);
-            for (const Part &pt : parts) if (pt.key == kx) g.nblk += ((size_t) pt.n + ppb - 1) / ppb;
-            nBlocks += g.nblk;
-            groups.push_back(g);
-        }
+    for (int key = 3; key >= 0; key--) {            // the 64-lane groups (the long targets) first
+        Group g{key, key >= 2 ? 64 : 32, (key & 1) ? 9 : 1, 0, 0, 0, nBlocks, 0};
+        for (const Part &pt : parts) if (pt.key == key) g.maxR = std::max(g.maxR, pt.R);
+        if (g.maxR == 0) continue;
+        g.waves = sw3Waves(g.maxR, g.HL, hasAA);
+        g.lds = sw3LdsBytes(g.maxR, g.HL, hasAA, g.waves);
+        const size_t ppb = (size_t) g.waves * 2 * (64 / g.HL);
+        for (const Part &pt : parts) if (pt.key == key) g.nblk += ((size_t) pt.n + ppb - 1) / ppb;
+        nBlocks += g.nblk;
+        groups.push_back(g);
     }
     const size_t descOff = (total * 4 + 15) / 16 * 16;
     if ((rc = ensurePinned(ctx, ctx->hS3pass, descOff + nBlocks * sizeof(SwBlockDesc))) != FSGPU_OK) return rc;
@@ -1807,11 +1806,11 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     {
         double cells = 0, pairs = 0, winsts = 0;
         for (Group &g : groups) {
-            const int ppb = g.waves * 2 * (64 / g.HL), ppw = 2 * (64 / g.HL), key = g.HL * 64 + g.R;
+            const int ppb = g.waves * 2 * (64 / g.HL), ppw = 2 * (64 / g.HL);
             size_t bp = g.blk0;
             for (const Part &pt : parts) {
-                if (pt.key != key) continue;
-                const int i = pt.q, L = q[i].L, lanes = (L + g.R - 1) / g.R;
+                if (pt.key != g.key) continue;
+                const int i = pt.q, L = q[i].L, lanes = (L + pt.R - 1) / pt.R;
                 for (int p0 = 0; p0 < pt.n; p0 += ppb) {
                     SwBlockDesc &d = hBlk[bp++];
                     d.imgOff = ctx->s3ImgOff[2 * i + (g.HL == 64 ? 1 : 0)]; d.firstPair = (uint32_t) (sbase[i] + pt.first + p0); d.nPairs = (uint16_t) std::min(ppb, pt.n - p0);
@@ -1820,7 +1819,7 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
                 // accounting in the units of the kernel's roofline: DP cells and the VALU wave-instructions its waves issue (a wave runs
                 // (longest of its targets) + lanes - 1 steps of 14 packed instructions per register row + 16 around them [+ the AA adds])
                 const uint32_t *tp = hTids + sbase[i] + pt.first;
-                const double perStep = 14.0 * g.R + 16.0 + (hasAA ? 2.0 * sw3Dw(g.R) + 4.0 : 0.0);
+                const double perStep = 14.0 * pt.R + 16.0 + (hasAA ? 2.0 * sw3Dw(pt.R) + 4.0 : 0.0);
                 for (int k = 0; k < pt.n; k++) {
                     const int lt = len[tp[k]];
                     cells += (double) L * lt;
@@ -1836,9 +1835,7 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
     if (dir == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir], ctx->stream));
-    // every class gets a stream (round robin over the side streams): their long-target tails overlap instead of queueing up; the 64-lane
-    // classes (the long targets) sort first and are launched first
-    std::sort(groups.begin(), groups.end(), [](const Group &x, const Group &y) { return x.HL != y.HL ? x.HL > y.HL : x.R > y.R; });
+    // every launch group gets a stream: their long-target tails overlap instead of queueing up
     const size_t nStreams = std::min<size_t>(groups.size(), 6);
     if (nStreams > 1) {
         if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
@@ -1859,7 +1856,7 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         sa.ge = (uint32_t) gapExtend | ((uint32_t) gapExtend << 16);
         sa.dir = dir;
         sa.res0 = (int32_t *) ctx->s3res.p;
-        rc = hasAA ? fsgpuLaunchSw3AA(ctx, g.R, g.HL, sa, (int) g.nblk, g.waves, gs) : fsgpuLaunchSw3NA(ctx, g.R, g.HL, sa, (int) g.nblk, g.waves, gs);
+        rc = hasAA ? fsgpuLaunchSw3AA(ctx, g.rlo, g.HL, sa, (int) g.nblk, g.waves, g.lds, gs) : fsgpuLaunchSw3NA(ctx, g.rlo, g.HL, sa, (int) g.nblk, g.waves, g.lds, gs);
         if (rc != FSGPU_OK) { for (size_t x = 1; x < nStreams; x++) (void) hipStreamSynchronize(ctx->swAux[x]); return rc; }
     }
     for (size_t k = 1; k < nStreams; k++) { HIPCHK(hipEventRecord(ctx->swAuxEv[k], ctx->swAux[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[k], 0)); }

@@ -14,45 +14,32 @@
 
 namespace {
 
-template <int R, int HL>
-int launchT(fsgpu_ctx *ctx, const Sw3Args &sa, int nBlocks, int waves, hipStream_t stream) {
+template <int HL, int RLO>
+int launchT(fsgpu_ctx *ctx, const Sw3Args &sa, int nBlocks, int waves, int lds, hipStream_t stream) {
     constexpr bool AA = FS_SW3_AA != 0;
-    const int lds = sw3LdsBytes(R, HL, AA, waves);
     static thread_local uint64_t attrDevs = 0;       // devices on which this thread has set the attribute (it is per device)
     const uint64_t devBit = 1ull << (ctx->device & 63);
     if (!(attrDevs & devBit)) {
-        HIPCHK(hipFuncSetAttribute((const void *) k_sw3<R, AA, HL>, hipFuncAttributeMaxDynamicSharedMemorySize, sw3LdsBytes(R, HL, AA, 8)));
+        HIPCHK(hipFuncSetAttribute((const void *) k_sw3<AA, HL, RLO>, hipFuncAttributeMaxDynamicSharedMemorySize, sw3LdsBytes(RLO + 7, HL, AA, 8)));
         attrDevs |= devBit;
     }
-    hipLaunchKernelGGL((k_sw3<R, AA, HL>), dim3(nBlocks), dim3(64 * waves), lds, stream, sa);
+    hipLaunchKernelGGL((k_sw3<AA, HL, RLO>), dim3(nBlocks), dim3(64 * waves), lds, stream, sa);
     HIPCHK(hipGetLastError());
     return FSGPU_OK;
 }
 
 } // namespace
 
+// rlo: 1 (queries with 1..8 rows per lane) or 9 (9..16); lds: dynamic LDS of the largest class among the launch's workgroups
 #if FS_SW3_AA
-int fsgpuLaunchSw3AA(fsgpu_ctx *ctx, int R, int HL, const Sw3Args &sa, int nBlocks, int waves, hipStream_t stream) {
+int fsgpuLaunchSw3AA(fsgpu_ctx *ctx, int rlo, int HL, const Sw3Args &sa, int nBlocks, int waves, int lds, hipStream_t stream) {
 #else
-int fsgpuLaunchSw3NA(fsgpu_ctx *ctx, int R, int HL, const Sw3Args &sa, int nBlocks, int waves, hipStream_t stream) {
+int fsgpuLaunchSw3NA(fsgpu_ctx *ctx, int rlo, int HL, const Sw3Args &sa, int nBlocks, int waves, int lds, hipStream_t stream) {
 #endif
-#define FS_C32(RR) case RR: return launchT<RR, 32>(ctx, sa, nBlocks, waves, stream);
-#define FS_C64(RR) case RR: return launchT<RR, 64>(ctx, sa, nBlocks, waves, stream);
-    if (HL == 32) {
-        switch (R) {
-            FS_C32(1) FS_C32(2) FS_C32(3) FS_C32(4) FS_C32(5) FS_C32(6) FS_C32(7) FS_C32(8)
-            FS_C32(9) FS_C32(10) FS_C32(11) FS_C32(12) FS_C32(13) FS_C32(14) FS_C32(15) FS_C32(16)
-            default: break;
-        }
-    } else if (HL == 64) {
-        switch (R) {
-            FS_C64(1) FS_C64(2) FS_C64(3) FS_C64(4) FS_C64(5) FS_C64(6) FS_C64(7) FS_C64(8)
-            FS_C64(9) FS_C64(10) FS_C64(11) FS_C64(12) FS_C64(13) FS_C64(14) FS_C64(15) FS_C64(16)
-            default: break;
-        }
-    }
-#undef FS_C32
-#undef FS_C64
+    if (HL == 32 && rlo == 1) return launchT<32, 1>(ctx, sa, nBlocks, waves, lds, stream);
+    if (HL == 32 && rlo == 9) return launchT<32, 9>(ctx, sa, nBlocks, waves, lds, stream);
+    if (HL == 64 && rlo == 1) return launchT<64, 1>(ctx, sa, nBlocks, waves, lds, stream);
+    if (HL == 64 && rlo == 9) return launchT<64, 9>(ctx, sa, nBlocks, waves, lds, stream);
     ctx->err = "internal: bad k_sw3 class";
     return FSGPU_E_ARG;
 }

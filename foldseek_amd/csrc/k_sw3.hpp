@@ -110,8 +110,9 @@ __device__ __forceinline__ uint64_t groupMaxU64(uint64_t k) {
     return k;
 }
 
+// the work of one workgroup for R rows per lane (the kernel below dispatches on the workgroup's R)
 template <int R, bool HAS_AA, int HL>
-__global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
+__device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd, unsigned char *smem) {
     using A = Pk16;
     static_assert(HL == 32 || HL == 64, "lanes per target pair");
     constexpr int ROWB = sw3RowBytes(R, HL);
@@ -123,8 +124,6 @@ __global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
     constexpr int EB = HAS_AA ? 16 : 8;                // bytes per ring entry: row offsets of (A, B) in the 3Di table [, (A, B) in the AA table]
     constexpr int RINGB = RING * EB;
     constexpr uint32_t kDeadOff = (uint32_t) kAlphabet * (uint32_t) ROWB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SwBlockDesc bd = a.blocks[blockIdx.x];
     const uint32_t *imgSrc = a.img + __builtin_amdgcn_readfirstlane(bd.imgOff) + (a.dir ? IMG / 4 : 0);
     const int rows = __builtin_amdgcn_readfirstlane((int) bd.rowsInTile), segLen = __builtin_amdgcn_readfirstlane((int) bd.segLen);
     const int pairBase = __builtin_amdgcn_readfirstlane((int) bd.firstPair), pairsHere = __builtin_amdgcn_readfirstlane((int) bd.nPairs);
@@ -297,6 +296,27 @@ __global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
             res[2] = (int32_t) (0xffffu - (uint32_t) ((key >> 16) & 0xffffu));
             res[3] = 1;
         }
+    }
+}
+
+// One launch serves every query of a batch whose rows-per-lane count lies in [RLO, RLO + 8): a workgroup reads its query's length from
+// its descriptor and runs the body instantiated for R = ceil(L / HL).  (One kernel per R made a batch of mixed lengths a dozen small
+// launches, each with its own long-target tail; register allocation is that of R = RLO + 7.)
+template <bool HAS_AA, int HL, int RLO>
+__global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SwBlockDesc bd = a.blocks[blockIdx.x];
+    const int R = __builtin_amdgcn_readfirstlane(((int) bd.rowsInTile + HL - 1) / HL);
+    switch (R - RLO) {
+        case 0: sw3Body<RLO + 0, HAS_AA, HL>(a, bd, smem); break;
+        case 1: sw3Body<RLO + 1, HAS_AA, HL>(a, bd, smem); break;
+        case 2: sw3Body<RLO + 2, HAS_AA, HL>(a, bd, smem); break;
+        case 3: sw3Body<RLO + 3, HAS_AA, HL>(a, bd, smem); break;
+        case 4: sw3Body<RLO + 4, HAS_AA, HL>(a, bd, smem); break;
+        case 5: sw3Body<RLO + 5, HAS_AA, HL>(a, bd, smem); break;
+        case 6: sw3Body<RLO + 6, HAS_AA, HL>(a, bd, smem); break;
+        case 7: sw3Body<RLO + 7, HAS_AA, HL>(a, bd, smem); break;
+        default: break;
     }
 }
 
