@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+T_START = time.perf_counter()
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 without a torchrun environment: bench.py launches them itself")
@@ -166,7 +169,9 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     """k-mer prefilter (Foldseek's default prefilter on CPUs) + structure SW on its hits, same resident DB.
     Every rank builds its own index from the broadcast DB (no collective) and searches its own queries."""
     import threading
-    nqk = max(32, args.kmer_queries // 32 * 32)
+    nqk_total = max(32, args.kmer_queries // 32 * 32)
+    # strong scaling: the section's queries are a fixed set split over the ranks (at least one batch of 32 each); weak: every rank runs them all
+    nqk = max(32, nqk_total // world // 32 * 32) if args.scaling == "strong" else nqk_total
     # this rank's own timed queries (their homologs are planted in the DB), repeated if the section asks for more
     q3 = [q3[i % len(q3)] for i in range(nqk)]
     qa = [qa[i % len(qa)] for i in range(nqk)]
@@ -310,21 +315,21 @@ def kmer_cpu_baseline(args, synth, db):
 
 def sw_roofline(passes, has_aa, solo=None):
     """issue-rate roofline of k_sw2: a wave-instruction of the DP row loop updates 64 lanes x 2 int16 halves = 128 cells and the
-    row costs 14 packed VALU instructions (16 with the AA table); packed 16-bit ops issue once per 4.3 cycles per SIMD (measured,
+    row costs 14 packed VALU instructions (15 with the AA table); packed 16-bit ops issue once per 4.3 cycles per SIMD (measured,
     profiles/r01_valu_lds_issue_rate_ubench.txt) -> 1024 SIMDs x 128 / 14 / 4.3 cyc x 2.4 GHz.  `passes` = fsgpu_sw_last_passes() arrays
     of the timed batches (forward + reversed-query pass each); achieved = DP cells of those passes / their device time (HIP events)."""
-    per = 16.0 if has_aa else 14.0
+    per = 15.0 if has_aa else 14.0          # k_sw3: the AA table is added on packed row pairs, one v_pk_add_i16 per row (k_sw2: two)
     peak = 1024 * 128 / per / 4.3 * 2.4          # Gcell/s
     cells = sum(float(p[d][1]) for p in passes for d in (0, 1) if p[d][0] >= 0)
     ms = sum(float(p[d][0]) for p in passes for d in (0, 1) if p[d][0] >= 0)
     instr = sum(float(p[d][3]) for p in passes for d in (0, 1) if p[d][0] >= 0)
-    out = {"bound": "valu-issue", "kernel": "k_sw2", "unit": "Gcell/s", "peak": peak, "achieved": cells / max(ms, 1e-9) / 1e6,
+    out = {"bound": "valu-issue", "kernel": "k_sw3", "unit": "Gcell/s", "peak": peak, "achieved": cells / max(ms, 1e-9) / 1e6,
            "frac": cells / max(ms, 1e-9) / 1e6 / peak, "cells_per_pass_pair": cells / max(1, len(passes)), "kernel_ms_per_pass_pair": ms / max(1, len(passes)),
            "traffic": None,
-           # the same passes priced in what the waves really issue: two targets per wave run max(LtA, LtB) + lanes - 1 steps of 14 R + 14 VALU
-           # instructions (16 R + 23 with the AA table; counted in the kernel's ISA), 4.3 cycles each.  frac / issued_valu_frac = the share of the
-           # issued stream that is the 14 (16) DP instructions of real cells: the rest is the step overhead, lane padding, wavefront fill / drain
-           # and the shorter target of a wave
+           # the same passes priced in what the waves really issue: a wave (four targets at 32 lanes per pair, two at 64) runs (its longest
+           # target) + lanes - 1 steps of 14 R + 16 VALU instructions (+ R + 4 with the AA table; counted in the kernel's ISA), 4.3 cycles each.
+           # frac / issued_valu_frac = the share of the issued stream that is the 14 (15) DP instructions of real cells: the rest is the step
+           # overhead, lane padding, wavefront fill / drain and the shorter targets of a wave
            "issued_valu_frac": instr / max(ms, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3),
            "note": "co-running with the other feeder threads' scans; DP cells = query rows x target columns of every pair of both passes"}
     if solo is not None:
@@ -707,6 +712,16 @@ def main():
     n_warm = args.warmup * G
     q_lo, q_hi = (int(x) for x in args.query_len.split(","))
     all_q3, all_qa = synth.make_queries(n_timed_total + world * n_warm, seed=1000, lo=q_lo, hi=q_hi)   # default 250..450: around the mean length 350; same on every rank
+    # querylen_full_range leg: queries over the DB's own length range (30..2000), their homologs planted like everybody's
+    n_full = max(0, args.fullrange_steps) * G if (q_lo, q_hi) != (30, 2000) and not args.dry_run else 0
+    fr_q3, fr_qa = synth.make_queries(n_full * world, seed=3000, lo=30, hi=2000) if n_full else ([], [])
+    phase = {}
+    t_phase = [time.perf_counter()]
+
+    def mark(name):
+        now = time.perf_counter()
+        phase[name] = phase.get(name, 0.0) + now - t_phase[0]
+        t_phase[0] = now
     if args.scaling == "weak":
         t_lo, t_hi = rank * per_rank_timed, (rank + 1) * per_rank_timed
     else:
@@ -723,8 +738,9 @@ def main():
         G_eff //= 2
     # ---- target DB: generated on rank 0 (vectorised), ONE broadcast (RCCL over xGMI), then resident in every GPU's HBM ----
     t_gen = time.perf_counter()
-    db = synth.make_db_fast(args.targets, (all_q3, all_qa), seed=20260923, homologs_per_query=args.homologs) if rank == 0 else None
+    db = synth.make_db_fast(args.targets, (all_q3 + fr_q3, all_qa + fr_qa), seed=20260923, homologs_per_query=args.homologs) if rank == 0 else None
     t_gen = time.perf_counter() - t_gen
+    mark("db_generation")
     if have_gpu:
         torch.cuda.synchronize()
     tb = time.perf_counter()
@@ -732,6 +748,7 @@ def main():
     if have_gpu:
         torch.cuda.synchronize()
     t_bcast = time.perf_counter() - tb if world > 1 else 0.0
+    mark("db_broadcast")
     bcast_backend = dist.get_backend() if world > 1 else "none"
     if world > 1 and have_gpu and backend == "nccl":
         # the one collective of the path must have gone over RCCL with one rank per device -- no silent fallback
@@ -749,6 +766,7 @@ def main():
             print(json.dumps({"metric": "residues aligned/sec (prefilter+align)", "value": 0.0, "unit": "residues/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": args.scaling,
                               "backend": bcast_backend, "db_broadcast_s": t_bcast, "db_generation_s": t_gen, "queries_per_step_effective": G_eff,
+                              "phase_wall_s": dict(phase, total_since_start=time.perf_counter() - T_START),
                               "ranks": [{"rank": r, "timed_queries": m, "db_entries": n, "db_digest": d} for r, m, n, d in sizes],
                               "config": {"workload": "dry run: no device work", "targets": int(db.n), "queries_per_step": G}}))
         if world > 1:
@@ -788,7 +806,9 @@ def main():
     timed = sorted(range(n_warm, nq), key=lambda i: len(q3[i]))
     batches = [timed[k:k + G_eff] for k in range(0, len(timed), G_eff)]
     warm = [list(range(k, min(k + G, n_warm))) for k in range(0, n_warm, G)]
+    mark("device_open")
     dt, rec, step = search_region(api, ctxs, searches, q3, qa, warm, batches, world, dev, fdist, True, nq)
+    mark("main_region_with_warmup")
     kms, sms, counts, host = rec["kms"], rec["sms"], rec["counts"], rec["host"]
     # dominant-kernel duration on an otherwise idle GPU (in the timed region the feeder threads' launches overlap, which
     # stretches each kernel's wall time)
@@ -882,6 +902,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], args.alignment_type, args.cpu_sample_targets,
                                                [q3[i] for i in range(n_warm + 1, min(nq, n_warm + max(1, args.cpu_sample_queries)))])
             t_pref_cpu = out["cpu_baseline"].get("prefilter_s_sample")
+    mark("solo_probes_and_cpu_baseline")
 
     # ---- configs[3]: the same search with --alignment-type 2 (3Di + AA substitution scores, Gotoh affine gaps) on the resident DB ----
     if args.type2_steps > 0 and args.alignment_type != 2:
@@ -919,6 +940,34 @@ def main():
             if rank == 0:
                 out["align_type2"] = {"error": repr(e)[:500]}
 
+    mark("align_type2_leg")
+    # ---- the DB's own query length range (30..2000): short queries pair up in a scan kernel, queries beyond 896 residues run row-tiled ----
+    if n_full > 0:
+        try:
+            f3, fa = fr_q3[rank * n_full:(rank + 1) * n_full], fr_qa[rank * n_full:(rank + 1) * n_full]
+            order = sorted(range(n_full), key=lambda i: len(f3[i]))
+            fb = [order[k:k + G_eff] for k in range(0, n_full, G_eff)]
+            pickw = [fb[i] for i in np.linspace(0, len(fb) - 1, min(nthreads, len(fb))).astype(np.int64)]      # untimed: one batch per feeder thread, spread over the lengths
+            dtf, recf, _ = search_region(api, ctxs, searches, f3, fa, pickw, fb, world, dev, fdist, True, n_full)
+            totf = fdist.gather_objects((recf["counts"][0], recf["counts"][1], n_full))
+            if rank == 0:
+                nft = sum(x[2] for x in totf)
+                lqf = [len(x) for x in f3]
+                out["querylen_full_range"] = {
+                    "workload": f"{len(fb)} more steps of {G_eff} queries with lengths drawn from the DB's own model over its whole range 30..2000 (mean {float(np.mean(lqf)):.0f}; "
+                                f"{sum(1 for x in lqf if x > 896)} of {len(lqf)} beyond 896 residues = row-tiled scans, {sum(1 for x in lqf if x <= 256)} up to 256 = paired scans), "
+                                f"same resident DB, --alignment-type {args.alignment_type}, {args.homologs} planted homologs per query",
+                    "value": nft * db.residues / dtf, "unit": "residues/s", "steps": len(fb), "ms_per_step": 1e3 * dtf / max(1, len(fb)),
+                    "queries_per_s": nft / dtf, "ms_per_query": 1e3 * dtf / max(1, nft / world), "mean_query_len": float(np.mean(lqf)),
+                    "hits_per_query": sum(x[0] for x in totf) / max(1, nft), "alignments_per_query": sum(x[1] for x in totf) / max(1, nft),
+                    "roofline": gapless_roofline(recf["kms"], lqf), "align_roofline": sw_roofline(recf["swp"], args.alignment_type == 2)}
+        except Exception as e:                                             # noqa: BLE001 -- see the k-mer leg below
+            if world > 1:
+                raise
+            if rank == 0:
+                out["querylen_full_range"] = {"error": repr(e)[:500]}
+    mark("querylen_full_range_leg")
+
     for x in searches[1:]:
         x.close()
     for c in ctxs[1:]:
@@ -938,6 +987,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and "error" not in kout:
             kout["cpu_baseline"] = kmer_cpu_baseline(args, synth, db)
         out["kmer_prefilter"] = kout
+    mark("kmer_leg")
     for x in searches:
         x.close()
     for c in ctxs:
@@ -956,7 +1006,9 @@ def main():
             for k in ("metric", "higher_is_better", "vs_baseline", "data"):
                 av.pop(k, None)
             out["allvsall"] = av
+    mark("allvsall_leg")
     if rank == 0:
+        out["phase_wall_s"] = dict(phase, total_since_start=time.perf_counter() - T_START)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

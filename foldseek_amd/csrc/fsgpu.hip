@@ -1668,7 +1668,9 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     // instructions per cell) and 64 lanes (R64 = ceil(L / 64), two targets per wave: half the instructions per target COLUMN).  A wave's
     // run time is (columns + lanes - 1) steps of ~(14 R + 16) dependent-ish instructions, so the longest targets of a launch set its
     // critical path: pairs whose target is longer than the threshold take the 64-lane shape, the others the 32-lane one.
-    static const int longT = [] { const char *e = getenv("FSGPU_SW3_LONG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 640; }();
+    // (32 queries x 1000 random targets, forward pass alone on the device: thresholds 384 / 640 / 896 / none = 1.21 / 1.20 / 1.20 / 1.21 ms for 3Di,
+    // 1.37 / 1.30 / 1.28 / 1.31 ms for 3Di + AA -- the split matters little once all classes share a launch; FSGPU_SW3_LONG overrides it)
+    static const int longT = [] { const char *e = getenv("FSGPU_SW3_LONG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 896; }();
     auto nSel = [&](int i) { return cR[i] > 0 ? nSelAll(i) : 0; };
     for (int i = 0; i < nq; i++) sbase[i + 1] = sbase[i] + (size_t) nSel(i);
     const size_t total = sbase[nq];

@@ -1,7 +1,7 @@
 """The batch SW kernel alone on the device: one batch of 32 queries x 1000 random targets (100k-target synthetic DB), forward pass, 3Di and 3Di+AA.
 Default: k_sw3 (compact queries, fsgpu_sw_multi_dir_c; FSGPU_SW3_WAVES=2|4|8 overrides the waves per workgroup); FSGPU_SW_PROFILES=1: k_sw2
 (fsgpu_sw_multi_dir; FSGPU_SW2_PAIRS=8|16|32 overrides the pairs per workgroup).  Prints device ms of the pass (HIP events), Tcell/s, and the
-fraction of the packed-VALU issue bound (1024 SIMDs x 128 cells / (14 [16 with AA] instructions x 4.3 cycles) at 2.4 GHz)."""
+fraction of the packed-VALU issue bound (1024 SIMDs x 128 cells / (14 [with AA: 15 for k_sw3, 16 for k_sw2] instructions x 4.3 cycles) at 2.4 GHz)."""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foldseek_amd import api, synth
@@ -20,7 +20,8 @@ for at in (0, 2):
         if best is None or p[0][0] < best[0][0]:
             best = p
     ms, cells = float(best[0][0]), float(best[0][1])
-    peak = 1024 * 128 / ((16 if at == 2 else 14) * 4.3) * 2.4e9
+    legacy = os.environ.get("FSGPU_SW_PROFILES", "0") not in ("", "0")
+    peak = 1024 * 128 / (((16 if legacy else 15) if at == 2 else 14) * 4.3) * 2.4e9
     kern = "k_sw2 pairs/wg %s" % os.environ.get("FSGPU_SW2_PAIRS", "default") if os.environ.get("FSGPU_SW_PROFILES", "0") not in ("", "0") else \
         "k_sw3 waves/wg %s" % os.environ.get("FSGPU_SW3_WAVES", "default")
     print("alignment-type %d %s: forward pass %.3f ms per batch of 32 (%.4f ms/query), %.3e cells -> %.3f Tcell/s = %.3f of the issue bound; "
