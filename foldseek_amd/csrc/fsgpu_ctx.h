@@ -80,6 +80,7 @@ struct fsgpu_ctx {
     double kmerMs[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // ms of the last k-mer batch: [0] device total, [1..8] stages, [9] host tail, [10] k_kmer_lists alone
     uint32_t kmerSegs[7] = {0, 0, 0, 0, 0, 0, 0};   // last batch: segments resolved by one wave / in LDS / through global scratch, segments with candidates, all segments, bins
     double kmerHitsPerQuery = 0;       // index hits per query of the last batch (sizes the next one)
+    double kmerKPerPos = 0;            // similar k-mers per query position of the last batch (picks the wave / workgroup form of the next count pass)
     int kmerBatchCap = 0;              // > 0: a batch overflowed 2^32 hits, stay at or below this many queries
     uint64_t kmerCounts[4] = {0, 0, 0, 0};   // last batch: k-mer lists probed, index hits, double-diagonal candidates, elements handed to the host
 

@@ -580,9 +580,18 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     uint64_t nLists = 0, nHits = 0;
     uint32_t nCand = 0;
     // ---- stage 1: similar k-mers -> lists ---------------------------------------------------------------------
+    // one workgroup or one wave per query position (k_kmer.hpp): the wave form when positions have few similar k-mers -- for the count pass
+    // judged by the previous batch of this context, for the list pass by this batch's own count.  FSGPU_KMER_WAVE = 0 / 1 forces a form.
+    int waveForm = -1;
+    if (const char *e = getenv("FSGPU_KMER_WAVE")) waveForm = atoi(e) != 0;
     if (nPos) {
-        hipLaunchKernelGGL(k_kmer_count, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
-                           (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, (uint32_t *) S.K.p);
+        const bool w = waveForm >= 0 ? waveForm != 0 : (ctx->kmerKPerPos > 0 && ctx->kmerKPerPos < 2048);
+        if (w)
+            hipLaunchKernelGGL(k_kmer_count_w, dim3((unsigned) ((nPos + 3) / 4)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                               (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, (uint32_t *) S.K.p);
+        else
+            hipLaunchKernelGGL(k_kmer_count, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                               (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, (uint32_t *) S.K.p);
         RPCHK(hipGetLastError());
     }
     RPCHK(hipMemsetAsync((uint32_t *) S.K.p + nPos, 0, sizeof(uint32_t), st));
@@ -598,9 +607,15 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     CHK(ensureK(ctx, S.listP, (nLists + 1) * sizeof(uint64_t)));
     if (nLists) {
         RPCHK(hipEventRecord(S.ev[10], st));
-        hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
-                           (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
-                           (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+        ctx->kmerKPerPos = (double) nLists / (double) std::max<uint64_t>(nPos, 1);
+        if (waveForm >= 0 ? waveForm != 0 : ctx->kmerKPerPos < 2048)
+            hipLaunchKernelGGL(k_kmer_lists_w, dim3((unsigned) ((nPos + 3) / 4)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                               (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
+                               (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+        else
+            hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                               (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
+                               (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[11], st));
     }

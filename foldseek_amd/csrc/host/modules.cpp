@@ -466,7 +466,7 @@ struct DeviceSet {
             // FSGPU_REQUIRE_RCCL=1: a multi-GPU run whose replication silently fell back to peer copies is an error (scaling runs set it)
             { const char *e = getenv("FSGPU_REQUIRE_RCCL"); if (!usedRccl && e && *e && *e != '0' && !getenv("FSGPU_NO_RCCL")) { err = "GPU: the RCCL broadcast of the target DB was not used (FSGPU_REQUIRE_RCCL=1)"; return false; } }
         }
-        perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 16));
+        perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 32));
         return true;
     }
     // worker tix runs on GPU tix % nGpus; the first worker of a GPU uses its root context, the others a clone

@@ -339,6 +339,150 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     }
 }
 
+// ---- the same two passes with one WAVE per query position (four positions per workgroup) ----------------------------------------
+// At low sensitivity (-s 4.5 and below: a few dozen similar k-mers per position, the cluster workflow's prefilter steps) a 256-thread
+// workgroup per position leaves most lanes idle and its run time is a chain of ~40 dependent probes into the two score rows (three
+// binary searches per run).  Here a wave first copies the PASSING PREFIX of both rows (scores and 3-mer indices) into LDS with one or two
+// coalesced loads -- a row is sorted by descending score, only entries >= (cutoff of the row) can take part -- and searches there; a
+// row whose passing prefix is longer than kWaveRowCap entries is searched in global memory like before.  Runs are handled 256 at a time
+// (the r-th k-mer of a position is found by a search over the run offsets of the current batch of runs).  Same K, same lists, same order.
+constexpr int kWaveRowCap = 512;
+constexpr int kWaveRuns = 256;
+
+// leading entries of the descending row S (kRow3 entries) that are >= cut -> dst[0..n); false when there are more than kWaveRowCap
+__device__ inline bool kmerStagePrefix(const int16_t *S, const uint16_t *I, int cut, int16_t *dst, uint16_t *idst, int lane, int &n) {
+    n = 0;
+    for (int base = 0; base < kWaveRowCap; base += 64) {
+        const int16_t v = S[base + lane];
+        dst[base + lane] = v;
+        if (I) idst[base + lane] = I[base + lane];
+        const int cnt = __popcll(__ballot((int) v >= cut));
+        n += cnt;
+        if (cnt < 64) return true;
+    }
+    return (int) S[kWaveRowCap] < cut;
+}
+
+struct KmerWaveLds {
+    int16_t s1[kWaveRowCap], s2[kWaveRowCap];
+    uint16_t i1[kWaveRowCap], i2[kWaveRowCap];
+    uint32_t runOx[kWaveRuns + 1];
+    uint16_t runXs[kWaveRuns], runC[kWaveRuns];
+};
+
+__global__ __launch_bounds__(256) void k_kmer_count_w(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
+                                                      uint32_t nPos, KmerPattern pat, const int16_t *s3, uint32_t *K) {
+    __shared__ int16_t pre[4][2][kWaveRowCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * 4 + wave;
+    if (p >= nPos) return;
+    const KmerQ q = qs[posQuery[p]];
+    const KmerPosInfo info = kmerPosInfo(q, seqs, thrs, p, pat, s3);
+    if (info.skip || info.nV == 0) { if (lane == 0) K[p] = 0; return; }
+    const int16_t *S1 = s3 + (size_t) info.a * kRow3, *S2 = s3 + (size_t) info.b * kRow3;
+    int n1 = kRow3, n2 = kRow3;
+    {
+        int m1, m2;
+        const bool f1 = kmerStagePrefix(S1, nullptr, info.vmax - info.nV + 1, pre[wave][0], nullptr, lane, m1);
+        const bool f2 = kmerStagePrefix(S2, nullptr, (int) (int16_t) (info.thr - info.vmax), pre[wave][1], nullptr, lane, m2);
+        if (f1) { S1 = pre[wave][0]; n1 = m1; }
+        if (f2) { S2 = pre[wave][1]; n2 = m2; }
+    }
+    unsigned long long mine = 0;
+    for (int t = lane; t < info.nV; t += 64) {
+        const int v = info.vmax - t;
+        const int xs = countGE(S1, n1, v + 1), len = countGE(S1, n1, v) - xs;
+        const int c = len ? countGE(S2, n2, (int) (int16_t) (info.thr - v)) : 0;
+        mine += (unsigned long long) len * (unsigned) c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if (lane == 0) K[p] = (uint32_t) (mine < (unsigned long long) (kMaxKmerResult - 1) ? mine : (kMaxKmerResult - 1));
+}
+
+__global__ __launch_bounds__(256) void k_kmer_lists_w(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
+                                                      uint32_t nPos, KmerPattern pat, const int16_t *s3, const uint16_t *i3,
+                                                      const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets, const uint32_t *bitmap,
+                                                      uint32_t *listStart, uint32_t *listSize, uint32_t *listPos) {
+    __shared__ KmerWaveLds lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t p = blockIdx.x * 4 + wave;
+    if (p >= nPos) return;
+    const uint32_t Kp = Kcount[p];
+    if (Kp == 0) return;
+    KmerWaveLds &W = lds[wave];
+    const KmerQ q = qs[posQuery[p]];
+    const KmerPosInfo info = kmerPosInfo(q, seqs, thrs, p, pat, s3);
+    const int16_t *S1 = s3 + (size_t) info.a * kRow3, *S2 = s3 + (size_t) info.b * kRow3;
+    const uint16_t *I1 = i3 + (size_t) info.a * kRow3, *I2 = i3 + (size_t) info.b * kRow3;
+    int n1 = kRow3, n2 = kRow3;
+    {
+        int m1, m2;
+        const bool f1 = kmerStagePrefix(S1, I1, info.vmax - info.nV + 1, W.s1, W.i1, lane, m1);
+        const bool f2 = kmerStagePrefix(S2, I2, (int) (int16_t) (info.thr - info.vmax), W.s2, W.i2, lane, m2);
+        if (f1) { S1 = W.s1; I1 = W.i1; n1 = m1; }
+        if (f2) { S2 = W.s2; I2 = W.i2; n2 = m2; }
+    }
+    const uint64_t base = Kbase[p];
+    const uint32_t qpos = ((uint32_t) posQuery[p] << 16) | (p - q.posBase);
+    uint32_t carry = 0;                        // similar k-mers of the runs before the current batch of runs
+    for (int t0 = 0; t0 < info.nV && carry < Kp; t0 += kWaveRuns) {
+        const int nR = min(kWaveRuns, info.nV - t0);
+        uint32_t batchTotal = 0;
+        for (int tb = 0; tb < nR; tb += 64) {
+            const int t = t0 + tb + lane;
+            int xs = 0, len = 0, c = 0;
+            if (tb + lane < nR) {
+                const int v = info.vmax - t;
+                xs = countGE(S1, n1, v + 1); len = countGE(S1, n1, v) - xs;
+                c = len ? countGE(S2, n2, (int) (int16_t) (info.thr - v)) : 0;
+            }
+            const uint32_t prod = (uint32_t) len * (uint32_t) c;
+            uint32_t incl = prod;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            if (tb + lane < nR) { W.runOx[tb + lane] = batchTotal + incl - prod; W.runXs[tb + lane] = (uint16_t) xs; W.runC[tb + lane] = (uint16_t) c; }
+            batchTotal += __shfl(incl, 63);
+        }
+        if (lane == 0) W.runOx[nR] = batchTotal;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t end = min(Kp, carry + batchTotal);          // r in [carry, end) lies in this batch of runs
+        for (uint32_t r0 = carry + lane; r0 < end; r0 += 4 * 64) {
+            uint32_t kmer[4], st[4], en[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t r = r0 + u * 64;
+                kmer[u] = 0;
+                if (r < end) {
+                    const uint32_t rr = r - carry;
+                    int lo = 0, hi = nR;          // last run with runOx <= rr (empty runs share their offset with the successor)
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (W.runOx[mid] <= rr) lo = mid; else hi = mid; }
+                    const uint32_t d = rr - W.runOx[lo], c = W.runC[lo];
+                    const uint32_t dx = d / c;
+                    kmer[u] = kmerDeviceIndex(I1[W.runXs[lo] + dx], I2[d - dx * c]);
+                }
+            }
+            uint32_t bm[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) bm[u] = bitmap[kmer[u] >> 5];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                st[u] = 0; en[u] = 0;
+                if ((bm[u] >> (kmer[u] & 31)) & 1u) { st[u] = offsets[kmer[u]]; en[u] = offsets[kmer[u] + 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t r = r0 + u * 64;
+                if (r < end) { listStart[base + r] = st[u]; listSize[base + r] = en[u] - st[u]; listPos[base + r] = qpos; }
+            }
+        }
+        carry += batchTotal;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // per-query bases: list slots and hit-stream start (Kbase / listP are exclusive scans with the total appended)
 __global__ void k_kmer_qbases(KmerQ *qs, int nq, const uint64_t *Kbase, const uint64_t *listP) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;

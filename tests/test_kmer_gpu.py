@@ -212,6 +212,39 @@ def test_low_threshold_long_row_prefixes():
         ctx.close()
 
 
+@pytest.mark.parametrize("thr", [130, 100, 78, 25, 0])
+def test_wave_and_workgroup_forms_of_the_similar_kmer_passes(thr, monkeypatch):
+    """k_kmer_count / k_kmer_lists exist in two forms -- one workgroup per query position, and one WAVE per position with the passing row
+    prefixes staged in LDS (the form a low-sensitivity batch takes, e.g. the cluster workflow's -s 1 / -s 4.5 steps) -- picked from the
+    number of similar k-mers per position.  Both forced in turn, from thresholds that leave a handful of similar k-mers per position
+    to thresholds that make more than 512 row entries pass (the wave form then searches that row in global memory) and reach the
+    k-mer cap: same statistics, same hit lists as the oracle."""
+    O = K.load_ora()
+    q3, qa = synth.make_queries(4, seed=77, mean_len=60, lo=40, hi=80)
+    db = synth.make_db(400, (q3, qa), seed=78, homologs_per_query=10, mean_len=120, lo=30, hi=300)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    o = K.OraKpf(O, ksub, pb, usub, targets, kmerThr=thr, maxResListLen=100)
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=thr)
+    qs = (list(q3) + [q3[0][:7], q3[1][3:9]]) if thr else [q3[0][:16]]
+    want = [o.query(q, -1) for q in qs]
+    prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=thr) for q in qs]
+    for form in ("0", "1"):
+        monkeypatch.setenv("FSGPU_KMER_WAVE", form)
+        res, status, stats = ctx.kmer_search(prep, max_res=100, l2_cache_size=2 << 20, want_stats=True)
+        for i in range(len(qs)):
+            b, st = want[i]
+            assert status[i] == 0 and np.allclose(stats[i], st), (thr, form, i, stats[i], st)
+            assert len(res[i]) == len(b) and (res[i] == b).all(), (thr, form, i)
+    monkeypatch.delenv("FSGPU_KMER_WAVE")
+    o.close()
+    ctx.close()
+
+
 def test_unstable_sort_branch_matches_compiled_reference():
     """resultSize >= foundDiagonalsSize/2: the reference leaves its radix path for std::sort (QueryMatcher.cpp:205-215).
     The C oracle does not model libstdc++'s introsort, so this one is checked against the compiled reference itself
