@@ -122,6 +122,7 @@ def lib():
         "fsgpu_sw_multi": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "fsgpu_sw_multi_dir": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "fsgpu_sw_multi_dir_c": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "fsgpu_sw_multi_c": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
         "fshost_search_stats": (None, [vp, vp]),
         "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -153,7 +154,7 @@ def lib():
 def exported_symbols():
     return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
-            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_multi_dir_c", "fsgpu_sw_launch", "fsgpu_sw_finish",
+            "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_multi_dir_c", "fsgpu_sw_multi_c", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_db_broadcast", "fsgpu_device_count", "fsgpu_gapless_plan_items",
             "fsgpu_last_kernel_ms", "fsgpu_sw_last_passes", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
             "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_bins", "fsgpu_kmer_batch_hint"]
@@ -482,6 +483,33 @@ class Context:
         for k in keep[:nq]:
             res.append(out[b:b + len(k[0])].copy()); b += len(k[0])
         return res
+
+    def sw_multi_c(self, mat3di, matAA, queries, gap_open=10, gap_extend=1):
+        """both directions in one submission (fsgpu_sw_multi_c); queries as in sw_multi_dir_c.  Returns (fwd arrays, rev arrays)."""
+        class Q(C.Structure):
+            _fields_ = [("qAA", C.c_void_p), ("q3Di", C.c_void_p), ("cbAA_fwd", C.c_void_p), ("cb3Di_fwd", C.c_void_p), ("cbAA_rev", C.c_void_p),
+                        ("cb3Di_rev", C.c_void_p), ("L", C.c_int32), ("n", C.c_int32), ("targetIds", C.c_void_p)]
+        nq = len(queries)
+        m3 = np.ascontiguousarray(mat3di, np.int8)
+        mA = None if matAA is None else np.ascontiguousarray(matAA, np.int8)
+        keep, arr = [], (Q * nq)()
+        for i, (qa, q3, cbaf, cb3f, cbar, cb3r, ids) in enumerate(queries):
+            q3 = np.ascontiguousarray(q3, np.uint8)
+            qa = None if qa is None else np.ascontiguousarray(qa, np.uint8)
+            cbs = [None if x is None else np.ascontiguousarray(x, np.int8) for x in (cbaf, cb3f, cbar, cb3r)]
+            ids = np.ascontiguousarray(ids, np.uint32)
+            keep.append((ids, q3, qa, cbs))
+            arr[i].qAA, arr[i].q3Di = (None if qa is None else qa.ctypes.data), q3.ctypes.data
+            arr[i].cbAA_fwd, arr[i].cb3Di_fwd, arr[i].cbAA_rev, arr[i].cb3Di_rev = [None if b is None else b.ctypes.data for b in cbs]
+            arr[i].L, arr[i].n, arr[i].targetIds = len(q3), len(ids), ids.ctypes.data
+        total = sum(len(k[0]) for k in keep)
+        fwd, rev = np.zeros(max(1, total), SWRES_DT), np.zeros(max(1, total), SWRES_DT)
+        self._chk(lib().fsgpu_sw_multi_c(self.h, m3.ctypes.data, None if mA is None else mA.ctypes.data, C.cast(arr, C.c_void_p), nq, gap_open, gap_extend,
+                                         fwd.ctypes.data, rev.ctypes.data), "fsgpu_sw_multi_c")
+        rf, rr, b = [], [], 0
+        for k in keep:
+            rf.append(fwd[b:b + len(k[0])].copy()); rr.append(rev[b:b + len(k[0])].copy()); b += len(k[0])
+        return rf, rr
 
     def sw_batch(self, pAAf, p3f, pAAr, p3r, target_ids, gap_open=10, gap_extend=1):
         p3f = np.ascontiguousarray(p3f, np.int16)

@@ -1602,9 +1602,12 @@ static void sw3Materialize(const int8_t *mat, const uint8_t *codes, const int8_t
             out[(size_t) a * L + i] = (int16_t) ((int) mat[a * kAlphabet + codes[reversed ? L - 1 - i : i]] + (cb ? (int) cb[i] : 0));
 }
 
-int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend, int dir,
-                         const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out) {
-    if (!ctx || !mat3Di || nq < 0 || (nq > 0 && (!q || !out)) || (dir != 0 && dir != 1) || ((sel == nullptr) != (nsel == nullptr))) return FSGPU_E_ARG;
+// dir 0 / 1: one direction into out; dir 2: both directions in ONE submission (forward into out, reversed into out2)
+static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend, int dir,
+                        const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out, fsgpu_swres *out2) {
+    if (!ctx || !mat3Di || nq < 0 || (nq > 0 && (!q || !out)) || dir < 0 || dir > 2 || (dir == 2 && nq > 0 && !out2) || ((sel == nullptr) != (nsel == nullptr))) return FSGPU_E_ARG;
+    const int slot = dir == 1 ? 1 : 0;                // accounting slot of fsgpu_sw_last_passes
+    const int nDirs = dir == 2 ? 2 : 1, dir0 = dir == 2 ? 0 : dir;
     if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (!(gapOpen > gapExtend && gapExtend >= 0 && gapOpen < 32768)) {
         ctx->err = "device SW requires gapOpen > gapExtend >= 0 (the striped reference kernel's lazy-F shortcut is only reproduced for that case)";
@@ -1654,13 +1657,16 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
             ctotal += (size_t) q[i].n;
         }
         std::vector<fsgpu_swres> cout(std::max<size_t>(ctotal, 1));
-        rc = fsgpu_sw_multi_dir(ctx, cq.data(), (int) cq.size(), gapOpen, gapExtend, dir, sel ? csel.data() : nullptr, sel ? cnsel.data() : nullptr, cout.data());
-        if (rc != FSGPU_OK) return rc;
-        size_t cb = 0;
-        for (size_t c = 0; c < classic.size(); c++) {
-            const int i = classic[c];
-            for (int k = 0; k < nSelAll(i); k++) { const int j = selIdx(i, k); out[base[i] + j] = cout[cb + j]; }
-            cb += (size_t) q[i].n;
+        for (int d = 0; d < nDirs; d++) {
+            rc = fsgpu_sw_multi_dir(ctx, cq.data(), (int) cq.size(), gapOpen, gapExtend, dir0 + d, sel ? csel.data() : nullptr, sel ? cnsel.data() : nullptr, cout.data());
+            if (rc != FSGPU_OK) return rc;
+            fsgpu_swres *dst = d == 0 ? out : out2;
+            size_t cb = 0;
+            for (size_t c = 0; c < classic.size(); c++) {
+                const int i = classic[c];
+                for (int k = 0; k < nSelAll(i); k++) { const int j = selIdx(i, k); dst[base[i] + j] = cout[cb + j]; }
+                cb += (size_t) q[i].n;
+            }
         }
     }
     // ---- k_sw3 ----
@@ -1675,9 +1681,9 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     for (int i = 0; i < nq; i++) sbase[i + 1] = sbase[i] + (size_t) nSel(i);
     const size_t total = sbase[nq];
     if (!ctx->swDirEv[3]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->swDirEv[i]));
-    ctx->swDirValid[dir] = false;
-    if (dir == 0) ctx->swDirValid[1] = false;
-    ctx->swDirCells[dir] = 0; ctx->swDirPairs[dir] = 0; ctx->swDirWaveSteps[dir] = 0;
+    ctx->swDirValid[slot] = false;
+    if (slot == 0) ctx->swDirValid[1] = false;
+    ctx->swDirCells[slot] = 0; ctx->swDirPairs[slot] = 0; ctx->swDirWaveSteps[slot] = 0;
     if (total == 0) return FSGPU_OK;
     const std::vector<int32_t> &len = ctx->db->hLengths;
     // target ids of the pass, longest first inside a query (neighbours share a wave), and the split into the two shapes
@@ -1797,8 +1803,8 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
     const size_t descOff = (total * 4 + 15) / 16 * 16;
     if ((rc = ensurePinned(ctx, ctx->hS3pass, descOff + nBlocks * sizeof(SwBlockDesc))) != FSGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->s3pass, descOff + nBlocks * sizeof(SwBlockDesc))) != FSGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->s3res, total * 16)) != FSGPU_OK) return rc;
-    if ((rc = ensurePinned(ctx, ctx->hS3res, total * 16)) != FSGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->s3res, total * 16 * nDirs)) != FSGPU_OK) return rc;
+    if ((rc = ensurePinned(ctx, ctx->hS3res, total * 16 * nDirs)) != FSGPU_OK) return rc;
     uint32_t *hTids = (uint32_t *) ctx->hS3pass.p;
     SwBlockDesc *hBlk = (SwBlockDesc *) ((unsigned char *) ctx->hS3pass.p + descOff);
     for (int i = 0; i < nq; i++) {
@@ -1832,11 +1838,11 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
             // first pair of a workgroup is its longest: longest workgroups first
             std::stable_sort(hBlk + g.blk0, hBlk + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return len[hTids[x.firstPair]] > len[hTids[y.firstPair]]; });
         }
-        ctx->swDirCells[dir] = cells; ctx->swDirPairs[dir] = pairs; ctx->swDirWaveSteps[dir] = winsts;
+        ctx->swDirCells[slot] = cells * nDirs; ctx->swDirPairs[slot] = pairs * nDirs; ctx->swDirWaveSteps[slot] = winsts * nDirs;
     }
     HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
-    if (dir == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-    HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir], ctx->stream));
+    if (slot == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot], ctx->stream));
     // every launch group gets a stream: their long-target tails overlap instead of queueing up
     const size_t nStreams = std::min<size_t>(groups.size(), 6);
     if (nStreams > 1) {
@@ -1845,7 +1851,9 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         HIPCHK(hipEventRecord(ctx->swAuxEv[6], ctx->stream));
         for (size_t k = 1; k < nStreams; k++) HIPCHK(hipStreamWaitEvent(ctx->swAux[k], ctx->swAuxEv[6], 0));
     }
-    for (size_t gi = 0; gi < groups.size(); gi++) {
+    for (size_t gx = 0; gx < groups.size() * (size_t) nDirs; gx++) {
+        const size_t gi = gx % groups.size();
+        const int d = (int) (gx / groups.size());
         const Group &g = groups[gi];
         const size_t k = gi % nStreams;
         hipStream_t gs = k == 0 ? ctx->stream : ctx->swAux[k];
@@ -1856,22 +1864,23 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         sa.blocks = (const SwBlockDesc *) ((const unsigned char *) ctx->s3pass.p + descOff) + g.blk0;
         sa.go = (uint32_t) gapOpen | ((uint32_t) gapOpen << 16);
         sa.ge = (uint32_t) gapExtend | ((uint32_t) gapExtend << 16);
-        sa.dir = dir;
-        sa.res0 = (int32_t *) ctx->s3res.p;
+        sa.dir = dir0 + d;
+        sa.res0 = (int32_t *) ctx->s3res.p + (size_t) d * total * 4;
         rc = hasAA ? fsgpuLaunchSw3AA(ctx, g.rlo, g.HL, sa, (int) g.nblk, g.waves, g.lds, gs) : fsgpuLaunchSw3NA(ctx, g.rlo, g.HL, sa, (int) g.nblk, g.waves, g.lds, gs);
         if (rc != FSGPU_OK) { for (size_t x = 1; x < nStreams; x++) (void) hipStreamSynchronize(ctx->swAux[x]); return rc; }
     }
     for (size_t k = 1; k < nStreams; k++) { HIPCHK(hipEventRecord(ctx->swAuxEv[k], ctx->swAux[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[k], 0)); }
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-    HIPCHK(hipEventRecord(ctx->swDirEv[2 * dir + 1], ctx->stream));
-    ctx->swDirValid[dir] = true;
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot + 1], ctx->stream));
+    ctx->swDirValid[slot] = true;
     ctx->evValid[1] = true;
-    HIPCHK(hipMemcpyAsync(ctx->hS3res.p, ctx->s3res.p, total * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->hS3res.p, ctx->s3res.p, total * 16 * nDirs, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
-    {
-        const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hS3res.p;
+    for (int d = 0; d < nDirs; d++) {
+        const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hS3res.p + (size_t) d * total;
+        fsgpu_swres *dst = d == 0 ? out : out2;
         for (int i = 0; i < nq; i++)
-            for (int k = 0; k < nSel(i); k++) out[base[i] + perm[sbase[i] + k]] = r0[sbase[i] + k];
+            for (int k = 0; k < nSel(i); k++) dst[base[i] + perm[sbase[i] + k]] = r0[sbase[i] + k];
     }
     // int16-saturated pairs: the single-query path re-runs them with the int32 kernel (computes both directions, keeps `dir`)
     std::vector<fsgpu_swres> f2, r2;
@@ -1882,7 +1891,7 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         std::vector<int> where;
         for (int k = 0; k < ns; k++) {
             const int j = selIdx(i, k);
-            if (out[base[i] + j].score == 32767) { ids.push_back(q[i].targetIds[j]); where.push_back(j); }
+            if (out[base[i] + j].score == 32767 || (dir == 2 && out2[base[i] + j].score == 32767)) { ids.push_back(q[i].targetIds[j]); where.push_back(j); }
         }
         if (ids.empty()) continue;
         Prof pr;
@@ -1891,10 +1900,27 @@ int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *mat
         rc = fsgpu_sw_batch(ctx, hasAA ? pr.aF.data() : nullptr, pr.sF.data(), hasAA ? pr.aR.data() : nullptr, pr.sR.data(), q[i].L, ids.data(), (int) ids.size(),
                             gapOpen, gapExtend, f2.data(), r2.data());
         if (rc != FSGPU_OK) return rc;
-        for (size_t k = 0; k < ids.size(); k++) out[base[i] + where[k]] = dir == 0 ? f2[k] : r2[k];
+        for (size_t k = 0; k < ids.size(); k++) {
+            if (dir == 2) {           // only the saturated direction is replaced (the other one's int16 result stands, as in two separate passes)
+                if (out[base[i] + where[k]].score == 32767) out[base[i] + where[k]] = f2[k];
+                if (out2[base[i] + where[k]].score == 32767) out2[base[i] + where[k]] = r2[k];
+            } else out[base[i] + where[k]] = dir == 0 ? f2[k] : r2[k];
+        }
     }
     return FSGPU_OK;
 }
+
+int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend, int dir,
+                         const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out) {
+    if (dir != 0 && dir != 1) return FSGPU_E_ARG;
+    return sw3MultiImpl(ctx, mat3Di, matAA, q, nq, gapOpen, gapExtend, dir, sel, nsel, out, nullptr);
+}
+
+int fsgpu_sw_multi_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend,
+                     fsgpu_swres *fwd, fsgpu_swres *rev) {
+    return sw3MultiImpl(ctx, mat3Di, matAA, q, nq, gapOpen, gapExtend, 2, nullptr, nullptr, fwd, rev);
+}
+
 
 // both directions of every pair: two fsgpu_sw_multi_dir passes (callers that gate between the passes save most of the second)
 int fsgpu_sw_multi(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapOpen, int gapExtend, fsgpu_swres *fwd, fsgpu_swres *rev) {

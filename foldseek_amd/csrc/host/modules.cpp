@@ -438,7 +438,7 @@ struct DeviceSet {
     std::vector<fsgpu_ctx *> root;            // one context per GPU, each owning that GPU's resident DB (+ k-mer index)
     int perGpuThreads = 1;
     int threads() const { return (int) root.size() * perGpuThreads; }
-    bool open(const Options &o, const PaddedTarget &pt, bool withAA, int defaultThreads, std::string &err) {
+    bool open(const Options &o, const PaddedTarget &pt, bool withAA, int defaultThreads, std::string &err, bool alignFeeders = false) {
         int count = 0;
         const int first = o.geti("--gpu-device", 0);
         auto it = o.kv.find("--gpus");
@@ -467,6 +467,17 @@ struct DeviceSet {
             { const char *e = getenv("FSGPU_REQUIRE_RCCL"); if (!usedRccl && e && *e && *e != '0' && !getenv("FSGPU_NO_RCCL")) { err = "GPU: the RCCL broadcast of the target DB was not used (FSGPU_REQUIRE_RCCL=1)"; return false; } }
         }
         perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 32));
+        if (alignFeeders) {
+            // Modules that align (search, structurealign): --threads is the number of cores the job may use, as for the reference's OpenMP
+            // loop.  The per-hit backtraces -- most of the host work once a hit list holds real homologs -- run in the process-wide worker
+            // pool (search.cpp::HostPool, --threads workers), the feeder threads issue the device batches and sleep while they wait: half
+            // as many feeders as cores, at most 8 per GPU.  All-vs-all of 200 000 structures, 16-core quota (tools/allvsall_ab2.sh):
+            // 16 feeders + 6 workers 3.23 s, 12 + 8 3.07 s, 8 + 8 2.81 s, 8 + 16 2.58 s, 4 + 14 2.77 s.  FSGPU_FEEDERS / FSGPU_HOST_WORKERS override.
+            const int cores = perGpuThreads;
+            const char *ef = getenv("FSGPU_FEEDERS");
+            perGpuThreads = ef ? std::max(1, std::min(atoi(ef), 32)) : std::max(1, std::min(8, (cores + 1) / 2));
+            if (!getenv("FSGPU_HOST_WORKERS")) fshost_set_host_workers(cores >= 4 ? cores : std::max(0, cores - 1));
+        }
         return true;
     }
     // worker tix runs on GPU tix % nGpus; the first worker of a GPU uses its root context, the others a clone
@@ -954,7 +965,7 @@ int fsmod_search(int argc, const char **argv) {
     if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
     const double tLoaded = nowSec();
     DeviceSet ds;
-    if (!ds.open(o, pt, true, 3, err)) { ds.close(); return fail(err); }
+    if (!ds.open(o, pt, true, 3, err, true)) { ds.close(); return fail(err); }
     const int maxRes = (int) std::min<uint64_t>((uint64_t) par.maxResListLen, std::max<uint64_t>(t3.size(), 1));
     if (prefMode == 0) {
         fsgpu_kmer_index_params ip;
@@ -1146,7 +1157,7 @@ int fsmod_structurealign(int argc, const char **argv) {
     PaddedTarget pt;
     if (!loadPadded(t3, &tA, m3, &mA, pt, err)) return fail(err);
     DeviceSet ds;
-    if (!ds.open(o, pt, true, 3, err)) { ds.close(); return fail(err); }
+    if (!ds.open(o, pt, true, 3, err, true)) { ds.close(); return fail(err); }
     DbWriter w;
     if (!w.open(o.pos[3], DBTYPE_ALIGNMENT_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();

@@ -80,7 +80,11 @@ public:
         for (;;) { const int i = job.next.fetch_add(1); if (i >= n) break; fn(i); job.done.fetch_add(1); }
         if (n > 1 && workers() > 0) {
             { std::lock_guard<std::mutex> g(m_); jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job)); }
-            while (job.done.load(std::memory_order_acquire) < n || job.inside.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+            // the tail of the job is in the workers' hands: wait without burning the core they may need (a spinning owner per feeder thread
+            // cost the all-vs-all module 10 % of its wall time on a 16-core quota)
+            for (int spins = 0; job.done.load(std::memory_order_acquire) < n || job.inside.load(std::memory_order_acquire) > 0; spins++) {
+                if (spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
         }
     }
     void resize(int n) {
@@ -608,8 +612,27 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
     };
     s->fwd.resize(total); s->rev.assign(total, fsgpu_swres{0, 0, 0, 0});
     const double t1 = nowSec();
-    // forward pass over every pair; the reversed-query pass only over the pairs whose forward score passes the gates
-    int rc = pass(0, nullptr, nullptr, s->fwd.data());
+    // A small batch (the all-vs-all steps: a few thousand pairs per call) is bound by round trips, not by DP cells: both directions of
+    // every pair in one submission.  Otherwise: forward pass over every pair, the reversed-query pass only over the pairs whose forward
+    // score passes the gates (3-16 % of a search's hit lists).  FSGPU_SW_ONEPASS_PAIRS overrides the limit (0 = never).
+    static const size_t onePassPairs = [] { const char *e = getenv("FSGPU_SW_ONEPASS_PAIRS"); return e ? (size_t) atoll(e) : (size_t) 16384; }();
+    int rc;
+    if (!viaProfiles && total > 0 && total <= onePassPairs) {
+        rc = fsgpu_sw_multi_c(s->ctx, m3, mA, dq.data(), nq, par.gapOpen, par.gapExtend, s->fwd.data(), s->rev.data());
+        if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+        size_t b = 0, any = 0;
+        for (int i = 0; i < nq; i++) {
+            for (int k = 0; k < n[i]; k++) {
+                const uint32_t tid = targetIds[i][k];
+                if (tid >= s->keys.size()) { s->err = "target id out of range"; return FSGPU_E_ARG; }
+                if (needsReversePass(s, aq[i], tid, s->fwd[b + k])) any++;
+                else s->rev[b + k] = fsgpu_swres{0, 0, 0, 0};          // what the two-pass form leaves for pairs structurealign never reverses
+            }
+            b += (size_t) n[i];
+        }
+        s->stats[7] = (double) any;
+    } else {
+    rc = pass(0, nullptr, nullptr, s->fwd.data());
     if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
     {
         std::vector<std::vector<int32_t>> sel(nq);
@@ -630,6 +653,7 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
             rc = pass(1, selp.data(), nsel.data(), s->rev.data());
             if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
         }
+    }
     }
     const double t2 = nowSec();
     double tBack = 0;

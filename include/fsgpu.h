@@ -199,6 +199,11 @@ typedef struct {
 } fsgpu_sw_cquery;
 int fsgpu_sw_multi_dir_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend,
                          int dir, const int32_t *const *sel, const int32_t *nsel, fsgpu_swres *out);
+/* Both directions of every pair in ONE submission (one upload, one wait): for batches whose device time is small against a round trip --
+ * all-vs-all steps with a handful of hits per query -- computing the reversed-query score of every pair is cheaper than gating on the
+ * host between two passes.  fwd / rev as in fsgpu_sw_multi. */
+int fsgpu_sw_multi_c(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matAA, const fsgpu_sw_cquery *q, int nq, int gapOpen, int gapExtend,
+                     fsgpu_swres *fwd, fsgpu_swres *rev);
 /* Asynchronous halves of fsgpu_sw_batch.  The four profile arrays and targetIds are BORROWED until fsgpu_sw_finish returns
  * (the int32 re-run of saturated pairs reads the profiles again); after a failed _launch nothing is pending. */
 int fsgpu_sw_launch(fsgpu_ctx *ctx, const int16_t *pAA_fwd, const int16_t *p3Di_fwd,

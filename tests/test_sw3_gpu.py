@@ -131,6 +131,9 @@ def test_sw3_gap_costs_and_int16_saturation(env):
         got = ctx.sw_multi_dir_c(t3, tA, [(qa, q3, cb, cb, cb, cb, ids)], d)
         _same(got[0], want[d], ("saturated", d))
         assert (got[0]["word"] == want[d]["word"]).all()
+    both = ctx.sw_multi_c(t3, tA, [(qa, q3, cb, cb, cb, cb, ids)])
+    for d in (0, 1):
+        _same(both[d][0], want[d], ("saturated, one submission", d))
 
 
 def test_sw3_large_batch_of_small_hit_lists(env):
@@ -151,6 +154,9 @@ def test_sw3_large_batch_of_small_hit_lists(env):
         queries.append((qa, q3, cba_f, cb3_f, cba_r, cb3_r, ids))
     got_f = ctx.sw_multi_dir_c(t3, tA, queries, 0)
     got_r = ctx.sw_multi_dir_c(t3, tA, queries, 1)
+    both_f, both_r = ctx.sw_multi_c(t3, tA, queries)            # both directions in one submission
+    for k in range(len(queries)):
+        assert both_f[k].tobytes() == got_f[k].tobytes() and both_r[k].tobytes() == got_r[k].tobytes(), k
     for k in range(0, len(queries), 7):          # every 7th query against the per-pair kernel
         qa, q3, cba_f, cb3_f, cba_r, cb3_r, ids = queries[k]
         f, r = ctx.sw_batch(_profiles(tA, qa, cba_f), _profiles(t3, q3, cb3_f), _profiles(tA, qa, cba_r, True), _profiles(t3, q3, cb3_r, True), ids)
