@@ -44,6 +44,16 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     ctx->numCU = prop.multiProcessorCount;
     if (const char *e2 = getenv("FSGPU_GAPLESS_BLOCKS_PER_CU")) ctx->gaplessBlocksPerCU = std::max(1, atoi(e2));
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    {
+        // the batch SW of a context runs on a stream of the highest priority: its launches are short and a host thread waits for them, while the
+        // scans and k-mer batches of the other contexts would otherwise keep them queueing (FSGPU_SW_PRIORITY=0: use the context's stream)
+        const char *pe = getenv("FSGPU_SW_PRIORITY");
+        int lo = 0, hi = 0;
+        if (!(pe && atoi(pe) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
+            if (hipStreamCreateWithPriority(&ctx->swHi, hipStreamNonBlocking, hi) != hipSuccess) { ctx->swHi = nullptr; (void) hipGetLastError(); }
+            ctx->swHiPrio = hi;
+        }
+    }
     for (int i = 0; i < 4; i++)
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipMalloc((void **) &ctx->dMeta, sizeof(SelMeta))) != hipSuccess) return fail("hipMalloc", e);
@@ -87,6 +97,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p); hipHostFree(ctx->hLbuf.p); hipHostFree(ctx->hLres.p);
     hipHostFree(ctx->hS3pass.p); hipHostFree(ctx->hS3build.p); hipHostFree(ctx->hS3res.p);
     if (ctx->swLong) (void) hipStreamDestroy(ctx->swLong);
+    if (ctx->swHi) (void) hipStreamDestroy(ctx->swHi);
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);
     hipHostFree(ctx->hMqPssm.p); hipHostFree(ctx->hMqRec.p); hipHostFree(ctx->hMqMeta.p); hipHostFree(ctx->hMqOutId.p); hipHostFree(ctx->hMqOutScore.p); hipHostFree(ctx->hMqIdent.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
@@ -1618,6 +1629,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     const bool hasAA = matAA != nullptr;
     if (hasAA && !ctx->db->hasAA) { ctx->err = "AA matrix given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
     HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t S = ctx->swHi ? ctx->swHi : ctx->stream;          // everything of the k_sw3 path: uploads, image build, launches, download
     std::vector<size_t> base(nq + 1, 0), sbase(nq + 1, 0);
     for (int i = 0; i < nq; i++) {
         if (!q[i].q3Di || (hasAA && !q[i].qAA) || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN || q[i].n < 0 || (q[i].n > 0 && !q[i].targetIds)) { ctx->err = "fsgpu_sw_multi_dir_c: bad query"; return FSGPU_E_ARG; }
@@ -1768,17 +1780,19 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
             dpos += (6 * L + 15) / 16 * 16;
             if (dpos - dataOff0 >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: query data of one call exceeds 4 GiB"; return FSGPU_E_NOMEM; }
         }
-        HIPCHK(hipMemcpyAsync(ctx->s3build.p, hb, dpos, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->s3build.p, hb, dpos, hipMemcpyHostToDevice, S));
         const unsigned char *db = (const unsigned char *) ctx->s3build.p;
         rc = fsgpuLaunchSw3Image(ctx, (const Sw3ImgQuery *) db, nImg, maxDw, db + dataOff0, (const int8_t *) (db + matOff), (const int8_t *) (db + matOff + 512),
-                                 (uint32_t *) ctx->s3img.p, hasAA, ctx->stream);
+                                 (uint32_t *) ctx->s3img.p, hasAA, S);
         if (rc != FSGPU_OK) return rc;
         ctx->s3Sig = sig;
     }
-    // ---- workgroup descriptors: one launch per (lanes per target pair, rows-per-lane range 1..8 / 9..16) ----
+    // ---- workgroup descriptors: one launch per (lanes per target pair, rows-per-lane range 1..4 / 5..8 / 9..12 / 13..16) ----
     struct Part { int q, key, R, first, n; };       // pairs [first, first + n) of query q's sorted list run with R rows per lane in launch group `key`
     std::vector<Part> parts;
-    auto keyOf = [](int HL, int R) { return (HL == 64 ? 2 : 0) + (R > 8 ? 1 : 0); };
+    // launch groups: lanes per target pair x rows-per-lane range of four (the dynamic LDS of a launch is that of its largest R: a query of
+    // 9 rows per lane must not take the 106 KB of one with 16 and lose its second workgroup per CU); kernels exist for R = 1..8 and 9..16
+    auto keyOf = [](int HL, int R) { return (HL == 64 ? 4 : 0) + (R - 1) / 4; };
     for (int i = 0; i < nq; i++) {
         const int ns = nSel(i);
         if (ns == 0) continue;
@@ -1789,8 +1803,8 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     struct Group { int key, HL, rlo, maxR, waves, lds; size_t blk0, nblk; };
     std::vector<Group> groups;
     size_t nBlocks = 0;
-    for (int key = 3; key >= 0; key--) {            // the 64-lane groups (the long targets) first
-        Group g{key, key >= 2 ? 64 : 32, (key & 1) ? 9 : 1, 0, 0, 0, nBlocks, 0};
+    for (int key = 7; key >= 0; key--) {            // the 64-lane groups (the long targets) first
+        Group g{key, key >= 4 ? 64 : 32, (key & 3) >= 2 ? 9 : 1, 0, 0, 0, nBlocks, 0};
         for (const Part &pt : parts) if (pt.key == key) g.maxR = std::max(g.maxR, pt.R);
         if (g.maxR == 0) continue;
         g.waves = sw3Waves(g.maxR, g.HL, hasAA);
@@ -1840,15 +1854,15 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         }
         ctx->swDirCells[slot] = cells * nDirs; ctx->swDirPairs[slot] = pairs * nDirs; ctx->swDirWaveSteps[slot] = winsts * nDirs;
     }
-    HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
-    if (slot == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-    HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot], ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, S));
+    if (slot == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], S));
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot], S));
     // every launch group gets a stream: their long-target tails overlap instead of queueing up
     const size_t nStreams = std::min<size_t>(groups.size(), 6);
     if (nStreams > 1) {
         if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
-        for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking));
-        HIPCHK(hipEventRecord(ctx->swAuxEv[6], ctx->stream));
+        for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) { if (ctx->swHi) HIPCHK(hipStreamCreateWithPriority(&ctx->swAux[k], hipStreamNonBlocking, ctx->swHiPrio)); else HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking)); }
+        HIPCHK(hipEventRecord(ctx->swAuxEv[6], S));
         for (size_t k = 1; k < nStreams; k++) HIPCHK(hipStreamWaitEvent(ctx->swAux[k], ctx->swAuxEv[6], 0));
     }
     for (size_t gx = 0; gx < groups.size() * (size_t) nDirs; gx++) {
@@ -1856,7 +1870,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         const int d = (int) (gx / groups.size());
         const Group &g = groups[gi];
         const size_t k = gi % nStreams;
-        hipStream_t gs = k == 0 ? ctx->stream : ctx->swAux[k];
+        hipStream_t gs = k == 0 ? S : ctx->swAux[k];
         Sw3Args sa;
         sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
         sa.targetIds = (const uint32_t *) ctx->s3pass.p;
@@ -1869,13 +1883,13 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         rc = hasAA ? fsgpuLaunchSw3AA(ctx, g.rlo, g.HL, sa, (int) g.nblk, g.waves, g.lds, gs) : fsgpuLaunchSw3NA(ctx, g.rlo, g.HL, sa, (int) g.nblk, g.waves, g.lds, gs);
         if (rc != FSGPU_OK) { for (size_t x = 1; x < nStreams; x++) (void) hipStreamSynchronize(ctx->swAux[x]); return rc; }
     }
-    for (size_t k = 1; k < nStreams; k++) { HIPCHK(hipEventRecord(ctx->swAuxEv[k], ctx->swAux[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->swAuxEv[k], 0)); }
-    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-    HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot + 1], ctx->stream));
+    for (size_t k = 1; k < nStreams; k++) { HIPCHK(hipEventRecord(ctx->swAuxEv[k], ctx->swAux[k])); HIPCHK(hipStreamWaitEvent(S, ctx->swAuxEv[k], 0)); }
+    HIPCHK(hipEventRecord(ctx->ev[3], S));
+    HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot + 1], S));
     ctx->swDirValid[slot] = true;
     ctx->evValid[1] = true;
-    HIPCHK(hipMemcpyAsync(ctx->hS3res.p, ctx->s3res.p, total * 16 * nDirs, hipMemcpyDeviceToHost, ctx->stream));
-    if ((rc = syncStream(ctx)) != FSGPU_OK) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->hS3res.p, ctx->s3res.p, total * 16 * nDirs, hipMemcpyDeviceToHost, S));
+    if ((rc = syncStreamOf(ctx, S)) != FSGPU_OK) return rc;
     for (int d = 0; d < nDirs; d++) {
         const fsgpu_swres *r0 = (const fsgpu_swres *) ctx->hS3res.p + (size_t) d * total;
         fsgpu_swres *dst = d == 0 ? out : out2;

@@ -102,6 +102,8 @@ struct fsgpu_ctx {
     std::vector<int> mqSlot;                    // query index of the last call -> slice of mqScores (-1: went through the single-query path)
 
     // sw scratch
+    hipStream_t swHi = nullptr;                 // highest-priority stream of the batch SW (fsgpu_sw_multi_dir_c); null: ctx->stream
+    int swHiPrio = 0;
     hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
     hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf img, tids, res0, res1, border0, border1, keys;

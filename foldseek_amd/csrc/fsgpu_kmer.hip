@@ -117,9 +117,21 @@ void fsgpu_kmer_free_scratch(KmerScratch *s) {
 static inline unsigned gridFor(uint64_t n, unsigned block) { return (unsigned) std::max<uint64_t>(1, (n + block - 1) / block); }
 
 // scratch grows geometrically: batch sizes differ from call to call and a hipFree/hipMalloc pair costs milliseconds
+// scratch of a k-mer batch.  Out of device memory is reported as FSGPU_E_NOMEM (with the over-allocation dropped first): the caller of
+// kmerBatch halves the batch instead of failing the search
 static int ensureK(fsgpu_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.cap >= bytes && b.p) return FSGPU_OK;
-    return ensure(ctx, b, bytes + bytes / 2 + (1u << 20));
+    if (b.p) { RPCHK(hipStreamSynchronize(ctx->stream)); (void) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t wants[2] = {bytes + bytes / 2 + (1u << 20), bytes};
+    for (size_t want : wants) {
+        const hipError_t e = hipMalloc(&b.p, want);
+        if (e == hipSuccess) { b.cap = want; return FSGPU_OK; }
+        b.p = nullptr;
+        (void) hipGetLastError();
+        if (e != hipErrorOutOfMemory) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return FSGPU_E_HIP; }
+    }
+    ctx->err = "k-mer search: out of device memory for the scratch of one batch (" + std::to_string(bytes >> 20) + " MiB requested)";
+    return FSGPU_E_NOMEM;
 }
 
 template <class T>
@@ -482,6 +494,8 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
 
 } // namespace
 
+constexpr double kKmerHitBudget = 2.4e8;          // index hits of one device batch (24 B of scratch each)
+
 static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const fsgpu_kmer_query *queries, int nq,
                      fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats) {
     KmerIndex &ix = *ctx->kidx;
@@ -495,7 +509,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     const uint64_t maxDbMatches = sp.maxDbMatches ? (uint64_t) sp.maxDbMatches : big * 2;
     const uint32_t maxHits = (uint32_t) std::min<uint64_t>((uint64_t) sp.maxResListLen, n);
     int rc;
-#define CHK(x) do { rc = (x); if (rc != FSGPU_OK) return rc; } while (0)
+#define CHK(x) do { rc = (x); if (rc == FSGPU_E_NOMEM && nq > 1) return 1; if (rc != FSGPU_OK) return rc; } while (0)
     // FSGPU_KMER_TRACE=1: host wall clock of the phases of a batch on stderr (where a feeder thread's time goes between the device stages)
     static const bool trace = getenv("FSGPU_KMER_TRACE") != nullptr;
     auto tPrev = std::chrono::steady_clock::now();
@@ -635,6 +649,9 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         if (nq > 1) return 1;                                // caller halves the batch
         ctx->err = "k-mer search: a single query produces more than 2^32 index hits"; return FSGPU_E_UNSUPPORTED;
     }
+    // the batch was sized from the PREVIOUS batch's hits per query: one that comes out far beyond the budget (long queries after short
+    // ones, a first call with many queries) is split here, where its size is known and none of the 24-bytes-per-hit scratch exists yet
+    if (nq > 1 && (double) nHits > 2.0 * kKmerHitBudget) return 1;
     const KmerChunks *hck = (const KmerChunks *) S.hChunks.p;
     // ---- stage 2: hit stream -> (query, bin) segments -> double-diagonal candidates (k_kmer.hpp) ---------------------
     KmerDupArgs da{};
@@ -839,8 +856,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         static const int a[9] = {0, 0, 1, 2, 3, 4, 5, 6, 7}, b[9] = {9, 1, 2, 3, 4, 5, 6, 7, 8};
         // [0] total, [1] count+scan, [2] lists+chunks, [3] emit, [4] sort, [5] dup flags+scan, [6] compact+score, [7] walk, [8] hist/cut/out
         // summed over the device batches of one fsgpu_kmer_search call (the caller resets them)
-        for (int i = 0; i < 9; i++) if (hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess) ctx->kmerMs[i] += (double) ms;
-        if (nLists && hipEventElapsedTime(&ms, S.ev[10], S.ev[11]) == hipSuccess) ctx->kmerMs[10] += (double) ms;
+        for (int i = 0; i < 9; i++) if (hipEventElapsedTime(&ms, S.ev[a[i]], S.ev[b[i]]) == hipSuccess) ctx->kmerMs[i] = std::max(0.0, ctx->kmerMs[i]) + (double) ms;
+        if (nLists && hipEventElapsedTime(&ms, S.ev[10], S.ev[11]) == hipSuccess) ctx->kmerMs[10] = std::max(0.0, ctx->kmerMs[10]) + (double) ms;
         (void) hipGetLastError();   // an elapsed-time query must never leave a sticky error behind
         ctx->kmerCounts[0] += nLists; ctx->kmerCounts[1] += nHits; ctx->kmerCounts[2] += nCand; ctx->kmerCounts[3] += totalOut;
     }
@@ -868,7 +885,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             stats[q * 4 + 3] = (double) pickBins(sp, n);
         }
     }
-    ctx->kmerMs[9] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTail).count();
+    ctx->kmerMs[9] = std::max(0.0, ctx->kmerMs[9]) + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTail).count();
     mark("host tail");
     if (trace) fprintf(stderr, "kmer batch nq=%d hits=%llu cand=%u:%s\n", nq, (unsigned long long) nHits, nCand, traceLine.c_str());
 #undef CHK
@@ -889,12 +906,12 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
     // size of the next one, a batch that still comes out too large is halved and redone
     const int tb = ctx->kidx->tbits;
     const int maxBatch = std::max(1, std::min(1 << std::min(12, 32 - tb), 1024));
-    const double hitBudget = 2.4e8;
-    for (int i = 0; i < 12; i++) ctx->kmerMs[i] = 0;
+    const double hitBudget = kKmerHitBudget;
+    for (int i = 0; i < 12; i++) ctx->kmerMs[i] = -1;          // < 0: nothing recorded (fsgpu_last_kernel_ms)
     for (int i = 0; i < 4; i++) ctx->kmerCounts[i] = 0;
     int q0 = 0;
     while (q0 < nq) {
-        int batch = maxBatch;
+        int batch = std::min(maxBatch, 32);                   // no history on this context: a batch of 32 shows what a query costs here
         if (ctx->kmerHitsPerQuery > 0) batch = (int) std::max(8.0, std::min((double) maxBatch, hitBudget / ctx->kmerHitsPerQuery));
         batch = std::min(batch, maxBatch);
         if (ctx->kmerBatchCap > 0) batch = std::min(batch, ctx->kmerBatchCap);
@@ -903,8 +920,9 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
         const int m = (left + parts - 1) / parts;
         const uint64_t hitsBefore = ctx->kmerCounts[1];
         int rc = kmerBatch(ctx, *p, queries + q0, m, out + (size_t) q0 * p->maxResListLen, nout + q0, status + q0, stats ? stats + (size_t) q0 * 4 : nullptr);
-        if (rc == 1) { ctx->kmerBatchCap = std::max(1, m / 2); continue; }            // more than 2^32 hits: redo with half the queries
+        if (rc == 1) { ctx->kmerBatchCap = std::max(1, m / 2); continue; }            // too many hits / out of memory: redo with half the queries
         if (rc != FSGPU_OK) return rc;
+        if (ctx->kmerBatchCap > 0) ctx->kmerBatchCap = 2 * ctx->kmerBatchCap >= maxBatch ? 0 : 2 * ctx->kmerBatchCap;   // one heavy batch does not cap the context for good
         ctx->kmerHitsPerQuery = (double) (ctx->kmerCounts[1] - hitsBefore) / (double) std::max(1, m);
         q0 += m;
     }

@@ -118,7 +118,12 @@ void Marv::setDb(void *dbhandle) {
             size_t at = 0;
             for (size_t i = k; i < db->n; i += N) {
                 const size_t len = extent(i);
-                memcpy(packed.data() + at, db->data + db->offsets[i], len);
+                // a database not written by makepaddedseqdb may end an entry without its padding: never read past the caller's buffer,
+                // the missing bytes are X like the padding would be
+                if (db->offsets[i] > db->bytes || (size_t) db->lengths[i] > db->bytes - db->offsets[i]) die("target database: an entry lies outside the data buffer");
+                const size_t have = std::min<size_t>(len, db->bytes - db->offsets[i]);
+                memcpy(packed.data() + at, db->data + db->offsets[i], have);
+                if (have < len) memset(packed.data() + at + have, 20, len - have);
                 sh.offsets.push_back(at); sh.lengths.push_back(db->lengths[i]); sh.globalId.push_back((uint32_t) i);
                 at += len;
             }
