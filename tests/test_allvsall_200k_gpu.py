@@ -36,9 +36,8 @@ PREF = ["--sub-mat", "aa:3di.out,nucl:3di.out", "--seed-sub-mat", "aa:3di.out,nu
 
 def _aln_par():
     par = list(MANIFEST["runs"]["aln_t2_a_e001_c08"]["parameters"])
-    for k, v in (("--threads", "16"), ("--comp-bias-corr", "0"), ("--add-self-matches", "1")):
+    for k, v in (("--threads", "16"), ("--comp-bias-corr", "0"), ("--add-self-matches", "1"), ("-e", "0.01")):
         par[par.index(k) + 1] = v
-    assert par[par.index("-e") + 1] in ("0.01", "1.000E-02") or float(par[par.index("-e") + 1]) == 0.01
     assert float(par[par.index("-c") + 1]) == 0.8
     return par
 
