@@ -500,6 +500,19 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         dist.barrier()
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
     gc.enable()
+    # one batch alone on the device (the middle one of this rank's timed batches): the solo figures of both rooflines
+    solo = None
+    if timed:
+        keep_stat = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in stat.items()}
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            run(0, timed[len(timed) // 2], False)
+            ms_i, cnt_i, swp_i = ctxs[0].kmer_stage_ms(), ctxs[0].kmer_counts(), ctxs[0].sw_last_passes()
+            if best is None or ms_i[0] < best[0][0]:
+                best = (ms_i, cnt_i, swp_i)
+        solo = best
+        stat.update(keep_stat)
     stat["stage"] = stat["stage"].tolist(); stat["cnt"] = stat["cnt"].tolist()
     mine_swp = stat.pop("swp")
     tot = fdist.gather_objects(stat)
@@ -513,6 +526,16 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         # 8 per similar k-mer (two u32 offsets of the probe) + 8 per index hit (the entry gathered) + the target residues under every scored diagonal
         alg = 8.0 * s0["cnt"][0] + 8.0 * s0["cnt"][1] + s0["diag_bytes"]
         dev_s = s0["stage"][0] * 1e-3
+        e, traffic_src = pmc_traffic_entry(os.path.join(ROOT, "profiles", "pmc_traffic_allvsall.json"), targets)
+        per_hit = None if e is None else e.get("k_kmer_all_bytes_per_index_hit")
+        solo_obj = None
+        if solo is not None:
+            mean_l = s0["res"] / max(1, s0["q"])
+            salg = 8.0 * float(solo[1][0]) + 8.0 * float(solo[1][1]) + float(solo[1][2]) * mean_l
+            solo_obj = {"note": "one batch alone on the device", "kernel_ms": float(solo[0][0]), "algorithmic_bytes": salg,
+                        "achieved": salg / max(float(solo[0][0]) * 1e-3, 1e-12) / 1e9, "frac": salg / max(float(solo[0][0]) * 1e-3, 1e-12) / 1e9 / 8000.0,
+                        "index_hits_per_launch": float(solo[1][1]), "traffic": None if per_hit is None else per_hit * float(solo[1][1]),
+                        "stage_ms": {k: float(solo[0][i]) for i, k in enumerate(names)}}
         out = {"metric": "residues aligned/sec (prefilter+align)", "value": nq * db.residues / dt, "unit": "residues/s", "n_gpus": world,
                "steps": len(timed), "warmup": len(warm), "ms_per_step": 1e3 * dt / max(1, len(timed)), "higher_is_better": True,
                "scaling": "strong" if (steps <= 0 or strong) else "weak", "vs_baseline": None, "dtype": "u8 k-mer index probes / diagonal scores + i16 SW", "data": "synthetic",
@@ -531,10 +554,11 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
                "similar_kmers_per_query": s0["cnt"][0] / max(1, s0["q"]), "index_hits_per_query": s0["cnt"][1] / max(1, s0["q"]),
                "candidates_per_query": s0["cnt"][2] / max(1, s0["q"]),
                "roofline": {"bound": "hbm", "kernel": f"k_kmer_* (the device part of one prefilter batch of {AB} queries, all kernels)", "unit": "GB/s", "peak": 8000.0,
-                            "achieved": alg / max(dev_s, 1e-12) / 1e9, "frac": alg / max(dev_s, 1e-12) / 1e9 / 8000.0, "traffic": None,
-                            "algorithmic_bytes": alg / nb0, "kernel_ms": s0["stage"][0] / nb0,
+                            "achieved": alg / max(dev_s, 1e-12) / 1e9, "frac": alg / max(dev_s, 1e-12) / 1e9 / 8000.0,
+                            "traffic": None if per_hit is None else per_hit * s0["cnt"][1] / nb0, "traffic_source": traffic_src,
+                            "algorithmic_bytes": alg / nb0, "kernel_ms": s0["stage"][0] / nb0, "solo": solo_obj,
                             "note": "co-running with the other feeder threads' batches and SW launches; bytes = 8 per similar k-mer + 8 per index hit + diagonal residues"},
-               "align_roofline": sw_roofline(mine_swp, True)}
+               "align_roofline": sw_roofline(mine_swp, True, None if solo is None else solo[2])}
         if with_cpu:
             out["cpu_baseline"] = allvsall_cpu_baseline(db, thr)
     for x in searches:
@@ -690,6 +714,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    require_rccl = os.environ.get("FSGPU_REQUIRE_RCCL", "0") not in ("", "0")
+    if world == 1 and require_rccl and have_gpu and not dist.is_initialized():
+        # one GPU: the DB "broadcast" still goes through a (one-rank) RCCL communicator, so that the transport the N-GPU run depends on has run
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
     if have_gpu:
         torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
@@ -747,9 +777,13 @@ def main():
     tensors, db = fdist.broadcast_db(db, dev)
     if have_gpu:
         torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - tb if world > 1 else 0.0
+    if world == 1 and dist.is_initialized():
+        for x in tensors:                      # the one-rank communicator: every buffer of the DB through ncclBroadcast once
+            dist.broadcast(x, 0)
+        torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - tb if (world > 1 or dist.is_initialized()) else 0.0
     mark("db_broadcast")
-    bcast_backend = dist.get_backend() if world > 1 else "none"
+    bcast_backend = dist.get_backend() if dist.is_initialized() else "none"
     if world > 1 and have_gpu and backend == "nccl":
         # the one collective of the path must have gone over RCCL with one rank per device -- no silent fallback
         devs = fdist.gather_objects((rank, torch.cuda.current_device(), str(tensors[0].device)))
@@ -1010,7 +1044,7 @@ def main():
     if rank == 0:
         out["phase_wall_s"] = dict(phase, total_since_start=time.perf_counter() - T_START)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -70,6 +70,7 @@ def lib():
         "fsgpu_device_count": (i32, []),
         "fsgpu_gapless_plan_items": (i64, [vp, C.c_uint32, i32, f64, vp, u64, vp]),
         "fsgpu_db_broadcast": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32)]),
+        "fsgpu_rccl_selfcheck": (i32, [vp]),
         "fsgpu_stream": (vp, [vp]),
         "fsgpu_db_load": (i32, [vp, vp, vp, vp, vp, u64, u64]),
         "fsgpu_db_adopt_device": (i32, [vp, vp, vp, vp, vp, u64, u64]),
@@ -155,7 +156,7 @@ def exported_symbols():
     return ["fsgpu_create", "fsgpu_destroy", "fsgpu_last_error", "fsgpu_device", "fsgpu_stream", "fsgpu_db_load",
             "fsgpu_db_adopt_device", "fsgpu_db_size", "fsgpu_db_residues", "fsgpu_gapless_scan", "fsgpu_gapless_scores",
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_multi_dir_c", "fsgpu_sw_multi_c", "fsgpu_sw_launch", "fsgpu_sw_finish",
-            "fsgpu_db_broadcast", "fsgpu_device_count", "fsgpu_gapless_plan_items",
+            "fsgpu_db_broadcast", "fsgpu_rccl_selfcheck", "fsgpu_device_count", "fsgpu_gapless_plan_items",
             "fsgpu_last_kernel_ms", "fsgpu_sw_last_passes", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
             "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_bins", "fsgpu_kmer_batch_hint"]
 
@@ -288,6 +289,10 @@ class Context:
         for o in others:
             o._keep = self._keep
         return bool(used.value)
+
+    def rccl_selfcheck(self):
+        """librccl on this device alone (one-rank communicator, 1 MiB broadcast in place); raises when it does not run"""
+        self._chk(lib().fsgpu_rccl_selfcheck(self.h), "fsgpu_rccl_selfcheck")
 
     def _chk(self, rc, what):
         if rc != 0:

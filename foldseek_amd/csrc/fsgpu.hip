@@ -304,6 +304,35 @@ struct Rccl {
 };
 } // namespace
 
+// librccl on this context's device, alone: a one-rank communicator broadcasts a 1 MiB buffer in place.  What a single-GPU box can show of
+// the multi-GPU replication path: the library loads, a communicator comes up on the device, a grouped ncclBroadcast runs on the
+// context's stream (FSGPU_REQUIRE_RCCL=1 makes the modules call it even when one GPU is used).
+extern "C" int fsgpu_rccl_selfcheck(fsgpu_ctx *ctx) {
+    if (!ctx) return FSGPU_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    Rccl rccl;
+    if (!rccl.load()) { ctx->err = "fsgpu_rccl_selfcheck: librccl could not be loaded (or FSGPU_NO_RCCL is set)"; return FSGPU_E_UNSUPPORTED; }
+    const size_t bytes = 1 << 20;
+    unsigned char *buf = nullptr;
+    HIPCHK(hipMalloc((void **) &buf, bytes));
+    std::vector<unsigned char> host(bytes);
+    for (size_t i = 0; i < bytes; i++) host[i] = (unsigned char) (i * 131 + 7);
+    int rc = FSGPU_OK;
+    void *comm = nullptr;
+    const int dev = ctx->device;
+    if (hipMemcpy(buf, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "fsgpu_rccl_selfcheck: copy failed"; rc = FSGPU_E_HIP; }
+    else if (rccl.CommInitAll(&comm, 1, &dev) != 0) { ctx->err = "fsgpu_rccl_selfcheck: ncclCommInitAll failed"; rc = FSGPU_E_HIP; }
+    else {
+        const bool ok = rccl.GroupStart() == 0 && rccl.Broadcast(buf, buf, bytes, 1 /*ncclUint8*/, 0, comm, ctx->stream) == 0 && rccl.GroupEnd() == 0 &&
+                        hipStreamSynchronize(ctx->stream) == hipSuccess;
+        std::vector<unsigned char> back(bytes);
+        if (!ok || hipMemcpy(back.data(), buf, bytes, hipMemcpyDeviceToHost) != hipSuccess || back != host) { ctx->err = "fsgpu_rccl_selfcheck: the one-rank ncclBroadcast failed"; rc = FSGPU_E_HIP; }
+        rccl.CommDestroy(comm);
+    }
+    (void) hipFree(buf);
+    return rc;
+}
+
 extern "C" int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *usedRccl) {
     fsgpu_ctx *ctx = src;       // HIPCHK reports into the source context
     if (usedRccl) *usedRccl = 0;

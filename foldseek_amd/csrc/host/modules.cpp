@@ -466,6 +466,14 @@ struct DeviceSet {
             // FSGPU_REQUIRE_RCCL=1: a multi-GPU run whose replication silently fell back to peer copies is an error (scaling runs set it)
             { const char *e = getenv("FSGPU_REQUIRE_RCCL"); if (!usedRccl && e && *e && *e != '0' && !getenv("FSGPU_NO_RCCL")) { err = "GPU: the RCCL broadcast of the target DB was not used (FSGPU_REQUIRE_RCCL=1)"; return false; } }
         }
+        if (want == 1) {
+            // FSGPU_REQUIRE_RCCL=1 on one GPU: nothing to replicate, but the library the replication would use must work on this device
+            const char *e = getenv("FSGPU_REQUIRE_RCCL");
+            if (e && *e && *e != '0' && !getenv("FSGPU_NO_RCCL")) {
+                if (fsgpu_rccl_selfcheck(c0) != FSGPU_OK) { err = std::string("GPU: ") + fsgpu_last_error(c0) + " (FSGPU_REQUIRE_RCCL=1)"; return false; }
+                fprintf(stderr, "RCCL self-check on device %d: one-rank communicator + ncclBroadcast ok (usedRccl 1)\n", first);
+            }
+        }
         perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 32));
         if (alignFeeders) {
             // Modules that align (search, structurealign): --threads is the number of cores the job may use, as for the reference's OpenMP
@@ -478,6 +486,9 @@ struct DeviceSet {
             perGpuThreads = ef ? std::max(1, std::min(atoi(ef), 32)) : std::max(1, std::min(8, (cores + 1) / 2));
             if (!getenv("FSGPU_HOST_WORKERS")) fshost_set_host_workers(cores >= 4 ? cores : std::max(0, cores - 1));
         }
+        if (moduleTiming() || getenv("FSGPU_REQUIRE_RCCL"))
+            fprintf(stderr, "host budget: %d usable cores (cgroup quota), %d GPU(s), %d feeder thread(s) per GPU, %d backtrace workers\n",
+                    fshost_usable_cores(), (int) root.size(), perGpuThreads, fshost_host_workers());
         return true;
     }
     // worker tix runs on GPU tix % nGpus; the first worker of a GPU uses its root context, the others a clone

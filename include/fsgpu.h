@@ -84,6 +84,9 @@ int fsgpu_clone(const fsgpu_ctx *src, fsgpu_ctx **out);
  * devices with no further communication (the reference's multi-GPU path shards TARGETS per device and
  * merges top-N lists, M/lib/libmarv/src/cudasw4.cuh:1477-1553 -- not needed when the DB fits every GPU's 288 GB). */
 int fsgpu_db_broadcast(fsgpu_ctx *src, fsgpu_ctx **dst, int n, int *usedRccl);
+/* librccl alone on this context's device: a one-rank communicator broadcasts 1 MiB in place on the context's stream.  FSGPU_OK when the
+ * library loaded and the call sequence of fsgpu_db_broadcast's RCCL branch ran; what a one-GPU box can verify of the replication path. */
+int fsgpu_rccl_selfcheck(fsgpu_ctx *ctx);
 int fsgpu_device(const fsgpu_ctx *ctx);
 int fsgpu_device_count(void);      /* visible HIP devices, 0 when there is none */
 /* HIP stream all kernels of this context are launched on (a hipStream_t), for callers that time with events */

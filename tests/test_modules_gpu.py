@@ -289,3 +289,38 @@ def test_db_replication_and_gpus_option(tmp_path):
     if ngpu > 1:       # more than one device on this box: the real thing, RCCL broadcast included
         subprocess.check_call([BIN, "ungappedprefilter", qdb, tdb, str(tmp_path / "d"), "--max-seqs", "100", "--gpus", "all"])
         assert dbio.read_db(a) == dbio.read_db(str(tmp_path / "d"))
+
+
+def test_single_gpu_paths_run_through_rccl_when_required(tmp_path):
+    """FSGPU_REQUIRE_RCCL=1 on a one-GPU box (what can be checked here of the 8-GPU replication path): the library's RCCL branch runs on the
+    device through a one-rank communicator (fsgpu_rccl_selfcheck: librccl loads, ncclCommInitAll + a grouped ncclBroadcast on the context's
+    stream); `fsgpu-modules search --gpus all` performs that check, prints the host budget it runs with, and fails when RCCL is switched off;
+    `bench.py --gpus 1` puts the target DB through a one-rank RCCL process group and says so on its line."""
+    import json
+    import sys
+    ctx = api.Context(0)
+    ctx.rccl_selfcheck()
+    ctx.close()
+    q3, qa = synth.make_queries(3, seed=191, mean_len=180, lo=60, hi=350)
+    db = synth.make_db(800, (q3, qa), seed=192, homologs_per_query=20, mask_frac=0.02)
+    for name, which in (("t_ss", "3di"), ("t", "aa")):
+        dbio.write_seq_db_from_padded(str(tmp_path / name), db, which)
+    dbio.write_seq_db(str(tmp_path / "q_ss"), q3, [1, 2, 3])
+    dbio.write_seq_db(str(tmp_path / "q"), qa, [1, 2, 3])
+    cmd = [BIN, "search", "q", "t", "aln", "--gpus", "all", "--threads", "4", "-s", "9.5", "--max-seqs", "100", "--alignment-type", "2", "--sort-by-structure-bits", "0"]
+    env = dict(os.environ, FSGPU_REQUIRE_RCCL="1")
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ngpu = api.lib().fsgpu_device_count()
+    assert ("RCCL self-check" in r.stderr and "usedRccl 1" in r.stderr) if ngpu == 1 else "RCCL broadcast" in r.stderr, r.stderr[-2000:]
+    assert "host budget:" in r.stderr and "feeder thread(s) per GPU" in r.stderr
+    plain = subprocess.run(cmd[:4] + ["aln2"] + cmd[5:], cwd=tmp_path, capture_output=True, text=True)
+    assert plain.returncode == 0 and dbio.read_db(str(tmp_path / "aln")) == dbio.read_db(str(tmp_path / "aln2"))
+    if ngpu == 1:
+        bad = subprocess.run(cmd, cwd=tmp_path, env=dict(env, FSGPU_NO_RCCL="1"), capture_output=True, text=True)
+        assert bad.returncode == 0            # FSGPU_NO_RCCL is the explicit opt-out: no check, no failure
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--targets", "20000", "--no-kmer", "--type2-steps", "0",
+                        "--allvsall-steps", "0", "--fullrange-steps", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert b.returncode == 0, b.stderr[-3000:]
+    line = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["broadcast_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
