@@ -657,4 +657,17 @@ void block_cigar_eq_aa_trace(BlockHandle b, const PaddedBytes *q, const PaddedBy
 }
 void block_free_aa_trace(BlockHandle b) { delete (Block *) b; }
 
+// The regions the last alignment computed, in the order the trace stack holds them (the crate's Trace::blocks(), scan_block.rs:2009-2030;
+// a Rust API the crate's C header does not export): out[5 k ..] = {row, column, height, width, right} of region k.  Returns their number.
+// For tests that hold the block TRAJECTORY against an independent model (tests/ba_model.py).
+uintptr_t block_trace_blocks(BlockHandle b, uint32_t *out, uintptr_t cap) {
+    const Trace &t = ((Block *) b)->trace;
+    for (size_t k = 0; k < t.blockIdx && k < cap; k++) {
+        out[5 * k] = t.blockStart[2 * k]; out[5 * k + 1] = t.blockStart[2 * k + 1];
+        out[5 * k + 2] = t.blockSize[2 * k]; out[5 * k + 3] = t.blockSize[2 * k + 1];
+        out[5 * k + 4] = (uint32_t) ((t.right[k / 64] >> (k % 64)) & 1u);
+    }
+    return t.blockIdx;
+}
+
 } // extern "C"

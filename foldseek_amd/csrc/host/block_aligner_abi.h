@@ -74,6 +74,10 @@ void block_cigar_aa_trace(BlockHandle b, uintptr_t query_idx, uintptr_t referenc
 void block_cigar_eq_aa_trace(BlockHandle b, const PaddedBytes *q, const PaddedBytes *r, uintptr_t query_idx, uintptr_t reference_idx, Cigar *cigar);
 void block_free_aa_trace(BlockHandle b);
 
+// not in the crate's C header: the crate's Rust API Trace::blocks() (scan_block.rs:2009-2030) for either handle type -- the regions the
+// last alignment computed, out[5 k ..] = {row, column, height, width, right}; returns their number (tests/ba_model.py compares trajectories)
+uintptr_t block_trace_blocks(BlockHandle b, uint32_t *out, uintptr_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
 //        alignStartPosBacktraceBlock (F/src/commons/StructureSmithWaterman.cpp:369-537): min block size 32, 64, ... 4096 until the
 //        x-drop alignment of the two (already reversed) strings reaches <target score>; <name> carries the target score after '@'
 //   aa   <name> <gapOpen> <gapExtend> <minSize> <maxSize> <xdrop or -1 for the global variant> <q> <r>      Block::align with one matrix
+//   nw   <name> <gapOpen> <gapExtend> <match> <mismatch> <minSize> <maxSize> <xdrop or -1> <q> <r>          the same with AAMatrix::new_simple
 // matrices: mat_aa.txt / mat_3di.txt next to the case file (first line: letters, then one row of integers per letter).
 #include <cstdio>
 #include <cstdlib>
@@ -95,11 +96,14 @@ int main(int argc, char **argv) {
             block_free_padded_aa(pqa); block_free_padded_aa(pq3); block_free_padded_aa(pta); block_free_padded_aa(pt3);
             block_free_pos_bias(pqb); block_free_pos_bias(ptb);
             block_free_aa_trace_xdrop(blk);
-        } else if (kind == "aa") {
+        } else if (kind == "aa" || kind == "nw") {
             size_t minSize, maxSize;
-            int xdrop;
+            int xdrop, match = 0, mismatch = 0;
             std::string q, r;
+            if (kind == "nw") in >> match >> mismatch;          // Block::align with AAMatrix::new_simple(match, mismatch)
             in >> minSize >> maxSize >> xdrop >> q >> r;
+            AAMatrix *mNw = kind == "nw" ? block_new_simple_aamatrix((int8_t) match, (int8_t) mismatch) : nullptr;
+            const AAMatrix *mUse = mNw ? mNw : mAA;
             PaddedBytes *pq = block_new_padded_aa(q.size(), maxSize), *pr = block_new_padded_aa(r.size(), maxSize);
             block_set_bytes_padded_aa(pq, (const uint8_t *) q.data(), q.size(), maxSize);
             block_set_bytes_padded_aa(pr, (const uint8_t *) r.data(), r.size(), maxSize);
@@ -108,13 +112,13 @@ int main(int argc, char **argv) {
             AlignResult res;
             if (xdrop >= 0) {
                 BlockHandle blk = block_new_aa_trace_xdrop(q.size() + 64, r.size() + 64, maxSize);
-                block_align_aa_trace_xdrop(blk, pq, pr, mAA, gaps, range, xdrop);
+                block_align_aa_trace_xdrop(blk, pq, pr, mUse, gaps, range, xdrop);
                 res = block_res_aa_trace_xdrop(blk);
                 block_cigar_aa_trace_xdrop(blk, res.query_idx, res.reference_idx, cg);
                 block_free_aa_trace_xdrop(blk);
             } else {
                 BlockHandle blk = block_new_aa_trace(q.size() + 64, r.size() + 64, maxSize);
-                block_align_aa_trace(blk, pq, pr, mAA, gaps, range, 0);
+                block_align_aa_trace(blk, pq, pr, mUse, gaps, range, 0);
                 res = block_res_aa_trace(blk);
                 block_cigar_aa_trace(blk, res.query_idx, res.reference_idx, cg);
                 block_free_aa_trace(blk);
@@ -122,6 +126,7 @@ int main(int argc, char **argv) {
             printf("%s\t%d\t%zu\t%zu\t%s\t-\n", name.c_str(), res.score, (size_t) res.query_idx, (size_t) res.reference_idx, cigarString(cg).c_str());
             block_free_cigar(cg);
             block_free_padded_aa(pq); block_free_padded_aa(pr);
+            if (mNw) block_free_aamatrix(mNw);
         }
     }
     block_free_aamatrix(mAA); block_free_aamatrix(m3);
