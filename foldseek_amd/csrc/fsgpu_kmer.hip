@@ -197,7 +197,7 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     RPCHK(hipGetLastError());
 
     // masked lookup
-    RPCHK(hipMalloc((void **) &ix->masked, bytes));
+    RPCHK(hipMalloc((void **) &ix->masked, bytes + 16));          // + 16: k_kmer_score8 reads whole 8-byte words around a diagonal
     RPCHK(hipMemsetAsync(ix->masked, 20, bytes, ctx->stream));
     if (n) {
         hipLaunchKernelGGL(k_kmer_mask, dim3(gridFor(n, 128)), dim3(128), 0, ctx->stream, db.raw3di, db.dOffsets, db.dLengths, n,
@@ -798,9 +798,16 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             int maxL = 0;
             for (int q = 0; q < nq; q++) maxL = std::max(maxL, queries[q].L);
             const int ldsBytes = std::min(maxL * 21, 60 * 1024);
-            hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), (size_t) ldsBytes, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
-                               (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
-                               ldsBytes, (uint8_t *) S.kept.p, (int32_t *) S.score.p);
+            // eight lanes per candidate (k_kmer_score8) unless FSGPU_KMER_SCORE8=0 asks for the one-lane-per-candidate form (A/B runs)
+            static const bool score8 = [] { const char *e = getenv("FSGPU_KMER_SCORE8"); return !(e && atoi(e) == 0); }();
+            if (score8)
+                hipLaunchKernelGGL(k_kmer_score8, dim3(gridFor(nCand, 32)), dim3(256), (size_t) ldsBytes, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                                   (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
+                                   ldsBytes, (uint8_t *) S.kept.p, (int32_t *) S.score.p);
+            else
+                hipLaunchKernelGGL(k_kmer_score, dim3(gridFor(nCand, 256)), dim3(256), (size_t) ldsBytes, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                                   (const uint32_t *) S.nCand.p, tbits, (const KmerQ *) S.qs.p, (const int8_t *) S.profiles.p, ix.masked, db.dOffsets, db.dLengths,
+                                   ldsBytes, (uint8_t *) S.kept.p, (int32_t *) S.score.p);
             RPCHK(hipGetLastError());
             RPCHK(hipEventRecord(S.ev[6], st));
             // ---- stage 4: per-target replay ----------------------------------------------------------------------

@@ -1275,6 +1275,104 @@ __global__ __launch_bounds__(256) void k_kmer_score(const uint32_t *ckeys, const
     score[j] = mx;
 }
 
+// The same scores with EIGHT lanes per candidate (k_kmer_score gives every candidate one lane: 64 lanes of a wave then stream 64 different
+// targets eight bytes at a time -- every 8-byte load opens its own 64-byte sector, the lines of 64 targets per wave and 32 waves per CU do
+// not survive in L2 until their next 8 bytes are wanted, and the pass fetched 2.7x the diagonals' residues).  Here the diagonal is cut into
+// eight contiguous parts of whole 8-byte words; lane g runs the reference's recurrence (s = max(0, s + x), best = max(best, s):
+// UngappedAlignment.cpp:36-120, scalar form) over part g and keeps FOUR numbers that describe the part as a function of the run value s it
+// is entered with:  A = sum,  S0 = end value from s = 0,  P = best from s = 0,  Q = best prefix sum  (end(s) = max(S0, s + A), best(s) =
+// max(P, s + Q)).  Parts compose associatively, in order:  (L . R):  A = AL + AR,  S0 = max(S0R, S0L + AR),  P = max(PL, PR, S0L + QR),
+// Q = max(QL, AL + QR) -- three butterfly steps over the eight lanes give the whole diagonal's P, exactly the sequential result.
+struct KmerSum { int A, S0, P, Q; };
+__device__ __forceinline__ KmerSum kmerSumJoin(const KmerSum &l, const KmerSum &r) {
+    KmerSum o;
+    o.A = l.A + r.A;
+    o.S0 = max(r.S0, l.S0 + r.A);
+    o.P = max(max(l.P, r.P), l.S0 + r.Q);
+    o.Q = max(l.Q, l.A + r.Q);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_kmer_score8(const uint32_t *ckeys, const uint64_t *cvals, const uint32_t *nCandPtr, int tbits, const KmerQ *qs,
+                                                     const int8_t *profiles, const uint8_t *masked, const uint64_t *offsets, const int32_t *lengths,
+                                                     int ldsBytes, uint8_t *kept, int32_t *score) {
+    extern __shared__ int8_t sprof[];
+    __shared__ uint32_t q0s;
+    const uint64_t nCand = *nCandPtr;
+    const uint64_t j0 = (uint64_t) blockIdx.x * 32;
+    if (j0 >= nCand) return;
+    if (threadIdx.x == 0) q0s = ckeys[j0] >> tbits;
+    __syncthreads();
+    const uint32_t q0 = q0s;
+    const int L0 = (int) qs[q0].L;
+    const bool staged = L0 * 21 <= ldsBytes;
+    if (staged) {
+        const int8_t *src = profiles + qs[q0].profOff;
+        const int nb = L0 * 21;
+        for (int i = threadIdx.x; i < nb; i += 256) sprof[i] = src[i];
+    }
+    __syncthreads();
+    const int g = threadIdx.x & 7;
+    const uint64_t j = j0 + (threadIdx.x >> 3);
+    const bool live = j < nCand;
+    bool keep = false;
+    KmerSum sum{0, 0, 0, 0};
+    if (live) {
+        const uint32_t k = ckeys[j];
+        const uint64_t v = cvals[j];
+        keep = true;
+        if (j > 0 && ckeys[j - 1] == k) { const uint64_t pv = cvals[j - 1]; if (hitChunk(pv) == hitChunk(v) && hitD8(pv) == hitD8(v)) keep = false; }
+        if (keep) {
+            const uint32_t t = k & ((1u << tbits) - 1u);
+            const uint32_t qi = k >> tbits;
+            const KmerQ &q = qs[qi];
+            const uint8_t *db = masked + offsets[t];
+            const int dbLen = lengths[t], qLen = (int) q.L;
+            const uint32_t d = hitDiag(v);
+            const int diagonal = (int) (int16_t) (uint16_t) d;
+            const int minDist = (int) min((0u - d) & 0xffffu, d);
+            int len = 0, poff = 0;
+            if (diagonal >= 0 && minDist < qLen) { len = min(dbLen, qLen - minDist); poff = minDist * 21; }
+            else if (diagonal < 0 && minDist < dbLen) { len = min(dbLen - minDist, qLen); db += minDist; }
+            const int8_t *prof = (staged && qi == q0) ? sprof + poff : profiles + q.profOff + poff;
+            if (len > 0) {
+                // whole 8-byte words of the target; word w covers positions 8 w - head .. 8 w - head + 7 of the diagonal
+                const int head = (int) ((uintptr_t) db & 7);
+                const uint64_t *words = reinterpret_cast<const uint64_t *>(db - head);
+                const int nW = (head + len + 7) >> 3, per = (nW + 7) >> 3;
+                const int w0 = g * per, w1 = min(nW, w0 + per);
+                int A = 0, S0 = 0, P = 0, Q = 0;
+                uint64_t wNext = w0 < w1 ? words[w0] : 0;
+                for (int w = w0; w < w1; w++) {
+                    const uint64_t cur = wNext;
+                    if (w + 1 < w1) wNext = words[w + 1];
+                    const int p0 = 8 * w - head;
+                    const int8_t *p = prof + p0 * 21;
+                    int x[8];
+                    if (p0 >= 0 && p0 + 8 <= len) {
+#pragma unroll
+                        for (int b = 0; b < 8; b++) x[b] = p[b * 21 + (int) ((cur >> (8 * b)) & 0xff)];
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 8; b++) x[b] = ((unsigned) (p0 + b) < (unsigned) len) ? (int) p[b * 21 + (int) ((cur >> (8 * b)) & 0xff)] : 0;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; b++) { A += x[b]; Q = max(Q, A); S0 = max(0, S0 + x[b]); P = max(P, S0); }
+                }
+                sum = KmerSum{A, S0, P, Q};
+            }
+        }
+    }
+    // ordered reduction over the eight lanes of a candidate (lane g holds part g; at distance d the lower lane's block is the left operand)
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        KmerSum o;
+        o.A = __shfl_xor(sum.A, d); o.S0 = __shfl_xor(sum.S0, d); o.P = __shfl_xor(sum.P, d); o.Q = __shfl_xor(sum.Q, d);
+        sum = (g & d) ? kmerSumJoin(o, sum) : kmerSumJoin(sum, o);
+    }
+    if (live && g == 0) { kept[j] = keep ? 1 : 0; score[j] = keep ? sum.P : 0; }
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // search, stage 4: per-target replay of QueryMatcher::match's overflow rounds + final keepMaxScoreElementOnly.
 // One thread per (query, target) segment of the candidate array.  List elements are (candidate index << 8 | count).
