@@ -1336,25 +1336,28 @@ __global__ __launch_bounds__(256) void k_kmer_score8(const uint32_t *ckeys, cons
             else if (diagonal < 0 && minDist < dbLen) { len = min(dbLen - minDist, qLen); db += minDist; }
             const int8_t *prof = (staged && qi == q0) ? sprof + poff : profiles + q.profOff + poff;
             if (len > 0) {
-                // whole 8-byte words of the target; word w covers positions 8 w - head .. 8 w - head + 7 of the diagonal
-                const int head = (int) ((uintptr_t) db & 7);
-                const uint64_t *words = reinterpret_cast<const uint64_t *>(db - head);
-                const int nW = (head + len + 7) >> 3, per = (nW + 7) >> 3;
-                const int w0 = g * per, w1 = min(nW, w0 + per);
+                // positions [0, head) up to the first 8-byte boundary of the target go to lane 0 byte by byte (they are the leftmost part);
+                // the aligned words behind them are dealt out in eight contiguous runs.  No address below `prof` / `db` is ever formed: a flat
+                // access whose base register lies under the LDS aperture faults even when base + offset does not.
+                const int head = min(len, (int) ((8 - ((uintptr_t) db & 7)) & 7));
                 int A = 0, S0 = 0, P = 0, Q = 0;
+                if (g == 0)
+                    for (int pos = 0; pos < head; pos++) { const int x = prof[pos * 21 + db[pos]]; A += x; Q = max(Q, A); S0 = max(0, S0 + x); P = max(P, S0); }
+                const uint64_t *words = reinterpret_cast<const uint64_t *>(db + head);
+                const int rest = len - head, nW = (rest + 7) >> 3, per = (nW + 7) >> 3;
+                const int w0 = g * per, w1 = min(nW, w0 + per);
                 uint64_t wNext = w0 < w1 ? words[w0] : 0;
                 for (int w = w0; w < w1; w++) {
                     const uint64_t cur = wNext;
                     if (w + 1 < w1) wNext = words[w + 1];
-                    const int p0 = 8 * w - head;
-                    const int8_t *p = prof + p0 * 21;
+                    const int p0 = head + 8 * w;                       // first position of this word, >= 0
                     int x[8];
-                    if (p0 >= 0 && p0 + 8 <= len) {
+                    if (p0 + 8 <= len) {
 #pragma unroll
-                        for (int b = 0; b < 8; b++) x[b] = p[b * 21 + (int) ((cur >> (8 * b)) & 0xff)];
+                        for (int b = 0; b < 8; b++) x[b] = prof[(p0 + b) * 21 + (int) ((cur >> (8 * b)) & 0xff)];
                     } else {
 #pragma unroll
-                        for (int b = 0; b < 8; b++) x[b] = ((unsigned) (p0 + b) < (unsigned) len) ? (int) p[b * 21 + (int) ((cur >> (8 * b)) & 0xff)] : 0;
+                        for (int b = 0; b < 8; b++) x[b] = (p0 + b < len) ? (int) prof[(p0 + b) * 21 + (int) ((cur >> (8 * b)) & 0xff)] : 0;
                     }
 #pragma unroll
                     for (int b = 0; b < 8; b++) { A += x[b]; Q = max(Q, A); S0 = max(0, S0 + x[b]); P = max(P, S0); }

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Turn the --pmc summaries of tools/r03_profile.sh (gpurun_out/r03_prof/TAG_*) into the per-unit HBM bytes bench.py reports as
-`roofline.traffic` (profiles/pmc_traffic.json, profiles/pmc_traffic_kmer.json), stamped with the hash of the kernel sources they were
-collected on (tools/csrc_hash.py; bench.py drops an entry whose hash is not the running one).
-usage: pmc_to_traffic.py gpurun_out/r03_prof TAG profiles/<name of the committed summary files' prefix>"""
+"""Turn the --pmc summaries of tools/r04_profile.sh (gpurun_out/r04_prof/TAG_*) into the per-unit HBM bytes bench.py reports as
+`roofline.traffic` (profiles/pmc_traffic.json, profiles/pmc_traffic_kmer.json, profiles/pmc_traffic_allvsall.json), stamped with the hash of
+the kernel sources they were collected on (tools/csrc_hash.py; bench.py drops an entry whose hash is not the running one).
+usage: pmc_to_traffic.py gpurun_out/r04_prof TAG profiles/<name of the committed summary files' prefix>"""
 import json
 import os
 import sys
@@ -74,3 +74,32 @@ print(f"k-mer batch: {hits:.3e} hits, calibrations fetch {fcal:.3f} write {wcal:
 for n, r in rows.items():
     if r["bytes_per_index_hit"] > 0.05:
         print(f"   {n:32s} {r['bytes_per_index_hit']:7.2f} B/hit  (fetch {r['fetch_kb']:.0f} KB, write {r['write_kb']:.0f} KB)")
+
+# --- all-vs-all (configs[4]): every k_kmer_* kernel of a short run, per index hit, with the calibrations of the 1M batch above
+pa = os.path.join(d, f"{tag}_pmc_allvsall_200k.json")
+if os.path.exists(pa):
+    a = json.load(open(pa))
+    line = json.load(open(os.path.join(d, f"{tag}_pmc_allvsall_200k_benchline.json")))
+    nq = line["queries_per_s"] * line["ms_per_step"] * 1e-3 * line["steps"]            # timed queries; the counters also cover the warm-up batches
+    nb_all = line["steps"] + line["warmup"] + 3                                          # + the three solo repetitions
+    ahits = line["index_hits_per_query"] * line["queries_per_batch"] * nb_all
+    tot = 0.0
+    arows = {}
+    for n, v in a.items():
+        if "k_kmer" not in n and "rocprim" not in n:
+            continue
+        f, w = v["counters"].get("FETCH_SIZE", {}).get("total", 0.0), v["counters"].get("WRITE_SIZE", {}).get("total", 0.0)
+        stream = not any(x in n for x in ("k_kmer_lists", "k_kmer_count"))
+        cal = (f * (fcal if stream else 1.0) + w * wcal) * 1024.0
+        arows[n.replace("fs::", "")] = {"fetch_kb": f, "write_kb": w, "bytes_calibrated": cal}
+        tot += cal
+    pav = os.path.join(ROOT, "profiles", "pmc_traffic_allvsall.json")
+    tav = json.load(open(pav)) if os.path.exists(pav) else {}
+    tav["200000"] = {"kernel": "k_kmer_* + the scans of the all-vs-all prefilter batches", "index_hits": ahits, "batches": nb_all,
+                     "k_kmer_all_bytes_per_index_hit": tot / max(ahits, 1.0), "per_kernel": arows,
+                     "workload": f"bench.py --workload allvsall --targets 200000 --steps {line['steps']} --warmup {line['warmup']} --kmer-threads 1 (family DB, batches of {line['queries_per_batch']})",
+                     "note": "index hits = index_hits_per_query of the line x queries per batch x (timed + warm-up + three solo batches); fetch / write calibrations of the 1M k-mer batch pass",
+                     "source": f"{prefix}_pmc_allvsall_200k.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT collected in the run that prints it)",
+                     "csrc_hash": hash_k, "csrc_files": KMER_FILES}
+    json.dump(tav, open(pav, "w"), indent=1)
+    print(f"all-vs-all: {ahits:.3e} index hits over {nb_all} batches, {tot / max(ahits, 1.0):.1f} B per index hit")

@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round-4 evidence (same scheme as r03_profile.sh; counters never combined with tracing, MI355X_MICROARCH.md):
+#   r04_profile.sh pmc TAG    separate --pmc passes over a short bench run (k_gapless, k_sw3), over ONE k-mer prefilter batch of 32 queries at 1M
+#                             targets, and over a short all-vs-all run (configs[4], 200k family DB)
+#   r04_profile.sh bench TAG  default bench line, rocprofv3 kernel traces of the default command and of three k-mer batches
+# Output: gpurun_out/r04_prof/.  tools/pmc_to_traffic.py turns the pmc files into profiles/pmc_traffic*.json.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r04_prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+MODE=${1:-bench}
+TAG=${2:-x}
+if [ "$MODE" = pmc ]; then
+python $R/tools/csrc_hash.py k_gapless.hpp fs_kernels.h > $O/${TAG}_csrc_hash_gapless.txt
+python $R/tools/csrc_hash.py k_kmer.hpp fsgpu_kmer.hip fs_kernels.h > $O/${TAG}_csrc_hash_kmer.txt
+SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-kmer --type2-steps 0 --allvsall-steps 0 --fullrange-steps 0"
+pass() { rm -rf /tmp/pmc_$1; rocprofv3 --pmc "$@" -d /tmp/pmc_$1 -o p --output-format csv -- python $R/bench.py $SHORT > /tmp/pmc_$1.log 2>&1; }
+pass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
+pass SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+pass FETCH_SIZE
+pass WRITE_SIZE
+python $R/tools/pmc_family.py /tmp/pmc_SQ_WAVES /tmp/pmc_SQ_LDS_BANK_CONFLICT /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE --json $O/${TAG}_pmc_bench_1M.json > $O/${TAG}_pmc_bench_1M_steps3.txt 2>&1
+grep -h "^{" /tmp/pmc_SQ_WAVES.log | tail -1 > $O/${TAG}_pmc_bench_1M_benchline.json
+kpass() { rm -rf /tmp/kpmc_$1; rocprofv3 --pmc "$@" -d /tmp/kpmc_$1 -o p --output-format csv -- python $R/tools/kmer_bench.py 1000000 32 1 > /tmp/kpmc_$1.log 2>&1; }
+kpass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
+kpass SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+kpass FETCH_SIZE
+kpass WRITE_SIZE
+python $R/tools/pmc_family.py /tmp/kpmc_SQ_WAVES /tmp/kpmc_SQ_LDS_BANK_CONFLICT /tmp/kpmc_FETCH_SIZE /tmp/kpmc_WRITE_SIZE --from-first k_kmer_count --json $O/${TAG}_pmc_kmer_1M.json > $O/${TAG}_pmc_kmer_batch32_1M.txt 2>&1
+grep -h "^COUNTS\|^rep\|^segments" /tmp/kpmc_FETCH_SIZE.log > $O/${TAG}_pmc_kmer_1M_counts.txt
+# all-vs-all: 8 batches of 256 DB entries against the 200k family DB (k-mer prefilter + SW), no module run, no CPU baseline
+AV="--workload allvsall --targets 200000 --steps 8 --warmup 2 --no-cpu-baseline --kmer-threads 1"
+apass() { rm -rf /tmp/apmc_$1; rocprofv3 --pmc "$@" -d /tmp/apmc_$1 -o p --output-format csv -- python $R/bench.py $AV > /tmp/apmc_$1.log 2>&1; }
+apass FETCH_SIZE
+apass WRITE_SIZE
+python $R/tools/pmc_family.py /tmp/apmc_FETCH_SIZE /tmp/apmc_WRITE_SIZE --from-first k_kmer_count --json $O/${TAG}_pmc_allvsall_200k.json > $O/${TAG}_pmc_allvsall_200k.txt 2>&1
+grep -h "^{" /tmp/apmc_FETCH_SIZE.log | tail -1 > $O/${TAG}_pmc_allvsall_200k_benchline.json
+else
+python $R/bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err
+rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --no-cpu-baseline > /tmp/kt.log 2>&1
+python $R/tools/rocprof_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${TAG}_kernel_trace_bench_default.txt 2>&1
+grep -h "^{" /tmp/kt.log | tail -1 > $O/${TAG}_kernel_trace_benchline.json
+rm -rf /tmp/kkt && rocprofv3 --kernel-trace --stats -d /tmp/kkt -o kt -- python $R/tools/kmer_bench.py 1000000 32 3 > /tmp/kkt.log 2>&1
+python $R/tools/rocprof_summary.py $(find /tmp/kkt -name "*.db" | head -1) > $O/${TAG}_kernel_trace_kmer_batch32_1M.txt 2>&1
+grep -h "^COUNTS\|^rep\|^segments" /tmp/kkt.log >> $O/${TAG}_kernel_trace_kmer_batch32_1M.txt
+fi
+ls -la $O | tail -20
