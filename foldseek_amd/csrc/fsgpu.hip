@@ -1819,9 +1819,12 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // ---- workgroup descriptors: one launch per (lanes per target pair, rows-per-lane range 1..4 / 5..8 / 9..12 / 13..16) ----
     struct Part { int q, key, R, first, n; };       // pairs [first, first + n) of query q's sorted list run with R rows per lane in launch group `key`
     std::vector<Part> parts;
-    // launch groups: lanes per target pair x rows-per-lane range of four (the dynamic LDS of a launch is that of its largest R: a query of
-    // 9 rows per lane must not take the 106 KB of one with 16 and lose its second workgroup per CU); kernels exist for R = 1..8 and 9..16
-    auto keyOf = [](int HL, int R) { return (HL == 64 ? 4 : 0) + (R - 1) / 4; };
+    // launch groups: lanes per target pair x kernel (R = 1..8 / 9..16) x LDS occupancy class of the R range of four (the dynamic LDS of a
+    // launch is that of its largest R: a query of 9 rows per lane must not take the 106 KB of one with 16 and lose its second workgroup per CU)
+    // (a class whose largest member still fits three workgroups per CU shares its launch with the smaller ones: the register classes of a
+    // search batch then run as one or two launches, each with a single long-target tail)
+    auto occOf = [&](int HL, int R) { return std::min(3, (160 * 1024) / sw3LdsBytes(std::min(kSw3MaxR, (R + 3) / 4 * 4), HL, hasAA, 4)); };
+    auto keyOf = [&](int HL, int R) { return (HL == 64 ? 8 : 0) + (R > 8 ? 4 : 0) + occOf(HL, R); };
     for (int i = 0; i < nq; i++) {
         const int ns = nSel(i);
         if (ns == 0) continue;
@@ -1832,8 +1835,8 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     struct Group { int key, HL, rlo, maxR, waves, lds; size_t blk0, nblk; };
     std::vector<Group> groups;
     size_t nBlocks = 0;
-    for (int key = 7; key >= 0; key--) {            // the 64-lane groups (the long targets) first
-        Group g{key, key >= 4 ? 64 : 32, (key & 3) >= 2 ? 9 : 1, 0, 0, 0, nBlocks, 0};
+    for (int key = 15; key >= 0; key--) {           // the 64-lane groups (the long targets) first
+        Group g{key, key >= 8 ? 64 : 32, (key & 4) ? 9 : 1, 0, 0, 0, nBlocks, 0};
         for (const Part &pt : parts) if (pt.key == key) g.maxR = std::max(g.maxR, pt.R);
         if (g.maxR == 0) continue;
         g.waves = sw3Waves(g.maxR, g.HL, hasAA);

@@ -26,6 +26,7 @@ def run(n=200000, threads="4", fam=0, db=None, keep=False):
         dbio.write_seq_db_from_padded(os.path.join(w, "db"), db, "aa")
         t_gen = time.time() - t0
         env = dict(os.environ, FSGPU_MODULE_TIMING="1")
+        env.pop("FSGPU_SPIN_US", None)          # bench.py sets a polling wait for ITS three feeder threads; the module's feeders must sleep while they wait
         t0 = time.time()
         p = subprocess.run(os.environ.get("C5_WRAP", "").split() + [os.path.join(ROOT, "foldseek_amd", "bin", "fsgpu-modules"), "search", os.path.join(w, "db"), os.path.join(w, "db"), os.path.join(w, "aln"),
                             "--prefilter-mode", "0", "-s", "4.5", "--max-seqs", "200", "-c", "0.8", "--cov-mode", "0", "-e", "0.01", "--alignment-type", "2",
