@@ -375,9 +375,6 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
     int status = FSGPU_KMER_OK;
     bool empty = false;
     if (ck.aborted == 2) status = FSGPU_KMER_E_CHUNKS;
-    // --diag-score 0: after a refill the reference sums the rounds' counts per target in mergeScoreDuplicates (CacheFriendlyOperations.cpp:150-180),
-    // whose leftover byte array makes later elements of a target reappear with the previous element's diagonal byte as "score": not replayed
-    if (sp.kmerScoreOnly && C >= 1 && status == FSGPU_KMER_OK) status = FSGPU_KMER_E_REFILL_COUNTS;
     if (ck.aborted == 1) empty = true;
     const bool lastEmpty = ck.start[ck.nChunks] == ck.start[ck.nChunks - 1];
     if (C >= 1 && lastEmpty) empty = true;
@@ -406,6 +403,9 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
             }
             if (C >= 1) order.push_back({(int) C, 1});
             for (size_t z = 0; z < order.size(); z++) { rank[order[z].first] = (int) z; dir[order[z].first] = order[z].second; }
+            // --diag-score 0: mergeScoreDuplicates hands every element on in the order it came in -- the earlier rounds' elements, then the new
+            // chunk's -- so a bin holds its elements by round of origin, each round's in arrival order of the first candidate
+            if (sp.kmerScoreOnly) for (uint32_t c = 0; c <= C; c++) { rank[c] = (int) c; dir[c] = 1; }
         }
         auto chunkOf = [&](uint64_t g) { uint32_t c = 0; while (c + 1 < ck.nChunks && ck.start[c + 1] <= g) c++; return c; };
         // array order of the reference inside one score bucket: (bin, order the overflow rounds left the elements in)
@@ -788,9 +788,21 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         }
         RPCHK(hipGetLastError());
         if (sp.kmerScoreOnly) {
-            // --diag-score 0: the score of a target is the number of its candidates, no diagonal is scored and nothing is replayed
-            hipLaunchKernelGGL(k_kmer_count_heads, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint32_t *) S.nCand.p, tbits,
-                               (uint8_t *) S.kept.p, (int32_t *) S.score.p, (KmerBest *) S.best.p, (unsigned long long *) S.resSize.p);
+            // --diag-score 0: the score of a target is the number of its candidates, no diagonal is scored; a query that refilled databaseHits has
+            // the reference's merge of the per-refill counts replayed per (query, id >> shift) group (k_kmer_merge_heads)
+            bool refilled = false;
+            for (int q = 0; q < nq; q++) refilled = refilled || hck[q].nChunks > 1;
+            if (refilled) {
+                const unsigned B = pickBins(sp, n);
+                int shift = 0;
+                while ((1u << shift) < B) shift++;
+                hipLaunchKernelGGL(k_kmer_merge_heads, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const uint32_t *) S.nCand.p,
+                                   tbits, shift, (const KmerChunks *) S.chunks.p, (const uint32_t *) S.ec.p, (uint64_t *) S.scrA.p, (uint8_t *) S.kept.p, (int32_t *) S.score.p,
+                                   (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
+            } else {
+                hipLaunchKernelGGL(k_kmer_count_heads, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint32_t *) S.nCand.p, tbits,
+                                   (uint8_t *) S.kept.p, (int32_t *) S.score.p, (KmerBest *) S.best.p, (unsigned long long *) S.resSize.p);
+            }
             RPCHK(hipGetLastError());
             RPCHK(hipEventRecord(S.ev[6], st));
             RPCHK(hipEventRecord(S.ev[7], st));

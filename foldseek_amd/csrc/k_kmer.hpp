@@ -1509,6 +1509,95 @@ __global__ __launch_bounds__(256) void k_kmer_count_heads(const uint32_t *ckeys,
     best[j] = b;
 }
 
+// --diag-score 0 and the query refilled databaseHits (QueryMatcher.cpp:311-346): every refill's findDuplicates output -- one element per target
+// with candidates in that chunk: (count, diagonal of the first candidate) -- is appended to the elements of the earlier rounds and the whole list
+// goes through mergeScoreDuplicates (CacheFriendlyOperations.cpp:150-180).  As that function executes: per bin the counts of a target's elements
+// are summed (saturating at 255) INTO the target's byte of duplicateBitArray, every element is handed on with the byte's current value (dropped
+// when that is 0), and the byte is then left at the low byte of that element's diagonal -- so a target present in two rounds comes out twice
+// (the sum, then the first element's diagonal byte as "count"), and the byte one bin leaves behind is the starting value of the target of the
+// next bin that shares id >> shift (the B consecutive ids of one byte; bins are walked in ascending order, i.e. ascending id inside the group).
+// Elements keep their identity through the merges (target, round of origin, first candidate), only their counts move: the state of the replay
+// is one count per (target, chunk) run head, kept in cnt[head candidate].  The merge of round m only runs when an earlier round left elements
+// (first = first chunk of the QUERY with candidates: QueryMatcher.cpp:328 tests overflowHitCount != 0), with or without new ones.
+// heads: candidate indices of the group's run heads in (target, chunk) order.  roundAdd(c, n): n elements of this group are in foundDiagonals
+// when chunk c's findDuplicates starts (the host's output-capacity test).  Returns the group's elements after the last round.
+template <class RoundAdd>
+__host__ __device__ inline uint32_t kmerMergeScoreGroup(const uint64_t *heads, uint32_t nH, const uint32_t *ckeys, const uint64_t *cvals, int32_t *cnt,
+                                                        uint32_t first, uint32_t C, RoundAdd roundAdd) {
+    uint32_t alive = 0;
+    for (uint32_t k = 0; k < nH; k++) alive += hitChunk(cvals[heads[k]]) <= first ? 1u : 0u;
+    if (first < C) roundAdd(first + 1, alive);
+    for (uint32_t m = first + 1; m <= C; m++) {
+        uint32_t d = 0;
+        alive = 0;
+        for (uint32_t k = 0; k < nH;) {
+            const uint32_t key = ckeys[heads[k]];
+            uint32_t e = k;
+            for (; e < nH && ckeys[heads[e]] == key; e++) {
+                const uint64_t j = heads[e];
+                if (hitChunk(cvals[j]) <= m && cnt[j] > 0) { d += (uint32_t) cnt[j]; d = d > 255u ? 255u : d; }
+            }
+            for (uint32_t x = k; x < e; x++) {
+                const uint64_t j = heads[x];
+                if (hitChunk(cvals[j]) <= m && cnt[j] > 0) { cnt[j] = (int32_t) d; alive += d != 0 ? 1u : 0u; d = hitD8(cvals[j]); }
+            }
+            k = e;
+        }
+        if (m < C) roundAdd(m + 1, alive);
+    }
+    return alive;
+}
+
+// One thread per candidate; the first candidate of a (query, id >> shift) group replays the group (pass 1: run heads and run lengths, then
+// kmerMergeScoreGroup), every other thread only marks its own slot when it is not a run head.  Queries without refills come out as
+// k_kmer_count_heads leaves them.  scr: 8 bytes per candidate (the group's head list lives at its first candidate's slot).
+// The body is host-callable so that tests/test_kmer_merge_model.py can hold it to the reference's functions without a device.
+template <class RoundAdd, class ResultAdd>
+__host__ __device__ inline void kmerMergeHeadsThread(uint64_t j, const uint32_t *ckeys, const uint64_t *cvals, uint64_t nCand, int tbits, int shift, const KmerChunks *chunks,
+                                                     const uint32_t *ecCount, uint64_t *scr, uint8_t *kept, int32_t *score, KmerBest *best, RoundAdd roundAdd, ResultAdd resultAdd) {
+    const uint32_t key = ckeys[j], tmask = (1u << tbits) - 1u;
+    const uint32_t qi = key >> tbits, grp = (key & tmask) >> shift;
+    kept[j] = 1;
+    bool runHead = true, groupHead = true;
+    if (j > 0) {
+        const uint32_t pk = ckeys[j - 1];
+        runHead = pk != key || hitChunk(cvals[j - 1]) != hitChunk(cvals[j]);
+        groupHead = (pk >> tbits) != qi || ((pk & tmask) >> shift) != grp;
+    }
+    if (!runHead) { KmerBest b; b.nElems = 0xFFFFFFFFu; b.cand = 0; b.count = 0; b.pad = 0; best[j] = b; }
+    if (!groupHead) return;
+    // pass 1: the group's run heads with their run lengths (findDuplicates with computeTotalScore: one count per candidate, capped at 255)
+    uint64_t *heads = scr + j;
+    uint32_t nH = 0;
+    for (uint64_t p = j; p < nCand; p++) {
+        const uint32_t k = ckeys[p];
+        if ((k >> tbits) != qi || ((k & tmask) >> shift) != grp) break;
+        if (p == j || ckeys[p - 1] != k || hitChunk(cvals[p - 1]) != hitChunk(cvals[p])) { heads[nH++] = p; score[p] = 1; }
+        else { const uint64_t h = heads[nH - 1]; if (score[h] < 255) score[h]++; }
+    }
+    const uint32_t C = chunks[qi].nChunks - 1;
+    uint32_t first = 0;
+    while (first < C && ecCount[(size_t) qi * kMaxChunks + first] == 0) first++;
+    const uint32_t alive = kmerMergeScoreGroup(heads, nH, ckeys, cvals, score, first, C, [&](uint32_t c, uint32_t n) { if (n) roundAdd(qi, c, n); });
+    for (uint32_t k = 0; k < nH; k++) {
+        const uint64_t h = heads[k];
+        KmerBest b;
+        b.nElems = score[h] > 0 ? 1u : 0u; b.cand = (uint32_t) h; b.count = (uint32_t) score[h]; b.pad = 0;
+        best[h] = b;
+    }
+    if (alive) resultAdd(qi, alive);
+}
+__global__ __launch_bounds__(128) void k_kmer_merge_heads(const uint32_t *ckeys, const uint64_t *cvals, const uint32_t *nCandPtr, int tbits, int shift, const KmerChunks *chunks,
+                                                          const uint32_t *ecCount /*[nq][kMaxChunks]*/, uint64_t *scr, uint8_t *kept, int32_t *score, KmerBest *best,
+                                                          uint32_t *roundCount /*[nq][kMaxChunks]*/, unsigned long long *resultSize /*[nq]*/) {
+    const uint64_t nCand = *nCandPtr;
+    const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nCand) return;
+    kmerMergeHeadsThread(j, ckeys, cvals, nCand, tbits, shift, chunks, ecCount, scr, kept, score, best,
+                         [&](uint32_t q, uint32_t c, uint32_t n) { atomicAdd(&roundCount[(size_t) q * kMaxChunks + c], n); },
+                         [&](uint32_t q, uint32_t n) { atomicAdd(&resultSize[q], (unsigned long long) n); });
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // search, stage 5: score histogram, cut (computeScoreThreshold) and hand-over of everything at or above the cut
 // --------------------------------------------------------------------------------------------------------------

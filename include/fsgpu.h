@@ -304,7 +304,8 @@ enum {
                                     sequence, identical wherever both builds use libstdc++'s introsort (informational) */
     FSGPU_KMER_E_OUTPUT = -1,    /* the reference would have cut findDuplicates short (output array full); not replayed */
     FSGPU_KMER_E_CHUNKS = -2,    /* more than 255 databaseHits refills */
-    FSGPU_KMER_E_REFILL_COUNTS = -3  /* kmerScoreOnly and the query refilled databaseHits: the reference's merge of the per-refill counts is restated in oracle/ but not yet replayed here */
+    FSGPU_KMER_E_REFILL_COUNTS = -3  /* no longer returned (kept for the ABI): kmerScoreOnly queries that refill databaseHits have the reference's merge of the
+                                        per-refill counts (mergeScoreDuplicates, CacheFriendlyOperations.cpp:150-180) replayed on the device since round 4 */
 };
 /* Runs nq queries (batched on the device), writes per query q up to maxResListLen hits to out[q*maxResListLen ..],
  * their number to nout[q] and a FSGPU_KMER_* code to status[q]; hits are bit-identical to QueryMatcher::matchQuery

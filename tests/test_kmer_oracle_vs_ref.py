@@ -132,8 +132,8 @@ def test_hit_lists_without_diagonal_scoring(world, kw):
 def test_hit_lists_without_diagonal_scoring_with_refills(world, kw):
     """--diag-score 0 with databaseHits refills: mergeElementsByScore as the reference EXECUTES it (CacheFriendlyOperations.cpp:150-180) --
     a target present in two per-refill lists comes out twice (the sum, then the low byte of a diagonal as its "count") and bytes left by
-    one bin seed the sums of later bins.  The oracle restates exactly that; the device path answers such queries with
-    FSGPU_KMER_E_REFILL_COUNTS (tests/test_kmer_gpu.py) until it replays the merge.
+    one bin seed the sums of later bins.  The oracle restates exactly that; the device path replays it per (query, id >> shift) group
+    (k_kmer_merge_heads: tests/test_kmer_merge_model.py without a device, tests/test_kmer_gpu.py against the compiled reference).
     Entries that share (score, id) -- possible only through that duplication -- compare equal under the reference's
     compareHitsByScoreAndId, so their relative order is whatever its std::sort leaves: the lists are compared with such ties
     put in diagonal order on both sides, and each side is checked to be ordered by (score desc, id asc)."""
