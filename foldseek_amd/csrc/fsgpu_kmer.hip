@@ -835,7 +835,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         hipLaunchKernelGGL(k_kmer_cut, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const uint32_t *) S.hist.p, nq, maxHits, (uint32_t) sp.minDiagScoreThr, (uint32_t *) S.thr.p);
         hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
                            (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, nCand, (uint32_t *) S.outCount.p,
-                           (uint32_t *) S.nCand.p + 1, (KmerOut *) S.out.p);
+                           (uint32_t *) S.nCand.p + 1, (KmerOut *) S.out.p, (const uint64_t *) S.scrA.p, (const uint64_t *) S.scrB.p);
         RPCHK(hipGetLastError());
     } else {
         for (int e = 6; e <= 7; e++) RPCHK(hipEventRecord(S.ev[e], st));
@@ -915,8 +915,8 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
                                  fsgpu_kmer_hit *out, int32_t *nout, int32_t *status, double *stats) {
     if (!ctx || !p || (nq > 0 && (!queries || !out || !nout || !status))) return FSGPU_E_ARG;
     if (!ctx->kidx) { ctx->err = "k-mer index not built"; return FSGPU_E_NODB; }
-    if (p->maxResListLen <= 0 || p->minDiagScoreThr < (p->kmerScoreOnly ? 0 : 1) || p->minDiagScoreThr > 255 * (p->kmerScoreOnly ? 1 : 1000)) {
-        ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 1 required (minDiagScoreThr 0 only with kmerScoreOnly = --diag-score 0)"; return FSGPU_E_UNSUPPORTED;
+    if (p->maxResListLen <= 0 || p->minDiagScoreThr < 0 || p->minDiagScoreThr > 255 * (p->kmerScoreOnly ? 1 : 1000)) {
+        ctx->err = "k-mer search: maxResListLen >= 1 and minDiagScoreThr >= 0 required"; return FSGPU_E_UNSUPPORTED;
     }
     if (p->bins && (p->bins & (p->bins - 1))) { ctx->err = "k-mer search: bins must be a power of two"; return FSGPU_E_ARG; }
     RPCHK(hipSetDevice(ctx->device));

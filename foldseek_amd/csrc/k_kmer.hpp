@@ -1384,7 +1384,7 @@ struct KmerBest {          // written at the segment head; nElems == 0xFFFFFFFF 
     uint32_t nElems;       // elements this target contributes to resultSize (first max + later zero-score ones)
     uint32_t cand;         // candidate index of the kept element
     uint32_t count;        // its 8-bit score
-    uint32_t pad;
+    uint32_t pad;          // k_kmer_walk: length of the target's final list, bit 31 = it lives in the second scratch array (0 elsewhere)
 };
 
 __global__ __launch_bounds__(128) void k_kmer_walk(const uint32_t *ckeys, const uint64_t *cvals, const uint8_t *kept, const int32_t *score, const uint32_t *nCandPtr,
@@ -1476,7 +1476,8 @@ __global__ __launch_bounds__(128) void k_kmer_walk(const uint32_t *ckeys, const 
 #undef EL_CNT
 #undef EL_D8
     KmerBest b;
-    b.nElems = nF; b.cand = (uint32_t) (first >> 8); b.count = (uint32_t) first & 0xffu; b.pad = 0;
+    b.nElems = nF; b.cand = (uint32_t) (first >> 8); b.count = (uint32_t) first & 0xffu;
+    b.pad = nL | (Lst == B ? 0x80000000u : 0u);             // where the final list lives: k_kmer_out walks it again when the cut is 0
     best[s] = b;
     if (nF) { if (mine) atomicAdd(&rs, (unsigned long long) nF); else atomicAdd(&resultSize[qi], (unsigned long long) nF); }
 #undef ROUND_ADD
@@ -1636,41 +1637,86 @@ __global__ void k_kmer_cut(const uint32_t *hist, int nq, uint32_t maxHits, uint3
 }
 struct KmerOut { uint32_t id; uint32_t count /* 8-bit score | query << 8 */; uint32_t diag; int32_t score; uint64_t g; };
 // elements at or above their query's cut go to ONE output array shared by the batch (a place per wave-group from a single counter; the
-// host tail sorts by query anyway), per-query counts alongside
+// host tail sorts by query anyway), per-query counts alongside.
+// A cut of 0 (--min-ungapped-score 0 and fewer than max-seqs scored targets; diagonal-score mode) also takes the elements keepMaxScoreElementOnly
+// hands on with score 0 (CacheFriendlyOperations.cpp:112-148: after a target's best element every later zero-score element of it matches the zeroed
+// byte; a target whose best is 0 keeps all of them): the head walks its final list (KmerBest.pad, scrA / scrB of k_kmer_walk) once more and emits
+// one element per match, each with its own diagonal and arrival position.
 __global__ __launch_bounds__(256) void k_kmer_out(const uint32_t *ckeys, const uint64_t *cvals, const int32_t *score, const KmerBest *best, const uint32_t *nCandPtr, int tbits,
-                                                  const uint32_t *thr, uint32_t outCap, uint32_t *outCount /*[nq]*/, uint32_t *outTotal, KmerOut *out) {
+                                                  const uint32_t *thr, uint32_t outCap, uint32_t *outCount /*[nq]*/, uint32_t *outTotal, KmerOut *out,
+                                                  const uint64_t *scrA, const uint64_t *scrB) {
     const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    bool take = false;
+    uint32_t cnt = 0;
     uint32_t qi = 0;
     KmerBest b{};
     if (s < *nCandPtr) {
         b = best[s];
         if (b.nElems != 0xFFFFFFFFu && b.nElems != 0) {
             qi = ckeys[s] >> tbits;
-            take = b.count >= thr[qi] && b.count != 0;
+            const uint32_t t = thr[qi];
+            cnt = t == 0 ? b.nElems : (b.count >= t ? 1u : 0u);
         }
     }
+    const bool take = cnt != 0;
     const int lane = (int) (threadIdx.x & 63);
     const unsigned long long all = __ballot(take);
     if (!all) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(outTotal, (uint32_t) __popcll(all));
-    base = (uint32_t) __shfl((int) base, 0);
-    const uint32_t slot = base + (uint32_t) __popcll(all & ((1ull << lane) - 1ull));
+    const bool multi = __ballot(cnt > 1) != 0ull;
+    uint32_t slot;
+    if (!multi) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(outTotal, (uint32_t) __popcll(all));
+        base = (uint32_t) __shfl((int) base, 0);
+        slot = base + (uint32_t) __popcll(all & ((1ull << lane) - 1ull));
+    } else {
+        uint32_t incl = cnt;                               // inclusive wave scan of the element counts
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t) __shfl_up((int) incl, d); if (lane >= d) incl += v; }
+        uint32_t base = 0;
+        if (lane == 63) base = atomicAdd(outTotal, incl);
+        base = (uint32_t) __shfl((int) base, 63);
+        slot = base + incl - cnt;
+    }
     // one atomic per (wave, query) instead of one per element: same-address atomics serialise in L2
     unsigned long long pending = all;
     while (pending) {
         const int leader = __ffsll((long long) pending) - 1;
         const uint32_t q = (uint32_t) __shfl((int) qi, leader);
         const unsigned long long grp = __ballot(take && qi == q);
-        if (lane == leader) atomicAdd(&outCount[q], (uint32_t) __popcll(grp));
+        if (!multi) { if (lane == leader) atomicAdd(&outCount[q], (uint32_t) __popcll(grp)); }
+        else {
+            uint32_t sum = take && qi == q ? cnt : 0u;
+            for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t) __shfl_xor((int) sum, d);
+            if (lane == leader) atomicAdd(&outCount[q], sum);
+        }
         pending &= ~grp;
     }
-    if (!take || slot >= outCap) return;
-    const uint64_t v = cvals[b.cand];
-    KmerOut o;
-    o.id = ckeys[s] & ((1u << tbits) - 1u); o.count = b.count | (qi << 8); o.diag = hitDiag(v); o.score = score[b.cand]; o.g = hitG(v);
-    out[slot] = o;
+    if (!take) return;
+    const uint32_t id = ckeys[s] & ((1u << tbits) - 1u);
+    if (cnt == 1 && b.count != 0) {
+        if (slot >= outCap) return;
+        const uint64_t v = cvals[b.cand];
+        KmerOut o;
+        o.id = id; o.count = b.count | (qi << 8); o.diag = hitDiag(v); o.score = score[b.cand]; o.g = hitG(v);
+        out[slot] = o;
+        return;
+    }
+    // cut 0: the target's final list once more, as keepMaxScoreElementOnly reads it
+    const uint64_t *L = ((b.pad & 0x80000000u) ? scrB : scrA) + s;
+    const uint32_t nL = b.pad & 0x7fffffffu;
+    uint32_t arr = b.count, k = 0;
+    for (uint32_t n = 0; n < nL && k < cnt; n++) {
+        const uint64_t e = L[n];
+        if (arr != ((uint32_t) e & 0xffu)) continue;
+        arr = 0;
+        const uint32_t c = (uint32_t) (e >> 8);
+        if (slot + k < outCap) {
+            const uint64_t v = cvals[c];
+            KmerOut o;
+            o.id = id; o.count = ((uint32_t) e & 0xffu) | (qi << 8); o.diag = hitDiag(v); o.score = score[c]; o.g = hitG(v);
+            out[slot + k] = o;
+        }
+        k++;
+    }
 }
 
 } // namespace fs

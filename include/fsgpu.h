@@ -268,7 +268,7 @@ int fsgpu_kmer_row_copy(fsgpu_ctx *ctx, int row, int16_t *score, uint16_t *index
 
 typedef struct {
     int32_t maxResListLen;      /* --max-seqs */
-    int32_t minDiagScoreThr;    /* --min-ungapped-score, >= 1 (>= 0 with kmerScoreOnly) */
+    int32_t minDiagScoreThr;    /* --min-ungapped-score, >= 0 (0: a query with fewer than maxResListLen scored targets also gets the score-0 elements the reference hands on) */
     int32_t bins;               /* BINSIZE of CacheFriendlyOperations; 0 = derive from l2CacheSize like initDiagonalMatcher */
     int32_t kmerScoreOnly;      /* 1 = --diag-score 0 (QueryMatcher with diagonalScoring == false, QueryMatcher.cpp:215-232): no ungapped diagonal scores,
                                  * the score of a target is its number of double-diagonal k-mer matches (findDuplicates with computeTotalScore,

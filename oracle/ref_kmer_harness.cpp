@@ -172,6 +172,15 @@ void *ref_kpf_create(const RefKpfParams *pp, const char *tcat, const int64_t *to
     return h;
 }
 
+// Test knob: adds delta to every entry of the UNGAPPED matrix (UngappedAlignment::createProfile reads it per query), so that diagonals
+// score 0 and the elements keepMaxScoreElementOnly hands on with score 0 appear (--min-ungapped-score 0 with diagonal scores); the index and
+// the similar-k-mer lists keep the k-mer matrix.
+void ref_kpf_shift_ungapped(void *hv, int delta) {
+    Kpf *h = (Kpf *) hv;
+    for (int a = 0; a < h->ungappedSubMat->alphabetSize; a++)
+        for (int b = 0; b < h->ungappedSubMat->alphabetSize; b++) h->ungappedSubMat->subMatrix[a][b] = (short) (h->ungappedSubMat->subMatrix[a][b] + delta);
+}
+
 // query-time parameters may change between runs (everything except kmerSize / spaced / kmerThr / masking)
 void ref_kpf_set_params(void *hv, const RefKpfParams *pp) { ((Kpf *) hv)->p = *pp; }
 

@@ -396,3 +396,50 @@ def test_kmer_score_only_mode_equals_the_compiled_reference(thr, kw):
             dup += len(b) - len(np.unique(b["id"]))
     assert thr > 100 or (refills >= 12 and dup > 0), (refills, dup)
     ctx.close()
+
+
+@pytest.mark.parametrize("delta,kw", [(-6, dict(maxResListLen=5000, bins=4)), (-8, dict(maxResListLen=5000, bins=2, maxDbMatches=1000)),
+                                      (-8, dict(maxResListLen=40, bins=16, maxDbMatches=1500, compBias=0)), (-10, dict(maxResListLen=300, bins=16)),
+                                      (-7, dict(maxResListLen=5000, bins=64, maxDbMatches=800)), (-12, dict(maxResListLen=7, bins=8, maxDbMatches=6000)),
+                                      (-8, dict(kmerThr=60, maxResListLen=5000, bins=4, maxDbMatches=2500)), (-9, dict(kmerThr=60, maxResListLen=60, bins=32, maxDbMatches=1200))])
+def test_cut_zero_with_diagonal_scores_equals_the_compiled_reference(delta, kw):
+    """--min-ungapped-score 0 with diagonal scores: when fewer than --max-seqs targets score above 0 the cut is 0 and the reference also returns
+    the elements keepMaxScoreElementOnly hands on with score 0 -- after a target's best element every later zero-score element of it, all of them
+    for a target whose best is 0 (CacheFriendlyOperations.cpp:112-148, QueryMatcher.cpp:181-200) -- each with its own diagonal, the remaining
+    slots filled in the reference's array order.  Two k-mer matches on one diagonal score above 0 under the real matrix, so the case is produced
+    the way the checker can follow: the UNGAPPED matrix is lowered by `delta` on all three sides (oracle/ref_kmer_harness.cpp::ref_kpf_shift_ungapped
+    on the compiled reference's own object; the device takes the query profile from the caller), the k-mer matrix, index and similar-k-mer
+    lists stay as they are.  Settings with databaseHits refills and with cuts inside the zero elements included."""
+    R = K.load_ref()
+    if R is None or not hasattr(R, "ref_kpf_shift_ungapped"):
+        pytest.skip("oracle/_ref not built")
+    q3, qa = synth.make_queries(6, seed=5, mean_len=100, lo=10, hi=300)
+    db = synth.make_db(1500, (q3, qa), seed=6, homologs_per_query=20, mask_frac=0.1, mean_len=100, lo=8, hi=400)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ident = np.array([-1, 3, -1, -1, 7, -1], np.int64)
+    full = dict(kmerThr=78, minDiagScoreThr=0, compBias=1)
+    full.update(kw)
+    r = K.RefKpf(R, targets, threads=4, **full)
+    R.ref_kpf_shift_ungapped(r.h, delta)
+    rr, rs, _ = r.run(list(q3), ident)
+    r.close()
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=full["kmerThr"])
+    prep = []
+    for q in q3:
+        s, thr, prof = api.kmer_query_prepare(m8, m2, q, comp_bias=bool(full["compBias"]), scale=0.15, kmer_thr=full["kmerThr"])
+        prep.append((s, thr, np.clip(prof.astype(np.int32) + delta, -128, 127).astype(np.int8)))
+    res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=full["maxResListLen"], min_diag=0, bins=full["bins"],
+                                         max_db_matches=full.get("maxDbMatches", 0), want_stats=True)
+    canon = lambda a: a[np.lexsort((a["diag"], a["id"], -a["score"].astype(np.int64)))]
+    zeros = 0
+    for q in range(len(q3)):
+        assert status[q] == 0, (q, status[q])
+        a, b = res[q], rr[q]
+        assert len(a) == len(b) and (canon(a) == canon(b)).all(), (q, delta, kw, len(a), len(b), canon(a)[-5:], canon(b)[-5:])
+        assert np.allclose(stats[q][:3], rs[q][:3])
+        zeros += int((b["score"] == 0).sum())
+    assert zeros > 0 and ("maxDbMatches" not in kw or rs[:, 2].sum() > 0 or kw["maxDbMatches"] > 5000), (zeros, rs[:, 2])
+    ctx.close()

@@ -10,7 +10,7 @@ rng = np.random.default_rng(seed)
 O = K.load_ora()
 ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2); usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
 m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
-bad = refused = merged = 0
+bad = refused = merged = zeros = 0
 for rd in range(rounds):
     n = int(rng.integers(1, 2500))
     nq = int(rng.integers(1, 7))
@@ -27,6 +27,11 @@ for rd in range(rounds):
     if rng.random() < 0.25:          # --diag-score 0: k-mer match counts as scores (cut 0 allowed)
         kw["noDiagScore"] = 1
         kw["minDiagScoreThr"] = int(rng.choice([0, 0, 1, 3]))
+    delta = 0
+    if "noDiagScore" not in kw and rng.random() < 0.2:
+        # --min-ungapped-score 0 with diagonal scores: the ungapped matrix lowered on both sides so that score-0 elements exist (tests/test_kmer_gpu.py)
+        delta = int(rng.choice([-6, -8, -10]))
+        kw["minDiagScoreThr"] = 0
     qs = list(q3)
     if n > 3:
         qs.append(targets[int(rng.integers(n))].copy())            # a database member as query (identity path)
@@ -36,10 +41,12 @@ for rd in range(rounds):
     if len(sys.argv) > 3 and rd != int(sys.argv[3]):
         continue
     try:
-        o = K.OraKpf(O, ksub, pb, usub, targets, **kw)
+        o = K.OraKpf(O, ksub, pb, (usub + delta).astype(usub.dtype), targets, **kw)
         ctx = api.Context(0); ctx.load_db(db)
         ctx.kmer_index_build(m8, kmer_thr=thr, spaced=spaced, mask_lower_case=kw["maskLowerCase"], mask_n_repeats=kw["maskNrepeats"])
         prep = [api.kmer_query_prepare(m8, m2, q, comp_bias=bool(kw["compBias"]), kmer_thr=thr, spaced=spaced) for q in qs]
+        if delta:
+            prep = [(a, b, np.clip(c.astype(np.int32) + delta, -128, 127).astype(np.int8)) for (a, b, c) in prep]
         res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=kw["maxResListLen"], min_diag=kw["minDiagScoreThr"], bins=kw["bins"],
                                              max_db_matches=kw["maxDbMatches"], l2_cache_size=2 << 20, want_stats=True, kmer_score_only=bool(kw.get("noDiagScore", 0)))
         ok = True
@@ -60,6 +67,10 @@ for rd in range(rounds):
                 same = True
             elif status[i] < 0:
                 same = False
+            elif delta:
+                canon = lambda a: a[np.lexsort((a["diag"], a["id"], -a["score"].astype(np.int64)))]
+                same = len(res[i]) == len(b) and (canon(res[i]) == canon(b)).all() and (len(q) == 0 or np.allclose(stats[i], st))
+                zeros += int((b["score"] == 0).sum())
             else:
                 same = len(res[i]) == len(b) and (res[i] == b).all() and (len(q) == 0 or np.allclose(stats[i], st))
             if not same:
@@ -67,9 +78,9 @@ for rd in range(rounds):
                 print("  MISMATCH round", rd, "query", i, "L", len(q), "ident", ident[i], "status", status[i], "gpu n", len(res[i]), "ora n", None if b is None else len(b), kw, "n", n)
                 print("    gpu", res[i][:5].tolist(), "ora", None if b is None else b[:5].tolist(), "stats", stats[i].tolist(), None if b is None else st.tolist())
         bad += 0 if ok else 1
-        print("round %d n=%d nq=%d %s overflowed=%s %s" % (rd, n, len(qs), "ok" if ok else "BAD", stats[:, 2].tolist(), {k: kw.get(k, 0) for k in ("kmerThr", "spaced", "maxResListLen", "bins", "maxDbMatches", "noDiagScore")}), flush=True)
+        print("round %d n=%d nq=%d %s overflowed=%s %s" % (rd, n, len(qs), "ok" if ok else "BAD", stats[:, 2].tolist(), {k: kw.get(k, 0) for k in ("kmerThr", "spaced", "maxResListLen", "bins", "maxDbMatches", "noDiagScore")}), "delta", delta, flush=True)
         o.close(); ctx.close()
     except Exception as e:
         bad += 1
         print("round", rd, "EXCEPTION", repr(e), kw, "n", n, flush=True)
-print("fuzz done: %d bad of %d rounds (%d queries refused with FSGPU_KMER_E_OUTPUT, %d count-mode queries with refills replayed)" % (bad, rounds, refused, merged))
+print("fuzz done: %d bad of %d rounds (%d queries refused with FSGPU_KMER_E_OUTPUT, %d count-mode queries with refills replayed, %d score-0 hits under a cut of 0)" % (bad, rounds, refused, merged, zeros))
