@@ -549,6 +549,7 @@ extern "C" {
 
 int fsgpu_gapless_launch(fsgpu_ctx *ctx, const int8_t *pssm, int L, int scoreCap, int minScore, int64_t identityId, int maxRes) {
     if (!ctx) return FSGPU_E_ARG;
+    ctx->mqScanMs = -1.0;                                  // fsgpu_last_kernel_ms(ctx, 0) reads this call's own events again
     if (!pssm || L <= 0 || L > FSGPU_MAX_SEQ_LEN || maxRes <= 0) { ctx->err = "fsgpu_gapless_launch: bad argument"; return FSGPU_E_ARG; }
     if (!ctx->db || ctx->db->n == 0) { ctx->err = "no database loaded"; return FSGPU_E_NODB; }
     if (ctx->gaplessPending) { ctx->err = "previous gapless scan not finished"; return FSGPU_E_ARG; }
@@ -686,7 +687,7 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
     for (int i = 0; i < nq; i++)
         if (!q[i].pssm || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN) { ctx->err = "fsgpu_gapless_scan_multi: bad query"; return FSGPU_E_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
-    ctx->mqLaunches = 0; ctx->mqQueries = 0;
+    ctx->mqLaunches = 0; ctx->mqQueries = 0; ctx->mqScanMs = -1.0;
     ctx->mqSlot.assign(nq, -1);
     // ---- device batch: the single-tile queries, grouped by register class ----
     std::vector<int> batch, longQ;
@@ -880,10 +881,17 @@ int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int n
             nout[qi] = (int) m;
         }
     }
+    // scan time of the whole call (fsgpu_last_kernel_ms(ctx, 0)): the batch's launches plus the row-tiled scans of the long queries, which
+    // run one at a time and reuse the same pair of events
+    double scanMs = nb > 0 ? fsgpu_last_kernel_ms(ctx, 0) : 0.0;
     for (int qi : longQ) {
         const int rc = fsgpu_gapless_scan(ctx, q[qi].pssm, q[qi].L, q[qi].scoreCap, minScore, q[qi].identityId, maxRes, out + (size_t) qi * maxRes, &nout[qi]);
         if (rc != FSGPU_OK) return rc;
+        const double ms = fsgpu_last_kernel_ms(ctx, 0);
+        if (ms >= 0 && scanMs >= 0) scanMs += ms; else scanMs = -1.0;
+        ctx->mqLaunches++; ctx->mqQueries++;
     }
+    ctx->mqScanMs = scanMs;
     return FSGPU_OK;
 }
 
@@ -925,6 +933,7 @@ void fsgpu_sw_last_passes(const fsgpu_ctx *ctx, double *out) {
 double fsgpu_last_kernel_ms(const fsgpu_ctx *ctx, int which) {
     if (ctx && which >= 2 && which < 14) return ctx->kmerMs[which - 2];
     if (!ctx || which < 0 || which > 1 || !ctx->evValid[which]) return -1.0;
+    if (which == 0 && ctx->mqScanMs >= 0) return ctx->mqScanMs;      // a multi-query call with row-tiled queries: all of its scans
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]) != hipSuccess) return -1.0;
     return (double) ms;

@@ -97,6 +97,7 @@ struct fsgpu_ctx {
     DevBuf mqPssm, mqScores, mqQueues, mqRec, mqHist, mqBaseGt, mqBaseTie, mqMeta, mqOutId, mqOutScore, mqIdent;
     PinBuf hMqPssm, hMqRec, hMqMeta, hMqOutId, hMqOutScore, hMqIdent;
     int mqLaunches = 0, mqQueries = 0;          // scan kernel launches / queries of the last batch
+    double mqScanMs = -1.0;                     // >= 0: scan time of the last multi-query call incl. its row-tiled queries
     hipEvent_t scanDoneEv = nullptr;            // recorded after the last scan launch of a batch (chained through DbStore::lastScanDone)
     uint64_t mqScoreStride = 0;
     std::vector<int> mqSlot;                    // query index of the last call -> slice of mqScores (-1: went through the single-query path)
