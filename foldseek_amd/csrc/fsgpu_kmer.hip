@@ -85,7 +85,7 @@ extern "C" int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t
 struct KmerScratch {
     DevBuf qs, posQuery, seqs, thrs, profiles, K, Kbase, listStart, listSize, listPos, listP, chunks,
            rec, part, tmpA, binCount, segStart, cursor, segCand, candBase, segLast, candFlags, segLists, ckeys, cvals, kept, score, scrA, scrB, best,
-           ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand;
+           ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand, kept0, qSlot, truncHist, trunc;
     PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc;
     hipEvent_t ev[14] = {};
     bool evInit = false;
@@ -96,7 +96,8 @@ void fsgpu_kmer_free_scratch(KmerScratch *s) {
     DevBuf *d[] = {&s->qs, &s->posQuery, &s->seqs, &s->thrs, &s->profiles, &s->K, &s->Kbase, &s->listStart, &s->listSize, &s->listPos, &s->listP,
                    &s->chunks, &s->rec, &s->part, &s->tmpA, &s->binCount, &s->segStart, &s->cursor, &s->segCand, &s->candBase, &s->segLast, &s->candFlags, &s->segLists,
                    &s->ckeys, &s->cvals, &s->kept, &s->score,
-                   &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand};
+                   &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand,
+                   &s->kept0, &s->qSlot, &s->truncHist, &s->trunc};
     for (DevBuf *b : d) if (b->p) (void) hipFree(b->p);
     PinBuf *h[] = {&s->hQs, &s->hPosQuery, &s->hSeqs, &s->hThrs, &s->hProfiles, &s->hChunks, &s->hEc, &s->hRounds, &s->hResSize, &s->hThr,
                    &s->hOutCount, &s->hOut, &s->hMisc};
@@ -365,8 +366,20 @@ int scalarDiag(const int8_t *profile, int len, const uint8_t *db) {
 
 // The tail of QueryMatcher::matchQuery (:146-239) on the elements at or above the cut: array order of the reference
 // = (bin = id & (B-1), then the order the overflow rounds left the elements in), radix by score, getResult, final sort.
+// findDuplicates output capacity (CacheFriendlyOperations.cpp:217-219), conservative form: true when some chunk's candidates plus the elements the earlier
+// rounds left reach foundDiagonalsSize, i.e. when the reference MAY have cut that chunk short (the exact, per-bin test is replayOutputTruncation's)
+bool outputTestFires(const fsgpu_kmer_search_params &sp, uint64_t n, const KmerChunks &ck, const uint32_t *ec, const uint32_t *rounds) {
+    const uint64_t foundSize = sp.foundDiagonalsSize ? (uint64_t) sp.foundDiagonalsSize : std::max<uint64_t>(n, 1000000);
+    const uint32_t C = ck.nChunks - 1;
+    const bool lastEmpty = ck.start[ck.nChunks] == ck.start[ck.nChunks - 1];
+    if (ck.aborted != 0 || (C >= 1 && lastEmpty)) return false;          // answered empty / with another status
+    for (uint32_t c = 0; c <= C; c++)
+        if ((uint64_t) ec[c] + (c == 0 ? 0 : rounds[c]) >= foundSize) return true;
+    return false;
+}
+
 int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer_query &q, const KmerChunks &ck, const uint32_t *ec, const uint32_t *rounds,
-                uint64_t resultSize, uint32_t thr, std::vector<HostOut> &el, fsgpu_kmer_hit *out, int32_t *nout) {
+                uint64_t resultSize, uint32_t thr, std::vector<HostOut> &el, fsgpu_kmer_hit *out, int32_t *nout, bool truncationReplayed) {
     const uint64_t big = std::max<uint64_t>(n, 1000000);
     const uint64_t foundSize = sp.foundDiagonalsSize ? (uint64_t) sp.foundDiagonalsSize : big;
     const size_t maxHits = (size_t) std::min<uint64_t>((uint64_t) sp.maxResListLen, n);
@@ -379,7 +392,7 @@ int finishQuery(const fsgpu_kmer_search_params &sp, uint64_t n, const fsgpu_kmer
     const bool lastEmpty = ck.start[ck.nChunks] == ck.start[ck.nChunks - 1];
     if (C >= 1 && lastEmpty) empty = true;
     // findDuplicates output capacity (CacheFriendlyOperations.cpp:217-219): conservative replay
-    for (uint32_t c = 0; c <= C && status == FSGPU_KMER_OK && !empty; c++) {
+    for (uint32_t c = 0; c <= C && status == FSGPU_KMER_OK && !empty && !truncationReplayed; c++) {
         if (c == C && lastEmpty) break;
         const uint64_t before = c == 0 ? 0 : rounds[c];
         if ((uint64_t) ec[c] + before >= foundSize) status = FSGPU_KMER_E_OUTPUT;
@@ -849,6 +862,91 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     RPCHK(hipEventRecord(S.ev[8], st));
     CHK(syncStream(ctx));
     mark("score..out+sync");
+    // ---- findDuplicates cut short by its output capacity: replayed per (query, chunk) in the diagonal-score mode -----------------------------
+    // (--diag-score 0 keeps the status: there the reference's next merge reads the bytes the aborted bin left behind)
+    std::vector<char> truncReplayed;
+    if (nCand && !sp.kmerScoreOnly) {
+        std::vector<int> flagged;
+        for (int q = 0; q < nq; q++)
+            if (outputTestFires(sp, n, hck[q], (const uint32_t *) S.hEc.p + (size_t) q * kMaxChunks, (const uint32_t *) S.hRounds.p + (size_t) q * kMaxChunks)) flagged.push_back(q);
+        const uint32_t B = pickBins(sp, n);
+        const size_t histWords = flagged.size() * (size_t) kMaxChunks * B * 2;
+        if (!flagged.empty() && histWords <= (64u << 20)) {              // <= 256 MB of counters; beyond that the queries keep their status
+            const uint64_t foundSize = sp.foundDiagonalsSize ? (uint64_t) sp.foundDiagonalsSize : std::max<uint64_t>(n, 1000000);
+            std::vector<int32_t> slot(nq, -1);
+            for (size_t k = 0; k < flagged.size(); k++) slot[flagged[k]] = (int32_t) k;
+            CHK(ensureK(ctx, S.kept0, (size_t) nCand));
+            CHK(ensureK(ctx, S.qSlot, (size_t) nq * sizeof(int32_t)));
+            CHK(ensureK(ctx, S.truncHist, histWords * sizeof(uint32_t)));
+            CHK(ensureK(ctx, S.trunc, (size_t) nq * kMaxChunks * sizeof(uint32_t)));
+            RPCHK(hipMemcpyAsync(S.kept0.p, S.kept.p, (size_t) nCand, hipMemcpyDeviceToDevice, st));
+            RPCHK(hipMemcpyAsync(S.qSlot.p, slot.data(), (size_t) nq * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            RPCHK(hipMemsetAsync(S.truncHist.p, 0, histWords * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_kmer_trunc_hist, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const uint8_t *) S.kept.p,
+                               (const uint32_t *) S.nCand.p, tbits, B, (const int32_t *) S.qSlot.p, (uint32_t *) S.truncHist.p);
+            RPCHK(hipGetLastError());
+            std::vector<uint32_t> hh(histWords);
+            RPCHK(hipMemcpyAsync(hh.data(), S.truncHist.p, histWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CHK(syncStream(ctx));
+            std::vector<uint32_t> trunc((size_t) nq * kMaxChunks, 0xFFFFFFFFu);
+            std::vector<uint32_t> next(flagged.size(), 0);
+            bool any = false;
+            for (;;) {
+                bool changed = false;
+                for (size_t k = 0; k < flagged.size(); k++) {
+                    const int q = flagged[k];
+                    const KmerChunks &ck = hck[q];
+                    const uint32_t C = ck.nChunks - 1;
+                    const uint32_t *rounds = (const uint32_t *) S.hRounds.p + (size_t) q * kMaxChunks;
+                    while (next[k] <= C) {
+                        const uint32_t c = next[k]++;
+                        const uint64_t before = c == 0 ? 0 : rounds[c];
+                        const uint64_t outSize = foundSize > before ? foundSize - before : 0;
+                        const uint32_t *h = hh.data() + ((k * kMaxChunks + c) * (size_t) B) * 2;
+                        uint64_t dbl = 0;
+                        uint32_t cut = 0xFFFFFFFFu;
+                        for (uint32_t b = 0; b < B; b++) {
+                            if (dbl + h[2 * b] >= outSize) { cut = b; break; }
+                            dbl += h[2 * b + 1];
+                        }
+                        if (cut != 0xFFFFFFFFu) { trunc[(size_t) q * kMaxChunks + c] = cut; changed = true; break; }     // the later rounds' element counts are stale now
+                    }
+                }
+                if (!changed) break;
+                any = true;
+                RPCHK(hipMemcpyAsync(S.trunc.p, trunc.data(), trunc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                RPCHK(hipMemsetAsync(S.rounds.p, 0, (size_t) nq * kMaxChunks * sizeof(uint32_t), st));
+                RPCHK(hipMemsetAsync(S.resSize.p, 0, (size_t) nq * sizeof(uint64_t), st));
+                hipLaunchKernelGGL(k_kmer_apply_trunc, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const uint8_t *) S.kept0.p,
+                                   (const uint32_t *) S.nCand.p, tbits, B, (const uint32_t *) S.trunc.p, (uint8_t *) S.kept.p);
+                hipLaunchKernelGGL(k_kmer_walk, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                                   (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
+                                   (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
+                RPCHK(hipGetLastError());
+                RPCHK(hipMemcpyAsync(S.hRounds.p, S.rounds.p, (size_t) nq * kMaxChunks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                RPCHK(hipMemcpyAsync(S.hResSize.p, S.resSize.p, (size_t) nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+                CHK(syncStream(ctx));
+            }
+            if (any) {      // histogram, cut and hand-over once more, on the truncated lists
+                RPCHK(hipMemsetAsync(S.hist.p, 0, (size_t) nq * 256 * sizeof(uint32_t), st));
+                RPCHK(hipMemsetAsync(S.outCount.p, 0, (size_t) nq * sizeof(uint32_t), st));
+                RPCHK(hipMemsetAsync((uint32_t *) S.nCand.p + 1, 0, sizeof(uint32_t), st));
+                hipLaunchKernelGGL(k_kmer_hist, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const KmerBest *) S.best.p,
+                                   (const uint32_t *) S.nCand.p, tbits, (uint32_t *) S.hist.p);
+                hipLaunchKernelGGL(k_kmer_cut, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const uint32_t *) S.hist.p, nq, maxHits, (uint32_t) sp.minDiagScoreThr, (uint32_t *) S.thr.p);
+                hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
+                                   (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, nCand, (uint32_t *) S.outCount.p,
+                                   (uint32_t *) S.nCand.p + 1, (KmerOut *) S.out.p, (const uint64_t *) S.scrA.p, (const uint64_t *) S.scrB.p);
+                RPCHK(hipGetLastError());
+                RPCHK(hipMemcpyAsync(S.hThr.p, S.thr.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                RPCHK(hipMemcpyAsync(S.hOutCount.p, S.outCount.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                CHK(syncStream(ctx));
+            }
+            truncReplayed.assign(nq, 0);
+            for (int q : flagged) truncReplayed[q] = 1;
+            mark("truncation replay");
+        }
+    }
     const uint32_t *hOutCount = (const uint32_t *) S.hOutCount.p;
     size_t totalOut = 0;
     std::vector<size_t> outOff(nq + 1, 0);
@@ -890,7 +988,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         el.resize(c);
         if (c) memcpy(el.data(), (const HostOut *) S.hOut.p + outOff[q], c * sizeof(HostOut));
         status[q] = finishQuery(sp, n, queries[q], hck[q], (const uint32_t *) S.hEc.p + (size_t) q * kMaxChunks, (const uint32_t *) S.hRounds.p + (size_t) q * kMaxChunks,
-                                ((const uint64_t *) S.hResSize.p)[q], ((const uint32_t *) S.hThr.p)[q], el, out + (size_t) q * sp.maxResListLen, &nout[q]);
+                                ((const uint64_t *) S.hResSize.p)[q], ((const uint32_t *) S.hThr.p)[q], el, out + (size_t) q * sp.maxResListLen, &nout[q],
+                                !truncReplayed.empty() && truncReplayed[q]);
         if (stats) {
             uint64_t le = nLists;
             for (int r = q + 1; r < nq; r++) { le = hq2[r].listBase; break; }

@@ -1599,6 +1599,33 @@ __global__ __launch_bounds__(128) void k_kmer_merge_heads(const uint32_t *ckeys,
                          [&](uint32_t q, uint32_t n) { atomicAdd(&resultSize[q], (unsigned long long) n); });
 }
 
+// findDuplicates cut short (CacheFriendlyOperations.cpp:188-283): the reference walks its bins (id & (B - 1)) in order and RETURNS at the first bin whose
+// candidates would not fit behind what the earlier bins handed on -- doubleElementCount + elementCount >= outputSize, outputSize = foundDiagonalsSize minus
+// the elements the earlier rounds left (QueryMatcher.cpp:311-346) -- so a chunk loses the candidates of that bin and of every later one.  The host decides
+// per (query, chunk) which bin that is (fsgpu_kmer.hip: replayOutputTruncation) from the two counts per (query, chunk, bin) this kernel collects for the
+// queries its caller flagged: candidates, and candidates that survive the collapse of equal consecutive diagonals (= elements handed on).
+__global__ __launch_bounds__(256) void k_kmer_trunc_hist(const uint32_t *ckeys, const uint64_t *cvals, const uint8_t *kept, const uint32_t *nCandPtr, int tbits, uint32_t B,
+                                                         const int32_t *qSlot /*[nq]: slot of a flagged query, -1 otherwise*/, uint32_t *hist /*[slot][kMaxChunks][B][2]*/) {
+    const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *nCandPtr) return;
+    const uint32_t key = ckeys[j];
+    const int32_t slot = qSlot[key >> tbits];
+    if (slot < 0) return;
+    const uint32_t bin = (key & ((1u << tbits) - 1u)) & (B - 1u);
+    uint32_t *h = hist + (((size_t) slot * kMaxChunks + hitChunk(cvals[j])) * B + bin) * 2;
+    atomicAdd(&h[0], 1u);
+    if (kept[j]) atomicAdd(&h[1], 1u);
+}
+// kept[j] = the scoring pass's flag, cleared for the candidates of bins at or beyond their (query, chunk)'s truncation bin (0xFFFFFFFF = none)
+__global__ __launch_bounds__(256) void k_kmer_apply_trunc(const uint32_t *ckeys, const uint64_t *cvals, const uint8_t *kept0, const uint32_t *nCandPtr, int tbits, uint32_t B,
+                                                          const uint32_t *trunc /*[nq][kMaxChunks]*/, uint8_t *kept) {
+    const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *nCandPtr) return;
+    const uint32_t key = ckeys[j];
+    const uint32_t bin = (key & ((1u << tbits) - 1u)) & (B - 1u);
+    kept[j] = kept0[j] && bin < trunc[(size_t) (key >> tbits) * kMaxChunks + hitChunk(cvals[j])] ? 1 : 0;
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // search, stage 5: score histogram, cut (computeScoreThreshold) and hand-over of everything at or above the cut
 // --------------------------------------------------------------------------------------------------------------

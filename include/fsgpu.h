@@ -302,7 +302,8 @@ enum {
     FSGPU_KMER_UNSTABLE = 1,     /* >= foundDiagonalsSize/2 targets carried a diagonal: the reference orders equal scores with an
                                     unstable std::sort there (QueryMatcher.cpp:205-215); replayed with the same call on the same
                                     sequence, identical wherever both builds use libstdc++'s introsort (informational) */
-    FSGPU_KMER_E_OUTPUT = -1,    /* the reference would have cut findDuplicates short (output array full); not replayed */
+    FSGPU_KMER_E_OUTPUT = -1,    /* the reference would have cut findDuplicates short (output array full): replayed in the diagonal-score mode since round 4,
+                                    still a status with kmerScoreOnly (and beyond 256 MB of per-bin counters for the flagged queries of a batch) */
     FSGPU_KMER_E_CHUNKS = -2,    /* more than 255 databaseHits refills */
     FSGPU_KMER_E_REFILL_COUNTS = -3  /* no longer returned (kept for the ABI): kmerScoreOnly queries that refill databaseHits have the reference's merge of the
                                         per-refill counts (mergeScoreDuplicates, CacheFriendlyOperations.cpp:150-180) replayed on the device since round 4 */

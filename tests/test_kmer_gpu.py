@@ -443,3 +443,55 @@ def test_cut_zero_with_diagonal_scores_equals_the_compiled_reference(delta, kw):
         zeros += int((b["score"] == 0).sum())
     assert zeros > 0 and ("maxDbMatches" not in kw or rs[:, 2].sum() > 0 or kw["maxDbMatches"] > 5000), (zeros, rs[:, 2])
     ctx.close()
+
+
+def test_find_duplicates_cut_short_equals_the_compiled_reference():
+    """foundDiagonals full (CacheFriendlyOperations.cpp:188-283 `doubleElementCount + elementCount >= outputSize`; upstream issue #1092: more
+    than half a bin on one diagonal): the reference's findDuplicates walks its bins in order and RETURNS at the first one whose candidates do not
+    fit behind what the earlier bins handed on, so that chunk loses the candidates of that bin and of all later ones -- and the query goes on
+    with what fitted (later refills see fewer elements, results can be empty).  Replayed per (query, chunk) from per-bin candidate counts
+    (fsgpu_kmer.hip: truncation replay) instead of answered with FSGPU_KMER_E_OUTPUT.  Eight buffer / bin / threshold settings on the compiled
+    reference's QueryMatcher with its foundDiagonals shrunk (with and without databaseHits refills, truncation at bin 0 = no results at all,
+    queries that also take the unstable-sort branch): ids, scores, diagonals, order, statistics."""
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    q3, qa = synth.make_queries(6, seed=21, mean_len=200, lo=40, hi=600)
+    db = synth.make_db(3000, (q3, qa), seed=22, homologs_per_query=60, mask_frac=0.05, mean_len=200, lo=20, hi=800, stay=0.5)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ident = np.array([-1, 3, -1, -1, 7, -1], np.int64)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctxs = {}
+    cut = refilled = 0
+    for kw in [dict(foundDiagonalsSize=150, bins=16, maxDbMatches=3000), dict(foundDiagonalsSize=250, bins=4, maxDbMatches=9000), dict(foundDiagonalsSize=400, bins=2),
+               dict(foundDiagonalsSize=200, bins=64, maxDbMatches=20000, maxResListLen=50), dict(foundDiagonalsSize=120, bins=8, maxDbMatches=1500, kmerThr=90),
+               dict(foundDiagonalsSize=1500, bins=32, kmerThr=60), dict(foundDiagonalsSize=180, bins=2, maxDbMatches=2500, compBias=0),
+               dict(foundDiagonalsSize=2500, bins=8, kmerThr=60, maxDbMatches=30000)]:
+        full = dict(kmerThr=78, maxResListLen=1000, minDiagScoreThr=15, compBias=1)
+        full.update(kw)
+        r = K.RefKpf(R, targets, threads=4, **full)
+        rr, rs, _ = r.run(list(q3), ident)
+        r.close()
+        whole = dict(full, foundDiagonalsSize=0)
+        r = K.RefKpf(R, targets, threads=4, **whole)
+        rr0, _, _ = r.run(list(q3), ident)
+        r.close()
+        thr = full["kmerThr"]
+        if thr not in ctxs:
+            ctxs[thr] = api.Context(0)
+            ctxs[thr].load_db(db)
+            ctxs[thr].kmer_index_build(m8, kmer_thr=thr)
+        prep = [api.kmer_query_prepare(m8, m2, q, comp_bias=bool(full["compBias"]), scale=0.15, kmer_thr=thr) for q in q3]
+        res, status, stats = ctxs[thr].kmer_search(prep, identity=ident, max_res=full["maxResListLen"], min_diag=full["minDiagScoreThr"], bins=full["bins"],
+                                                   max_db_matches=full.get("maxDbMatches", 0), found_diagonals_size=full["foundDiagonalsSize"], want_stats=True)
+        for q in range(len(q3)):
+            assert status[q] >= 0, (q, status[q], kw)
+            a, b = res[q], rr[q]
+            assert len(a) == len(b) and (a == b).all(), (q, kw, status[q], len(a), len(b), a[:3], b[:3])
+            assert np.allclose(stats[q][:3], rs[q][:3])
+            differs = not (len(b) == len(rr0[q]) and (b == rr0[q]).all())
+            cut += differs
+            refilled += differs and rs[q][2] > 0
+    for c in ctxs.values():
+        c.close()
+    assert cut >= 30 and refilled >= 10, (cut, refilled)

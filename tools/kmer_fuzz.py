@@ -27,6 +27,8 @@ for rd in range(rounds):
     if rng.random() < 0.25:          # --diag-score 0: k-mer match counts as scores (cut 0 allowed)
         kw["noDiagScore"] = 1
         kw["minDiagScoreThr"] = int(rng.choice([0, 0, 1, 3]))
+    if "noDiagScore" not in kw and rng.random() < 0.25:
+        kw["foundDiagonalsSize"] = int(rng.choice([100, 200, 400, 1000, 3000]))      # findDuplicates cut short: replayed since round 4 (diagonal-score mode)
     delta = 0
     if "noDiagScore" not in kw and rng.random() < 0.2:
         # --min-ungapped-score 0 with diagonal scores: the ungapped matrix lowered on both sides so that score-0 elements exist (tests/test_kmer_gpu.py)
@@ -48,7 +50,8 @@ for rd in range(rounds):
         if delta:
             prep = [(a, b, np.clip(c.astype(np.int32) + delta, -128, 127).astype(np.int8)) for (a, b, c) in prep]
         res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=kw["maxResListLen"], min_diag=kw["minDiagScoreThr"], bins=kw["bins"],
-                                             max_db_matches=kw["maxDbMatches"], l2_cache_size=2 << 20, want_stats=True, kmer_score_only=bool(kw.get("noDiagScore", 0)))
+                                             max_db_matches=kw["maxDbMatches"], found_diagonals_size=kw.get("foundDiagonalsSize", 0), l2_cache_size=2 << 20, want_stats=True,
+                                             kmer_score_only=bool(kw.get("noDiagScore", 0)))
         ok = True
         for i, q in enumerate(qs):
             b, st = o.query(q, int(ident[i]))
@@ -60,9 +63,9 @@ for rd in range(rounds):
                 merged += 1
             elif b is None:
                 same = status[i] == 1          # the oracle does not model the std::sort branch
-            elif status[i] == -2:
-                # FSGPU_KMER_E_OUTPUT: the conservative "findDuplicates would run out of output space" test fired (only with the
-                # artificially small maxDbMatches of this fuzzer) -- the query is refused with a status, never answered wrongly
+            elif status[i] == -2 or (status[i] == -1 and kw.get("noDiagScore", 0)):
+                # FSGPU_KMER_E_CHUNKS (more than 255 databaseHits refills: only with the artificially small maxDbMatches of this fuzzer), or
+                # FSGPU_KMER_E_OUTPUT in the count mode (findDuplicates cut short there stays a status) -- refused with a status, never answered wrongly
                 refused += 1
                 same = True
             elif status[i] < 0:
@@ -78,9 +81,9 @@ for rd in range(rounds):
                 print("  MISMATCH round", rd, "query", i, "L", len(q), "ident", ident[i], "status", status[i], "gpu n", len(res[i]), "ora n", None if b is None else len(b), kw, "n", n)
                 print("    gpu", res[i][:5].tolist(), "ora", None if b is None else b[:5].tolist(), "stats", stats[i].tolist(), None if b is None else st.tolist())
         bad += 0 if ok else 1
-        print("round %d n=%d nq=%d %s overflowed=%s %s" % (rd, n, len(qs), "ok" if ok else "BAD", stats[:, 2].tolist(), {k: kw.get(k, 0) for k in ("kmerThr", "spaced", "maxResListLen", "bins", "maxDbMatches", "noDiagScore")}), "delta", delta, flush=True)
+        print("round %d n=%d nq=%d %s overflowed=%s %s" % (rd, n, len(qs), "ok" if ok else "BAD", stats[:, 2].tolist(), {k: kw.get(k, 0) for k in ("kmerThr", "spaced", "maxResListLen", "bins", "maxDbMatches", "noDiagScore", "foundDiagonalsSize")}), "delta", delta, flush=True)
         o.close(); ctx.close()
     except Exception as e:
         bad += 1
         print("round", rd, "EXCEPTION", repr(e), kw, "n", n, flush=True)
-print("fuzz done: %d bad of %d rounds (%d queries refused with FSGPU_KMER_E_OUTPUT, %d count-mode queries with refills replayed, %d score-0 hits under a cut of 0)" % (bad, rounds, refused, merged, zeros))
+print("fuzz done: %d bad of %d rounds (%d queries refused with a status, %d count-mode queries with refills replayed, %d score-0 hits under a cut of 0)" % (bad, rounds, refused, merged, zeros))
