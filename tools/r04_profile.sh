@@ -10,9 +10,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-bench}
 TAG=${2:-x}
-if [ "$MODE" = pmc ]; then
+#   r04_profile.sh pmck TAG   the k-mer and all-vs-all passes of `pmc` alone (the scan kernel's sources did not change: its pass of tag PREV=... is reused)
+if [ "$MODE" = pmc ] || [ "$MODE" = pmck ]; then
 python $R/tools/csrc_hash.py k_gapless.hpp fs_kernels.h > $O/${TAG}_csrc_hash_gapless.txt
 python $R/tools/csrc_hash.py k_kmer.hpp fsgpu_kmer.hip fs_kernels.h > $O/${TAG}_csrc_hash_kmer.txt
+if [ "$MODE" = pmc ]; then
 SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-kmer --type2-steps 0 --allvsall-steps 0 --fullrange-steps 0"
 pass() { rm -rf /tmp/pmc_$1; rocprofv3 --pmc "$@" -d /tmp/pmc_$1 -o p --output-format csv -- python $R/bench.py $SHORT > /tmp/pmc_$1.log 2>&1; }
 pass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
@@ -21,6 +23,9 @@ pass FETCH_SIZE
 pass WRITE_SIZE
 python $R/tools/pmc_family.py /tmp/pmc_SQ_WAVES /tmp/pmc_SQ_LDS_BANK_CONFLICT /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE --json $O/${TAG}_pmc_bench_1M.json > $O/${TAG}_pmc_bench_1M_steps3.txt 2>&1
 grep -h "^{" /tmp/pmc_SQ_WAVES.log | tail -1 > $O/${TAG}_pmc_bench_1M_benchline.json
+else
+cp $R/profiles/r04_${PREV:-z}_pmc_bench_1M.json $O/${TAG}_pmc_bench_1M.json
+fi
 kpass() { rm -rf /tmp/kpmc_$1; rocprofv3 --pmc "$@" -d /tmp/kpmc_$1 -o p --output-format csv -- python $R/tools/kmer_bench.py 1000000 32 1 > /tmp/kpmc_$1.log 2>&1; }
 kpass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
 kpass SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
