@@ -163,3 +163,86 @@ def test_hit_lists_without_diagonal_scoring_with_refills(world, kw):
         assert dup > 0 or base["maxResListLen"] < 100      # ... and the reference's duplicated targets are in the lists
     finally:
         r.set(noDiagScore=0, maxDbMatches=0, bins=0); o.set(noDiagScore=0, maxDbMatches=0, bins=0)
+
+
+def _canon(a):
+    return a[np.lexsort((a["diag"], a["id"], -a["score"].astype(np.int64)))]
+
+
+def test_cut_zero_elements_oracle_equals_the_compiled_reference():
+    """--min-ungapped-score 0 with diagonal scores: the score-0 elements keepMaxScoreElementOnly hands on (CacheFriendlyOperations.cpp:354-384: after a
+    target's best element every later zero-score element of it, all of them when its best is 0) come out when a query's cut is 0.  Two k-mer matches on
+    one diagonal score above 0 under the real matrix, so the reference's own ungapped matrix object is lowered (ref_kpf_shift_ungapped) and the oracle
+    gets the same matrix: random settings with refills, 2 .. 64 bins and cuts inside the zero elements (what the device is then held to:
+    tests/test_kmer_gpu.py::test_cut_zero_with_diagonal_scores_equals_the_compiled_reference)."""
+    R = K.load_ref()
+    if R is None or not hasattr(R, "ref_kpf_shift_ungapped"):
+        pytest.skip("oracle/_ref not built")
+    O = K.load_ora()
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    rng = np.random.default_rng(3)
+    zeros = refills = 0
+    for it in range(14):
+        thr = int(rng.choice([78, 60, 96])); delta = int(rng.choice([-5, -7, -8, -9, -12])); mean = int(rng.choice([40, 100, 250])); n = int(rng.choice([300, 1500]))
+        kw = dict(kmerThr=thr, maxResListLen=int(rng.choice([3, 20, 100, 5000])), minDiagScoreThr=0, compBias=int(rng.integers(0, 2)), bins=int(rng.choice([2, 4, 16, 64])),
+                  maxDbMatches=int(rng.choice([0, 800, 3000, 9000])))
+        q3, qa = synth.make_queries(5, seed=int(rng.integers(1 << 30)), mean_len=mean, lo=10, hi=int(mean * 3))
+        db = synth.make_db(n, (q3, qa), seed=int(rng.integers(1 << 30)), homologs_per_query=int(rng.integers(0, 30)), mask_frac=0.1, mean_len=mean, lo=8, hi=mean * 4)
+        targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+        o = K.OraKpf(O, ksub, pb, (usub + delta).astype(usub.dtype), targets, **kw)
+        r = K.RefKpf(R, targets, threads=2, **kw)
+        R.ref_kpf_shift_ungapped(r.h, delta)
+        ident = np.array([-1, 3, -1, -1, 7], np.int64)
+        rr, rs, _ = r.run(list(q3), ident)
+        for i, q in enumerate(q3):
+            b, st = o.query(q, int(ident[i]))
+            if b is None:
+                continue
+            assert len(b) == len(rr[i]) and (_canon(b) == _canon(rr[i])).all() and np.allclose(st[:3], rs[i][:3]), (it, i, kw, delta)
+            zeros += int((b["score"] == 0).sum())
+        refills += int(rs[:, 2].sum())
+        o.close(); r.close()
+    assert zeros > 300 and refills >= 5, (zeros, refills)
+
+
+def test_find_duplicates_cut_short_oracle_equals_the_compiled_reference():
+    """foundDiagonals full: findDuplicates returns at the first bin whose candidates do not fit (CacheFriendlyOperations.cpp:217-219) and the query goes on
+    with what fitted.  The oracle's restatement against the compiled reference with its buffer shrunk, on the database and the eight settings the device
+    is held to (tests/test_kmer_gpu.py::test_find_duplicates_cut_short_equals_the_compiled_reference), with and without refills; counted: the queries
+    whose answer differs from the one with the full-size buffer."""
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    O = K.load_ora()
+    ksub, pb = H.o_submat("MAT3DI", 8.0, -0.2)
+    usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
+    q3, qa = synth.make_queries(6, seed=21, mean_len=200, lo=40, hi=600)
+    db = synth.make_db(3000, (q3, qa), seed=22, homologs_per_query=60, mask_frac=0.05, mean_len=200, lo=20, hi=800, stay=0.5)
+    targets = [db.seq(i, "3di", unmask=False) for i in range(db.n)]
+    ident = np.array([-1, 3, -1, -1, 7, -1], np.int64)
+    cut = cut_refilled = compared = 0
+    for kw in [dict(foundDiagonalsSize=150, bins=16, maxDbMatches=3000), dict(foundDiagonalsSize=250, bins=4, maxDbMatches=9000), dict(foundDiagonalsSize=400, bins=2),
+               dict(foundDiagonalsSize=200, bins=64, maxDbMatches=20000, maxResListLen=50), dict(foundDiagonalsSize=120, bins=8, maxDbMatches=1500, kmerThr=90),
+               dict(foundDiagonalsSize=1500, bins=32, kmerThr=60), dict(foundDiagonalsSize=180, bins=2, maxDbMatches=2500, compBias=0),
+               dict(foundDiagonalsSize=2500, bins=8, kmerThr=60, maxDbMatches=30000)]:
+        full = dict(kmerThr=78, maxResListLen=1000, minDiagScoreThr=15, compBias=1)
+        full.update(kw)
+        o = K.OraKpf(O, ksub, pb, usub, targets, **full)
+        r = K.RefKpf(R, targets, threads=4, **full)
+        rr, rs, _ = r.run(list(q3), ident)
+        r.close()
+        r = K.RefKpf(R, targets, threads=4, **dict(full, foundDiagonalsSize=0))
+        rr0, _, _ = r.run(list(q3), ident)
+        r.close()
+        for i, q in enumerate(q3):
+            differs = not (len(rr[i]) == len(rr0[i]) and (rr[i] == rr0[i]).all())
+            b, st = o.query(q, int(ident[i]))
+            if b is None:
+                continue                                 # std::sort branch: not modelled by the oracle (the device replays it, tests/test_kmer_gpu.py)
+            compared += 1
+            assert len(b) == len(rr[i]) and (b == rr[i]).all() and np.allclose(st[:3], rs[i][:3]), (i, kw)
+            cut += differs
+            cut_refilled += differs and st[2] > 0
+        o.close()
+    assert compared >= 25 and cut >= 15 and cut_refilled >= 5, (compared, cut, cut_refilled)
