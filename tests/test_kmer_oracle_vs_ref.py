@@ -183,7 +183,7 @@ def test_cut_zero_elements_oracle_equals_the_compiled_reference():
     usub, _ = H.o_submat("MAT3DI", 2.0, -0.2)
     rng = np.random.default_rng(3)
     zeros = refills = 0
-    for it in range(14):
+    for it in range(8):
         thr = int(rng.choice([78, 60, 96])); delta = int(rng.choice([-5, -7, -8, -9, -12])); mean = int(rng.choice([40, 100, 250])); n = int(rng.choice([300, 1500]))
         kw = dict(kmerThr=thr, maxResListLen=int(rng.choice([3, 20, 100, 5000])), minDiagScoreThr=0, compBias=int(rng.integers(0, 2)), bins=int(rng.choice([2, 4, 16, 64])),
                   maxDbMatches=int(rng.choice([0, 800, 3000, 9000])))
@@ -203,7 +203,7 @@ def test_cut_zero_elements_oracle_equals_the_compiled_reference():
             zeros += int((b["score"] == 0).sum())
         refills += int(rs[:, 2].sum())
         o.close(); r.close()
-    assert zeros > 300 and refills >= 5, (zeros, refills)
+    assert zeros > 100 and refills >= 3, (zeros, refills)
 
 
 def test_find_duplicates_cut_short_oracle_equals_the_compiled_reference():
