@@ -126,8 +126,8 @@ typedef struct {
     int64_t identityId;     /* target id that is always kept, or -1 */
 } fsgpu_gapless_query;
 int fsgpu_gapless_scan_multi(fsgpu_ctx *ctx, const fsgpu_gapless_query *q, int nq, int minScore, int maxRes, fsgpu_hit *out, int *nout);
-/* scan kernel launches / device-batched queries of the last fsgpu_gapless_scan_multi; fsgpu_last_kernel_ms(ctx, 0) then is
- * the device time of all its scan launches together */
+/* scans / queries of the last fsgpu_gapless_scan_multi: one per launch of the device batch plus one per row-tiled query (> 896 residues, run on
+ * its own); fsgpu_last_kernel_ms(ctx, 0) then is the device time of all of them together */
 int fsgpu_gapless_last_batch(const fsgpu_ctx *ctx, int *launches, int *queries);
 /* raw scores of query `queryIndex` of the last fsgpu_gapless_scan_multi call (queries of <= 896 residues); for tests */
 int fsgpu_gapless_scores_multi(fsgpu_ctx *ctx, int queryIndex, uint8_t *scores_out);
