@@ -210,10 +210,15 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
         run(t, batches[0], False)                                 # warm every host thread's context
     ready, go = threading.Barrier(KT + 1), threading.Barrier(KT + 1)
 
+    failed = []
+
     def worker(t):
         ready.wait(); go.wait()
-        for b in range(t, len(batches), KT):
-            run(t, batches[b], True)
+        try:
+            for b in range(t, len(batches), KT):
+                run(t, batches[b], True)
+        except BaseException as e:          # reported after the join: a leg with a dead feeder thread must not print partial numbers
+            failed.append(e)
 
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(KT)]
     for th in ths:
@@ -231,6 +236,8 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
     torch.cuda.synchronize()
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
     gc.enable()
+    if failed:
+        raise RuntimeError(f"k-mer leg: a feeder thread failed: {failed[0]!r}") from failed[0]
     # solo batch on an idle GPU for the roofline of the dominant kernel: the fastest of three (the first one can still overlap the last SW
     # launches of the timed region)
     solo_ms = None
@@ -477,10 +484,15 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
             run(t, b, False)
     ready, go = threading.Barrier(KT + 1), threading.Barrier(KT + 1)
 
+    failed = []
+
     def worker(t):
         ready.wait(); go.wait()
-        for b in timed[t::KT]:
-            run(t, b, True)
+        try:
+            for b in timed[t::KT]:
+                run(t, b, True)
+        except BaseException as e:          # reported after the join: a leg with a dead feeder thread must not print partial numbers
+            failed.append(e)
 
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(KT)]
     for th in ths:
@@ -500,6 +512,8 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         dist.barrier()
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
     gc.enable()
+    if failed:
+        raise RuntimeError(f"all-vs-all leg: a feeder thread failed: {failed[0]!r}") from failed[0]
     # one batch alone on the device (the middle one of this rank's timed batches): the solo figures of both rooflines
     solo = None
     if timed:
@@ -603,7 +617,16 @@ def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev
         rs = searches[t].align_batch([qa[i] for i in ids], [q3[i] for i in ids], [h["id"] for h in hl])
         return hl, rs, (scan_ms, launches, nbatched, sum(len(q3[i]) for i in ids))
 
+    failed = []
+
     def worker(t):
+        try:
+            worker_body(t)
+        except BaseException as e:          # a feeder thread that dies must not leave the others (and the main thread) waiting at a barrier for good
+            failed.append(e)
+            ready.abort(); go.abort()
+
+    def worker_body(t):
         # untimed warm-up inside the worker: the first HIP calls of a host thread initialise per-thread state
         for b in warm_batches[t::nthreads]:
             step(t, b)
@@ -635,7 +658,16 @@ def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
     for th in ths:
         th.start()
-    ready.wait()
+
+    def wait_at(barrier):
+        try:
+            barrier.wait()
+        except threading.BrokenBarrierError:
+            for th in ths:
+                th.join()
+            raise RuntimeError(f"bench.py: a feeder thread failed: {failed[0]!r}" if failed else "bench.py: feeder barrier broken") from (failed[0] if failed else None)
+
+    wait_at(ready)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -643,9 +675,12 @@ def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev
     gc.disable()            # a generation-2 collection of the interpreter (torch is imported: ~50 ms) would stall every feeder thread at once
     t0 = time.perf_counter()
     t_go[0] = t0
-    go.wait()
+    wait_at(go)
     for th in ths:
         th.join()
+    if failed:
+        gc.enable()
+        raise RuntimeError(f"bench.py: a feeder thread failed: {failed[0]!r}") from failed[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
