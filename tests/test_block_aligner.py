@@ -635,3 +635,21 @@ def test_ba_kat_harness_and_crate_answers_when_present(tmp_path):
     assert len(want) == len(ours)
     bad = [(a, b) for a, b in zip(ours, want) if a != b]
     assert not bad, bad[:5]
+
+
+def test_restatement_follows_the_model_in_the_foldseek_call_shape_on_long_pairs():
+    """tools/ba_model_sweep.py on a fresh seed: 80 homolog pairs of up to 500 residues with long insertions / deletions in the call shape of
+    alignStartPosBacktraceBlock (both matrices, composition bias, block sizes 32, 64, ... until the SW score is reached) -- the restatement through
+    oracle/ba_kat/ba_kat.cpp against tests/ba_model.py: score, end cell, CIGAR and the block sizes tried, every case.  (The committed KAT cases stop at
+    110 residues; 8000 such cases over 20 other seeds up to 600 residues: 0 mismatches)"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ba_model_sweep.py"), "7", "80", "500"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "80 cases" in last and " 0 mismatches" in last and "target score missed 0x" in last, r.stdout[-2000:]
+    attempts = eval(re.search(r"attempts per case (\{[^}]*\})", last).group(1))
+    assert sum(v for k, v in attempts.items() if k >= 2) >= 3, attempts            # the retry with a larger block happened
