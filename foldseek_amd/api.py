@@ -137,6 +137,7 @@ def lib():
         "fsgpu_sw_batch_seqs": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "fsgpu_diag_rescore": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]),
         "fshost_search_prefilter_batch": (i32, [vp, i32, vp, vp, vp, vp, vp]),
+        "fshost_search_kmer_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "fshost_search_rescore_diagonal_batch": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "fshost_banded_backtrace": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
         "fshost_search_startpos_backtrace": (i32, [vp, vp, vp, i32, C.c_uint32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
@@ -619,6 +620,29 @@ class Search:
         if with_backtrace:
             bts = [[lib().fshost_search_backtrace(self.h, C.c_void_p(out[i][k:k + 1].ctypes.data)).decode() for k in range(len(out[i]))] for i in range(nq)]
             return out, bts
+        return out
+
+    def kmer_batch(self, m_kmer, m_ungapped, kmer_thr, spaced, qaa_ptrs, q3_ptrs, lens, pref_identity=None, aln_identity=None, max_res=200, min_diag=30,
+                   kmer_score_only=False):
+        """fshost_search_kmer_batch: k-mer prefilter + coverage pre-filter + structure alignment of a batch of queries in ONE library call (the per-batch
+        body of the `search` module).  qaa_ptrs / q3_ptrs: uint64 arrays with the host addresses of the queries' code strings (0..20), lens: their lengths.
+        Returns a dict: nhits, status, nkept, nres (int32[nq]), hits [nq, max_res], kept [nq, max_res], results [nq, max_res * (1 + alt)], seconds[4]."""
+        nq = len(lens)
+        pa = np.ascontiguousarray(qaa_ptrs, np.uint64); p3 = np.ascontiguousarray(q3_ptrs, np.uint64)
+        Ls = np.ascontiguousarray(lens, np.int32)
+        pi = None if pref_identity is None else np.ascontiguousarray(pref_identity, np.int64)
+        ai = None if aln_identity is None else np.ascontiguousarray(aln_identity, np.int64)
+        sp = KmerSearchParams(max_res, min_diag, 0, 1 if kmer_score_only else 0, 0, 0, 0)
+        rcap = max_res * (1 + max(0, self.par.altAlignment))
+        n1 = max(nq, 1)
+        out = {"hits": np.zeros((n1, max_res), KMER_HIT_DT), "nhits": np.zeros(n1, np.int32), "status": np.zeros(n1, np.int32),
+               "kept": np.zeros((n1, max_res), np.uint32), "nkept": np.zeros(n1, np.int32), "results": np.zeros((n1, rcap), RESULT_DT),
+               "nres": np.zeros(n1, np.int32), "seconds": np.zeros(4)}
+        rc = lib().fshost_search_kmer_batch(self.h, m_kmer.h, m_ungapped.h, C.cast(C.byref(sp), C.c_void_p), int(kmer_thr), int(spaced), nq, _ptr(pa), _ptr(p3), _ptr(Ls),
+                                            _ptr(pi), _ptr(ai), _ptr(out["hits"]), _ptr(out["nhits"]), _ptr(out["status"]), _ptr(out["kept"]), _ptr(out["nkept"]),
+                                            _ptr(out["results"]), _ptr(out["nres"]), _ptr(out["seconds"]))
+        if rc != 0:
+            raise FsgpuError(f"kmer_batch rc={rc}: {lib().fshost_search_error(self.h).decode()}")
         return out
 
     def startpos_backtrace(self, qAA, q3di, target_id, q_end, db_end, score):

@@ -79,6 +79,8 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->swLong) (void) hipStreamSynchronize(ctx->swLong);
+    if (ctx->swHi) (void) hipStreamSynchronize(ctx->swHi);          // the k_sw3 path runs here and on swAux: nothing may be in flight when its buffers go
+    for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamSynchronize(ctx->swAux[i]);
     if (ctx->scanDoneEv) {
         if (ctx->db) { std::lock_guard<std::mutex> g(ctx->db->scanMutex); if (ctx->db->lastScanDone == ctx->scanDoneEv) ctx->db->lastScanDone = nullptr; }
         (void) hipEventDestroy(ctx->scanDoneEv);
@@ -925,7 +927,7 @@ void fsgpu_sw_last_passes(const fsgpu_ctx *ctx, double *out) {
     for (int d = 0; d < 2; d++) {
         float ms = -1;
         if (!ctx || !ctx->swDirValid[d] || hipEventElapsedTime(&ms, ctx->swDirEv[2 * d], ctx->swDirEv[2 * d + 1]) != hipSuccess) { ms = -1; (void) hipGetLastError(); }
-        out[d * 4 + 0] = ms;
+        out[d * 4 + 0] = ms >= 0 ? ms + (float) ctx->swDirExtraMs[d] : ms;
         out[d * 4 + 1] = ctx ? ctx->swDirCells[d] : 0; out[d * 4 + 2] = ctx ? ctx->swDirPairs[d] : 0; out[d * 4 + 3] = ctx ? ctx->swDirWaveSteps[d] : 0;
     }
 }
@@ -1491,6 +1493,7 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
     if (!ctx->swDirEv[3]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->swDirEv[i]));
     ctx->swDirValid[dir] = false;
     if (dir == 0) ctx->swDirValid[1] = false;
+    ctx->swDirExtraMs[dir] = 0;
     {
         // work of this pass in the units of the kernel's roofline: DP cells (query rows x target columns of every single-tile pair) and
         // VALU wave-instructions (a wave carries two targets of one query and runs max(LtA, LtB) + lanes - 1 steps; a step is 14 packed
@@ -1668,6 +1671,12 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     if (hasAA && !ctx->db->hasAA) { ctx->err = "AA matrix given but the database was loaded without AA sequences"; return FSGPU_E_NODB; }
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t S = ctx->swHi ? ctx->swHi : ctx->stream;          // everything of the k_sw3 path: uploads, image build, launches, download
+    // an error return after work was enqueued must not leave copies out of the pinned staging buffers or kernels in flight: the next call (or
+    // fsgpu_destroy) would refill / free memory that is still being read
+    struct Drain {
+        fsgpu_ctx *c; hipStream_t s; bool ok = false;
+        ~Drain() { if (ok) return; (void) hipStreamSynchronize(s); for (int i = 0; i < 6; i++) if (c->swAux[i]) (void) hipStreamSynchronize(c->swAux[i]); (void) hipGetLastError(); }
+    } drain{ctx, S};
     std::vector<size_t> base(nq + 1, 0), sbase(nq + 1, 0);
     for (int i = 0; i < nq; i++) {
         if (!q[i].q3Di || (hasAA && !q[i].qAA) || q[i].L <= 0 || q[i].L > FSGPU_MAX_SEQ_LEN || q[i].n < 0 || (q[i].n > 0 && !q[i].targetIds)) { ctx->err = "fsgpu_sw_multi_dir_c: bad query"; return FSGPU_E_ARG; }
@@ -1691,6 +1700,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         sw3Materialize(mat3Di, q[i].q3Di, q[i].cb3Di_rev, q[i].L, true, pr.sR);
         if (hasAA) { sw3Materialize(matAA, q[i].qAA, q[i].cbAA_fwd, q[i].L, false, pr.aF); sw3Materialize(matAA, q[i].qAA, q[i].cbAA_rev, q[i].L, true, pr.aR); }
     };
+    double clMs = 0, clCells = 0, clPairs = 0, clSteps = 0;          // what the sub-call below ran
     if (!classic.empty()) {
         std::vector<Prof> prof(classic.size());
         std::vector<fsgpu_sw_query> cq(classic.size());
@@ -1710,6 +1720,12 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         for (int d = 0; d < nDirs; d++) {
             rc = fsgpu_sw_multi_dir(ctx, cq.data(), (int) cq.size(), gapOpen, gapExtend, dir0 + d, sel ? csel.data() : nullptr, sel ? cnsel.data() : nullptr, cout.data());
             if (rc != FSGPU_OK) return rc;
+            {   // the sub-call's pass belongs to this submission's accounting (fsgpu_sw_last_passes): it is reset and re-recorded for the k_sw3 launches below
+                double pp[8];
+                fsgpu_sw_last_passes(ctx, pp);
+                const int cs = dir0 + d;
+                if (pp[cs * 4] >= 0) { clMs += pp[cs * 4]; clCells += pp[cs * 4 + 1]; clPairs += pp[cs * 4 + 2]; clSteps += pp[cs * 4 + 3]; }
+            }
             fsgpu_swres *dst = d == 0 ? out : out2;
             size_t cb = 0;
             for (size_t c = 0; c < classic.size(); c++) {
@@ -1733,8 +1749,17 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     if (!ctx->swDirEv[3]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&ctx->swDirEv[i]));
     ctx->swDirValid[slot] = false;
     if (slot == 0) ctx->swDirValid[1] = false;
-    ctx->swDirCells[slot] = 0; ctx->swDirPairs[slot] = 0; ctx->swDirWaveSteps[slot] = 0;
-    if (total == 0) return FSGPU_OK;
+    ctx->swDirCells[slot] = clCells; ctx->swDirPairs[slot] = clPairs; ctx->swDirWaveSteps[slot] = clSteps;
+    ctx->swDirExtraMs[slot] = clMs;
+    if (total == 0) {
+        if (!classic.empty()) {          // every query of the call was row-tiled: an empty k_sw3 interval carries the sub-call's figures
+            HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot], S)); HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot + 1], S));
+            if ((rc = syncStreamOf(ctx, S)) != FSGPU_OK) return rc;
+            ctx->swDirValid[slot] = true;
+        }
+        drain.ok = true;
+        return FSGPU_OK;
+    }
     const std::vector<int32_t> &len = ctx->db->hLengths;
     // target ids of the pass, longest first inside a query (neighbours share a wave), and the split into the two shapes
     if ((rc = ensurePinned(ctx, ctx->hS3pass, total * 4 + 64)) != FSGPU_OK) return rc;      // grown below once the descriptors are counted
@@ -1893,7 +1918,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
             // first pair of a workgroup is its longest: longest workgroups first
             std::stable_sort(hBlk + g.blk0, hBlk + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return len[hTids[x.firstPair]] > len[hTids[y.firstPair]]; });
         }
-        ctx->swDirCells[slot] = cells * nDirs; ctx->swDirPairs[slot] = pairs * nDirs; ctx->swDirWaveSteps[slot] = winsts * nDirs;
+        ctx->swDirCells[slot] = clCells + cells * nDirs; ctx->swDirPairs[slot] = clPairs + pairs * nDirs; ctx->swDirWaveSteps[slot] = clSteps + winsts * nDirs;
     }
     HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, S));
     if (slot == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], S));
@@ -1962,6 +1987,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
             } else out[base[i] + where[k]] = dir == 0 ? f2[k] : r2[k];
         }
     }
+    drain.ok = true;
     return FSGPU_OK;
 }
 

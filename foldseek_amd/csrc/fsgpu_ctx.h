@@ -82,6 +82,7 @@ struct fsgpu_ctx {
     double kmerHitsPerQuery = 0;       // index hits per query of the last batch (sizes the next one)
     double kmerKPerPos = 0;            // similar k-mers per query position of the last batch (picks the wave / workgroup form of the next count pass)
     int kmerBatchCap = 0;              // > 0: a batch overflowed 2^32 hits, stay at or below this many queries
+    int kmerBatchOk = 0;                           // batches that succeeded in a row under the current cap (it is relaxed after four)
     uint64_t kmerCounts[4] = {0, 0, 0, 0};   // last batch: k-mer lists probed, index hits, double-diagonal candidates, elements handed to the host
 
     // gapless scratch
@@ -113,6 +114,7 @@ struct fsgpu_ctx {
     hipEvent_t swDirEv[4] = {nullptr, nullptr, nullptr, nullptr};   // fwd start / stop, rev start / stop
     bool swDirValid[2] = {false, false};
     double swDirCells[2] = {0, 0}, swDirPairs[2] = {0, 0}, swDirWaveSteps[2] = {0, 0};
+    double swDirExtraMs[2] = {0, 0};               // device time of the row-tiled (> 1024 residues) queries' sub-call of a k_sw3 submission, outside swDirEv
     // multi-query row-tiled launches (queries longer than 512 rows inside fsgpu_sw_multi_dir): own stream, own staging
     hipStream_t swLong = nullptr;
     DevBuf lbuf, lres;                             // [ids | border bases | tile blocks per level | images], [fwd results | rev results]

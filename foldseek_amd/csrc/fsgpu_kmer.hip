@@ -25,7 +25,9 @@ struct KmerIndex {
     uint8_t *masked = nullptr;            // SequenceLookup: masked codes in the padded layout of the DB
     uint32_t *offsets = nullptr;          // 20^6 + 1, in device k-mer order (kmerDeviceIndex)
     uint32_t *bitmap = nullptr;           // 20^6 bits: list non-empty
-    uint64_t *entries = nullptr;          // seqId << 16 | first position
+    uint64_t *entries = nullptr;          // seqId << 16 | first position (posBits == 0) ...
+    uint32_t *entries32 = nullptr;        // ... or seqId << posBits | first position when id bits + position bits <= 32 (round 5: the gather of a list moves half the bytes)
+    int posBits = 0;
     uint64_t nEntries = 0;
     int16_t *s3 = nullptr;                // extended 3-mer matrix, rows sorted descending
     uint16_t *i3 = nullptr;
@@ -35,7 +37,7 @@ struct KmerIndex {
     std::vector<BinLevel> levels;
     uint64_t residues = 0;
     ~KmerIndex() {
-        (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(bitmap); (void) hipFree(entries); (void) hipFree(s3); (void) hipFree(i3);
+        (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(bitmap); (void) hipFree(entries); (void) hipFree(entries32); (void) hipFree(s3); (void) hipFree(i3);
         for (BinLevel &l : levels) { (void) hipFree(l.blk); (void) hipFree(l.blkCoarse); (void) hipFree(l.coarseFirst); (void) hipFree(l.binFirst); }
     }
 };
@@ -84,7 +86,7 @@ extern "C" int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t
 
 struct KmerScratch {
     DevBuf qs, posQuery, seqs, thrs, profiles, K, Kbase, listStart, listSize, listPos, listP, chunks,
-           rec, part, tmpA, binCount, segStart, cursor, segCand, candBase, segLast, candFlags, segLists, ckeys, cvals, kept, score, scrA, scrB, best,
+           rec, part, tmpA, tileL, binCount, segStart, cursor, segCand, candBase, segLast, candFlags, segLists, ckeys, cvals, kept, score, scrA, scrB, best,
            ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand, kept0, qSlot, truncHist, trunc;
     PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc;
     hipEvent_t ev[14] = {};
@@ -94,7 +96,7 @@ struct KmerScratch {
 void fsgpu_kmer_free_scratch(KmerScratch *s) {
     if (!s) return;
     DevBuf *d[] = {&s->qs, &s->posQuery, &s->seqs, &s->thrs, &s->profiles, &s->K, &s->Kbase, &s->listStart, &s->listSize, &s->listPos, &s->listP,
-                   &s->chunks, &s->rec, &s->part, &s->tmpA, &s->binCount, &s->segStart, &s->cursor, &s->segCand, &s->candBase, &s->segLast, &s->candFlags, &s->segLists,
+                   &s->chunks, &s->rec, &s->part, &s->tmpA, &s->tileL, &s->binCount, &s->segStart, &s->cursor, &s->segCand, &s->candBase, &s->segLast, &s->candFlags, &s->segLists,
                    &s->ckeys, &s->cvals, &s->kept, &s->score,
                    &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand,
                    &s->kept0, &s->qSlot, &s->truncHist, &s->trunc};
@@ -251,8 +253,18 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
         IXCHK(hipMemcpyAsync(&ne, scan + R, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         IXCHK(hipStreamSynchronize(ctx->stream));
         ix->nEntries = ne;
-        IXCHK(hipMalloc((void **) &ix->entries, std::max<uint64_t>(ne, 1) * sizeof(uint64_t)));
-        hipLaunchKernelGGL(k_kmer_compact_entries, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, v1, flags, scan, R, ix->entries);
+        {   // 4-byte entries while a target id and a position fit 32 bits together (FSGPU_KMER_ENTRY64=1 keeps the 8-byte form: A/B runs, tests)
+            const int pbits = bitsFor((uint64_t) std::max(db.maxLen, 1) + 1);
+            const char *e64 = getenv("FSGPU_KMER_ENTRY64");
+            ix->posBits = (ix->tbits + pbits <= 32 && pbits <= 16 && !(e64 && atoi(e64) != 0)) ? pbits : 0;
+        }
+        if (ix->posBits) {
+            IXCHK(hipMalloc((void **) &ix->entries32, std::max<uint64_t>(ne, 1) * sizeof(uint32_t)));
+            hipLaunchKernelGGL(k_kmer_compact_entries32, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, v1, flags, scan, R, ix->posBits, ix->entries32);
+        } else {
+            IXCHK(hipMalloc((void **) &ix->entries, std::max<uint64_t>(ne, 1) * sizeof(uint64_t)));
+            hipLaunchKernelGGL(k_kmer_compact_entries, dim3(gridFor(R, 256)), dim3(256), 0, ctx->stream, v1, flags, scan, R, ix->entries);
+        }
         IXCHK(hipGetLastError());
     } else {
         IXCHK(hipMalloc((void **) &ix->entries, sizeof(uint64_t)));
@@ -311,7 +323,17 @@ int fsgpu_kmer_index_copy(fsgpu_ctx *ctx, uint32_t *offsets /*64e6+1*/, uint64_t
     if (!ctx->kidx) { ctx->err = "k-mer index not built"; return FSGPU_E_NODB; }
     const KmerIndex &ix = *ctx->kidx;
     if (offsets) RPCHK(hipMemcpy(offsets, ix.offsets, (64000000ull + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (entries && ix.nEntries) RPCHK(hipMemcpy(entries, ix.entries, ix.nEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (entries && ix.nEntries) {
+        if (ix.posBits) {             // the accessor's format stays seqId << 16 | position
+            uint64_t *wide = nullptr;
+            RPCHK(hipMalloc((void **) &wide, ix.nEntries * sizeof(uint64_t)));
+            hipLaunchKernelGGL(k_kmer_widen_entries, dim3(gridFor(ix.nEntries, 256)), dim3(256), 0, ctx->stream, ix.entries32, ix.nEntries, ix.posBits, wide);
+            hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+            hipError_t e3 = hipMemcpy(entries, wide, ix.nEntries * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            (void) hipFree(wide);
+            RPCHK(e1); RPCHK(e2); RPCHK(e3);
+        } else RPCHK(hipMemcpy(entries, ix.entries, ix.nEntries * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
     if (masked && ix.db->bytes) RPCHK(hipMemcpy(masked, ix.masked, ix.db->bytes, hipMemcpyDeviceToHost));
     return FSGPU_OK;
 }
@@ -522,7 +544,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     const uint64_t maxDbMatches = sp.maxDbMatches ? (uint64_t) sp.maxDbMatches : big * 2;
     const uint32_t maxHits = (uint32_t) std::min<uint64_t>((uint64_t) sp.maxResListLen, n);
     int rc;
-#define CHK(x) do { rc = (x); if (rc == FSGPU_E_NOMEM && nq > 1) return 1; if (rc != FSGPU_OK) return rc; } while (0)
+#define CHK(x) do { rc = (x); if (rc == FSGPU_E_NOMEM && nq > 1) { (void) hipStreamSynchronize(ctx->stream); return 1; } if (rc != FSGPU_OK) return rc; } while (0)   // 1: the caller halves the batch; nothing of this attempt may still read the staging buffers
     // FSGPU_KMER_TRACE=1: host wall clock of the phases of a batch on stderr (where a feeder thread's time goes between the device stages)
     static const bool trace = getenv("FSGPU_KMER_TRACE") != nullptr;
     auto tPrev = std::chrono::steady_clock::now();
@@ -627,6 +649,10 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     CHK(syncStream(ctx));
     nLists = misc[0];
     mark("count+sync");
+    if (nLists >= 0xFFFFFF00ull) {                           // list slots are 32-bit in k_kmer_tile_lists (and 20 bytes of scratch each)
+        if (nq > 1) return 1;                                // caller halves the batch
+        ctx->err = "k-mer search: a single query produces more than 2^32 similar k-mers"; return FSGPU_E_UNSUPPORTED;
+    }
     RPCHK(hipEventRecord(S.ev[1], st));
     CHK(ensureK(ctx, S.listStart, (nLists + 1) * sizeof(uint32_t)));
     CHK(ensureK(ctx, S.listSize, (nLists + 1) * sizeof(uint32_t)));
@@ -696,8 +722,13 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         if (const char *e = getenv("FSGPU_KMER_BIN_LEVEL")) lv = &ix.levels[std::min<size_t>(ix.levels.size() - 1, (size_t) std::max(0, atoi(e)))];   // tests: force a level
         // hits per bincount / binscatter workgroup: about 16 per bin (128-byte runs per segment and tile, one reservation atomic per 16 hits),
         // but no fewer than 4 tiles per CU
+        // ... and sized so that the tiles fill whole rounds of the device's workgroup slots (four bincount workgroups fit a CU's LDS): 2180 tiles on
+        // 1024 slots ran three rounds, the last one 13 % full
         uint64_t hitTile = std::max<uint64_t>(16384, ((uint64_t) lv->nBins * 16 + 4095) / 4096 * 4096);
-        hitTile = std::max<uint64_t>(16384, std::min<uint64_t>(hitTile, (nHits / ((uint64_t) ctx->numCU * 4) + 4095) / 4096 * 4096));
+        {
+            const uint64_t slots = (uint64_t) ctx->numCU * 4, rounds = std::max<uint64_t>(1, (nHits + slots * hitTile - 1) / (slots * hitTile));
+            hitTile = std::max<uint64_t>(16384, ((nHits + rounds * slots - 1) / (rounds * slots) + 4095) / 4096 * 4096);
+        }
         const bool blkInLds = ((size_t) lv->nBins + lv->nBlk) * sizeof(uint32_t) <= 64 * 1024 - 256;
         const KmerBins bins{lv->blk, lv->blkCoarse, lv->coarseFirst, lv->binFirst, lv->nBlk, lv->nBins, lv->nCoarse, (uint32_t) hitTile, blkInLds ? 1u : 0u};
         const size_t ldsBins = ((size_t) lv->nBins + (blkInLds ? lv->nBlk : 0)) * sizeof(uint32_t);
@@ -720,8 +751,17 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         RPCHK(hipMemsetAsync(S.binCount.p, 0, ((size_t) nSeg + 1) * sizeof(uint32_t), st));
         RPCHK(hipMemsetAsync(segLists.counts, 0, 16 * sizeof(uint32_t), st));
         const unsigned nTiles = gridFor(nHits, hitTile);
-        hipLaunchKernelGGL(k_kmer_emit, dim3(gridFor(nHits, kEmitTile)), dim3(256), 0, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
-                           (const uint32_t *) S.listPos.p, ix.entries, nHits, (uint64_t *) S.rec.p);
+        {
+            const uint32_t nEmitTiles = gridFor(nHits, kEmitTile);
+            CHK(ensureK(ctx, S.tileL, (size_t) nEmitTiles * 2 * sizeof(uint32_t)));
+            hipLaunchKernelGGL(k_kmer_tile_lists, dim3(gridFor((uint64_t) nEmitTiles * 2, 256)), dim3(256), 0, st, (const uint64_t *) S.listP.p, nLists, nHits, nEmitTiles, (uint32_t *) S.tileL.p);
+            if (ix.posBits)
+                hipLaunchKernelGGL(k_kmer_emit<uint32_t>, dim3(nEmitTiles), dim3(256), 0, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
+                                   (const uint32_t *) S.listPos.p, (const uint32_t *) S.tileL.p, (const uint32_t *) ix.entries32, ix.posBits, nHits, (uint64_t *) S.rec.p);
+            else
+                hipLaunchKernelGGL(k_kmer_emit<uint64_t>, dim3(nEmitTiles), dim3(256), 0, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
+                                   (const uint32_t *) S.listPos.p, (const uint32_t *) S.tileL.p, (const uint64_t *) ix.entries, 16, nHits, (uint64_t *) S.rec.p);
+        }
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[3], st));
         hipLaunchKernelGGL(k_kmer_bincount, dim3(nTiles), dim3(256), ldsBins, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.rec.p, nHits, bins,
@@ -735,6 +775,8 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         RPCHK(hipMemcpyAsync(cursorA, coarseStart, (size_t) nOwners * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         // two staged levels: stream order -> (query, coarse bin) in the gaux buffers' place (tmpA), -> (query, bin) in part
         uint64_t *tmpA = (uint64_t *) S.tmpA.p;
+        // (round 5: persistent workgroups that prefetch their next tile into registers were measured and dropped -- 80 to 128 VGPRs for 4 to 6 workgroups
+        // per CU: coarse 1.12 -> 1.21 ms, fine 0.91 -> 1.03 ms per 1.6 x 10^8 hits; the kernels are not bound by the latency of their tile loads)
         hipLaunchKernelGGL(k_kmer_scatter_coarse, dim3(gridFor(nHits, kScTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.rec.p, nHits, bins, cursorA, tmpA);
         hipLaunchKernelGGL(k_kmer_scatter_fine, dim3(gridFor(nHits, kScTile)), dim3(256), 0, st, (const uint32_t *) coarseStart, nOwners, (const uint64_t *) tmpA, nHits, bins,
                            (uint32_t *) S.cursor.p, (uint64_t *) S.part.p);
@@ -836,9 +878,16 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             RPCHK(hipGetLastError());
             RPCHK(hipEventRecord(S.ev[6], st));
             // ---- stage 4: per-target replay ----------------------------------------------------------------------
-            hipLaunchKernelGGL(k_kmer_walk, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
-                               (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
-                               (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
+            // FSGPU_KMER_WALK_FF=0: every round of every target is walked (A/B runs; the truncation replay below always uses that form)
+            static const bool walkFF = [] { const char *e = getenv("FSGPU_KMER_WALK_FF"); return !(e && atoi(e) == 0); }();
+            if (walkFF)
+                hipLaunchKernelGGL(k_kmer_walk<true>, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                                   (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
+                                   (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
+            else
+                hipLaunchKernelGGL(k_kmer_walk<false>, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                                   (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
+                                   (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
             RPCHK(hipGetLastError());
             RPCHK(hipEventRecord(S.ev[7], st));
         }
@@ -919,7 +968,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
                 RPCHK(hipMemsetAsync(S.resSize.p, 0, (size_t) nq * sizeof(uint64_t), st));
                 hipLaunchKernelGGL(k_kmer_apply_trunc, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const uint8_t *) S.kept0.p,
                                    (const uint32_t *) S.nCand.p, tbits, B, (const uint32_t *) S.trunc.p, (uint8_t *) S.kept.p);
-                hipLaunchKernelGGL(k_kmer_walk, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
+                hipLaunchKernelGGL(k_kmer_walk<false>, dim3(gridFor(nCand, 128)), dim3(128), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p,
                                    (const uint8_t *) S.kept.p, (const int32_t *) S.score.p, (const uint32_t *) S.nCand.p, tbits, (const KmerChunks *) S.chunks.p,
                                    (uint64_t *) S.scrA.p, (uint64_t *) S.scrB.p, (KmerBest *) S.best.p, (uint32_t *) S.rounds.p, (unsigned long long *) S.resSize.p);
                 RPCHK(hipGetLastError());
@@ -1030,7 +1079,7 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
     int q0 = 0;
     while (q0 < nq) {
         int batch = std::min(maxBatch, 32);                   // no history on this context: a batch of 32 shows what a query costs here
-        if (ctx->kmerHitsPerQuery > 0) batch = (int) std::max(8.0, std::min((double) maxBatch, hitBudget / ctx->kmerHitsPerQuery));
+        if (ctx->kmerHitsPerQuery > 0) batch = (int) std::max(1.0, std::min((double) maxBatch, hitBudget / ctx->kmerHitsPerQuery));   // queries of more than budget / 8 hits each: fewer than 8 per batch
         batch = std::min(batch, maxBatch);
         if (ctx->kmerBatchCap > 0) batch = std::min(batch, ctx->kmerBatchCap);
         // the rest of the call in device batches of equal size
@@ -1038,9 +1087,11 @@ extern "C" int fsgpu_kmer_search(fsgpu_ctx *ctx, const fsgpu_kmer_search_params 
         const int m = (left + parts - 1) / parts;
         const uint64_t hitsBefore = ctx->kmerCounts[1];
         int rc = kmerBatch(ctx, *p, queries + q0, m, out + (size_t) q0 * p->maxResListLen, nout + q0, status + q0, stats ? stats + (size_t) q0 * 4 : nullptr);
-        if (rc == 1) { ctx->kmerBatchCap = std::max(1, m / 2); continue; }            // too many hits / out of memory: redo with half the queries
+        if (rc == 1) { ctx->kmerBatchCap = std::max(1, m / 2); ctx->kmerBatchOk = 0; continue; }            // too many hits / out of memory: redo with half the queries
         if (rc != FSGPU_OK) return rc;
-        if (ctx->kmerBatchCap > 0) ctx->kmerBatchCap = 2 * ctx->kmerBatchCap >= maxBatch ? 0 : 2 * ctx->kmerBatchCap;   // one heavy batch does not cap the context for good
+        // one heavy batch does not cap the context for good, but the cap is only relaxed after four batches in a row went through under it: doubling it
+        // after every success made every second batch of a run of heavy queries fail, be abandoned after its first stage and be redone
+        if (ctx->kmerBatchCap > 0 && ++ctx->kmerBatchOk >= 4) { ctx->kmerBatchCap = 2 * ctx->kmerBatchCap >= maxBatch ? 0 : 2 * ctx->kmerBatchCap; ctx->kmerBatchOk = 0; }
         ctx->kmerHitsPerQuery = (double) (ctx->kmerCounts[1] - hitsBefore) / (double) std::max(1, m);
         q0 += m;
     }

@@ -49,8 +49,11 @@ int fsgpuLaunchSw3Image(fsgpu_ctx *ctx, const Sw3ImgQuery *dq, int nq, int maxDw
                         uint32_t *img, bool hasAA, hipStream_t stream) {
     if (nq <= 0) return FSGPU_OK;
     const int bx = std::max(1, std::min(64, (maxDwords + 1023) / 1024));
-    hipLaunchKernelGGL(k_sw3_image, dim3(bx, nq), dim3(256), 0, stream, dq, data, mat3, matA, img, hasAA ? 1 : 0);
-    HIPCHK(hipGetLastError());
+    // a query can have two images (32- and 64-lane shape): up to 2 x 65535 of them per call, more than one grid's y extent
+    for (int i0 = 0; i0 < nq; i0 += 65535) {
+        hipLaunchKernelGGL(k_sw3_image, dim3(bx, std::min(65535, nq - i0)), dim3(256), 0, stream, dq + i0, data, mat3, matA, img, hasAA ? 1 : 0);
+        HIPCHK(hipGetLastError());
+    }
     return FSGPU_OK;
 }
 #endif

@@ -474,7 +474,10 @@ struct DeviceSet {
                 fprintf(stderr, "RCCL self-check on device %d: one-rank communicator + ncclBroadcast ok (usedRccl 1)\n", first);
             }
         }
-        perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), 32));
+        // Every feeder thread beyond the first owns a context clone with its own scratch -- for the k-mer prefilter up to 2 x 2.4e8 index hits x 24 B
+        // = 11.5 GB each: 16 of them fit a 288 GB device next to the resident DB and its index, 32 need not (the Prefiltering adapter inside the
+        // reference, adapters/prefiltering_fsgpu.inc, uses the same cap).  The aligning modules below take at most 8 feeders anyway.
+        perGpuThreads = std::max(1, std::min(o.geti("--threads", defaultThreads), alignFeeders ? 32 : 16));
         if (alignFeeders) {
             // Modules that align (search, structurealign): --threads is the number of cores the job may use, as for the reference's OpenMP
             // loop.  The per-hit backtraces -- most of the host work once a hit list holds real homologs -- run in the process-wide worker
@@ -486,7 +489,8 @@ struct DeviceSet {
             perGpuThreads = ef ? std::max(1, std::min(atoi(ef), 32)) : std::max(1, std::min(8, (cores + 1) / 2));
             if (!getenv("FSGPU_HOST_WORKERS")) fshost_set_host_workers(cores >= 4 ? cores : std::max(0, cores - 1));
         }
-        if (moduleTiming() || getenv("FSGPU_REQUIRE_RCCL"))
+        const char *rq = getenv("FSGPU_REQUIRE_RCCL");
+        if (moduleTiming() || (rq && *rq && *rq != '0'))
             fprintf(stderr, "host budget: %d usable cores (cgroup quota), %d GPU(s), %d feeder thread(s) per GPU, %d backtrace workers\n",
                     fshost_usable_cores(), (int) root.size(), perGpuThreads, fshost_host_workers());
         return true;
@@ -995,7 +999,7 @@ int fsmod_search(int argc, const char **argv) {
     const bool writePref = o.pos.size() == 4;
     if (writePref && !wp.open(o.pos[3], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();
-    const size_t batch = prefMode == 0 ? 512 : 16;       // k-mer prefilter: capacity of a thread's staging, a round takes fsgpu_kmer_batch_hint() queries
+    const size_t batch = prefMode == 0 ? 1024 : 16;      // k-mer prefilter: capacity of a thread's staging (the device batch limit), a round takes fsgpu_kmer_batch_hint() queries
     std::vector<std::string> results(q3.size()), prefs(writePref ? q3.size() : 0);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
@@ -1011,7 +1015,10 @@ int fsmod_search(int argc, const char **argv) {
         std::vector<std::vector<int16_t>> thr(batch);
         std::vector<std::vector<int8_t>> prof(batch);
         std::vector<fsgpu_kmer_query> kq(batch);
-        std::vector<fsgpu_kmer_hit> khits(batch * (size_t) maxRes);
+        std::vector<fsgpu_kmer_hit> khits(prefMode == 0 ? batch * (size_t) maxRes : 1);
+        std::vector<uint32_t> kkept(prefMode == 0 ? batch * (size_t) maxRes : 1);
+        std::vector<int32_t> nkept(batch), knres(batch);
+        std::vector<fshost_result> kres;
         std::vector<fsgpu_hit> ghits((size_t) maxRes);
         std::vector<int32_t> nout(batch), status(batch);
         std::vector<std::vector<uint32_t>> ids(batch);
@@ -1028,7 +1035,8 @@ int fsmod_search(int argc, const char **argv) {
             size_t take = batch;
             if (prefMode == 0) {
                 const size_t seen = next.load();
-                const size_t fair = std::max<size_t>(32, (q3.size() > seen ? q3.size() - seen : 0) / ((size_t) nthreads * 2));
+                const size_t left = q3.size() > seen ? q3.size() - seen : 0;
+                const size_t fair = nthreads == 1 ? std::max<size_t>(32, left) : std::max<size_t>(32, left / ((size_t) nthreads * 2));   // several feeders: none takes more than half its share of what is left
                 take = std::min<size_t>(std::min<size_t>(batch, (size_t) fsgpu_kmer_batch_hint(ctx)), fair);
             }
             const size_t b0 = next.fetch_add(take);
@@ -1051,23 +1059,45 @@ int fsmod_search(int argc, const char **argv) {
             // ---- prefilter ----
             double t0 = nowSec();
             if (prefMode == 0) {
-                for (size_t k = 0; k < nb; k++) {
-                    thr[k].resize(Ls[k] + 1); prof[k].resize((size_t) Ls[k] * 21 + 1);
-                    fshost_kmer_query_prepare(m8, m2, c3[k].data(), Ls[k], par.compBiasCorrection, par.prefCompBiasScale, kmerThr, 6, spaced, thr[k].data(), prof[k].data());
-                    kq[k].seq = c3[k].data(); kq[k].kmerThr = thr[k].data(); kq[k].profile = prof[k].data(); kq[k].L = Ls[k]; kq[k].reserved = 0; kq[k].identity = ident[k];
+                // the whole batch in one library call (fshost_search_kmer_batch: profiles, device prefilter, coverage pre-filter, alignment) -- the same entry
+                // point bench.py's all-vs-all leg drives
+                std::vector<int64_t> alnIdent(nb);
+                for (size_t k = 0; k < nb; k++) alnIdent[k] = (sameDB || includeIdentical) ? (int64_t) qid[k] : -1;   // structurealign compares reader INDICES (structurealign.cpp:359)
+                const size_t rcap = (size_t) maxRes * (size_t) (1 + std::max(0, par.altAlignment));
+                kres.resize(batch * rcap);
+                double sec[4] = {0, 0, 0, 0};
+                if (fshost_search_kmer_batch(s, m8, m2, &sp, kmerThr, spaced, (int) nb, pA.data(), p3.data(), Ls.data(), ident.data(), alnIdent.data(), khits.data(), nout.data(), status.data(),
+                                             kkept.data(), nkept.data(), kres.data(), knres.data(), sec) != FSGPU_OK) { if (!bad++) firstErr = fshost_search_error(s); break; }
+                usPrep += (int64_t) (sec[0] * 1e6); usPref += (int64_t) ((sec[1] + sec[2]) * 1e6); usAlign += (int64_t) (sec[3] * 1e6);
+                t0 = nowSec();
+                {
+                    double st[8];
+                    fshost_search_stats(s, st);
+                    usAlnPrep += (int64_t) (st[2] * 1e6); usAlnDev += (int64_t) (st[3] * 1e6); usAlnGate += (int64_t) (st[4] * 1e6); usAlnBack += (int64_t) (st[5] * 1e6);
+                    nRev += (int64_t) st[7];
                 }
-                { const double t1 = nowSec(); usPrep += (int64_t) ((t1 - t0) * 1e6); t0 = t1; }
-                if (fsgpu_kmer_search(ctx, &sp, kq.data(), (int) nb, khits.data(), nout.data(), status.data(), nullptr) != FSGPU_OK) { if (!bad++) firstErr = fsgpu_last_error(ctx); break; }
                 for (size_t k = 0; k < nb && !bad; k++) {
                     if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(qid[k])) + ": hit buffers of the reference would overflow"; break; }
-                    for (int h = 0; h < nout[k]; h++) {
-                        const fsgpu_kmer_hit &hit = khits[k * (size_t) maxRes + h];
-                        if (par.covThr > 0.0 && (par.covMode == 0 || par.covMode == 2 || par.covMode == 5) &&
-                            !canBeCovered(par.covThr, par.covMode, (float) Ls[k], (float) pt.lengths[hit.id])) continue;   // Prefiltering.cpp:880-887
-                        ids[k].push_back(hit.id);
-                        if (writePref) prefs[qid[k]].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
+                    nPairs += nkept[k];
+                    if (writePref) {
+                        const uint32_t *kept = kkept.data() + k * (size_t) maxRes;
+                        int kp = 0;                                  // the kept ids are a subsequence of the hits' ids
+                        for (int h = 0; h < nout[k] && kp < nkept[k]; h++) {
+                            const fsgpu_kmer_hit &hit = khits[k * (size_t) maxRes + h];
+                            if (hit.id != kept[kp]) continue;
+                            kp++;
+                            prefs[qid[k]].append(pl, fshost_format_prefilter_hit(pl, pt.keys[hit.id], hit.score, (int) (int16_t) hit.diagonal));
+                        }
+                    }
+                    std::string &out = results[qid[k]];
+                    for (int r = 0; r < knres[k]; r++) {
+                        const fshost_result *rr = &kres[k * rcap + (size_t) r];
+                        out.append(line.data(), fshost_format_result(line.data(), rr, fshost_search_backtrace(s, rr), par.addBacktrace));
                     }
                 }
+                if (bad) break;
+                usFormat += (int64_t) ((nowSec() - t0) * 1e6);
+                continue;
             } else {
                 std::vector<const uint8_t *> gq; std::vector<int> gL, gn; std::vector<int64_t> gi; std::vector<size_t> gk;
                 for (size_t k = 0; k < nb; k++) if (Ls[k] > 0) { gq.push_back(c3[k].data()); gL.push_back(Ls[k]); gi.push_back(ident[k]); gk.push_back(k); }

@@ -40,6 +40,9 @@ struct fshost_search {
     std::vector<uint8_t> rAA, r3Di, tAA, t3Di;
     std::vector<fsgpu_swres> fwd, rev;
     std::string cigars;
+    std::vector<std::vector<int16_t>> kThr;     // fshost_search_kmer_batch: per-query k-mer thresholds / ungapped profiles of the last batch
+    std::vector<std::vector<int8_t>> kProf;
+    std::vector<fsgpu_kmer_query> kq;
     // host-side wall time of the last calls, seconds: [0] prefilter profile, [1] prefilter device call (incl. wait),
     // [2] align profiles + e-value net, [3] SW device call (incl. wait), [4] gates, [5] block-aligner backtrace
     double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -675,6 +678,78 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
 // structurerescorediagonal's per-query body (F/src/strucclustutils/structurerescorediagonal.cpp:50-156, 300-370) for nq queries:
 // the Kadane scans run on the device (fsgpu_diag_rescore), here are the module's gates in the module's order.
 // diagonals[q][k] is the prefilter line's third column (a short, as parsePrefilterHit reads it).
+// Util::canBeCovered (M/src/commons/Util.cpp:542-559) for the three modes runSplit applies it to (Prefiltering.cpp:880-887)
+static bool kmerCanBeCovered(float covThr, int covMode, float q, float t) {
+    switch (covMode) {
+        case 0: return (q / t >= covThr) && (t / q >= covThr);
+        case 2: return (t / q) >= covThr;
+        case 5: return (std::min(t, q) / std::max(t, q)) >= covThr;
+        default: return true;
+    }
+}
+
+int fshost_search_kmer_batch(fshost_search *s, const fshost_matrix *mKmer, const fshost_matrix *mUngapped, const fsgpu_kmer_search_params *sp,
+                             int kmerThr, int spaced, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
+                             const int64_t *prefIdentity, const int64_t *alnIdentity, fsgpu_kmer_hit *hits, int32_t *nhits, int32_t *status,
+                             uint32_t *keptIds, int32_t *nkept, fshost_result *results, int32_t *nres, double *seconds) {
+    if (!s || !s->ctx || !mKmer || !mUngapped || !sp || nq < 0 || (nq > 0 && (!qAA || !q3di || !L || !hits || !nhits || !status || !keptIds || !nkept || !results || !nres))) return FSGPU_E_ARG;
+    if (sp->maxResListLen <= 0) { s->err = "fshost_search_kmer_batch: maxResListLen >= 1 required"; return FSGPU_E_ARG; }
+    const fshost_params &par = s->par;
+    const size_t cap = (size_t) sp->maxResListLen, rcap = cap * (size_t) (1 + std::max(0, par.altAlignment));
+    double t0 = nowSec();
+    if ((int) s->kThr.size() < nq) { s->kThr.resize(nq); s->kProf.resize(nq); }
+    s->kq.resize(std::max(nq, 1));
+    for (int k = 0; k < nq; k++) {
+        if (L[k] < 0 || (L[k] > 0 && (!q3di[k] || !qAA[k]))) { s->err = "fshost_search_kmer_batch: bad query"; return FSGPU_E_ARG; }
+        s->kThr[k].resize((size_t) L[k] + 1); s->kProf[k].resize((size_t) L[k] * 21 + 1);
+        fshost_kmer_query_prepare(mKmer, mUngapped, q3di[k], L[k], par.compBiasCorrection, par.prefCompBiasScale, kmerThr, 6, spaced, s->kThr[k].data(), s->kProf[k].data());
+        fsgpu_kmer_query &q = s->kq[k];
+        q.seq = q3di[k]; q.kmerThr = s->kThr[k].data(); q.profile = s->kProf[k].data(); q.L = L[k]; q.reserved = 0; q.identity = prefIdentity ? prefIdentity[k] : -1;
+    }
+    double t1 = nowSec();
+    if (seconds) seconds[0] = t1 - t0;
+    t0 = t1;
+    if (nq > 0) {
+        const int rc = fsgpu_kmer_search(s->ctx, sp, s->kq.data(), nq, hits, nhits, status, nullptr);
+        if (rc != FSGPU_OK) { s->err = fsgpu_last_error(s->ctx); return rc; }
+    }
+    t1 = nowSec();
+    if (seconds) seconds[1] = t1 - t0;
+    t0 = t1;
+    const bool cov = par.covThr > 0.0 && (par.covMode == 0 || par.covMode == 2 || par.covMode == 5);
+    std::vector<const uint8_t *> lA, l3;
+    std::vector<const uint32_t *> lT;
+    std::vector<fshost_result *> lR;
+    std::vector<int> lL, lN, lres, lq;
+    std::vector<int64_t> lI;
+    for (int k = 0; k < nq; k++) {
+        nres[k] = 0; nkept[k] = 0;
+        if (status[k] < 0) continue;
+        uint32_t *ids = keptIds + (size_t) k * cap;
+        int n = 0;
+        for (int h = 0; h < nhits[k]; h++) {
+            const fsgpu_kmer_hit &hit = hits[(size_t) k * cap + h];
+            if (cov && !kmerCanBeCovered((float) par.covThr, par.covMode, (float) L[k], (float) s->lengths[hit.id])) continue;
+            ids[n++] = hit.id;
+        }
+        nkept[k] = n;
+        if (n == 0 || L[k] <= 0) continue;
+        lq.push_back(k); lA.push_back(qAA[k]); l3.push_back(q3di[k]); lT.push_back(ids); lR.push_back(results + (size_t) k * rcap);
+        lL.push_back(L[k]); lN.push_back(n); lI.push_back(alnIdentity ? alnIdentity[k] : -1);
+    }
+    t1 = nowSec();
+    if (seconds) seconds[2] = t1 - t0;
+    t0 = t1;
+    if (!lq.empty()) {
+        lres.assign(lq.size(), 0);
+        const int rc = fshost_search_align_batch(s, (int) lq.size(), lA.data(), l3.data(), lL.data(), lI.data(), lT.data(), lN.data(), lR.data(), lres.data());
+        if (rc != FSGPU_OK) return rc;
+        for (size_t j = 0; j < lq.size(); j++) nres[lq[j]] = lres[j];
+    }
+    if (seconds) seconds[3] = nowSec() - t0;
+    return FSGPU_OK;
+}
+
 int fshost_search_rescore_diagonal_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
                                          const int64_t *identityId, const uint32_t *const *targetIds, const int16_t *const *diagonals,
                                          const int *n, fshost_result *const *results, int *nres) {

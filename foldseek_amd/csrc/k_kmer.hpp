@@ -137,6 +137,19 @@ __global__ void k_kmer_compact_entries(const uint64_t *vals, const uint32_t *fla
     if (i >= n) return;
     if (flags[i]) entries[scan[i]] = vals[i];
 }
+// the same as 4-byte entries seqId << posBits | position, for databases whose id and position bits fit 32 together (IndexTable.h:25-41 stores
+// {u32 seqId, u16 position}: six bytes; the search gathers whole sectors, so the entry width is what the gather of a short list costs)
+__global__ void k_kmer_compact_entries32(const uint64_t *vals, const uint32_t *flags, const uint32_t *scan, uint64_t n, int posBits, uint32_t *entries) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) { const uint64_t v = vals[i]; entries[scan[i]] = ((uint32_t) (v >> 16) << posBits) | ((uint32_t) v & 0xffffu); }
+}
+__global__ void k_kmer_widen_entries(const uint32_t *e32, uint64_t n, int posBits, uint64_t *e64) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = e32[i];
+    e64[i] = ((uint64_t) (e >> posBits) << 16) | (e & ((1u << posBits) - 1u));
+}
 
 // one bit per k-mer: list non-empty (8 MB instead of 256 MB: most probes of the search never reach the offset table)
 __global__ void k_kmer_bitmap(const uint32_t *offsets, uint32_t nWords, uint32_t *bitmap) {
@@ -585,27 +598,39 @@ __host__ __device__ inline uint32_t partO(uint64_t r) { return (uint32_t) (r >> 
 __host__ __device__ inline uint32_t partD16(uint64_t r) { return (uint32_t) r & 0xffffu; }
 __host__ __device__ inline uint32_t partD8(uint64_t r) { return (uint32_t) r & 0xffu; }
 
+// list that holds stream position o: the last l with listP[l] <= o (empty lists share their prefix with the successor, so that list is non-empty)
+__device__ inline uint64_t kmerListOf(const uint64_t *listP, uint64_t nLists, uint64_t o) {
+    uint64_t lo = 0, hi = nLists;
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
+    return lo;
+}
+// first and last list of every emit tile, one thread per tile.  (Until round 5 two threads of every emit workgroup ran these searches themselves: 27
+// dependent global loads before the tile's 256 threads could start -- more than the tile's own work takes.)
+__global__ void k_kmer_tile_lists(const uint64_t *listP, uint64_t nLists, uint64_t nHits, uint32_t nTiles, uint32_t *tileL /*[2 * nTiles]*/) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * nTiles) return;
+    const uint64_t o0 = (uint64_t) (t >> 1) * kEmitTile;
+    const uint64_t o = (t & 1u) ? min(nHits, o0 + kEmitTile) - 1 : o0;
+    tileL[t] = (uint32_t) kmerListOf(listP, nLists, o);          // list slots of a batch fit 32 bits (listStart / listSize / listPos are indexed by them)
+}
+
 // Output-balanced gather: one thread per hit, list found by binary search over the staged list prefixes.
+// E = uint64_t: entries seqId << 16 | position; E = uint32_t: seqId << posBits | position (k_kmer_compact_entries32)
+template <class E>
 __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64_t *listP, const uint32_t *listStart, const uint32_t *listPos /* query << 16 | position */,
-                                                   const uint64_t *entries, uint64_t nHits, uint64_t *rec) {
-    __shared__ uint64_t range[2];
-    __shared__ uint32_t rel[kEmitStage + 1];  // list prefix relative to the block's first list
+                                                   const uint32_t *tileL, const E *entries, int posBits, uint64_t nHits, uint64_t *rec) {
+    // list prefixes relative to the tile's first stream position, clamped below at 0 (only the tile's first list can start before the tile): < kEmitTile,
+    // 16 bits each -- 12 KB instead of 24, so the workgroups per CU are bounded by their waves, not by LDS
+    __shared__ uint16_t rel[kEmitStage + 1];
     const uint64_t o0 = (uint64_t) blockIdx.x * kEmitTile;
     if (o0 >= nHits) return;
     const uint64_t o1 = min(nHits, o0 + kEmitTile);
-    if (threadIdx.x < 2) {
-        const uint64_t o = threadIdx.x == 0 ? o0 : o1 - 1;
-        uint64_t lo = 0, hi = nLists;         // last l with listP[l] <= o (that list is non-empty and contains o)
-        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
-        range[threadIdx.x] = lo;
-    }
-    __syncthreads();
-    const uint64_t l0 = range[0], l1 = range[1];
+    const uint64_t l0 = tileL[2 * blockIdx.x], l1 = tileL[2 * blockIdx.x + 1];
     const uint64_t p0 = listP[l0];
     const int nl = (int) min<uint64_t>(l1 - l0 + 1, (uint64_t) kEmitStage + 1);
     const bool staged = l1 - l0 + 1 <= (uint64_t) kEmitStage;
     if (staged) {
-        for (int i = threadIdx.x; i < nl; i += 256) rel[i] = (uint32_t) (listP[l0 + i] - p0);
+        for (int i = threadIdx.x; i < nl; i += 256) { const uint64_t lp = listP[l0 + i]; rel[i] = (uint16_t) (lp > o0 ? lp - o0 : 0); }
         __syncthreads();
     }
     // 8 outputs per thread, handled phase by phase so that the dependent loads of all 8 are in flight together
@@ -616,12 +641,12 @@ __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64
         // step instead of 8 x 13 dependent ones
         uint32_t lo[U], ro[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { lo[u] = 0; ro[u] = (uint32_t) (min<uint64_t>(o0 + threadIdx.x + 256 * u, o1 - 1) - p0); }
+        for (int u = 0; u < U; u++) { lo[u] = 0; ro[u] = (uint32_t) (min<uint64_t>(o0 + threadIdx.x + 256 * u, o1 - 1) - o0); }
         for (uint32_t step = 4096; step >= 1; step >>= 1) {          // kEmitStage < 8192: last index with rel[index] <= ro
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t cand = lo[u] + step;
-                if (cand < (uint32_t) nl && rel[cand] <= ro[u]) lo[u] = cand;
+                if (cand < (uint32_t) nl && (uint32_t) rel[cand] <= ro[u]) lo[u] = cand;
             }
         }
 #pragma unroll
@@ -639,19 +664,21 @@ __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64
     uint32_t p[U], st[U];
     uint64_t lp[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) { p[u] = listPos[l[u]]; st[u] = listStart[l[u]]; lp[u] = staged ? p0 + rel[(uint32_t) (l[u] - l0)] : listP[l[u]]; }
-    uint64_t e[U];
+    for (int u = 0; u < U; u++) { p[u] = listPos[l[u]]; st[u] = listStart[l[u]]; lp[u] = !staged ? listP[l[u]] : l[u] == l0 ? p0 : o0 + rel[(uint32_t) (l[u] - l0)]; }
+    E e[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint64_t o = o0 + threadIdx.x + 256 * u;
-        e[u] = o < o1 ? entries[(uint64_t) st[u] + (o - lp[u])] : 0;
+        e[u] = o < o1 ? entries[(uint64_t) st[u] + (o - lp[u])] : (E) 0;
     }
+    const int pb = sizeof(E) == 8 ? 16 : posBits;
+    const uint32_t pmask = (1u << pb) - 1u;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint64_t o = o0 + threadIdx.x + 256 * u;
         if (o >= o1) continue;
-        const uint32_t posj = (uint32_t) e[u] & 0xffffu;
-        rec[o] = recPack((uint32_t) (e[u] >> 16), ((p[u] & 0xffffu) - posj) & 0xffffu);
+        const uint32_t posj = (uint32_t) e[u] & pmask;
+        rec[o] = recPack((uint32_t) (e[u] >> pb), ((p[u] & 0xffffu) - posj) & 0xffffu);
     }
 }
 
@@ -1293,6 +1320,39 @@ __device__ __forceinline__ KmerSum kmerSumJoin(const KmerSum &l, const KmerSum &
     return o;
 }
 
+// part g (of eight) of one diagonal: see k_kmer_score8.  Inlined once per address space of `prof`.
+__device__ __forceinline__ KmerSum kmerScorePart(const int8_t *prof, const uint8_t *db, int len, int g) {
+    // positions [0, head) up to the first 8-byte boundary of the target go to lane 0 byte by byte (they are the leftmost part);
+    // the aligned words behind them are dealt out in eight contiguous runs.  No address below `prof` / `db` is ever formed: a flat
+    // access whose base register lies under the LDS aperture faults even when base + offset does not.
+    const int head = min(len, (int) ((8 - ((uintptr_t) db & 7)) & 7));
+    int A = 0, S0 = 0, P = 0, Q = 0;
+    if (g == 0)
+        for (int pos = 0; pos < head; pos++) { const int x = prof[pos * 21 + db[pos]]; A += x; Q = max(Q, A); S0 = max(0, S0 + x); P = max(P, S0); }
+    const uint64_t *words = reinterpret_cast<const uint64_t *>(db + head);
+    const int rest = len - head, nW = (rest + 7) >> 3, per = (nW + 7) >> 3;
+    const int w0 = g * per, w1 = min(nW, w0 + per);
+    uint64_t wNext = w0 < w1 ? words[w0] : 0;
+    for (int w = w0; w < w1; w++) {
+        const uint64_t cur = wNext;
+        if (w + 1 < w1) wNext = words[w + 1];
+        const int p0 = head + 8 * w;                       // first position of this word, >= 0
+        const int8_t *pp = prof + p0 * 21;
+        const uint32_t lo = (uint32_t) cur, hi = (uint32_t) (cur >> 32);
+        int x[8];
+        if (p0 + 8 <= len) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) x[b] = pp[b * 21 + (int) (((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu)];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; b++) x[b] = (p0 + b < len) ? (int) pp[b * 21 + (int) (((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu)] : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) { A += x[b]; Q = max(Q, A); const int t = S0 + x[b]; P = max(P, t); S0 = max(0, t); }
+    }
+    return KmerSum{A, S0, P, Q};
+}
+
 __global__ __launch_bounds__(256) void k_kmer_score8(const uint32_t *ckeys, const uint64_t *cvals, const uint32_t *nCandPtr, int tbits, const KmerQ *qs,
                                                      const int8_t *profiles, const uint8_t *masked, const uint64_t *offsets, const int32_t *lengths,
                                                      int ldsBytes, uint8_t *kept, int32_t *score) {
@@ -1334,35 +1394,12 @@ __global__ __launch_bounds__(256) void k_kmer_score8(const uint32_t *ckeys, cons
             int len = 0, poff = 0;
             if (diagonal >= 0 && minDist < qLen) { len = min(dbLen, qLen - minDist); poff = minDist * 21; }
             else if (diagonal < 0 && minDist < dbLen) { len = min(dbLen - minDist, qLen); db += minDist; }
-            const int8_t *prof = (staged && qi == q0) ? sprof + poff : profiles + q.profOff + poff;
+            // two copies of the loop, one per address space of the profile: a pointer that may be LDS or global memory makes every profile byte a
+            // flat_load with a 64-bit address (four address instructions per cell, and flat accesses to LDS go through the vector memory pipe);
+            // the staged copy reads ds_read_i8 at a 32-bit address + immediate
             if (len > 0) {
-                // positions [0, head) up to the first 8-byte boundary of the target go to lane 0 byte by byte (they are the leftmost part);
-                // the aligned words behind them are dealt out in eight contiguous runs.  No address below `prof` / `db` is ever formed: a flat
-                // access whose base register lies under the LDS aperture faults even when base + offset does not.
-                const int head = min(len, (int) ((8 - ((uintptr_t) db & 7)) & 7));
-                int A = 0, S0 = 0, P = 0, Q = 0;
-                if (g == 0)
-                    for (int pos = 0; pos < head; pos++) { const int x = prof[pos * 21 + db[pos]]; A += x; Q = max(Q, A); S0 = max(0, S0 + x); P = max(P, S0); }
-                const uint64_t *words = reinterpret_cast<const uint64_t *>(db + head);
-                const int rest = len - head, nW = (rest + 7) >> 3, per = (nW + 7) >> 3;
-                const int w0 = g * per, w1 = min(nW, w0 + per);
-                uint64_t wNext = w0 < w1 ? words[w0] : 0;
-                for (int w = w0; w < w1; w++) {
-                    const uint64_t cur = wNext;
-                    if (w + 1 < w1) wNext = words[w + 1];
-                    const int p0 = head + 8 * w;                       // first position of this word, >= 0
-                    int x[8];
-                    if (p0 + 8 <= len) {
-#pragma unroll
-                        for (int b = 0; b < 8; b++) x[b] = prof[(p0 + b) * 21 + (int) ((cur >> (8 * b)) & 0xff)];
-                    } else {
-#pragma unroll
-                        for (int b = 0; b < 8; b++) x[b] = (p0 + b < len) ? (int) prof[(p0 + b) * 21 + (int) ((cur >> (8 * b)) & 0xff)] : 0;
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; b++) { A += x[b]; Q = max(Q, A); S0 = max(0, S0 + x[b]); P = max(P, S0); }
-                }
-                sum = KmerSum{A, S0, P, Q};
+                if (staged && qi == q0) sum = kmerScorePart(sprof + poff, db, len, g);
+                else sum = kmerScorePart(profiles + q.profOff + poff, db, len, g);
             }
         }
     }
@@ -1387,15 +1424,20 @@ struct KmerBest {          // written at the segment head; nElems == 0xFFFFFFFF 
     uint32_t pad;          // k_kmer_walk: length of the target's final list, bit 31 = it lives in the second scratch array (0 elsewhere)
 };
 
+// FF: rounds in which a target takes no new candidates are skipped (the per-round element counts of the skipped rounds go through a difference array)
+template <bool FF>
 __global__ __launch_bounds__(128) void k_kmer_walk(const uint32_t *ckeys, const uint64_t *cvals, const uint8_t *kept, const int32_t *score, const uint32_t *nCandPtr,
                             int tbits, const KmerChunks *chunks, uint64_t *scrA, uint64_t *scrB, KmerBest *best,
                             uint32_t *roundCount /*[nq][kMaxChunks]*/, unsigned long long *resultSize /*[nq]*/) {
     __shared__ uint32_t rc[kMaxChunks];       // per-round element counts / result size of the block's first query
+    __shared__ uint32_t rcd[kMaxChunks + 2];  // ... and their difference array: +1 at the first, -1 behind the last of a run of skipped rounds
+    __shared__ uint32_t rcw[2];
     __shared__ unsigned long long rs;
     __shared__ uint32_t q0;
     const uint64_t s = (uint64_t) blockIdx.x * 128 + threadIdx.x;
     const uint64_t nCand = *nCandPtr;
     rc[threadIdx.x] = 0; rc[threadIdx.x + 128] = 0;
+    rcd[threadIdx.x] = 0; rcd[threadIdx.x + 128] = 0; if (threadIdx.x < 2) rcd[256 + threadIdx.x] = 0;
     if (threadIdx.x == 0) { rs = 0; q0 = (uint64_t) blockIdx.x * 128 < nCand ? ckeys[(uint64_t) blockIdx.x * 128] >> tbits : 0; }
     __syncthreads();
     bool head = s < nCand;
@@ -1413,9 +1455,26 @@ __global__ __launch_bounds__(128) void k_kmer_walk(const uint32_t *ckeys, const 
     uint64_t pos = s;
 #define EL_CNT(e) ((uint32_t) (e) & 0xffu)
 #define EL_D8(e) hitD8(cvals[(e) >> 8])
+    bool settled = false;                                    // the list went through a merge round since it last took new candidates
     for (uint32_t j = 1; j <= C; j++) {
+        if (FF) {
+            // Rounds without new candidates (a target's candidates sit in one or two of the query's chunks): with no elements carried they do
+            // nothing; a single element that has been through a merge round comes out of every further one unchanged (scored elements survive
+            // mergeDiagonalKeepScoredHitsDuplicates, and keepMaxScoreElementOnly keeps the only element) and counts once per round.
+            const uint32_t cn = (pos < nCand && ckeys[pos] == key) ? hitChunk(cvals[pos]) : 0xFFFFFFFFu;      // chunks ascend inside a target's run
+            if (cn >= j) {
+                if (nE == 0) { if (cn >= C) break; j = cn; settled = false; continue; }                      // next round to do work: cn + 1
+                if (nE == 1 && settled) {
+                    const uint32_t jend = min(cn, C);                                                        // rounds j .. jend are no-ops
+                    if (mine) { atomicAdd(&rcd[j], 1u); atomicAdd(&rcd[jend + 1], 0xFFFFFFFFu); }
+                    else for (uint32_t jj = j; jj <= jend; jj++) atomicAdd(&roundCount[(size_t) qi * kMaxChunks + jj], 1u);
+                    j = jend; continue;
+                }
+            }
+        }
         uint32_t nS = nE;
         while (pos < nCand && ckeys[pos] == key && hitChunk(cvals[pos]) == j - 1) { if (kept[pos]) A[nS++] = pos << 8; pos++; }
+        settled = j > 1;
         if (j == 1) { nE = nS; ROUND_ADD(j, nE); continue; }
         if (nS == 0) { nE = 0; continue; }
         // mergeDiagonalKeepScoredHitsDuplicates: reverse walk, scored elements always survive
@@ -1483,6 +1542,18 @@ __global__ __launch_bounds__(128) void k_kmer_walk(const uint32_t *ckeys, const 
 #undef ROUND_ADD
     }
     __syncthreads();
+    if (FF) {       // prefix sum of the difference array (two entries per thread) onto the direct counts
+        const uint32_t d0 = rcd[2 * threadIdx.x], d1 = rcd[2 * threadIdx.x + 1], sum = d0 + d1;
+        uint32_t incl = sum;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) rcw[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        const uint32_t before = incl - sum + (threadIdx.x >= 64 ? rcw[0] : 0u);
+        rc[2 * threadIdx.x] += before + d0; rc[2 * threadIdx.x + 1] += before + sum;
+        __syncthreads();
+    }
     for (int j = threadIdx.x; j < kMaxChunks; j += 128) if (rc[j]) atomicAdd(&roundCount[(size_t) q0 * kMaxChunks + j], rc[j]);
     if (threadIdx.x == 0 && rs) atomicAdd(&resultSize[q0], rs);
 }

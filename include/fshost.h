@@ -149,6 +149,19 @@ int fshost_search_align(fshost_search *s, const uint8_t *qAA, const uint8_t *q3d
 int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
                               const int64_t *identityId, const uint32_t *const *targetIds, const int *n,
                               fshost_result *const *results, int *nres);
+/* The per-batch body of the fused `search` module with the k-mer prefilter, in ONE call: query profiles and k-mer thresholds
+ * (fshost_kmer_query_prepare), the device prefilter (fsgpu_kmer_search: QueryMatcher::matchQuery, M/src/prefiltering/QueryMatcher.cpp:103-240),
+ * runSplit's coverage pre-filter of its hits (Util::canBeCovered for --cov-mode 0 / 2 / 5, M/src/prefiltering/Prefiltering.cpp:880-887) and the
+ * structure alignment of what is left (fshost_search_align_batch: F/src/strucclustutils/structurealign.cpp:284-452).  mKmer / mUngapped as for
+ * fshost_kmer_query_prepare.  prefIdentity[q]: target id of the query itself for the prefilter's self hit (-1: none); alnIdentity[q]: the index
+ * structurealign compares with the target's (-1: none).  Outputs, cap = sp->maxResListLen per query: hits [nq * cap] with nhits[q] prefilter hits
+ * (before the coverage pre-filter), status[q] (FSGPU_KMER_*), keptIds [nq * cap] with nkept[q] ids handed to the aligner, results
+ * [nq * cap * (1 + altAlignment)] with nres[q] accepted alignments (backtraces through fshost_search_backtrace until the next call), seconds[4]:
+ * host wall time of prepare / prefilter call / coverage pre-filter / align call.  A query whose status is < 0 gets no alignments.  Returns 0 or < 0. */
+int fshost_search_kmer_batch(fshost_search *s, const fshost_matrix *mKmer, const fshost_matrix *mUngapped, const fsgpu_kmer_search_params *sp,
+                             int kmerThr, int spaced, int nq, const uint8_t *const *qAA, const uint8_t *const *q3di, const int *L,
+                             const int64_t *prefIdentity, const int64_t *alnIdentity, fsgpu_kmer_hit *hits, int32_t *nhits, int32_t *status,
+                             uint32_t *keptIds, int32_t *nkept, fshost_result *results, int32_t *nres, double *seconds);
 /* structurerescorediagonal for nq queries (F/src/strucclustutils/structurerescorediagonal.cpp:50-156,300-370): targetIds / diagonals
  * are the first and third column of the prefilter lines in their order; results[q] has room for n[q] entries; gates, e-value,
  * seq. id, ordering and (with addBacktrace) the all-match backtrace as the module writes them. */

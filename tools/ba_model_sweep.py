@@ -4,7 +4,10 @@ the independent trajectory model of the crate (tests/ba_model.py) in the CALL SH
 reversed prefixes, both matrices, the query's composition bias, block sizes 32, 64, ... until the target score is reached, x-drop = -(size * extend + open)) on
 freshly seeded homolog pairs -- longer than the committed cases (up to `maxlen` residues, so that block sizes beyond 64 and many shifts occur), four families
 (plain, homopolymer stretch, tandem repeat, two-state low complexity), four gap-cost pairs.
-usage: ba_model_sweep.py [seed=1] [cases=300] [maxlen=400]     prints the number of compared cases / mismatches, the block sizes reached and the decision-boundary counts"""
+usage: ba_model_sweep.py [seed=1] [cases=300] [maxlen=400] [dump=FILE] [per_boundary=40]
+prints the number of compared cases / mismatches, the block sizes reached and the decision-boundary counts; with dump=FILE the inputs on which one of the RARE
+decision boundaries fired (x-drop threshold met exactly / missed by one, second bad x-drop step, shrink with equality, a Grow that grew again) are appended to FILE
+in the format of oracle/ba_kat/cases.txt (at most per_boundary per boundary kind) -- the cases to freeze for the day the harness runs against the Rust crate"""
 import os
 import subprocess
 import sys
@@ -21,6 +24,8 @@ import make_cases as MC  # noqa: E402
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 maxlen = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+dump = sys.argv[4] if len(sys.argv) > 4 else None
+per_boundary = int(sys.argv[5]) if len(sys.argv) > 5 else 40
 rng = np.random.default_rng(seed)
 KAT = os.path.join(ROOT, "oracle", "ba_kat")
 w = tempfile.mkdtemp(prefix="ba_sweep_")
@@ -85,6 +90,8 @@ def load(path):
 
 fA, f3 = load(os.path.join(w, "mat_aa.txt")), load(os.path.join(w, "mat_3di.txt"))
 bad, sizes_seen, ties, missed = 0, {}, {}, 0
+RARE = ("xdrop_at_threshold", "xdrop_one_below", "xdrop_second_step", "shrink_equal", "grow_twice")
+dumped, dump_lines = {k: 0 for k in RARE}, []
 for k, line in enumerate(lines[1:]):
     f = line.split()
     name, go, ge = f[1], int(f[2]), int(f[3])
@@ -92,17 +99,31 @@ for k, line in enumerate(lines[1:]):
     target = int(name.split("@")[1])
     qbias = ([int(x) for x in qb.split(",")] + [0] * len(qa))[:len(qa)]
     res, sizes, ms = (-10 ** 9, 0, 0), [], 32
+    fired = set()
     while ms <= 4096 and res[0] < target:
         M = BlockModel(qa, ta, fA, -go, -ge, ms, 4096, x_drop=-(ms * (-ge) + (-go)), q_bias=qbias, r_bias=[0] * len(ta), score2=f3, q2=q3, r2=t3)
         res = M.align()
         sizes.append(f"{ms}:{res[0]}")
         for kk, v in M.ties.items():
             ties[kk] = ties.get(kk, 0) + (1 if v else 0)
+            if v:
+                fired.add(kk)
         ms *= 2
     got = "\t".join([name, str(res[0]), str(res[1]), str(res[2]), M.trace.cigar(res[1], res[2]) or "-", ",".join(sizes)])
     sizes_seen[len(sizes)] = sizes_seen.get(len(sizes), 0) + 1
     missed += res[0] != target
+    want = [kk for kk in RARE if kk in fired and dumped[kk] < per_boundary]
+    if dump and want:
+        for kk in want:
+            dumped[kk] += 1
+        f2 = line.split()
+        f2[1] = "swp" + str(seed) + "_" + "+".join(w_[:8] for w_ in want).replace("xdrop_", "xd") + "_" + f2[1]
+        dump_lines.append(" ".join(f2))
     if got != ours[k]:
         bad += 1
         print("MISMATCH", k, "\n  model", got[:300], "\n  ours ", ours[k][:300])
 print(f"seed {seed}: {len(lines) - 1} cases up to {maxlen} residues, {bad} mismatches, target score missed {missed}x, block-size attempts per case {dict(sorted(sizes_seen.items()))}, decision boundaries {ties}")
+if dump:
+    with open(dump, "a") as fh:
+        fh.write("".join(x + "\n" for x in dump_lines))
+    print(f"appended {len(dump_lines)} boundary cases to {dump}: {dumped}")
