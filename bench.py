@@ -342,7 +342,17 @@ def kmer_cpu_baseline(args, synth, db):
             "index_build_s": t_build}
 
 
-def sw_roofline(passes, has_aa, solo=None):
+def sw_traffic_per_pair(targets, has_aa):
+    """HBM bytes per target pair of the batch SW from the committed PMC pass (profiles/pmc_traffic_sw.json), or (None, reason)"""
+    e, src = pmc_traffic_entry(os.path.join(ROOT, "profiles", "pmc_traffic_sw.json"), targets)
+    if e is None:
+        return None, src
+    if str(e.get("alignment_type")) != ("2" if has_aa else "0"):
+        return None, f"the PMC pass ran --alignment-type {e.get('alignment_type')}"
+    return float(e["bytes_per_pair"]), src
+
+
+def sw_roofline(passes, has_aa, solo=None, targets=None):
     """issue-rate roofline of k_sw2: a wave-instruction of the DP row loop updates 64 lanes x 2 int16 halves = 128 cells and the
     row costs 14 packed VALU instructions (15 with the AA table); packed 16-bit ops issue once per 4.3 cycles per SIMD (measured,
     profiles/r01_valu_lds_issue_rate_ubench.txt) -> 1024 SIMDs x 128 / 14 / 4.3 cyc x 2.4 GHz.  `passes` = fsgpu_sw_last_passes() arrays
@@ -355,12 +365,18 @@ def sw_roofline(passes, has_aa, solo=None):
     out = {"bound": "valu-issue", "kernel": "k_sw3", "unit": "Gcell/s", "peak": peak, "achieved": cells / max(ms, 1e-9) / 1e6,
            "frac": cells / max(ms, 1e-9) / 1e6 / peak, "cells_per_pass_pair": cells / max(1, len(passes)), "kernel_ms_per_pass_pair": ms / max(1, len(passes)),
            "traffic": None,
+           "pairs_per_pass_pair": sum(float(p[d][2]) for p in passes for d in (0, 1) if p[d][0] >= 0) / max(1, len(passes)),
            # the same passes priced in what the waves really issue: a wave (four targets at 32 lanes per pair, two at 64) runs (its longest
            # target) + lanes - 1 steps of 14 R + 16 VALU instructions (+ R + 4 with the AA table; counted in the kernel's ISA), 4.3 cycles each.
            # frac / issued_valu_frac = the share of the issued stream that is the 14 (15) DP instructions of real cells: the rest is the step
            # overhead, lane padding, wavefront fill / drain and the shorter targets of a wave
            "issued_valu_frac": instr / max(ms, 1e-9) / 1e-3 / (1024 * 2.4e9 / 4.3),
            "note": "co-running with the other feeder threads' scans; DP cells = query rows x target columns of every pair of both passes"}
+    if targets is not None:
+        per_pair, src = sw_traffic_per_pair(targets, has_aa)
+        out["traffic_source"] = src
+        if per_pair is not None:
+            out["traffic"] = per_pair * out["pairs_per_pass_pair"]        # HBM bytes of one forward + reversed pass pair (PMC bytes per target pair x its pairs)
     if solo is not None:
         c = sum(float(solo[d][1]) for d in (0, 1) if solo[d][0] >= 0)
         m = sum(float(solo[d][0]) for d in (0, 1) if solo[d][0] >= 0)
@@ -1055,7 +1071,7 @@ def main():
                           "host_profiles_ms_per_query": 1e3 * mine["profiles_s"] / max(1, n_mine),
                           "sw_call_wall_ms_per_query": 1e3 * mine["sw_wait_s"] / max(1, n_mine),
                           "sw_kernels_ms_per_query": float(np.mean(sms)), "sw_kernel_ms_single_query_solo": float(np.mean(solo_s)),
-                          "roofline": sw_roofline(rec["swp"], args.alignment_type == 2, solo_swp)},
+                          "roofline": sw_roofline(rec["swp"], args.alignment_type == 2, solo_swp, args.targets)},
             # per-launch duration of the dominant kernel from HIP events on the library's stream, averaged over the launches
             # of the TIMED region (the host threads overlap their launches there, which stretches each one); the same
             # kernel alone on the device is reported under "solo"
@@ -1098,7 +1114,7 @@ def main():
                        "queries_per_s": n2t / dt2, "ms_per_query": 1e3 * dt2 / max(1, n2t / world), "mean_query_len": float(np.mean(lq2)),
                        "hits_per_query": sum(x[0] for x in tot2) / max(1, n2t), "alignments_per_query": sum(x[1] for x in tot2) / max(1, n2t),
                        "sw_kernels_ms_per_query": float(np.mean(rec2["sms"])),
-                       "roofline": gapless_roofline(rec2["kms"], lq2), "align_roofline": sw_roofline(rec2["swp"], True, solo2)}
+                       "roofline": gapless_roofline(rec2["kms"], lq2), "align_roofline": sw_roofline(rec2["swp"], True, solo2, args.targets)}
                 if not args.no_cpu_baseline and world == 1:
                     hits, _ = step1(0, n_warm, searches2)
                     leg["cpu_baseline"] = cpu_baseline(db, q3[n_warm], qa[n_warm], hits["id"], 2, args.cpu_sample_targets, reuse_prefilter=t_pref_cpu)

@@ -82,6 +82,7 @@ struct fsgpu_ctx {
     double kmerHitsPerQuery = 0;       // index hits per query of the last batch (sizes the next one)
     double kmerKPerPos = 0;            // similar k-mers per query position of the last batch (picks the wave / workgroup form of the next count pass)
     int kmerBatchCap = 0;              // > 0: a batch overflowed 2^32 hits, stay at or below this many queries
+    bool kmerBincountAttr = false;                 // k_kmer_bincount may use more than 64 KB of dynamic LDS on this context's device (> 16 M targets)
     int kmerBatchOk = 0;                           // batches that succeeded in a row under the current cap (it is relaxed after four)
     uint64_t kmerCounts[4] = {0, 0, 0, 0};   // last batch: k-mer lists probed, index hits, double-diagonal candidates, elements handed to the host
 

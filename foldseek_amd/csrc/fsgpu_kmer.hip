@@ -16,6 +16,9 @@
 #include "fsgpu_ctx.h"
 #include "k_kmer.hpp"
 
+#include <functional>
+void fshostParallelFor(int n, const std::function<void(int)> &fn);      // host/search.cpp: the library's host worker pool
+
 struct KmerIndex {
     fsgpu_kmer_index_params p{};
     KmerPattern pat{};
@@ -278,13 +281,13 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     // bin levels of the hit-stream partition
     {
         ix->residues = R;
-        if ((n + 1023) / 1024 > (uint64_t) kMaxBins) {
-            ctx->err = "k-mer prefilter: more than " + std::to_string((uint64_t) kMaxBins * 1024) + " targets are not supported by the device hit-stream partition";
+        if ((n + 1023) / 1024 > (uint64_t) kMaxBins || (n + 65535) / 65536 > (uint64_t) kMaxCoarse) {
+            ctx->err = "k-mer prefilter: more than " + std::to_string((uint64_t) kMaxCoarse * 65536) + " targets are not supported by the device hit-stream partition";
             cleanup(); return FSGPU_E_UNSUPPORTED;
         }
         std::vector<uint32_t> bk, bf;
         uint64_t resCap0 = 16384;                              // levels that cannot fit kMaxBins bins are not worth planning
-        while (R / resCap0 > (uint64_t) kMaxBins / 2) resCap0 *= 2;
+        while (R / resCap0 > (uint64_t) kPlanBins / 2) resCap0 *= 2;
         uint32_t prevNb = 0;
         for (uint64_t resCap = resCap0; ; resCap *= 2) {
             planBins(db.hLengths.data(), n, resCap, bk, bf);
@@ -666,7 +669,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
                                (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
                                (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
         else
-            hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) nPos), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+            hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) (nPos + nLists / kListSlice + 1)), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
                                (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
                                (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
         RPCHK(hipGetLastError());
@@ -729,7 +732,13 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             const uint64_t slots = (uint64_t) ctx->numCU * 4, rounds = std::max<uint64_t>(1, (nHits + slots * hitTile - 1) / (slots * hitTile));
             hitTile = std::max<uint64_t>(16384, ((nHits + rounds * slots - 1) / (rounds * slots) + 4095) / 4096 * 4096);
         }
+        // k_kmer_bincount's dynamic LDS: the bin counters, and behind them the block table while both fit what fitted before round 5 (64 KB: four
+        // workgroups per CU); databases of more than 16 M targets have more bins than that and run one workgroup per CU with up to 141 KB of counters
         const bool blkInLds = ((size_t) lv->nBins + lv->nBlk) * sizeof(uint32_t) <= 64 * 1024 - 256;
+        if ((size_t) lv->nBins * sizeof(uint32_t) > 64 * 1024 - 256 && !ctx->kmerBincountAttr) {        // the attribute belongs to the device: once per context
+            RPCHK(hipFuncSetAttribute((const void *) k_kmer_bincount, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * (int) sizeof(uint32_t)));
+            ctx->kmerBincountAttr = true;
+        }
         const KmerBins bins{lv->blk, lv->blkCoarse, lv->coarseFirst, lv->binFirst, lv->nBlk, lv->nBins, lv->nCoarse, (uint32_t) hitTile, blkInLds ? 1u : 0u};
         const size_t ldsBins = ((size_t) lv->nBins + (blkInLds ? lv->nBlk : 0)) * sizeof(uint32_t);
         const uint32_t nOwners = (uint32_t) nq * lv->nCoarse;
@@ -895,7 +904,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         hipLaunchKernelGGL(k_kmer_hist, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const KmerBest *) S.best.p,
                            (const uint32_t *) S.nCand.p, tbits, (uint32_t *) S.hist.p);
         hipLaunchKernelGGL(k_kmer_cut, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const uint32_t *) S.hist.p, nq, maxHits, (uint32_t) sp.minDiagScoreThr, (uint32_t *) S.thr.p);
-        hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
+        hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 1024)), dim3(1024), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
                            (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, nCand, (uint32_t *) S.outCount.p,
                            (uint32_t *) S.nCand.p + 1, (KmerOut *) S.out.p, (const uint64_t *) S.scrA.p, (const uint64_t *) S.scrB.p);
         RPCHK(hipGetLastError());
@@ -983,7 +992,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
                 hipLaunchKernelGGL(k_kmer_hist, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const KmerBest *) S.best.p,
                                    (const uint32_t *) S.nCand.p, tbits, (uint32_t *) S.hist.p);
                 hipLaunchKernelGGL(k_kmer_cut, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const uint32_t *) S.hist.p, nq, maxHits, (uint32_t) sp.minDiagScoreThr, (uint32_t *) S.thr.p);
-                hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
+                hipLaunchKernelGGL(k_kmer_out, dim3(gridFor(nCand, 1024)), dim3(1024), 0, st, (const uint32_t *) S.ckeys.p, (const uint64_t *) S.cvals.p, (const int32_t *) S.score.p,
                                    (const KmerBest *) S.best.p, (const uint32_t *) S.nCand.p, tbits, (const uint32_t *) S.thr.p, nCand, (uint32_t *) S.outCount.p,
                                    (uint32_t *) S.nCand.p + 1, (KmerOut *) S.out.p, (const uint64_t *) S.scrA.p, (const uint64_t *) S.scrB.p);
                 RPCHK(hipGetLastError());
@@ -1031,8 +1040,10 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     // ---- host tail ---------------------------------------------------------------------------------------------
     const auto tTail = std::chrono::steady_clock::now();
     const KmerQ *hq2 = (const KmerQ *) S.hQs.p;
-    std::vector<HostOut> el;
-    for (int q = 0; q < nq; q++) {
+    // one query per call of the host pool (search.cpp::HostPool; the caller takes part): the tails of a batch are independent -- 40 us each, 1.3 ms per batch
+    // of 32 when a single feeder thread walks them
+    fshostParallelFor(nq, [&](int q) {
+        std::vector<HostOut> el;
         const size_t c = outOff[q + 1] - outOff[q];
         el.resize(c);
         if (c) memcpy(el.data(), (const HostOut *) S.hOut.p + outOff[q], c * sizeof(HostOut));
@@ -1051,7 +1062,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
             stats[q * 4 + 2] = hck[q].nChunks > 1 ? 1.0 : 0.0;
             stats[q * 4 + 3] = (double) pickBins(sp, n);
         }
-    }
+    });
     ctx->kmerMs[9] = std::max(0.0, ctx->kmerMs[9]) + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tTail).count();
     mark("host tail");
     if (trace) fprintf(stderr, "kmer batch nq=%d hits=%llu cand=%u:%s\n", nq, (unsigned long long) nHits, nCand, traceLine.c_str());

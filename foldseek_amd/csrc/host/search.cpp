@@ -125,6 +125,9 @@ private:
 
 } // namespace
 
+// the process-wide pool for other translation units of the library (fsgpu_kmer.hip: the per-query tail of a k-mer batch)
+void fshostParallelFor(int n, const std::function<void(int)> &fn) { HostPool::get().parallelFor(n, fn); }
+
 extern "C" {
 void fshost_set_host_workers(int n) { HostPool::get().resize(n); }
 int fshost_host_workers(void) { return HostPool::get().workers(); }

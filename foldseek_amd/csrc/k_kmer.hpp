@@ -280,14 +280,28 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_count(const KmerQ *qs, cons
 // pass 2: enumerate the similar k-mers of position p in the reference's order, probe bitmap + offset table and write one
 // (entry start, size, position) triple per k-mer into the list arrays at Kbase[p].  HBM traffic = one sector per
 // non-empty list + the list arrays; everything else is served by LDS / L1 / L2.
+// Work items are SLICES of kListSlice similar k-mers of one position (round 5): a position has between none and 8 M similar k-mers (mean 7 000, 1 % of
+// the positions beyond 40 000 at -s 9.5), and with one workgroup per position the launch lasted as long as its heaviest positions.  Slice s of position p
+// sits at grid slot p + floor(Kbase[p] / kListSlice) + s -- slots of different positions never collide (floor(a + b) - floor(a) >= floor(b)), a slot without a
+// slice exits -- so the grid is nPos + nLists / kListSlice + 1 workgroups and needs no item table.  Every slice rebuilds its position's run table.
+constexpr uint32_t kListSlice = 8192;
 __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
                                                            uint32_t nPos, KmerPattern pat, const int16_t *s3, const uint16_t *i3,
                                                            const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets, const uint32_t *bitmap,
                                                            uint32_t *listStart, uint32_t *listSize, uint32_t *listPos) {
-    const uint32_t p = blockIdx.x;
-    if (p >= nPos) return;
+    __shared__ uint32_t pSh;
+    if (threadIdx.x == 0) {
+        const uint64_t slot = blockIdx.x;
+        uint32_t lo = 0, hi = nPos;                // last position whose first slot is <= this slot
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t) mid + Kbase[mid] / kListSlice <= slot) lo = mid; else hi = mid; }
+        pSh = lo;
+    }
+    __syncthreads();
+    const uint32_t p = pSh;
     const uint32_t Kp = Kcount[p];
-    if (Kp == 0) return;
+    const uint32_t slice = (uint32_t) ((uint64_t) blockIdx.x - ((uint64_t) p + Kbase[p] / kListSlice));
+    if ((uint64_t) slice * kListSlice >= Kp) return;            // (covers Kp == 0)
+    const uint32_t rBeg = slice * kListSlice, rEnd = min(Kp, rBeg + kListSlice);
     const KmerQ q = qs[posQuery[p]];
     __shared__ KmerPosInfo info;
     __shared__ uint32_t runOx[kMaxRuns + 1];  // exclusive prefix of len * c over the runs
@@ -322,13 +336,13 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
     __syncthreads();
     const uint64_t base = Kbase[p];
     const uint32_t qpos = ((uint32_t) posQuery[p] << 16) | (p - q.posBase);     // what k_kmer_emit needs of a list: its query and the k-mer's position in it
-    for (uint32_t r0 = threadIdx.x; r0 < Kp; r0 += 4 * kKmerBlock) {
+    for (uint32_t r0 = rBeg + threadIdx.x; r0 < rEnd; r0 += 4 * kKmerBlock) {
         uint32_t kmer[4], st[4], en[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t r = r0 + u * kKmerBlock;
             kmer[u] = 0;
-            if (r < Kp) {
+            if (r < rEnd) {
                 int lo = 0, hi = nV;          // last run with runOx <= r (empty runs share their offset with the successor)
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (runOx[mid] <= r) lo = mid; else hi = mid; }
                 const uint32_t d = r - runOx[lo], c = runC[lo];
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t r = r0 + u * kKmerBlock;
-            if (r < Kp) { listStart[base + r] = st[u]; listSize[base + r] = en[u] - st[u]; listPos[base + r] = qpos; }
+            if (r < rEnd) { listStart[base + r] = st[u]; listSize[base + r] = en[u] - st[u]; listPos[base + r] = qpos; }
         }
     }
 }
@@ -567,7 +581,9 @@ constexpr int kDupSmall = 64;                 // ... at most this many: one wave
 constexpr int kDupWindow = 2048;              // a group's bins start inside one window of this many target ids ...
 constexpr int kBinTargets = 1024;             // ... and a bin holds at most this many targets: a group spans fewer than kDupWindow + kBinTargets targets
 constexpr int kDupCounters = kDupWindow + kBinTargets;
-constexpr int kMaxBins = 16000;               // LDS counters of bincount / binscatter: 4 B per bin, under 64 KB
+constexpr int kMaxBins = 36000;               // LDS counters of k_kmer_bincount: 4 B per bin, 141 KB of a CU's 160 KB (a block of 1024 target ids is at least one bin:
+                                              // 36.8 M targets; the 512 coarse bins of a query, one per 65536 ids at least, stop at 33.5 M)
+constexpr int kPlanBins = 16000;              // bin levels are planned for at most this many bins where the residues allow it (64 KB of counters: four workgroups per CU)
 
 // Bins are power-of-two aligned id ranges inside blocks of 1024 target ids: bin(t) = base[t >> 10] + ((t & 1023) >> shift[t >> 10]), the shift
 // chosen per block from its residue count (fsgpu_kmer_plan_bins) -- a table of n / 1024 words that lives in LDS, so the per-hit bin
@@ -1017,6 +1033,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
     typedef typename Cnt::T CT;
     extern __shared__ __attribute__((aligned(16))) unsigned char shDup[];
     __shared__ uint32_t wsum[NT / 64];
+    __shared__ uint32_t needCnt;              // hits of the current group whose flag needs their databaseHits chunk
     // byte offsets into the dynamic LDS block (plain pointer arithmetic on shDup: an integer round trip would turn every access below into
     // a flat_* instruction -- address-space inference stops at ptrtoint -- and flat accesses to LDS go through the vector memory pipe)
     constexpr uint32_t kCntBytes = (uint32_t) ((kDupCounters + 4) * sizeof(CT));
@@ -1059,6 +1076,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
             for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; rNext[u] = e < g.m ? a.part[g.s0 + e] : 0; }
         }
         if (it + 2 * gridDim.x < n) gNext = kmerLoadGroup(list, it + 2 * gridDim.x);
+        if (threadIdx.x == 0) needCnt = 0;
         for (uint32_t i = threadIdx.x; i < (T + 2) / 2 + 1; i += NT) {       // zero as dwords (both counter widths)
             if (BIG) { off[2 * i] = 0; off[2 * i + 1] = 0; } else reinterpret_cast<uint32_t *>(off)[i] = 0;
         }
@@ -1138,26 +1156,42 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
             for (int u = 0; u < PER; u++)
                 if (threadIdx.x + NT * u < m) { so[sp[u]] = o0[u]; sd[sp[u]] = (uint8_t) td[u]; }
             __syncthreads();
-            uint32_t flags = 0;
+            // The rule: a hit is flagged when its 8-bit diagonal equals that of its predecessor (previous hit of the target) if both lie in the same
+            // databaseHits chunk, and equals 0 otherwise.  With eq = "equals the predecessor's" and z = "is 0" the chunk only matters when eq != z --
+            // one hit in thirty -- and finding it is a binary search over the query's chunk starts, a third of this phase's instructions when every
+            // lane runs it.  Those hits are set aside (their sorted position + the two bits, in the dead target | diagonal array) and a few threads
+            // look their chunks up afterwards; everybody reads its flag back from the prefix array.
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 if (threadIdx.x + NT * u < m) {
-                    uint32_t prevD8 = 0;
-                    if (sp[u] > blo[u]) {
-                        bool same = true;
-                        if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, o0[u] - hb); same = so[sp[u] - 1] - hb >= cst[c]; }
-                        if (same) prevD8 = sd[sp[u] - 1];
-                    }
-                    const uint32_t f = (td[u] & 0xffu) == prevD8 ? 1u : 0u;
-                    flags |= f << u;
+                    const bool has = sp[u] > blo[u];
+                    const uint32_t d8 = td[u] & 0xffu;
+                    const bool z = d8 == 0, eq = has && d8 == (uint32_t) sd[sp[u] - (has ? 1u : 0u)];
+                    uint32_t f;
+                    if (!has) f = z ? 1u : 0u;
+                    else if (nCh <= 1 || eq == z) f = eq ? 1u : 0u;
+                    else { f = 0; at[atomicAdd(&needCnt, 1u)] = sp[u] | (eq ? 1u << 30 : 0u) | (z ? 1u << 31 : 0u); }
                     lpfx[sp[u]] = (uint16_t) f;
                 }
             }
             __syncthreads();
+            if (nCh > 1) {
+                const uint32_t nNeed = needCnt;
+                for (uint32_t k = threadIdx.x; k < nNeed; k += NT) {
+                    const uint32_t e = at[k], spk = e & 0x3fffffffu;
+                    const uint32_t c = kmerChunkOf(cst, nCh, so[spk] - hb);
+                    const bool same = so[spk - 1] - hb >= cst[c];
+                    if (same ? (e >> 30) & 1u : e >> 31) lpfx[spk] = 1;
+                }
+                __syncthreads();
+            }
             nc = kmerBlockScan<uint16_t, false, NT>(lpfx, m, wsum);
 #pragma unroll
             for (int u = 0; u < PER; u++)
-                if ((flags >> u) & 1u) a.part[s0 + lpfx[sp[u]]] = partPack(td[u] >> 16, o0[u], td[u] & 0xffffu);   // the group's range can be overwritten: it was read into registers
+                if (threadIdx.x + NT * u < m) {
+                    const uint32_t at0 = lpfx[sp[u]], at1 = sp[u] + 1 < m ? (uint32_t) lpfx[sp[u] + 1] : nc;
+                    if (at1 != at0) a.part[s0 + at0] = partPack(td[u] >> 16, o0[u], td[u] & 0xffffu);   // the group's range can be overwritten: it was read into registers
+                }
         }
         if (threadIdx.x == 0) a.segCand[seg] = nc;
         __syncthreads();                      // LDS arrays are reused by the next group
@@ -1740,14 +1774,21 @@ struct KmerOut { uint32_t id; uint32_t count /* 8-bit score | query << 8 */; uin
 // hands on with score 0 (CacheFriendlyOperations.cpp:112-148: after a target's best element every later zero-score element of it matches the zeroed
 // byte; a target whose best is 0 keeps all of them): the head walks its final list (KmerBest.pad, scrA / scrB of k_kmer_walk) once more and emits
 // one element per match, each with its own diagonal and arrival position.
-__global__ __launch_bounds__(256) void k_kmer_out(const uint32_t *ckeys, const uint64_t *cvals, const int32_t *score, const KmerBest *best, const uint32_t *nCandPtr, int tbits,
-                                                  const uint32_t *thr, uint32_t outCap, uint32_t *outCount /*[nq]*/, uint32_t *outTotal, KmerOut *out,
-                                                  const uint64_t *scrA, const uint64_t *scrB) {
+// Slots come from ONE counter of the batch: a workgroup of 1024 threads sums its elements in LDS and takes its range with a single global atomic
+// (until round 5 every wave with an element went to that counter and to its query's: ~130 k same-address atomics per batch, 0.45 ms for a pass that
+// reads 170 MB); the per-query counts of the workgroup's first query are collected in LDS too.
+__global__ __launch_bounds__(1024) void k_kmer_out(const uint32_t *ckeys, const uint64_t *cvals, const int32_t *score, const KmerBest *best, const uint32_t *nCandPtr, int tbits,
+                                                   const uint32_t *thr, uint32_t outCap, uint32_t *outCount /*[nq]*/, uint32_t *outTotal, KmerOut *out,
+                                                   const uint64_t *scrA, const uint64_t *scrB) {
+    __shared__ uint32_t blockTotal, blockBase, q0s, q0Count;
     const uint64_t s = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nCand = *nCandPtr;
+    if (threadIdx.x == 0) { blockTotal = 0; q0Count = 0; q0s = (uint64_t) blockIdx.x * blockDim.x < nCand ? ckeys[(uint64_t) blockIdx.x * blockDim.x] >> tbits : 0; }
+    __syncthreads();
     uint32_t cnt = 0;
     uint32_t qi = 0;
     KmerBest b{};
-    if (s < *nCandPtr) {
+    if (s < nCand) {
         b = best[s];
         if (b.nElems != 0xFFFFFFFFu && b.nElems != 0) {
             qi = ckeys[s] >> tbits;
@@ -1758,36 +1799,33 @@ __global__ __launch_bounds__(256) void k_kmer_out(const uint32_t *ckeys, const u
     const bool take = cnt != 0;
     const int lane = (int) (threadIdx.x & 63);
     const unsigned long long all = __ballot(take);
-    if (!all) return;
-    const bool multi = __ballot(cnt > 1) != 0ull;
-    uint32_t slot;
-    if (!multi) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(outTotal, (uint32_t) __popcll(all));
-        base = (uint32_t) __shfl((int) base, 0);
-        slot = base + (uint32_t) __popcll(all & ((1ull << lane) - 1ull));
-    } else {
-        uint32_t incl = cnt;                               // inclusive wave scan of the element counts
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t) __shfl_up((int) incl, d); if (lane >= d) incl += v; }
-        uint32_t base = 0;
-        if (lane == 63) base = atomicAdd(outTotal, incl);
-        base = (uint32_t) __shfl((int) base, 63);
-        slot = base + incl - cnt;
-    }
-    // one atomic per (wave, query) instead of one per element: same-address atomics serialise in L2
-    unsigned long long pending = all;
-    while (pending) {
-        const int leader = __ffsll((long long) pending) - 1;
-        const uint32_t q = (uint32_t) __shfl((int) qi, leader);
-        const unsigned long long grp = __ballot(take && qi == q);
-        if (!multi) { if (lane == leader) atomicAdd(&outCount[q], (uint32_t) __popcll(grp)); }
-        else {
+    uint32_t incl = cnt, waveBase = 0;                         // inclusive wave scan of the element counts (a ballot count when nobody has more than one)
+    if (all) {
+        if (__ballot(cnt > 1) == 0ull) incl = (uint32_t) __popcll(all & ((2ull << lane) - 1ull));
+        else for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t) __shfl_up((int) incl, d); if (lane >= d) incl += v; }
+        const uint32_t waveTotal = (uint32_t) __shfl((int) incl, 63);
+        if (lane == 0) waveBase = atomicAdd(&blockTotal, waveTotal);
+        waveBase = (uint32_t) __shfl((int) waveBase, 0);
+        // one atomic per (wave, query): the workgroup's first query into LDS, the others (a workgroup that runs into the next query) to memory
+        const uint32_t q0 = q0s;
+        unsigned long long pending = all;
+        while (pending) {
+            const int leader = __ffsll((long long) pending) - 1;
+            const uint32_t q = (uint32_t) __shfl((int) qi, leader);
+            const unsigned long long grp = __ballot(take && qi == q);
             uint32_t sum = take && qi == q ? cnt : 0u;
             for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t) __shfl_xor((int) sum, d);
-            if (lane == leader) atomicAdd(&outCount[q], sum);
+            if (lane == leader) { if (q == q0) atomicAdd(&q0Count, sum); else atomicAdd(&outCount[q], sum); }
+            pending &= ~grp;
         }
-        pending &= ~grp;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blockBase = blockTotal ? atomicAdd(outTotal, blockTotal) : 0u;
+        if (q0Count) atomicAdd(&outCount[q0s], q0Count);
+    }
+    __syncthreads();
+    const uint32_t slot = blockBase + waveBase + incl - cnt;
     if (!take) return;
     const uint32_t id = ckeys[s] & ((1u << tbits) - 1u);
     if (cnt == 1 && b.count != 0) {

@@ -257,7 +257,11 @@ typedef struct {
 /* Builds, in HBM and from the resident 3Di database (fsgpu_db_load / fsgpu_db_adopt_device), the masked sequence
  * lookup, the k-mer index (offset table over 20^6 k-mers + one (seqId, first position) entry per distinct k-mer of
  * every target, lists ordered by seqId) and the sorted 8000 x 8000 extended 3-mer matrix of kmerSubMat21x21
- * (the 8-bit "k-mer" matrix of the prefilter: SubstitutionMatrix(3di.out, 8.0, -0.2), int16 row-major 21x21). */
+ * (the 8-bit "k-mer" matrix of the prefilter: SubstitutionMatrix(3di.out, 8.0, -0.2), int16 row-major 21x21).
+ * Limits (FSGPU_E_UNSUPPORTED beyond them): k = 6; fewer than 2^32 residues in the database (the reference switches to k = 7 from 3.35e9 residues
+ * on, IndexTable.h:456-458, before that limit is reached); at most 33.5 M targets (512 coarse bins of the hit-stream partition, each inside one block of
+ * 65536 target ids; 16.4 M until round 5); no target of 32768 residues or more.  Index entries are 4 bytes (seqId << posBits | position) while the id
+ * bits and the position bits of the database fit 32 together, 8 bytes otherwise. */
 int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, const int16_t *kmerSubMat21x21);
 uint64_t fsgpu_kmer_index_entries(const fsgpu_ctx *ctx);
 /* Inspection (tests): copy the offset table (64e6+1 uint32), the entries (seqId << 16 | position) and/or the masked

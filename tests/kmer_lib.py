@@ -90,6 +90,19 @@ class RefKpf:
         self.n = len(targets)
         self.h = C.c_void_p(L.ref_kpf_create(C.byref(self.p), _vp(cat), _vp(off), _vp(lens), C.c_int64(self.n), threads))
 
+    @classmethod
+    def from_padded(cls, L, db, threads=8, **kw):
+        """the same over a padded database (synth.PaddedDB) without per-target Python objects: the whole 3Di buffer becomes ASCII in one go, the harness
+        reads the sequences through the database's own offsets / lengths (the padding between them is never looked at)"""
+        self = cls.__new__(cls)
+        self.L, self.p = L, default_params(RefParams, **kw)
+        cat = np.ascontiguousarray(to_ascii(db.data3di))
+        off = np.ascontiguousarray(db.offsets, np.int64)
+        lens = np.ascontiguousarray(db.lengths, np.int32)
+        self.n = int(db.n)
+        self.h = C.c_void_p(L.ref_kpf_create(C.byref(self.p), _vp(cat), _vp(off), _vp(lens), C.c_int64(self.n), threads))
+        return self
+
     def close(self):
         if self.h:
             self.L.ref_kpf_free(self.h)

@@ -122,3 +122,35 @@ def test_equals_compiled_reference_at_1M_targets():
     for q in range(len(q3)):
         assert len(res[q]) == len(rr[q]) and (res[q] == rr[q]).all(), q
         assert np.allclose(stats[q][:3], rs[q][:3])
+
+
+def test_equals_compiled_reference_beyond_16M_targets():
+    """More targets than the hit-stream partition took until round 5 (16.4 M: one LDS counter per bin, a block of 1024 target ids is at least one bin): 17 M
+    short structures (30 .. 64 residues, 0.6 G residues; 25 id bits, so a device batch holds 128 queries and the index entries stay 4 bytes), four
+    queries with planted homologs against the compiled reference's QueryMatcher over the same sequences.  The limit that remains is 33.5 M targets
+    (512 coarse bins of at most 65536 ids) and 2^32 residues (k = 6), include/fsgpu.h."""
+    R = K.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    q3, qa = synth.make_queries(4, seed=17, mean_len=52, lo=44, hi=64)
+    db = synth.make_db_fast(17000000, (q3, qa), seed=1717, homologs_per_query=40, mean_len=36.0, lo=30, hi=64)
+    assert db.n > 16400000
+    ctx = api.Context(0)
+    ctx.load_db(db)
+    m8, m2 = api.Matrix(0, 8.0, -0.2), api.Matrix(0, 2.0, -0.2)
+    ctx.kmer_index_build(m8, kmer_thr=78)
+    prep = [api.kmer_query_prepare(m8, m2, q) for q in q3]
+    l2 = int(R.ref_l2_cache_size())
+    ident = np.full(len(q3), -1, np.int64)
+    ident[2] = 16999999
+    res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=1000, l2_cache_size=l2, want_stats=True)
+    assert (status >= 0).all()
+    assert ctx.kmer_segments()[5] > 16000                                 # more bins than the old LDS limit
+    r = K.RefKpf.from_padded(R, db, threads=16)
+    rr, rs, _ = r.run(q3, ident, threads=4)
+    r.close()
+    ctx.close()
+    for q in range(len(q3)):
+        assert len(res[q]) == len(rr[q]) and (res[q] == rr[q]).all(), q
+        assert len(res[q]) >= 20                                           # the planted homologs are found
+        assert np.allclose(stats[q][:3], rs[q][:3])

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Turn the --pmc summaries of tools/r04_profile.sh (gpurun_out/r04_prof/TAG_*) into the per-unit HBM bytes bench.py reports as
+"""Turn the --pmc summaries of tools/r05_profile.sh (gpurun_out/r05_prof/TAG_*) into the per-unit HBM bytes bench.py reports as
 `roofline.traffic` (profiles/pmc_traffic.json, profiles/pmc_traffic_kmer.json, profiles/pmc_traffic_allvsall.json), stamped with the hash of
 the kernel sources they were collected on (tools/csrc_hash.py; bench.py drops an entry whose hash is not the running one).
-usage: pmc_to_traffic.py gpurun_out/r04_prof TAG profiles/<name of the committed summary files' prefix>"""
+usage: pmc_to_traffic.py gpurun_out/r05_prof TAG profiles/<name of the committed summary files' prefix>"""
 import json
 import os
 import sys
@@ -32,6 +32,32 @@ e.update({"fetch_size_kb": g["FETCH_SIZE"]["per_query"], "write_size_kb": g["WRI
 json.dump(t, open(pt, "w"), indent=1)
 valu = g["SQ_INSTS_VALU"]["per_query"]
 print(f"k_gapless: FETCH {e['fetch_size_kb']:.1f} KB x2 + WRITE {e['write_size_kb']:.1f} KB per query slot; SQ_INSTS_VALU per query slot {valu:.4e}")
+
+# --- structure SW of the same run: k_sw3 (+ its image builder), per target pair.  Pairs of the pass = what the line of the SAME run reports
+# (timed queries x hits per query x (1 + reversed fraction)) scaled by (steps + warm-up) / steps: the counters also cover the warm-up step; the eight
+# single-query solo probes run k_sw and are not in the k_sw3 family.  An estimate to a few per cent, said so in the entry.
+SW_FILES = ["k_sw3.hpp", "k_sw.hpp", "fsgpu_sw3.hip", "fs_kernels.h"]
+lp = os.path.join(d, f"{tag}_pmc_bench_1M_benchline.json")
+if "fs::k_sw3" in b and os.path.exists(lp):
+    line = json.load(open(lp))
+    sw = b["fs::k_sw3"]["counters"]
+    im = b.get("fs::k_sw3_image", {}).get("counters", {})
+    nq = line["config"]["queries_total"]
+    pairs = nq * line["hits_per_query"] * (1.0 + line["align_leg"]["reverse_pass_fraction"]) * (line["steps"] + line["warmup"] + 1) / line["steps"]
+    fkb = sw["FETCH_SIZE"]["total"] + im.get("FETCH_SIZE", {}).get("total", 0.0)
+    wkb = sw["WRITE_SIZE"]["total"] + im.get("WRITE_SIZE", {}).get("total", 0.0)
+    ps = os.path.join(ROOT, "profiles", "pmc_traffic_sw.json")
+    ts = json.load(open(ps)) if os.path.exists(ps) else {}
+    ts["1000000"] = {"kernel": "k_sw3 + k_sw3_image (batch structure SW, both passes)", "fetch_size_kb": fkb, "write_size_kb": wkb, "fetch_correction": 2.0,
+                     "pairs_estimate": pairs, "bytes_per_pair": (2.0 * fkb + wkb) * 1024.0 / max(pairs, 1.0), "alignment_type": line["config"]["workload"].split("--alignment-type ")[1][:1],
+                     "note": "pairs = queries_total x hits_per_query x (1 + reverse_pass_fraction) of the pass's own bench line x (steps + warm-up + the solo batch) / steps; "
+                             "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (wide reads: the LDS images and the target codes). Algorithmic bytes of a pair: its target's codes "
+                             "(1 B per residue and table) + 16 B of result; the rest is the workgroups' LDS images (30-106 KB per workgroup of 8-32 pairs, mostly L2 hits)",
+                     "source": f"{prefix}_pmc_bench_1M_steps3.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT collected in the run that prints it)",
+                     "csrc_hash": csrc_hash(SW_FILES) if open(os.path.join(d, f"{tag}_csrc_hash_sw.txt")).read().strip() == csrc_hash(SW_FILES) else open(os.path.join(d, f"{tag}_csrc_hash_sw.txt")).read().strip(),
+                     "csrc_files": SW_FILES}
+    json.dump(ts, open(ps, "w"), indent=1)
+    print(f"k_sw3: FETCH {fkb:.0f} KB x2 + WRITE {wkb:.0f} KB over ~{pairs:.0f} pairs = {ts['1000000']['bytes_per_pair']:.0f} B per pair")
 
 # --- k-mer prefilter: every kernel of one 32-query batch, per index hit
 k = json.load(open(os.path.join(d, f"{tag}_pmc_kmer_1M.json")))

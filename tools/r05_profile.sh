@@ -1,21 +1,26 @@
 #!/bin/bash
-# Round-4 evidence (same scheme as r03_profile.sh; counters never combined with tracing, MI355X_MICROARCH.md):
-#   r04_profile.sh pmc TAG    separate --pmc passes over a short bench run (k_gapless, k_sw3), over ONE k-mer prefilter batch of 32 queries at 1M
+# Round-5 evidence (counters never combined with tracing, MI355X_MICROARCH.md):
+#   r05_profile.sh emu TAG    bench.py --emulate-rank-share 8, weak and strong scaling: what ONE rank of an 8-rank node runs, on one GPU with that rank's 2 cores
+#   r05_profile.sh pmc TAG    separate --pmc passes over a short bench run (k_gapless, k_sw3), over ONE k-mer prefilter batch of 32 queries at 1M
 #                             targets, and over a short all-vs-all run (configs[4], 200k family DB)
-#   r04_profile.sh bench TAG  default bench line, rocprofv3 kernel traces of the default command and of three k-mer batches
-# Output: gpurun_out/r04_prof/.  tools/pmc_to_traffic.py turns the pmc files into profiles/pmc_traffic*.json.
+#   r05_profile.sh bench TAG  default bench line, rocprofv3 kernel traces of the default command and of three k-mer batches
+# Output: gpurun_out/r05_prof/.  tools/pmc_to_traffic.py turns the pmc files into profiles/pmc_traffic*.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04_prof
+O=$R/gpurun_out/r05_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-bench}
 TAG=${2:-x}
-#   r04_profile.sh pmck TAG   the k-mer and all-vs-all passes of `pmc` alone (the scan kernel's sources did not change: its pass of tag PREV=... is reused)
-if [ "$MODE" = pmc ] || [ "$MODE" = pmck ]; then
+#   r05_profile.sh pmck TAG   the k-mer and all-vs-all passes of `pmc` alone (the scan kernel's sources did not change: its pass of tag PREV=... is reused)
+if [ "$MODE" = emu ]; then
+python $R/bench.py --emulate-rank-share 8 --scaling weak > $O/${TAG}_bench_emulate_rank_share8_weak.json 2> $O/${TAG}_emu_weak.err
+python $R/bench.py --emulate-rank-share 8 --scaling strong --steps 20 > $O/${TAG}_bench_emulate_rank_share8_strong.json 2> $O/${TAG}_emu_strong.err
+elif [ "$MODE" = pmc ] || [ "$MODE" = pmck ]; then
 python $R/tools/csrc_hash.py k_gapless.hpp fs_kernels.h > $O/${TAG}_csrc_hash_gapless.txt
 python $R/tools/csrc_hash.py k_kmer.hpp fsgpu_kmer.hip fs_kernels.h > $O/${TAG}_csrc_hash_kmer.txt
+python $R/tools/csrc_hash.py k_sw3.hpp k_sw.hpp fsgpu_sw3.hip fs_kernels.h > $O/${TAG}_csrc_hash_sw.txt
 if [ "$MODE" = pmc ]; then
-SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-kmer --type2-steps 0 --allvsall-steps 0 --fullrange-steps 0"
+SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-kmer --type2-steps 0 --allvsall-steps 0 --fullrange-steps 0 --single-targets 0"
 pass() { rm -rf /tmp/pmc_$1; rocprofv3 --pmc "$@" -d /tmp/pmc_$1 -o p --output-format csv -- python $R/bench.py $SHORT > /tmp/pmc_$1.log 2>&1; }
 pass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
 pass SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
@@ -24,7 +29,7 @@ pass WRITE_SIZE
 python $R/tools/pmc_family.py /tmp/pmc_SQ_WAVES /tmp/pmc_SQ_LDS_BANK_CONFLICT /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE --json $O/${TAG}_pmc_bench_1M.json > $O/${TAG}_pmc_bench_1M_steps3.txt 2>&1
 grep -h "^{" /tmp/pmc_SQ_WAVES.log | tail -1 > $O/${TAG}_pmc_bench_1M_benchline.json
 else
-cp $R/profiles/r04_${PREV:-z}_pmc_bench_1M.json $O/${TAG}_pmc_bench_1M.json
+cp $R/profiles/${PREV:-r04_z}_pmc_bench_1M.json $O/${TAG}_pmc_bench_1M.json
 fi
 kpass() { rm -rf /tmp/kpmc_$1; rocprofv3 --pmc "$@" -d /tmp/kpmc_$1 -o p --output-format csv -- python $R/tools/kmer_bench.py 1000000 32 1 > /tmp/kpmc_$1.log 2>&1; }
 kpass SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
@@ -34,7 +39,7 @@ kpass WRITE_SIZE
 python $R/tools/pmc_family.py /tmp/kpmc_SQ_WAVES /tmp/kpmc_SQ_LDS_BANK_CONFLICT /tmp/kpmc_FETCH_SIZE /tmp/kpmc_WRITE_SIZE --from-first k_kmer_count --json $O/${TAG}_pmc_kmer_1M.json > $O/${TAG}_pmc_kmer_batch32_1M.txt 2>&1
 grep -h "^COUNTS\|^rep\|^segments" /tmp/kpmc_FETCH_SIZE.log > $O/${TAG}_pmc_kmer_1M_counts.txt
 # all-vs-all: 8 batches of 256 DB entries against the 200k family DB (k-mer prefilter + SW), no module run, no CPU baseline
-AV="--workload allvsall --targets 200000 --steps 8 --warmup 2 --no-cpu-baseline --kmer-threads 1"
+AV="--workload allvsall --targets 200000 --steps 8 --warmup 2 --no-cpu-baseline --kmer-threads 1 --allvsall-batch 1024"
 apass() { rm -rf /tmp/apmc_$1; rocprofv3 --pmc "$@" -d /tmp/apmc_$1 -o p --output-format csv -- python $R/bench.py $AV > /tmp/apmc_$1.log 2>&1; }
 apass FETCH_SIZE
 apass WRITE_SIZE
