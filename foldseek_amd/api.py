@@ -126,6 +126,7 @@ def lib():
         "fsgpu_sw_multi_c": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         "fshost_search_backtrace": (C.c_char_p, [vp, vp]),
         "fshost_search_stats": (None, [vp, vp]),
+        "fshost_search_backtrace_counts": (None, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "fshost_search_last_sw": (None, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "fshost_block_backtrace": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32),
                                          C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]),
@@ -655,6 +656,12 @@ class Search:
         if rc < 0:
             raise FsgpuError(f"startpos_backtrace rc={rc}: {lib().fshost_search_error(self.h).decode()}")
         return rc == 1, qs.value, ds.value, ident.value, buf.value.decode()
+
+    def backtrace_counts(self):
+        """last align_batch: (accepted hits answered by the device block aligner, all accepted hits)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        lib().fshost_search_backtrace_counts(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def stats(self):
         out = np.zeros(8)

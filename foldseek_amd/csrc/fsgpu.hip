@@ -91,6 +91,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->gBorder0, &ctx->gBorder1, &ctx->scoreAcc, &ctx->pssm, &ctx->scores, &ctx->chunkHist, &ctx->baseGt, &ctx->baseTie, &ctx->outId, &ctx->outScore,
                       &ctx->img, &ctx->tids, &ctx->res0, &ctx->res1, &ctx->border0, &ctx->border1, &ctx->keys, &ctx->lbuf, &ctx->lres,
                       &ctx->ovAA, &ctx->ovSS, &ctx->ovOff, &ctx->ovLen, &ctx->s3img, &ctx->s3pass, &ctx->s3build, &ctx->s3res,
+                      &ctx->btSeq, &ctx->btTrace, &ctx->btBlocks, &ctx->btOut, &ctx->btIn,
                       &ctx->mqPssm, &ctx->mqScores, &ctx->mqQueues, &ctx->mqRec, &ctx->mqHist, &ctx->mqBaseGt, &ctx->mqBaseTie, &ctx->mqMeta,
                       &ctx->mqOutId, &ctx->mqOutScore, &ctx->mqIdent};
     for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
@@ -98,6 +99,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipHostFree(ctx->hMeta); hipHostFree(ctx->hOutId.p); hipHostFree(ctx->hOutScore.p);
     hipHostFree(ctx->hRes0.p); hipHostFree(ctx->hRes1.p); hipHostFree(ctx->hLbuf.p); hipHostFree(ctx->hLres.p);
     hipHostFree(ctx->hS3pass.p); hipHostFree(ctx->hS3build.p); hipHostFree(ctx->hS3res.p);
+    hipHostFree(ctx->hBtIn.p); hipHostFree(ctx->hBtOut.p);
     if (ctx->swLong) (void) hipStreamDestroy(ctx->swLong);
     if (ctx->swHi) (void) hipStreamDestroy(ctx->swHi);
     hipHostFree(ctx->hPssm.p); hipHostFree(ctx->hImg.p); hipHostFree(ctx->hTids.p);

@@ -130,6 +130,8 @@ struct fsgpu_ctx {
     uint64_t s3Sig = 0;
     std::vector<uint32_t> s3ImgOff;                // per query of the call the images were built for: dword offset of its images
     PinBuf hRes0, hRes1;                           // pinned result staging
+    DevBuf btSeq, btTrace, btBlocks, btOut, btIn;  // fsgpu_block_backtrace (k_btrace.hpp): padded reversed prefixes, trace words, block lists, [backtraces | results], inputs
+    PinBuf hBtIn, hBtOut;
     struct {
         bool pending = false;
         int n = 0, L = 0, go = 0, ge = 0;

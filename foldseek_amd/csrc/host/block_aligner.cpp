@@ -586,6 +586,7 @@ void block_set_aamatrix_num(AAMatrix *m, int8_t a, int8_t b, int8_t score) {
     m->scores[(size_t) (uint8_t) b * 32 + (uint8_t) a] = score;
 }
 void block_free_aamatrix(AAMatrix *m) { delete m; }
+const int8_t *block_aamatrix_scores(const AAMatrix *m) { return m->scores; }
 
 Cigar *block_new_cigar(uintptr_t q, uintptr_t r) {
     Cigar *c = new Cigar();

@@ -77,6 +77,8 @@ void block_free_aa_trace(BlockHandle b);
 // not in the crate's C header: the crate's Rust API Trace::blocks() (scan_block.rs:2009-2030) for either handle type -- the regions the
 // last alignment computed, out[5 k ..] = {row, column, height, width, right}; returns their number (tests/ba_model.py compares trajectories)
 uintptr_t block_trace_blocks(BlockHandle b, uint32_t *out, uintptr_t cap);
+/* not in the crate's header either: the 27 x 32 int8 score table of an AAMatrix (scores.rs:44-70), what the device aligner (k_btrace.hpp) is handed */
+const int8_t *block_aamatrix_scores(const AAMatrix *m);
 
 #ifdef __cplusplus
 }

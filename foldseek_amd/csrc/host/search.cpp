@@ -5,6 +5,7 @@
 // The DP itself runs on the device through fsgpu_gapless_scan / fsgpu_sw_batch; this file only prepares profiles,
 // applies the reference's gates in the reference's order, and formats results.
 #include "hostlib.h"
+#include "block_aligner_abi.h"
 
 #include <algorithm>
 #include <atomic>
@@ -40,6 +41,9 @@ struct fshost_search {
     std::vector<uint8_t> rAA, r3Di, tAA, t3Di;
     std::vector<fsgpu_swres> fwd, rev;
     std::string cigars;
+    int64_t lastDeviceBt = 0, lastBtTasks = 0;  // last fshost_search_align_batch: accepted hits answered by the device aligner / all of them
+    std::vector<int8_t> btTblAA, btTbl3;        // device backtrace (fsgpu_block_backtrace): the block aligner's two AAMatrix tables and the code -> letter maps
+    std::vector<uint8_t> btLetAA, btLet3;
     std::vector<std::vector<int16_t>> kThr;     // fshost_search_kmer_batch: per-query k-mer thresholds / ungapped profiles of the last batch
     std::vector<std::vector<int8_t>> kProf;
     std::vector<fsgpu_kmer_query> kq;
@@ -510,6 +514,7 @@ struct PreBacktrace {
     std::vector<BlockAlnOut> outs;
     std::vector<std::vector<int>> idx;       // [query][pair] -> outs index or -1
     double seconds = 0;                       // wall time of the parallel section
+    size_t onDevice = 0;                      // hits the device aligner answered
 };
 void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> &aq, const uint32_t *const *targetIds, const int *n,
                           const fsgpu_swres *fwd, const fsgpu_swres *rev, PreBacktrace &pb) {
@@ -534,7 +539,64 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     }
     pb.outs.resize(tasks.size());
     const double t0 = nowSec();
-    HostPool::get().parallelFor((int) tasks.size(), [&](int t) {
+    // ---- device path (round 5): one wave per accepted hit runs the block aligner (k_btrace.hpp); what it hands back (blocks beyond 128 rows) and
+    // everything when it is switched off (FSGPU_DEVICE_BACKTRACE=0) or cannot run (database without AA sequences) goes to the host pool ----
+    std::vector<int> hostTasks;
+    const char *envDev = getenv("FSGPU_DEVICE_BACKTRACE");            // read per call: the tests switch it inside one process
+    const bool deviceOn = !(envDev && atoi(envDev) == 0);
+    const fshost_params &par = s->par;
+    bool onDevice = deviceOn && s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
+    if (onDevice) {
+        fshost_search *ms = const_cast<fshost_search *>(s);
+        if (ms->btTblAA.empty()) {
+            // the two AAMatrix tables exactly as blockBacktrace fills them (block_set_aamatrix per letter pair, StructureSmithWaterman.cpp:428-447)
+            AAMatrix *ma = block_new_simple_aamatrix(1, -1), *m3 = block_new_simple_aamatrix(1, -1);
+            for (int a = 0; a < s->matAA.n; a++)
+                for (int b = 0; b < s->matAA.n; b++) block_set_aamatrix(ma, (uint8_t) s->matAA.letters[a], (uint8_t) s->matAA.letters[b], (int8_t) s->matAA.sub[a * s->matAA.n + b]);
+            for (int a = 0; a < s->mat3Di.n; a++)
+                for (int b = 0; b < s->mat3Di.n; b++) block_set_aamatrix(m3, (uint8_t) s->mat3Di.letters[a], (uint8_t) s->mat3Di.letters[b], (int8_t) s->mat3Di.sub[a * s->mat3Di.n + b]);
+            ms->btTblAA.assign(block_aamatrix_scores(ma), block_aamatrix_scores(ma) + 27 * 32);
+            ms->btTbl3.assign(block_aamatrix_scores(m3), block_aamatrix_scores(m3) + 27 * 32);
+            block_free_aamatrix(ma); block_free_aamatrix(m3);
+            auto letterIdx = [](char c) { return (uint8_t) (((c >= 'a' && c <= 'z') ? c - 32 : c) - 'A'); };
+            ms->btLetAA.assign(21, 23); ms->btLet3.assign(21, 23);
+            for (int a = 0; a < std::min(21, s->matAA.n); a++) ms->btLetAA[a] = letterIdx(s->matAA.letters[a]);
+            for (int a = 0; a < std::min(21, s->mat3Di.n); a++) ms->btLet3[a] = letterIdx(s->mat3Di.letters[a]);
+        }
+        std::vector<fsgpu_bt_query> bq(nq);
+        for (int i = 0; i < nq; i++) { bq[i].qAA = aq[i].qAA; bq[i].q3Di = aq[i].q3di; bq[i].cbAA = aq[i].cbAA.data(); bq[i].cbSS = aq[i].cbSS.data(); bq[i].L = aq[i].L; bq[i].reserved = 0; }
+        std::vector<fsgpu_bt_task> bt;
+        std::vector<fsgpu_bt_res> br;
+        const size_t chunk = 16384;                       // tasks per device call: 60-120 KB of trace scratch each
+        for (size_t c0 = 0; c0 < tasks.size() && onDevice; c0 += chunk) {
+            const size_t c1 = std::min(tasks.size(), c0 + chunk);
+            bt.resize(c1 - c0); br.resize(c1 - c0);
+            for (size_t t = c0; t < c1; t++) {
+                const Task &tk = tasks[t];
+                const fsgpu_swres &f = fwd[tk.base + tk.k];
+                bt[t - c0] = fsgpu_bt_task{(uint32_t) tk.q, targetIds[tk.q][tk.k], f.qEnd, f.dbEnd, f.score};
+            }
+            const char *base = nullptr;
+            if (fsgpu_block_backtrace(s->ctx, ms->btTblAA.data(), ms->btTbl3.data(), ms->btLetAA.data(), ms->btLet3.data(), bq.data(), nq, bt.data(), (int) bt.size(),
+                                      par.gapOpen, par.gapExtend, br.data(), &base) != FSGPU_OK) {
+                for (size_t t = c0; t < tasks.size(); t++) hostTasks.push_back((int) t);      // (scratch did not fit, ...): the host path answers the rest
+                onDevice = false;
+                break;
+            }
+            for (size_t t = c0; t < c1; t++) {
+                const fsgpu_bt_res &r = br[t - c0];
+                BlockAlnOut &o = pb.outs[t];
+                o = BlockAlnOut();
+                if (r.status == 1) { o.ok = true; o.qStart = r.qStart; o.dbStart = r.dbStart; o.identicalAA = (unsigned int) r.identicalAA; o.backtrace.assign(base + r.btOff, (size_t) r.btLen); }
+                else if (r.status != 2) hostTasks.push_back((int) t);
+            }
+        }
+    } else {
+        for (size_t t = 0; t < tasks.size(); t++) hostTasks.push_back((int) t);
+    }
+    pb.onDevice = tasks.size() - hostTasks.size();
+    HostPool::get().parallelFor((int) hostTasks.size(), [&](int h) {
+        const int t = hostTasks[h];
         const Task &tk = tasks[t];
         pairBacktrace(s, aq[tk.q], targetIds[tk.q][tk.k], fwd[tk.base + tk.k], pb.outs[t]);
     });
@@ -675,6 +737,7 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
         base += (size_t) n[i];
     }
     s->stats[2] = t1 - t0; s->stats[3] = t2 - t1; s->stats[5] = tBack; s->stats[4] = nowSec() - t2 - tBack;
+    s->lastDeviceBt = (int64_t) pb.onDevice; s->lastBtTasks = (int64_t) pb.outs.size();
     return FSGPU_OK;
 }
 
@@ -900,6 +963,10 @@ int fshost_search_startpos_backtrace(fshost_search *s, const uint8_t *qAA, const
 
 const char *fshost_search_backtrace(const fshost_search *s, const fshost_result *r) { return s->cigars.c_str() + r->backtraceOff; }
 
+void fshost_search_backtrace_counts(const fshost_search *s, int64_t *onDevice, int64_t *all) {
+    if (onDevice) *onDevice = s ? s->lastDeviceBt : 0;
+    if (all) *all = s ? s->lastBtTasks : 0;
+}
 void fshost_search_stats(const fshost_search *s, double *out8) { memcpy(out8, s->stats, sizeof(s->stats)); }
 
 void fshost_search_last_sw(const fshost_search *s, const fsgpu_swres **fwd, const fsgpu_swres **rev) {

@@ -1,0 +1,484 @@
+// k_btrace.hpp -- start position + backtrace of accepted hits ON THE DEVICE (round 5): the adaptive-block X-drop aligner structurealign
+// takes them from (StructureSmithWaterman::alignStartPosBacktraceBlock, F/src/commons/StructureSmithWaterman.cpp:369-537, over the Rust crate
+// M/lib/block-aligner: align_core scan_block.rs:120-630, place_block_3di :1302-1443, Trace / cigar :1726-2007, AVX2 configuration L = 16).
+//
+// The host restatement (host/block_aligner.cpp) is a lane-exact emulation of the crate's 16 x int16 vector code, because CIGARs depend on its
+// saturation corners, tie-breaks and block trajectory.  Here ONE WAVE RUNS ONE ALIGNMENT and a 16-lane DPP row IS the crate's vector: lane k of
+// a row holds lane k of every vector as a sign-extended int, each vector helper of the host file is the same expression on row shuffles
+// (simd_sl_i16 = row shift by one, simd_step = rotate by 8, the 128-bit-half quirks of the prefix scan as written there), and everything
+// align_core decides per block (direction, grow / shrink, x-drop, checkpoints) is wave-uniform scalar control flow -- no divergence.  The four
+// rows of a wave compute the same alignment (the work is latency bound: 30 k vector steps per alignment, thousands of alignments in flight);
+// only row 0's ballots and stores count.  Column / row state lives in LDS, the trace words and the block list of an alignment in global
+// scratch.  The block may grow to kBtMaxBlock rows; an alignment that wants a larger block, or does not reach the SW score with starting sizes
+// 32 .. kBtMaxBlock, is handed back (status 0) and takes the host path -- same answers either way, which is what tests/test_btrace_gpu.py holds.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fs {
+
+constexpr int kBtL = 16;                 // avx2.rs:11
+constexpr int kBtZero = 1 << 14;         // avx2.rs:15
+constexpr int kBtMin = 0;                // avx2.rs:16
+constexpr int kBtStep = 8;               // scan_block.rs:813
+constexpr int kBtXDropIter = 2;          // scan_block.rs:814
+constexpr int kBtMaxBlock = 128;         // largest block size the device grows to (the crate: 4096)
+constexpr int kBtPad = kBtMaxBlock + 2 * kBtL + 16;      // readable bytes behind a sequence
+constexpr int kBtNull = 26;              // AA_NULL: b'A' + 26 - b'A'
+
+struct BtTask {                          // one accepted hit
+    uint32_t query, target;              // index into the call's queries / target id in the resident DB
+    int32_t qEnd, dbEnd, score;          // end cell and score of the forward SW
+    uint32_t pad;
+    uint64_t seqOff, traceOff, blockOff, btOff;   // this task's slices of the scratch buffers (bytes / words / blocks / bytes)
+};
+struct BtQuery { uint32_t off, L; };     // forward codes AA [L], 3Di [L], bias int16 [L] (cbAA + cbSS) at off / off + L / off + 2 L (bias 2-byte aligned)
+struct BtRes { int32_t status, qStart, dbStart, identicalAA, btLen, blockSizes; };   // status: 0 = host path, 1 = ok, 2 = SW score not reproduced (start -1, no backtrace)
+
+struct BtArgs {
+    const BtTask *tasks; int nTasks;
+    const BtQuery *queries; const uint8_t *qdata;
+    const uint8_t *dbAA, *dbSS; const uint64_t *dbOff; const int32_t *dbLen;
+    const int8_t *tblAA, *tblSS;         // [27][32] block-aligner matrices, letter-indexed
+    const uint8_t *letAA, *letSS;        // [21] code -> letter index (letter - 'A')
+    int gapOpen, gapExtend;              // negative (Gaps of the crate)
+    uint8_t *seq; uint32_t *trace; uint4 *blocks; char *bt; BtRes *res;
+};
+
+// ---- the crate's vector helpers on a 16-lane row (host/block_aligner.cpp, scalar definitions) ----
+__device__ __forceinline__ int btSat(int x) { return min(max(x, -32768), 32767); }
+__device__ __forceinline__ int btAdds(int a, int b) { return btSat(a + b); }
+__device__ __forceinline__ int btSubs(int a, int b) { return btSat(a - b); }
+__device__ __forceinline__ int btLane(int v, int k) { return __shfl(v, k, kBtL); }
+__device__ __forceinline__ int btSl1(int a, int b, int ln) { const int t = __shfl_up(a, 1, kBtL), c = __shfl(b, kBtL - 1, kBtL); return ln == 0 ? c : t; }
+__device__ __forceinline__ int btStep8(int a, int b, int ln) { const int xa = __shfl_xor(a, 8, kBtL), xb = __shfl_xor(b, 8, kBtL); return ln < 8 ? xb : xa; }
+template <int N> __device__ __forceinline__ int btSllz(int a, int ln) { const int t = __shfl_up(a, N, kBtL); return (ln & 7) >= N ? t : 0; }
+template <int B> __device__ __forceinline__ int btSlli16(int a) { return (int) (int16_t) (uint16_t) ((uint32_t) a << B); }
+__device__ __forceinline__ int btHmax(int a) {
+#pragma unroll
+    for (int d = 1; d < kBtL; d <<= 1) a = max(a, __shfl_xor(a, d, kBtL));
+    return a;
+}
+struct BtScanConsts { int gapExtendAll, lane; };
+__device__ __forceinline__ BtScanConsts btPrefixScanConsts(int gap, int ln) {
+    const int shift1 = btAdds(btSllz<1>(gap, ln), gap);
+    const int shift2 = btAdds(btSllz<2>(shift1, ln), shift1);
+    const int shift4 = btAdds(btSllz<4>(shift2, ln), shift2);
+    const int s7 = __shfl(shift4, 7, kBtL);
+    BtScanConsts c;
+    c.gapExtendAll = btAdds(ln < 8 ? 0 : s7, shift4);
+    c.lane = shift4;
+    return c;
+}
+__device__ __forceinline__ int btPrefixScan(int Rmax, int gapCost, int gapCostLane, int ln) {
+    const int shift1 = max(Rmax, btAdds(btSllz<1>(Rmax, ln), gapCost));
+    const int shift2 = max(shift1, btAdds(btSllz<2>(shift1, ln), btSlli16<1>(gapCost)));
+    const int shift4 = max(shift2, btAdds(btSllz<4>(shift2, ln), btSlli16<2>(gapCost)));
+    const int lowq = __shfl(shift4, ln & 3, kBtL), s7 = __shfl(shift4, 7, kBtL);
+    const int correct1 = btAdds(ln < 8 ? lowq : s7, gapCostLane);
+    return max(shift4, correct1);
+}
+__device__ __forceinline__ uint32_t btSpread16(uint32_t x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+// bit 2k <- lo lane k, bit 2k + 1 <- hi lane k (row 0 of the wave)
+__device__ __forceinline__ uint32_t btMask2(bool lo, bool hi) {
+    const uint32_t a = (uint32_t) __ballot(lo), b = (uint32_t) __ballot(hi);
+    return btSpread16(a) | (btSpread16(b) << 1);
+}
+
+struct BtSeq { const uint8_t *aa, *ss; const int16_t *bias; int len; };      // padded: index 0 = AA_NULL, residues at 1 .. len, AA_NULL behind
+
+struct BtState {                       // per-wave LDS
+    int16_t Dcol[kBtMaxBlock + kBtL], Ccol[kBtMaxBlock + kBtL], Drow[kBtMaxBlock + kBtL], Rrow[kBtMaxBlock + kBtL];
+    int16_t DcolCk[kBtMaxBlock + kBtL], CcolCk[kBtMaxBlock + kBtL], DrowCk[kBtMaxBlock + kBtL], RrowCk[kBtMaxBlock + kBtL];
+    int16_t tmp1[kBtL], tmp2[kBtL];
+};
+
+struct BtTrace {                       // wave-uniform scalars + the task's global arrays
+    uint32_t *trace, *trace2;
+    uint4 *blocks;                     // {i, j, height | width << 16, right}
+    uint32_t traceIdx, blockIdx, ckptTraceIdx, ckptBlockIdx;
+};
+
+struct BtPB { int Dmax, argI, argJ; };
+
+__device__ __forceinline__ void btWaveSync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// place_block_3di (scan_block.rs:1302-1443); `query` runs along the vector dimension
+__device__ __forceinline__ BtPB btPlaceBlock(const BtSeq &query, const BtSeq &reference, const int8_t *tblAA, const int8_t *tblSS, int gapOpen, int gapExtend,
+                                             int startI, int startJ, int width, int height, int16_t *DcolP, int16_t *CcolP, int16_t *DrowP, int16_t *RrowP,
+                                             int Dcorner, BtTrace &tr, int ln, bool row0) {
+    const BtScanConsts sc = btPrefixScanConsts(gapExtend, ln);
+    BtPB out; out.Dmax = kBtMin; out.argI = 0; out.argJ = 0;
+    if (width == 0 || height == 0) return out;
+    const int openMinusExt = btSubs(gapOpen, gapExtend);
+    for (int j = 0; j < width; j++) {
+        int R01 = kBtMin, D11 = kBtMin, R11 = kBtMin;
+        bool prevTraceR = false;
+        const int c = reference.aa[startJ + j], c3 = reference.ss[startJ + j];
+        const int refBias = reference.bias ? (int) reference.bias[startJ + j] : 0;
+        for (int i = 0; i < height; i += kBtL) {
+            const int D10 = DcolP[i + ln], C10 = CcolP[i + ln];
+            const int D00 = btSl1(D10, Dcorner, ln);
+            Dcorner = D10;
+            int scores = tblAA[c * 32 + (query.aa[startI + i + ln] & 31)];
+            {
+                const int s3 = tblSS[c3 * 32 + (query.ss[startI + i + ln] & 31)];
+                const int qBias = query.bias ? (int) query.bias[startI + i + ln] : 0;
+                scores = btAdds(btAdds(scores, s3), btAdds(refBias, qBias));
+            }
+            D11 = btAdds(D00, scores);
+            if (startI + i == 0 && startJ + j == 0 && ln == 0) D11 = kBtZero;
+            const int C11open = btAdds(D10, gapOpen);
+            const int C11 = max(btAdds(C10, gapExtend), C11open);
+            D11 = max(D11, C11);
+            const int D11open = btAdds(D11, openMinusExt);
+            R11 = btPrefixScan(D11open, gapExtend, sc.lane, ln);
+            R11 = max(R11, btAdds(__shfl(R01, kBtL - 1, kBtL), sc.gapExtendAll));
+            D11 = max(D11, R11);
+            R01 = R11;
+            {
+                const uint32_t t = btMask2(D11 == C11, D11 == R11);
+                const bool tempTraceR = R11 == D11open;
+                // traceR = simd_sl_i16(tempTraceR, prevTraceR, 1)
+                const int up = __shfl_up((int) tempTraceR, 1, kBtL), last = __shfl((int) prevTraceR, kBtL - 1, kBtL);
+                const bool traceR = (ln == 0 ? last : up) != 0;
+                const uint32_t t2 = btMask2(C11 == C11open, traceR);
+                prevTraceR = tempTraceR;
+                if (row0 && ln == 0) { tr.trace[tr.traceIdx] = t; tr.trace2[tr.traceIdx] = t2; }
+                tr.traceIdx++;
+            }
+            out.Dmax = max(out.Dmax, D11);
+            if (out.Dmax == D11) { out.argI = i; out.argJ = j; }
+            // (LDS executes a wave's accesses in order and these go through one base pointer: no barrier needed between the loads above and the stores)
+            DcolP[i + ln] = (int16_t) D11;
+            CcolP[i + ln] = (int16_t) C11;
+        }
+        Dcorner = kBtMin;
+        if (ln == kBtL - 1) { DrowP[j] = (int16_t) D11; RrowP[j] = (int16_t) R11; }
+        btWaveSync();
+    }
+    return out;
+}
+
+__device__ __forceinline__ void btJustOffset(int blockSize, int16_t *b1, int16_t *b2, int offAdd, int ln) {
+    for (int i = 0; i < blockSize; i += kBtL) { b1[i + ln] = (int16_t) btAdds(b1[i + ln], offAdd); b2[i + ln] = (int16_t) btAdds(b2[i + ln], offAdd); }
+    btWaveSync();
+}
+// shift_and_offset (scan_block.rs:1096-1123)
+__device__ __forceinline__ int btShiftAndOffset(int blockSize, int16_t *b1, int16_t *b2, const int16_t *t1, const int16_t *t2, int offAdd, int ln) {
+    int curr1 = btAdds(b1[ln], offAdd);
+    const int Dcorner = btLane(curr1, kBtStep - 1);
+    int curr2 = btAdds(b2[ln], offAdd);
+    int i = 0;
+    while (i < blockSize - kBtL) {
+        const int next1 = btAdds(b1[i + kBtL + ln], offAdd), next2 = btAdds(b2[i + kBtL + ln], offAdd);
+        btWaveSync();
+        b1[i + ln] = (int16_t) btStep8(next1, curr1, ln);
+        b2[i + ln] = (int16_t) btStep8(next2, curr2, ln);
+        btWaveSync();
+        curr1 = next1; curr2 = next2;
+        i += kBtL;
+    }
+    const int a1 = t1[ln], a2 = t2[ln];
+    btWaveSync();
+    b1[blockSize - kBtL + ln] = (int16_t) btStep8(a1, curr1, ln);
+    b2[blockSize - kBtL + ln] = (int16_t) btStep8(a2, curr2, ln);
+    btWaveSync();
+    return Dcorner;
+}
+__device__ __forceinline__ int btPrefixHmax8(const int16_t *p, int ln) { return btHmax(ln < 8 ? (int) p[ln] : -32768); }
+__device__ __forceinline__ int btSuffixHmax2(const int16_t *p) { return max((int) p[kBtL - 1], (int) p[kBtL - 2]); }
+__device__ __forceinline__ void btCopy(int16_t *dst, const int16_t *src, int n, int ln) {
+    for (int i = 0; i < n; i += kBtL) dst[i + ln] = src[i + ln];
+}
+__device__ __forceinline__ int btClamp16(int x) { return btSat(x); }
+
+enum { kBtRight = 0, kBtDown = 1, kBtGrow = 2 };
+
+// align_core (scan_block.rs:120-630) with trace and x-drop.  Returns false when the block wants to grow beyond kBtMaxBlock.
+__device__ __forceinline__ bool btAlign(BtState &S, BtTrace &tr, const BtSeq &query, const BtSeq &reference, const int8_t *tblAA, const int8_t *tblSS, int gapOpen, int gapExtend,
+                                        int minSize, int maxSize, int xDropThr, int ln, bool row0, int &resScore, int &resQ, int &resR) {
+    // clear
+    tr.traceIdx = tr.blockIdx = tr.ckptTraceIdx = tr.ckptBlockIdx = 0;
+    for (int i = 0; i < kBtMaxBlock + kBtL; i += kBtL) {
+        S.Dcol[i + ln] = kBtMin; S.Ccol[i + ln] = kBtMin; S.Drow[i + ln] = kBtMin; S.Rrow[i + ln] = kBtMin;
+        S.DcolCk[i + ln] = kBtMin; S.CcolCk[i + ln] = kBtMin; S.DrowCk[i + ln] = kBtMin; S.RrowCk[i + ln] = kBtMin;
+    }
+    S.tmp1[ln] = kBtMin; S.tmp2[ln] = kBtMin;
+    btWaveSync();
+    int si = 0, sj = 0;
+    int bestMax = 0, bestArgI = 0, bestArgJ = 0;
+    int prevDir = kBtGrow, dir = kBtGrow;
+    int prevSize = 0, blockSize = minSize;
+    int off = 0, prevOff, offMax = 0;
+    int yDropIter = 0, xDropIter = 0;
+    int iCkpt = si, jCkpt = sj, offCkpt = 0;
+    int Dcorner = kBtMin;
+    const int qLen = query.len, rLen = reference.len;
+    const uint32_t blockCap = (uint32_t) (qLen + rLen + 12);
+    auto addBlock = [&](int i, int j, int width, int height, int right) {
+        if (row0 && ln == 0 && tr.blockIdx < blockCap) tr.blocks[tr.blockIdx] = make_uint4((uint32_t) i, (uint32_t) j, (uint32_t) height | ((uint32_t) width << 16), (uint32_t) right);
+        tr.blockIdx++;
+    };
+    auto copyToCkpt = [&](int n) {
+        btCopy(S.DcolCk, S.Dcol, n, ln); btCopy(S.CcolCk, S.Ccol, n, ln); btCopy(S.DrowCk, S.Drow, n, ln); btCopy(S.RrowCk, S.Rrow, n, ln);
+        btWaveSync();
+    };
+    for (;;) {
+        if (tr.blockIdx + 2 >= blockCap) return false;            // cannot happen while the walk follows the crate (a block per 8 rows or columns); the host path answers
+        prevOff = off;
+        int growDmax = kBtMin, growArgI = 0, growArgJ = 0;
+        BtPB pb;
+        int rightMax, downMax;
+        if (dir == kBtRight) {
+            off = offMax;
+            const int offAdd = btClamp16(prevOff - off);
+            addBlock(si, sj + blockSize - kBtStep, kBtStep, blockSize, 1);
+            btJustOffset(blockSize, S.Dcol, S.Ccol, offAdd, ln);
+            pb = btPlaceBlock(query, reference, tblAA, tblSS, gapOpen, gapExtend, si, sj + blockSize - kBtStep, kBtStep, blockSize, S.Dcol, S.Ccol, S.tmp1, S.tmp2,
+                              prevDir == kBtDown ? btAdds(Dcorner, offAdd) : kBtMin, tr, ln, row0);
+            rightMax = btPrefixHmax8(S.Dcol, ln);
+            Dcorner = btShiftAndOffset(blockSize, S.Drow, S.Rrow, S.tmp1, S.tmp2, offAdd, ln);
+            downMax = btPrefixHmax8(S.Drow, ln);
+        } else if (dir == kBtDown) {
+            off = offMax;
+            const int offAdd = btClamp16(prevOff - off);
+            addBlock(si + blockSize - kBtStep, sj, blockSize, kBtStep, 0);
+            btJustOffset(blockSize, S.Drow, S.Rrow, offAdd, ln);
+            pb = btPlaceBlock(reference, query, tblAA, tblSS, gapOpen, gapExtend, sj, si + blockSize - kBtStep, kBtStep, blockSize, S.Drow, S.Rrow, S.tmp1, S.tmp2,
+                              prevDir == kBtRight ? btAdds(Dcorner, offAdd) : kBtMin, tr, ln, row0);
+            downMax = btPrefixHmax8(S.Drow, ln);
+            Dcorner = btShiftAndOffset(blockSize, S.Dcol, S.Ccol, S.tmp1, S.tmp2, offAdd, ln);
+            rightMax = btPrefixHmax8(S.Dcol, ln);
+        } else {
+            Dcorner = kBtMin;
+            const int growStep = blockSize - prevSize;
+            addBlock(si + prevSize, sj, prevSize, growStep, 0);
+            const BtPB p1 = btPlaceBlock(reference, query, tblAA, tblSS, gapOpen, gapExtend, sj, si + prevSize, growStep, prevSize, S.Drow, S.Rrow, S.Dcol + prevSize,
+                                         S.Ccol + prevSize, kBtMin, tr, ln, row0);
+            addBlock(si, sj + prevSize, growStep, blockSize, 1);
+            pb = btPlaceBlock(query, reference, tblAA, tblSS, gapOpen, gapExtend, si, sj + prevSize, growStep, blockSize, S.Dcol, S.Ccol, S.Drow + prevSize,
+                              S.Rrow + prevSize, kBtMin, tr, ln, row0);
+            rightMax = btPrefixHmax8(S.Dcol, ln);
+            downMax = btPrefixHmax8(S.Drow, ln);
+            growDmax = p1.Dmax; growArgI = p1.argI; growArgJ = p1.argJ;
+            copyToCkpt(blockSize);
+            tr.ckptTraceIdx = tr.traceIdx; tr.ckptBlockIdx = tr.blockIdx;
+        }
+        prevDir = dir;
+        const int DmaxMax = btHmax(pb.Dmax), growMax = btHmax(growDmax);
+        const int mx = max(DmaxMax, growMax);
+        offMax = off + mx - kBtZero;
+        yDropIter++;
+        bool growNoMax = dir == kBtGrow;
+        if (offMax > bestMax) {
+            {
+                const bool grow = dir == kBtGrow && DmaxMax < growMax;
+                const int currMax = grow ? growMax : DmaxMax;
+                const int cd = grow ? growDmax : pb.Dmax, ci = grow ? growArgI : pb.argI, cj = grow ? growArgJ : pb.argJ;
+                // per lane: the cell of its maximum; between lanes the largest column, then the largest row (the sequential "better" of the crate
+                // is a strict lexicographic maximum starting from (0, 0))
+                unsigned long long key = 0;
+                if (cd == currMax) {
+                    const int idxI = (int) (uint16_t) ci, idxJ = (int) (uint16_t) cj;
+                    const int r = idxI + ln, c = (blockSize - kBtStep) + idxJ;
+                    int gi, gj;
+                    if (grow) { gi = si + prevSize + idxJ; gj = sj + idxI + ln; }
+                    else if (dir == kBtRight) { gi = si + r; gj = sj + c; }
+                    else if (dir == kBtDown) { gi = si + c; gj = sj + r; }
+                    else { gi = si + idxI + ln; gj = sj + prevSize + idxJ; }
+                    key = ((unsigned long long) (uint32_t) gj << 32) | (uint32_t) gi;
+                }
+#pragma unroll
+                for (int d = 1; d < kBtL; d <<= 1) {
+                    const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) key, d, kBtL), hi = (uint32_t) __shfl_xor((int) (uint32_t) (key >> 32), d, kBtL);
+                    const unsigned long long o = ((unsigned long long) hi << 32) | lo;
+                    key = o > key ? o : key;
+                }
+                bestArgI = (int) (uint32_t) key; bestArgJ = (int) (uint32_t) (key >> 32);
+            }
+            if (blockSize < maxSize) {
+                iCkpt = si; jCkpt = sj; offCkpt = off;
+                copyToCkpt(blockSize);
+                tr.ckptTraceIdx = tr.traceIdx; tr.ckptBlockIdx = tr.blockIdx;
+                growNoMax = false;
+            }
+            bestMax = offMax;
+            yDropIter = 0;
+        }
+        if (offMax < bestMax - xDropThr) {
+            if (xDropIter < kBtXDropIter - 1) xDropIter++;
+            else break;
+        } else {
+            xDropIter = 0;
+        }
+        if (si + blockSize > qLen && sj + blockSize > rLen) break;
+        if (sj + blockSize > rLen) { si += kBtStep; dir = kBtDown; continue; }
+        if (si + blockSize > qLen) { sj += kBtStep; dir = kBtRight; continue; }
+        const int nextSize = blockSize * 2;
+        if (nextSize <= maxSize) {
+            if (yDropIter > (blockSize / kBtStep) - 1 || growNoMax) {
+                if (nextSize > kBtMaxBlock) return false;          // the host path continues where the device's LDS ends
+                prevSize = blockSize;
+                blockSize = nextSize;
+                dir = kBtGrow;
+                si = iCkpt; sj = jCkpt; off = offCkpt;
+                btCopy(S.Dcol, S.DcolCk, prevSize, ln); btCopy(S.Ccol, S.CcolCk, prevSize, ln); btCopy(S.Drow, S.DrowCk, prevSize, ln); btCopy(S.Rrow, S.RrowCk, prevSize, ln);
+                btWaveSync();
+                tr.traceIdx = tr.ckptTraceIdx; tr.blockIdx = tr.ckptBlockIdx;
+                yDropIter = 0;
+                continue;
+            }
+        }
+        if (blockSize > minSize && yDropIter == 0) {              // SHRINK
+            const int shrinkMax = max(btSuffixHmax2(S.Drow + blockSize - kBtL), btSuffixHmax2(S.Dcol + blockSize - kBtL));
+            if (shrinkMax >= mx) {
+                prevDir = kBtGrow;
+                blockSize /= 2;
+                for (int i = 0; i < blockSize; i += kBtL) {
+                    const int a = S.Dcol[i + blockSize + ln], b = S.Ccol[i + blockSize + ln], c = S.Drow[i + blockSize + ln], d = S.Rrow[i + blockSize + ln];
+                    btWaveSync();
+                    S.Dcol[i + ln] = (int16_t) a; S.Ccol[i + ln] = (int16_t) b; S.Drow[i + ln] = (int16_t) c; S.Rrow[i + ln] = (int16_t) d;
+                    btWaveSync();
+                }
+                si += blockSize; sj += blockSize;
+                iCkpt = si; jCkpt = sj; offCkpt = off;
+                copyToCkpt(blockSize);
+                rightMax = btPrefixHmax8(S.Dcol, ln);
+                downMax = btPrefixHmax8(S.Drow, ln);
+                tr.ckptTraceIdx = tr.traceIdx; tr.ckptBlockIdx = tr.blockIdx;
+                yDropIter = 0;
+            }
+        }
+        if (downMax > rightMax) { si += kBtStep; dir = kBtDown; }
+        else { sj += kBtStep; dir = kBtRight; }
+    }
+    resScore = bestMax; resQ = bestArgI; resR = bestArgJ;
+    return true;
+}
+
+// Trace::cigar_core (scan_block.rs:1844-2007) from cell (i, j) back to (0, 0): writes one character per operation in the order the steps are taken
+// (= the forward order of the ORIGINAL alignment: the aligned sequences are the reversed prefixes) and counts identical amino acids under M.
+__device__ __forceinline__ int btCigar(const BtTrace &tr, int i, int j, const uint8_t *qAA, const uint8_t *rAA, char *bt, int &identical, bool writer) {
+    uint32_t blockIdx = tr.blockIdx, traceIdx = tr.traceIdx;
+    int blockI = 0, blockJ = 0, blockW = 0, blockH = 0, rightFlag = 0;
+    int table = 0;                                       // 0 = D, 1 = C, 2 = R
+    int n = 0;
+    identical = 0;
+    const int limit = i + j + 4;                         // a walk takes at most i + j steps: anything longer is a broken trace, not an answer
+    while (i > 0 || j > 0) {
+        for (;;) {
+            if (blockIdx == 0) return -1;
+            blockIdx--;
+            const uint4 b = tr.blocks[blockIdx];
+            blockI = (int) b.x; blockJ = (int) b.y; blockH = (int) (b.z & 0xffffu); blockW = (int) (b.z >> 16);
+            traceIdx -= (uint32_t) (blockW * blockH / kBtL);
+            if (i >= blockI && j >= blockJ) { rightFlag = (int) b.w; break; }
+        }
+        while (i >= blockI && j >= blockJ && (i > 0 || j > 0)) {
+            const int ci = i - blockI, cj = j - blockJ;
+            uint32_t idx, sh;
+            if (rightFlag) { idx = traceIdx + (uint32_t) (ci / kBtL + cj * (blockH / kBtL)); sh = (uint32_t) (ci % kBtL) * 2; }
+            else { idx = traceIdx + (uint32_t) (cj / kBtL + ci * (blockW / kBtL)); sh = (uint32_t) (cj % kBtL) * 2; }
+            const uint32_t t = (tr.trace[idx] >> sh) & 3u, t2 = (tr.trace2[idx] >> sh) & 3u;
+            const bool t2b0 = t2 & 1u, t2b1 = t2 & 2u;
+            // the crate's OP_LUT (scan_block.rs:1870-1925): first operand of every pair is the table the walk is in
+            int op, di, dj, nt;                          // op: 0 = M, 1 = I, 2 = D
+            if (rightFlag) {
+                if (table == 1) { op = 2; di = 0; dj = 1; nt = t2b0 ? 0 : 1; }
+                else if (table == 2) { op = 1; di = 1; dj = 0; nt = t2b1 ? 0 : 2; }
+                else if (t == 0) { op = 0; di = 1; dj = 1; nt = 0; }
+                else if (t == 1 || t == 3) { op = 2; di = 0; dj = 1; nt = t2b0 ? 0 : 1; }
+                else { op = 1; di = 1; dj = 0; nt = t2b1 ? 0 : 2; }
+            } else {
+                if (table == 2) { op = 1; di = 1; dj = 0; nt = t2b0 ? 0 : 2; }
+                else if (table == 1) { op = 2; di = 0; dj = 1; nt = t2b1 ? 0 : 1; }
+                else if (t == 0) { op = 0; di = 1; dj = 1; nt = 0; }
+                else if (t == 1 || t == 3) { op = 1; di = 1; dj = 0; nt = t2b0 ? 0 : 2; }
+                else { op = 2; di = 0; dj = 1; nt = t2b1 ? 0 : 1; }
+            }
+            if (op == 0 && qAA[i] == rAA[j]) identical++;   // padded index i <-> reversed-prefix residue i - 1 of both sequences
+            if (n >= limit) return -1;
+            if (writer) bt[n] = op == 0 ? 'M' : op == 1 ? 'I' : 'D';
+            n++;
+            i -= di; j -= dj; table = nt;
+        }
+    }
+    return n;
+}
+
+// alignStartPosBacktraceBlock (StructureSmithWaterman.cpp:369-537) for a batch of accepted hits: one wave per task
+__global__ __launch_bounds__(256) void k_block_backtrace(BtArgs a) {
+    __shared__ BtState states[4];
+    __shared__ int8_t tAA[27 * 32], tSS[27 * 32];
+    for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) { tAA[i] = a.tblAA[i]; tSS[i] = a.tblSS[i]; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & (kBtL - 1);
+    const bool row0 = lane < kBtL;
+    BtState &S = states[wave];
+    for (int task = blockIdx.x * 4 + wave; task < a.nTasks; task += gridDim.x * 4) {
+        const BtTask tk = a.tasks[task];
+        const BtQuery q = a.queries[tk.query];
+        const int qn = tk.qEnd + 1, tn = tk.dbEnd + 1;
+        // ---- the padded, reversed prefixes: letter indices, AA_NULL in front and behind; the query's position bias (cbAA + cbSS) ----
+        const size_t qStride = ((size_t) 1 + qn + kBtPad + 15) & ~(size_t) 15, tStride = ((size_t) 1 + tn + kBtPad + 15) & ~(size_t) 15;
+        uint8_t *pq = a.seq + tk.seqOff, *pq3 = pq + qStride, *pt = pq3 + qStride, *pt3 = pt + tStride;
+        int16_t *pb = (int16_t *) (pt3 + tStride);
+        const uint8_t *qa = a.qdata + q.off, *q3 = qa + q.L;
+        const int16_t *qb = (const int16_t *) (a.qdata + q.off + 2 * (size_t) q.L);      // q.off is a multiple of 16
+        const uint8_t *ta = a.dbAA + a.dbOff[tk.target], *t3 = a.dbSS + a.dbOff[tk.target];
+        for (int i = lane; i < (int) qStride; i += 64) {
+            const int k = i - 1;                             // reversed-prefix index
+            const bool in = k >= 0 && k < qn;
+            pq[i] = in ? a.letAA[min((int) qa[tk.qEnd - k], 20)] : (uint8_t) kBtNull;
+            pq3[i] = in ? a.letSS[min((int) q3[tk.qEnd - k], 20)] : (uint8_t) kBtNull;
+            pb[i] = in ? qb[tk.qEnd - k] : (int16_t) 0;
+        }
+        for (int i = lane; i < (int) tStride; i += 64) {
+            const int k = i - 1;
+            const bool in = k >= 0 && k < tn;
+            pt[i] = in ? a.letAA[min((int) ta[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;
+            pt3[i] = in ? a.letSS[min((int) t3[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;
+        }
+        __threadfence_block();
+        btWaveSync();
+        const BtSeq qs{pq, pq3, pb, qn}, rs{pt, pt3, nullptr, tn};
+        BtTrace tr;
+        const size_t traceWords = (size_t) (kBtMaxBlock / kBtL) * ((size_t) qn + tn + 2 * kBtMaxBlock);
+        tr.trace = a.trace + tk.traceOff; tr.trace2 = tr.trace + traceWords;
+        tr.blocks = a.blocks + tk.blockOff;
+        int score = -1000000000, rq = -1, rr = -1, sizes = 0;
+        bool onDevice = true;
+        for (int minSize = 32; minSize <= kBtMaxBlock && score < tk.score; minSize *= 2) {
+            const int xDrop = -(minSize * a.gapExtend + a.gapOpen);
+            onDevice = btAlign(S, tr, qs, rs, tAA, tSS, a.gapOpen, a.gapExtend, minSize, 4096, xDrop, ln, row0, score, rq, rr);
+            sizes++;
+            if (!onDevice) break;
+        }
+        BtRes r;
+        r.status = 0; r.qStart = -1; r.dbStart = -1; r.identicalAA = 0; r.btLen = 0; r.blockSizes = sizes;
+        if (onDevice && score >= tk.score) {
+            // reached (a larger starting size is never tried once the score is there); like the host: a score that differs from the SW score
+            // leaves the hit without start position, except at int16 saturation
+            if (!(score != tk.score && !(tk.score == 32767 && score >= tk.score))) {
+                __threadfence_block();
+                btWaveSync();
+                int ident = 0;
+                const int n = btCigar(tr, rq, rr, pq, pt, a.bt + tk.btOff, ident, row0 && ln == 0);
+                if (n >= 0) { r.status = 1; r.qStart = (tk.qEnd + 1) - rq; r.dbStart = (tk.dbEnd + 1) - rr; r.identicalAA = ident; r.btLen = n; }
+            } else r.status = 2;
+        }
+        if (lane == 0) a.res[task] = r;
+        btWaveSync();
+    }
+}
+
+} // namespace fs

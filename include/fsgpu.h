@@ -244,6 +244,23 @@ typedef struct {
 int fsgpu_diag_rescore(fsgpu_ctx *ctx, const uint8_t *qAA, const uint8_t *q3Di, const uint64_t *qOffsets, const int32_t *qLengths,
                        int nq, const int16_t *mat3Di, const int16_t *matAA, const fsgpu_diag_pair *pairs, int64_t n, fsgpu_diag_res *out);
 
+/* ---- start position + backtrace of accepted hits on the device (round 5) ------------------------------------------------
+ * StructureSmithWaterman::alignStartPosBacktraceBlock (F/src/commons/StructureSmithWaterman.cpp:369-537) over the block-aligner crate's align_3di
+ * (M/lib/block-aligner/src/scan_block.rs:120-630, 1302-1443, 1844-2007) for a batch of hits: the reversed prefixes query[0..qEnd], target[0..dbEnd] are
+ * aligned from their ends with starting block sizes 32, 64, 128 until the SW score is reproduced.  tblAA / tbl3Di: the crate's AAMatrix of the two
+ * substitution matrices ([27][32] int8, letter-indexed, as block_set_aamatrix fills them: host/block_aligner.cpp, block_aamatrix_scores); letterAA /
+ * letter3Di [21]: residue code -> letter - 'A'.  cbAA / cbSS: the query's forward composition bias (int8 per residue, StructureSmithWaterman.cpp:1566-1640).
+ * status 1: qStart / dbStart / identicalAA and btLen characters ('M', 'I', 'D', query start to end) at *btBase + btOff (valid until the next call on this
+ * context); status 2: the aligner's score differs from the SW score -- the reference leaves such a hit without start position and backtrace
+ * (structurealign.cpp:83); status 0: the alignment needs a block of more than 128 rows (the crate grows to 4096): not computed here, the caller runs
+ * its host path (fshost_block_backtrace) -- same answer either way.  Needs a database loaded WITH AA sequences. */
+typedef struct { const uint8_t *qAA, *q3Di; const int8_t *cbAA, *cbSS; int32_t L; int32_t reserved; } fsgpu_bt_query;
+typedef struct { uint32_t query, target; int32_t qEnd, dbEnd, score; } fsgpu_bt_task;
+typedef struct { int32_t status, qStart, dbStart, identicalAA, btLen, blockSizes; uint64_t btOff; } fsgpu_bt_res;
+int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const int8_t *tbl3Di, const uint8_t *letterAA, const uint8_t *letter3Di,
+                          const fsgpu_bt_query *queries, int nq, const fsgpu_bt_task *tasks, int nt, int gapOpen, int gapExtend,
+                          fsgpu_bt_res *res, const char **btBase);
+
 /* ---- prefilter: k-mer matching with double-diagonal hits + ungapped diagonal scoring ------------------------- */
 /* Index parameters == the subset of Prefiltering's members that shape IndexTable / SequenceLookup.  Sequence-
  * sequence searches with k = 6 only (what setupSplit picks below 3.35e9 residues, IndexTable.h:456-458). */

@@ -180,6 +180,9 @@ const char *fshost_search_backtrace(const fshost_search *s, const fshost_result 
  * [1] fsgpu_gapless_scan incl. wait, [2] align profiles + e-value net, [3] fsgpu_sw_batch incl. wait, [4] gates,
  * [5] block-aligner backtrace; [6..7] reserved. */
 void fshost_search_stats(const fshost_search *s, double *out8);
+/* last fshost_search_align_batch (also behind fshost_search_kmer_batch): the accepted hits whose start position and backtrace came from the device
+ * block aligner (fsgpu_block_backtrace) and all of them; the difference took the host aligner (blocks beyond 128 rows, FSGPU_DEVICE_BACKTRACE=0) */
+void fshost_search_backtrace_counts(const fshost_search *s, int64_t *onDevice, int64_t *all);
 /* Host worker pool for the per-hit backtraces (block aligner, ~20 us each): a feeder thread hands the accepted pairs of its
  * batch to the pool and takes part itself.  n = 0: the calling threads do everything themselves.  Default:
  * FSGPU_HOST_WORKERS or min(6, usable cores - 1), "usable" = hardware threads capped by the cgroup CPU quota. */
