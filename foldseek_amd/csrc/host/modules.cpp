@@ -486,7 +486,9 @@ struct DeviceSet {
             // 16 feeders + 6 workers 3.23 s, 12 + 8 3.07 s, 8 + 8 2.81 s, 8 + 16 2.58 s, 4 + 14 2.77 s.  FSGPU_FEEDERS / FSGPU_HOST_WORKERS override.
             const int cores = perGpuThreads;
             const char *ef = getenv("FSGPU_FEEDERS");
-            perGpuThreads = ef ? std::max(1, std::min(atoi(ef), 32)) : std::max(1, std::min(8, (cores + 1) / 2));
+            // (round 5: at least two feeders from two cores on -- with the backtraces of a batch on the device a feeder mostly sleeps in its waits, and a
+            // lone feeder leaves the device idle while it prepares, gates and formats: one rank's share of a 16-core node is two cores)
+            perGpuThreads = ef ? std::max(1, std::min(atoi(ef), 32)) : std::max(cores >= 2 ? 2 : 1, std::min(8, (cores + 1) / 2));
             if (!getenv("FSGPU_HOST_WORKERS")) fshost_set_host_workers(cores >= 4 ? cores : std::max(0, cores - 1));
         }
         const char *rq = getenv("FSGPU_REQUIRE_RCCL");

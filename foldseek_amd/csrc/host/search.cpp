@@ -542,8 +542,14 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     // ---- device path (round 5): one wave per accepted hit runs the block aligner (k_btrace.hpp); what it hands back (blocks beyond 128 rows) and
     // everything when it is switched off (FSGPU_DEVICE_BACKTRACE=0) or cannot run (database without AA sequences) goes to the host pool ----
     std::vector<int> hostTasks;
-    const char *envDev = getenv("FSGPU_DEVICE_BACKTRACE");            // read per call: the tests switch it inside one process
-    const bool deviceOn = !(envDev && atoi(envDev) == 0);
+    // FSGPU_DEVICE_BACKTRACE = 1 / 0 forces the device / the host aligner (read per call: the tests switch it inside one process).  Unset: whichever is
+    // expected to answer the batch sooner, from what tools/btrace_probe.py measures on one MI355X and its 16-core host -- an alignment of two 350-residue
+    // structures is ~36 us of one host core (the pool spreads a batch over its workers + the caller) and ~1.5 ms of LATENCY in a wave, of which three
+    // thousand run at once: device 1.5 ms + 0.8 us per hit (50 hits 1.5 ms, 1 600 hits 3.2 ms, 12 800 hits 11.6 ms) against host 0.23 / 4.3 / 33 ms with
+    // 13 workers.  With the two cores one of eight ranks of a node gets, the host aligner is what a rank waits for (bench.py --emulate-rank-share 8).
+    const char *envDev = getenv("FSGPU_DEVICE_BACKTRACE");
+    const double nTasks = (double) tasks.size();
+    const bool deviceOn = envDev ? atoi(envDev) != 0 : nTasks * 36e-6 / (double) (HostPool::get().workers() + 1) > 1.5e-3 + nTasks * 0.8e-6;
     const fshost_params &par = s->par;
     bool onDevice = deviceOn && s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
     if (onDevice) {

@@ -25,6 +25,7 @@ constexpr int kBtXDropIter = 2;          // scan_block.rs:814
 constexpr int kBtMaxBlock = 128;         // largest block size the device grows to (the crate: 4096)
 constexpr int kBtPad = kBtMaxBlock + 2 * kBtL + 16;      // readable bytes behind a sequence
 constexpr int kBtNull = 26;              // AA_NULL: b'A' + 26 - b'A'
+constexpr int kBtSeqLds = 8192;          // per wave: the padded prefixes of an alignment live in LDS when they fit (two sequences of up to ~1000 residues), in global scratch otherwise
 
 struct BtTask {                          // one accepted hit
     uint32_t query, target;              // index into the call's queries / target id in the resident DB
@@ -49,14 +50,17 @@ struct BtArgs {
 __device__ __forceinline__ int btSat(int x) { return min(max(x, -32768), 32767); }
 __device__ __forceinline__ int btAdds(int a, int b) { return btSat(a + b); }
 __device__ __forceinline__ int btSubs(int a, int b) { return btSat(a - b); }
-__device__ __forceinline__ int btLane(int v, int k) { return __shfl(v, k, kBtL); }
-__device__ __forceinline__ int btSl1(int a, int b, int ln) { const int t = __shfl_up(a, 1, kBtL), c = __shfl(b, kBtL - 1, kBtL); return ln == 0 ? c : t; }
-__device__ __forceinline__ int btStep8(int a, int b, int ln) { const int xa = __shfl_xor(a, 8, kBtL), xb = __shfl_xor(b, 8, kBtL); return ln < 8 ? xb : xa; }
-template <int N> __device__ __forceinline__ int btSllz(int a, int ln) { const int t = __shfl_up(a, N, kBtL); return (ln & 7) >= N ? t : 0; }
+// Row shuffles as DPP modifiers (a 16-lane DPP row is the vector; ds_bpermute costs an LDS round trip per shuffle and a block step is a chain of a dozen):
+// row_shr:n = 0x110 + n (lane i takes lane i - n, 0 where there is none), row_ror:n = 0x120 + n.  The four rows of a wave hold the same values, so a
+// broadcast of one lane is v_readlane of row 0's.
+template <int CTRL> __device__ __forceinline__ int btDpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int btLane(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ int btSl1(int a, int b, int ln) { const int t = btDpp<0x111>(a), c = btLane(b, kBtL - 1); return ln == 0 ? c : t; }
+__device__ __forceinline__ int btStep8(int a, int b, int ln) { const int xa = btDpp<0x128>(a), xb = btDpp<0x128>(b); return ln < 8 ? xb : xa; }
+template <int N> __device__ __forceinline__ int btSllz(int a, int ln) { const int t = btDpp<0x110 + N>(a); return (ln & 7) >= N ? t : 0; }
 template <int B> __device__ __forceinline__ int btSlli16(int a) { return (int) (int16_t) (uint16_t) ((uint32_t) a << B); }
-__device__ __forceinline__ int btHmax(int a) {
-#pragma unroll
-    for (int d = 1; d < kBtL; d <<= 1) a = max(a, __shfl_xor(a, d, kBtL));
+__device__ __forceinline__ int btHmax(int a) {          // all-reduce by rotations: every lane ends with the row's maximum
+    a = max(a, btDpp<0x121>(a)); a = max(a, btDpp<0x122>(a)); a = max(a, btDpp<0x124>(a)); a = max(a, btDpp<0x128>(a));
     return a;
 }
 struct BtScanConsts { int gapExtendAll, lane; };
@@ -64,7 +68,7 @@ __device__ __forceinline__ BtScanConsts btPrefixScanConsts(int gap, int ln) {
     const int shift1 = btAdds(btSllz<1>(gap, ln), gap);
     const int shift2 = btAdds(btSllz<2>(shift1, ln), shift1);
     const int shift4 = btAdds(btSllz<4>(shift2, ln), shift2);
-    const int s7 = __shfl(shift4, 7, kBtL);
+    const int s7 = btLane(shift4, 7);
     BtScanConsts c;
     c.gapExtendAll = btAdds(ln < 8 ? 0 : s7, shift4);
     c.lane = shift4;
@@ -74,7 +78,7 @@ __device__ __forceinline__ int btPrefixScan(int Rmax, int gapCost, int gapCostLa
     const int shift1 = max(Rmax, btAdds(btSllz<1>(Rmax, ln), gapCost));
     const int shift2 = max(shift1, btAdds(btSllz<2>(shift1, ln), btSlli16<1>(gapCost)));
     const int shift4 = max(shift2, btAdds(btSllz<4>(shift2, ln), btSlli16<2>(gapCost)));
-    const int lowq = __shfl(shift4, ln & 3, kBtL), s7 = __shfl(shift4, 7, kBtL);
+    const int lowq = ln < 4 ? shift4 : btDpp<0x114>(shift4), s7 = btLane(shift4, 7);          // lanes 0..7 take lane (ln & 3)
     const int correct1 = btAdds(ln < 8 ? lowq : s7, gapCostLane);
     return max(shift4, correct1);
 }
@@ -141,14 +145,14 @@ __device__ __forceinline__ BtPB btPlaceBlock(const BtSeq &query, const BtSeq &re
             D11 = max(D11, C11);
             const int D11open = btAdds(D11, openMinusExt);
             R11 = btPrefixScan(D11open, gapExtend, sc.lane, ln);
-            R11 = max(R11, btAdds(__shfl(R01, kBtL - 1, kBtL), sc.gapExtendAll));
+            R11 = max(R11, btAdds(btLane(R01, kBtL - 1), sc.gapExtendAll));
             D11 = max(D11, R11);
             R01 = R11;
             {
                 const uint32_t t = btMask2(D11 == C11, D11 == R11);
                 const bool tempTraceR = R11 == D11open;
                 // traceR = simd_sl_i16(tempTraceR, prevTraceR, 1)
-                const int up = __shfl_up((int) tempTraceR, 1, kBtL), last = __shfl((int) prevTraceR, kBtL - 1, kBtL);
+                const int up = btDpp<0x111>((int) tempTraceR), last = btLane((int) prevTraceR, kBtL - 1);
                 const bool traceR = (ln == 0 ? last : up) != 0;
                 const uint32_t t2 = btMask2(C11 == C11open, traceR);
                 prevTraceR = tempTraceR;
@@ -297,12 +301,14 @@ __device__ __forceinline__ bool btAlign(BtState &S, BtTrace &tr, const BtSeq &qu
                     else { gi = si + idxI + ln; gj = sj + prevSize + idxJ; }
                     key = ((unsigned long long) (uint32_t) gj << 32) | (uint32_t) gi;
                 }
-#pragma unroll
-                for (int d = 1; d < kBtL; d <<= 1) {
-                    const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) key, d, kBtL), hi = (uint32_t) __shfl_xor((int) (uint32_t) (key >> 32), d, kBtL);
-                    const unsigned long long o = ((unsigned long long) hi << 32) | lo;
-                    key = o > key ? o : key;
+#define FS_BT_KEYMAX(CTRL)                                                                                                        \
+                {                                                                                                                 \
+                    const uint32_t lo = (uint32_t) btDpp<CTRL>((int) (uint32_t) key), hi = (uint32_t) btDpp<CTRL>((int) (uint32_t) (key >> 32)); \
+                    const unsigned long long o = ((unsigned long long) hi << 32) | lo;                                           \
+                    key = o > key ? o : key;                                                                                      \
                 }
+                FS_BT_KEYMAX(0x121) FS_BT_KEYMAX(0x122) FS_BT_KEYMAX(0x124) FS_BT_KEYMAX(0x128)
+#undef FS_BT_KEYMAX
                 bestArgI = (int) (uint32_t) key; bestArgJ = (int) (uint32_t) (key >> 32);
             }
             if (blockSize < maxSize) {
@@ -418,6 +424,7 @@ __device__ __forceinline__ int btCigar(const BtTrace &tr, int i, int j, const ui
 // alignStartPosBacktraceBlock (StructureSmithWaterman.cpp:369-537) for a batch of accepted hits: one wave per task
 __global__ __launch_bounds__(256) void k_block_backtrace(BtArgs a) {
     __shared__ BtState states[4];
+    __shared__ __attribute__((aligned(16))) uint8_t seqLds[4][kBtSeqLds];
     __shared__ int8_t tAA[27 * 32], tSS[27 * 32];
     for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) { tAA[i] = a.tblAA[i]; tSS[i] = a.tblSS[i]; }
     __syncthreads();
@@ -430,52 +437,66 @@ __global__ __launch_bounds__(256) void k_block_backtrace(BtArgs a) {
         const int qn = tk.qEnd + 1, tn = tk.dbEnd + 1;
         // ---- the padded, reversed prefixes: letter indices, AA_NULL in front and behind; the query's position bias (cbAA + cbSS) ----
         const size_t qStride = ((size_t) 1 + qn + kBtPad + 15) & ~(size_t) 15, tStride = ((size_t) 1 + tn + kBtPad + 15) & ~(size_t) 15;
-        uint8_t *pq = a.seq + tk.seqOff, *pq3 = pq + qStride, *pt = pq3 + qStride, *pt3 = pt + tStride;
-        int16_t *pb = (int16_t *) (pt3 + tStride);
         const uint8_t *qa = a.qdata + q.off, *q3 = qa + q.L;
         const int16_t *qb = (const int16_t *) (a.qdata + q.off + 2 * (size_t) q.L);      // q.off is a multiple of 16
         const uint8_t *ta = a.dbAA + a.dbOff[tk.target], *t3 = a.dbSS + a.dbOff[tk.target];
-        for (int i = lane; i < (int) qStride; i += 64) {
-            const int k = i - 1;                             // reversed-prefix index
-            const bool in = k >= 0 && k < qn;
-            pq[i] = in ? a.letAA[min((int) qa[tk.qEnd - k], 20)] : (uint8_t) kBtNull;
-            pq3[i] = in ? a.letSS[min((int) q3[tk.qEnd - k], 20)] : (uint8_t) kBtNull;
-            pb[i] = in ? qb[tk.qEnd - k] : (int16_t) 0;
-        }
-        for (int i = lane; i < (int) tStride; i += 64) {
-            const int k = i - 1;
-            const bool in = k >= 0 && k < tn;
-            pt[i] = in ? a.letAA[min((int) ta[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;
-            pt3[i] = in ? a.letSS[min((int) t3[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;
-        }
-        __threadfence_block();
-        btWaveSync();
-        const BtSeq qs{pq, pq3, pb, qn}, rs{pt, pt3, nullptr, tn};
         BtTrace tr;
         const size_t traceWords = (size_t) (kBtMaxBlock / kBtL) * ((size_t) qn + tn + 2 * kBtMaxBlock);
         tr.trace = a.trace + tk.traceOff; tr.trace2 = tr.trace + traceWords;
         tr.blocks = a.blocks + tk.blockOff;
-        int score = -1000000000, rq = -1, rr = -1, sizes = 0;
-        bool onDevice = true;
-        for (int minSize = 32; minSize <= kBtMaxBlock && score < tk.score; minSize *= 2) {
-            const int xDrop = -(minSize * a.gapExtend + a.gapOpen);
-            onDevice = btAlign(S, tr, qs, rs, tAA, tSS, a.gapOpen, a.gapExtend, minSize, 4096, xDrop, ln, row0, score, rq, rr);
-            sizes++;
-            if (!onDevice) break;
-        }
         BtRes r;
-        r.status = 0; r.qStart = -1; r.dbStart = -1; r.identicalAA = 0; r.btLen = 0; r.blockSizes = sizes;
-        if (onDevice && score >= tk.score) {
-            // reached (a larger starting size is never tried once the score is there); like the host: a score that differs from the SW score
-            // leaves the hit without start position, except at int16 saturation
-            if (!(score != tk.score && !(tk.score == 32767 && score >= tk.score))) {
-                __threadfence_block();
-                btWaveSync();
-                int ident = 0;
-                const int n = btCigar(tr, rq, rr, pq, pt, a.bt + tk.btOff, ident, row0 && ln == 0);
-                if (n >= 0) { r.status = 1; r.qStart = (tk.qEnd + 1) - rq; r.dbStart = (tk.dbEnd + 1) - rr; r.identicalAA = ident; r.btLen = n; }
-            } else r.status = 2;
+        r.status = 0; r.qStart = -1; r.dbStart = -1; r.identicalAA = 0; r.btLen = 0; r.blockSizes = 0;
+        // the same body twice, once per address space of the sequences (a pointer that may be LDS or global memory compiles to flat accesses)
+#define FS_BT_RUN(PQ, PQ3, PT, PT3, PB)                                                                                                                  \
+        {                                                                                                                                               \
+            for (int i = lane; i < (int) qStride; i += 64) {                                                                                            \
+                const int k = i - 1;                             /* reversed-prefix index */                                                           \
+                const bool in = k >= 0 && k < qn;                                                                                                       \
+                (PQ)[i] = in ? a.letAA[min((int) qa[tk.qEnd - k], 20)] : (uint8_t) kBtNull;                                                             \
+                (PQ3)[i] = in ? a.letSS[min((int) q3[tk.qEnd - k], 20)] : (uint8_t) kBtNull;                                                            \
+                (PB)[i] = in ? qb[tk.qEnd - k] : (int16_t) 0;                                                                                           \
+            }                                                                                                                                           \
+            for (int i = lane; i < (int) tStride; i += 64) {                                                                                            \
+                const int k = i - 1;                                                                                                                    \
+                const bool in = k >= 0 && k < tn;                                                                                                       \
+                (PT)[i] = in ? a.letAA[min((int) ta[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;                                                            \
+                (PT3)[i] = in ? a.letSS[min((int) t3[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;                                                           \
+            }                                                                                                                                           \
+            __threadfence_block();                                                                                                                      \
+            btWaveSync();                                                                                                                               \
+            const BtSeq qs{(PQ), (PQ3), (PB), qn}, rs{(PT), (PT3), nullptr, tn};                                                                        \
+            int score = -1000000000, rq = -1, rr = -1, sizes = 0;                                                                                       \
+            bool onDevice = true;                                                                                                                       \
+            for (int minSize = 32; minSize <= kBtMaxBlock && score < tk.score; minSize *= 2) {                                                          \
+                const int xDrop = -(minSize * a.gapExtend + a.gapOpen);                                                                                 \
+                onDevice = btAlign(S, tr, qs, rs, tAA, tSS, a.gapOpen, a.gapExtend, minSize, 4096, xDrop, ln, row0, score, rq, rr);                     \
+                sizes++;                                                                                                                                \
+                if (!onDevice) break;                                                                                                                   \
+            }                                                                                                                                           \
+            r.blockSizes = sizes;                                                                                                                       \
+            if (onDevice && score >= tk.score) {                                                                                                        \
+                /* reached (a larger starting size is never tried once the score is there); like the host: a score that differs from the SW score */  \
+                /* leaves the hit without start position, except at int16 saturation */                                                                \
+                if (!(score != tk.score && !(tk.score == 32767 && score >= tk.score))) {                                                                \
+                    __threadfence_block();                                                                                                              \
+                    btWaveSync();                                                                                                                       \
+                    int ident = 0;                                                                                                                      \
+                    const int n = btCigar(tr, rq, rr, (PQ), (PT), a.bt + tk.btOff, ident, row0 && ln == 0);                                             \
+                    if (n >= 0) { r.status = 1; r.qStart = (tk.qEnd + 1) - rq; r.dbStart = (tk.dbEnd + 1) - rr; r.identicalAA = ident; r.btLen = n; }  \
+                } else r.status = 2;                                                                                                                    \
+            }                                                                                                                                           \
         }
+        if (4 * qStride + 2 * tStride <= (size_t) kBtSeqLds) {
+            uint8_t *base = seqLds[wave];
+            uint8_t *lq = base, *lq3 = lq + qStride, *lt = lq3 + qStride, *lt3 = lt + tStride;
+            int16_t *lb = (int16_t *) (lt3 + tStride);
+            FS_BT_RUN(lq, lq3, lt, lt3, lb)
+        } else {
+            uint8_t *pq = a.seq + tk.seqOff, *pq3 = pq + qStride, *pt = pq3 + qStride, *pt3 = pt + tStride;
+            int16_t *pb = (int16_t *) (pt3 + tStride);
+            FS_BT_RUN(pq, pq3, pt, pt3, pb)
+        }
+#undef FS_BT_RUN
         if (lane == 0) a.res[task] = r;
         btWaveSync();
     }
