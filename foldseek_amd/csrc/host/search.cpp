@@ -549,7 +549,11 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     // 13 workers.  With the two cores one of eight ranks of a node gets, the host aligner is what a rank waits for (bench.py --emulate-rank-share 8).
     const char *envDev = getenv("FSGPU_DEVICE_BACKTRACE");
     const double nTasks = (double) tasks.size();
-    const bool deviceOn = envDev ? atoi(envDev) != 0 : nTasks * 36e-6 / (double) (HostPool::get().workers() + 1) > 1.5e-3 + nTasks * 0.8e-6;
+    // The host gets the benefit of the doubt (factor 4): pool workers of a 16-core job run while the feeders' other batches keep the device busy, and a
+    // device aligner that runs BESIDE a scan launch waits for issue slots -- 9.7 ms per 3 200-hit call on average, 45 ms at worst, in the traced bench run
+    // against 4 ms alone -- and costs the scan something too (bench.py at N = 1 with the device aligner on every large batch: headline -0.7 ... -1.0 %,
+    // all-vs-all leg +6 %, k-mer leg +3 %, module unchanged).  In practice: 16 cores -> host, up to four cores -> device from ~200 hits on.
+    const bool deviceOn = envDev ? atoi(envDev) != 0 : nTasks * 36e-6 / (double) (HostPool::get().workers() + 1) > 4.0 * (1.5e-3 + nTasks * 0.8e-6);
     const fshost_params &par = s->par;
     bool onDevice = deviceOn && s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
     if (onDevice) {
