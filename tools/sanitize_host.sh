@@ -15,7 +15,7 @@ for f in host/*.cpp; do
     g++ -O1 -g -std=c++17 -fPIC -Wall -mavx2 -mfma $SAN -I../../include -I../data -c "$f" -o "$ROOT/.san/host/$b.o" &
 done
 wait
-g++ -shared -fPIC $SAN -o "$ROOT/.san/libfsgpu.so" fsgpu.o fsgpu_kmer.o fsgpu_diag.o fsgpu_sw3_na.o fsgpu_sw3_aa.o "$ROOT"/.san/host/*.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
+g++ -shared -fPIC $SAN -o "$ROOT/.san/libfsgpu.so" fsgpu.o fsgpu_kmer.o fsgpu_diag.o fsgpu_btrace.o fsgpu_sw3_na.o fsgpu_sw3_aa.o "$ROOT"/.san/host/*.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
 g++ -O1 -g -std=c++17 $SAN -I../../include -o "$ROOT/.san/bin/fsgpu-modules" host/main_modules.cc -L"$ROOT/.san" -lfsgpu -Wl,-rpath,'$ORIGIN/..' -lpthread
 cd "$ROOT"
 cp foldseek_amd/libfsgpu.so .san/libfsgpu.so.orig
