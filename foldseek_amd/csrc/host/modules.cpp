@@ -1001,7 +1001,10 @@ int fsmod_search(int argc, const char **argv) {
     const bool writePref = o.pos.size() == 4;
     if (writePref && !wp.open(o.pos[3], DBTYPE_PREFILTER_RES, err)) { ds.close(); return fail(err); }
     const int nthreads = ds.threads();
-    const size_t batch = prefMode == 0 ? 1024 : 16;      // k-mer prefilter: capacity of a thread's staging (the device batch limit), a round takes fsgpu_kmer_batch_hint() queries
+    // k-mer prefilter: capacity of a thread's staging (1024 = the device batch limit; fewer when --max-seqs is so large that 1024 result slabs would
+    // not fit 256 MB per thread), a round takes fsgpu_kmer_batch_hint() queries
+    const size_t kmerSlab = (size_t) maxRes * (size_t) (1 + std::max(0, par.altAlignment)) * sizeof(fshost_result);
+    const size_t batch = prefMode == 0 ? std::max<size_t>(1, std::min<size_t>(1024, ((size_t) 256 << 20) / std::max<size_t>(kmerSlab, 1))) : 16;
     std::vector<std::string> results(q3.size()), prefs(writePref ? q3.size() : 0);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
