@@ -52,7 +52,8 @@ def emit_line(obj):
     if _REAL_STDOUT is None:
         sys.stdout.write(data.decode()); sys.stdout.flush()
     else:
-        os.write(_REAL_STDOUT, data)
+        while data:                                   # a write to a pipe may be partial
+            data = data[os.write(_REAL_STDOUT, data):]
 
 
 def parse(argv=None):
