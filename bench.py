@@ -303,7 +303,7 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
            "candidates_per_query": float(reg_cnt[2]) / 32,
            "hits_per_query": stat["hits"] / nqk, "alignments_per_query": stat["aln"] / nqk, "unsupported_queries": stat.get("bad", 0),
            "stage_ms_per_batch32_solo": {k: solo_ms[i] for i, k in enumerate(["device_total", "count", "lists", "emit", "partition", "dup", "score", "replay", "select", "host_tail", "k_kmer_lists"])},
-           "segments_solo": {k: int(v) for k, v in zip(["groups_one_wave", "groups_lds", "groups_global_scratch", "segments_with_candidates", "segments", "bins", "groups_lds_1024_threads"], kctx[0].kmer_segments())},
+           "segments_solo": {k: int(v) for k, v in zip(["unused0", "runs", "unused2", "tiles", "runs_all", "coarse_keys", "ids_of_widest_key"], kctx[0].kmer_segments()) if not k.startswith("unused")},
            # kernel_ms: mean over the batches of the timed region (the host threads overlap their batches and the SW launches);
            # "solo" = the same batch alone on the device
            "roofline": {"bound": "hbm", "kernel": "k_kmer_* (the device part of one prefilter batch of 32 queries, all kernels)", "kernel_ms": reg_ms,

@@ -93,7 +93,7 @@ def lib():
         "fsgpu_kmer_last_counts": (None, [vp, vp]),
         "fsgpu_kmer_last_segments": (None, [vp, vp]),
         "fsgpu_kmer_batch_hint": (i32, [vp]),
-        "fsgpu_kmer_plan_bins": (i32, [vp, u64, u64, vp, vp, C.c_uint32]),
+        "fsgpu_kmer_plan_coarse": (i32, [vp, u64, C.c_uint32, vp, vp, C.c_uint32]),
         "fshost_kmer_query_prepare": (i32, [vp, vp, vp, i32, i32, f32, i32, i32, i32, vp, vp]),
         "fshost_kmer_threshold": (i32, [f32, i32]),
         "fshost_matrix_create": (vp, [i32, f32, f32]),
@@ -160,7 +160,7 @@ def exported_symbols():
             "fsgpu_gapless_launch", "fsgpu_gapless_finish", "fsgpu_sw_batch", "fsgpu_sw_multi", "fsgpu_sw_multi_dir", "fsgpu_sw_multi_dir_c", "fsgpu_sw_multi_c", "fsgpu_sw_launch", "fsgpu_sw_finish",
             "fsgpu_db_broadcast", "fsgpu_rccl_selfcheck", "fsgpu_device_count", "fsgpu_gapless_plan_items",
             "fsgpu_last_kernel_ms", "fsgpu_sw_last_passes", "fsgpu_kmer_index_build", "fsgpu_kmer_index_entries", "fsgpu_kmer_search",
-            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_bins", "fsgpu_kmer_batch_hint"]
+            "fsgpu_kmer_index_copy", "fsgpu_kmer_row_copy", "fsgpu_kmer_last_counts", "fsgpu_kmer_last_segments", "fsgpu_kmer_plan_coarse", "fsgpu_kmer_batch_hint"]
 
 
 def _ptr(a):
@@ -402,7 +402,7 @@ class Context:
         return out
 
     def kmer_segments(self):
-        """last batch's partition: segments resolved by one wave / in LDS / through global scratch, segments with candidates, all segments, bins"""
+        """last batch's partition: [1] = [4] (query, chunk, key) runs of the duplicate stage, [3] tiles, [5] coarse keys, [6] ids of the widest key"""
         out = np.zeros(7, np.uint32)
         lib().fsgpu_kmer_last_segments(self.h, _ptr(out))
         return out

@@ -78,11 +78,11 @@ struct fsgpu_ctx {
     std::shared_ptr<KmerIndex> kidx;   // k-mer prefilter index (shared with clones)
     KmerScratch *kmer = nullptr;       // per-context k-mer prefilter scratch
     double kmerMs[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // ms of the last k-mer batch: [0] device total, [1..8] stages, [9] host tail, [10] k_kmer_lists alone
-    uint32_t kmerSegs[7] = {0, 0, 0, 0, 0, 0, 0};   // last batch: segments resolved by one wave / in LDS / through global scratch, segments with candidates, all segments, bins
+    uint32_t kmerSegs[7] = {0, 0, 0, 0, 0, 0, 0};   // last batch: [1] = [4] (query, chunk, key) runs of the duplicate stage, [3] tiles, [5] coarse keys, [6] target ids of the widest key
     double kmerHitsPerQuery = 0;       // index hits per query of the last batch (sizes the next one)
     double kmerKPerPos = 0;            // similar k-mers per query position of the last batch (picks the wave / workgroup form of the next count pass)
     int kmerBatchCap = 0;              // > 0: a batch overflowed 2^32 hits, stay at or below this many queries
-    bool kmerBincountAttr = false;                 // k_kmer_bincount may use more than 64 KB of dynamic LDS on this context's device (> 16 M targets)
+    bool kmerDupAttr = false;                      // k_kmer_dup_stream may use more than 64 KB of dynamic LDS on this context's device (keys of more than 24 k target ids)
     int kmerBatchOk = 0;                           // batches that succeeded in a row under the current cap (it is relaxed after four)
     uint64_t kmerCounts[4] = {0, 0, 0, 0};   // last batch: k-mer lists probed, index hits, double-diagonal candidates, elements handed to the host
 

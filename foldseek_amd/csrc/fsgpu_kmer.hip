@@ -34,64 +34,65 @@ struct KmerIndex {
     uint64_t nEntries = 0;
     int16_t *s3 = nullptr;                // extended 3-mer matrix, rows sorted descending
     uint16_t *i3 = nullptr;
-    // target bins of the hit-stream partition (k_kmer.hpp, stage 2): contiguous id ranges with at most tcap targets and at most
-    // resCap residues, several granularities; a batch picks the coarsest level whose expected segment still fits the LDS path
-    struct BinLevel { uint64_t resCap = 0; uint32_t nBins = 0, nBlk = 0, nCoarse = 0; uint32_t *blk = nullptr; uint16_t *blkCoarse = nullptr; uint32_t *coarseFirst = nullptr, *binFirst = nullptr; };   // k_kmer.hpp KmerBins
-    std::vector<BinLevel> levels;
+    // coarse keys of the hit-stream partition (k_kmer.hpp, stage 2): runs of blocks of 1024 target ids.  levels[0] balances the residues over about
+    // 128 keys (what a batch of the metric's size uses); the others hold a fixed number of blocks per key (1, 2, 4 ... 64) for batches with few
+    // hits per query and for tests that force a granularity
+    struct CoarseLevel { uint32_t nKeys = 0, nBlk = 0, maxIds = 0, blocksPerKey = 0; uint16_t *blkKey = nullptr; uint32_t *keyFirst = nullptr; };   // k_kmer.hpp KmerCoarse
+    std::vector<CoarseLevel> levels;
     uint64_t residues = 0;
     ~KmerIndex() {
         (void) hipFree(masked); (void) hipFree(offsets); (void) hipFree(bitmap); (void) hipFree(entries); (void) hipFree(entries32); (void) hipFree(s3); (void) hipFree(i3);
-        for (BinLevel &l : levels) { (void) hipFree(l.blk); (void) hipFree(l.blkCoarse); (void) hipFree(l.coarseFirst); (void) hipFree(l.binFirst); }
+        for (CoarseLevel &l : levels) { (void) hipFree(l.blkKey); (void) hipFree(l.keyFirst); }
     }
 };
 
-// bins of one level (KmerBins): every block of 1024 target ids is cut into 2^k equal id ranges, k the smallest value that keeps a bin's share
-// of the block's residues at or below resCap (k <= 10: a bin holds at least one id).  Target databases are sorted by length or in random
-// order, so the residues of a block spread evenly over its ids.  Host-only, tested without a GPU through fsgpu_kmer_plan_bins.
-static void planBins(const int32_t *lengths, uint64_t n, uint64_t resCap, std::vector<uint32_t> &blk, std::vector<uint32_t> &binFirst) {
-    const uint64_t nBlk = (n + 1023) / 1024;
-    blk.assign(nBlk, 0); binFirst.clear();
+// Coarse keys of one level (KmerCoarse): consecutive blocks of 1024 target ids are joined into keys.  blocksPerKey > 0: that many blocks per key.
+// blocksPerKey == 0: about 128 keys of equal residue count (index hits are proportional to residues; a length-sorted database would otherwise
+// give the keys of its long end several times the hits of the others), no key longer than twice the average number of blocks (the duplicate
+// stage keeps 16 bits of LDS per target id of a key) nor than kCoarseBlocks (the low 16 bits of an id must be unique inside a key).
+// Host-only, tested without a GPU through fsgpu_kmer_plan_coarse.
+static void planCoarse(const int32_t *lengths, uint64_t n, uint32_t blocksPerKey, std::vector<uint16_t> &blkKey, std::vector<uint32_t> &keyFirst) {
+    const uint64_t nBlk = std::max<uint64_t>(1, (n + 1023) / 1024);
+    blkKey.assign(nBlk, 0); keyFirst.clear();
+    if (blocksPerKey == 0) {
+        std::vector<uint64_t> res(nBlk, 0);
+        uint64_t R = 0;
+        for (uint64_t i = 0; i < n; i++) { res[i >> 10] += (uint64_t) std::max(lengths[i], 0); R += (uint64_t) std::max(lengths[i], 0); }
+        const uint64_t target = std::max<uint64_t>(1, (R + 127) / 128);
+        const uint64_t cap = std::min<uint64_t>(kCoarseBlocks, std::max<uint64_t>(1, 2 * ((nBlk + 127) / 128)));
+        uint64_t acc = 0, cnt = 0;
+        for (uint64_t k = 0; k < nBlk; k++) {
+            if (cnt > 0 && (cnt >= cap || acc + res[k] > target)) { acc = 0; cnt = 0; }
+            if (cnt == 0) keyFirst.push_back((uint32_t) (k * 1024));
+            blkKey[k] = (uint16_t) (keyFirst.size() - 1);
+            acc += res[k]; cnt++;
+        }
+        if (keyFirst.size() <= (size_t) kMaxCoarse) { keyFirst.push_back((uint32_t) n); return; }
+        blocksPerKey = (uint32_t) ((nBlk + kMaxCoarse - 1) / kMaxCoarse);        // too many keys (cannot happen below 33.5 M targets): equal id ranges instead
+        keyFirst.clear();
+    }
     for (uint64_t k = 0; k < nBlk; k++) {
-        const uint64_t t0 = k * 1024, t1 = std::min<uint64_t>(n, t0 + 1024);
-        uint64_t res = 0;
-        for (uint64_t i = t0; i < t1; i++) res += (uint64_t) std::max(lengths[i], 0);
-        uint32_t shift = 10;
-        while (shift > 3 && (res >> (10 - shift)) > resCap) shift--;           // 2^(10 - shift) <= kCoarseKeys bins in this block
-        blk[k] = ((uint32_t) binFirst.size() << 8) | shift;
-        for (uint64_t i = t0; i < t1; i += (1ull << shift)) binFirst.push_back((uint32_t) i);
+        if (k % blocksPerKey == 0) keyFirst.push_back((uint32_t) (k * 1024));
+        blkKey[k] = (uint16_t) (k / blocksPerKey);
     }
-    if (binFirst.empty()) binFirst.push_back(0);
-    binFirst.push_back((uint32_t) n);
-}
-// coarse bins of the two-level scatter: runs of 1024-id blocks holding at most kCoarseKeys bins, never across a multiple of 65536 ids
-static void planCoarse(const std::vector<uint32_t> &blk, uint32_t nBins, std::vector<uint16_t> &blkCoarse, std::vector<uint32_t> &coarseFirst) {
-    blkCoarse.assign(blk.size(), 0); coarseFirst.clear();
-    uint32_t inCoarse = 0;
-    for (size_t k = 0; k < blk.size(); k++) {
-        const uint32_t first = blk[k] >> 8, next = k + 1 < blk.size() ? blk[k + 1] >> 8 : nBins, cnt = next - first;
-        if (coarseFirst.empty() || (k & 63) == 0 || inCoarse + cnt > (uint32_t) kCoarseKeys) { coarseFirst.push_back(first); inCoarse = 0; }
-        blkCoarse[k] = (uint16_t) (coarseFirst.size() - 1);
-        inCoarse += cnt;
-    }
-    if (coarseFirst.empty()) coarseFirst.push_back(0);
-    coarseFirst.push_back(nBins);
+    keyFirst.push_back((uint32_t) n);
 }
 
-extern "C" int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t resCap, uint32_t *blk /*[ceil(n / 1024)]*/, uint32_t *binFirst /*[cap]*/, uint32_t cap) {
-    if (!lengths || resCap == 0) return FSGPU_E_ARG;
-    std::vector<uint32_t> bk, bf;
-    planBins(lengths, n, resCap, bk, bf);
-    if (bf.size() > cap) return FSGPU_E_ARG;
-    if (blk) std::copy(bk.begin(), bk.end(), blk);
-    if (binFirst) std::copy(bf.begin(), bf.end(), binFirst);
-    return (int) bf.size() - 1;
+extern "C" int fsgpu_kmer_plan_coarse(const int32_t *lengths, uint64_t n, uint32_t blocksPerKey, uint16_t *blkKey /*[max(1, ceil(n / 1024))]*/, uint32_t *keyFirst /*[cap]*/, uint32_t cap) {
+    if ((!lengths && n) || blocksPerKey > (uint32_t) kCoarseBlocks) return FSGPU_E_ARG;
+    std::vector<uint16_t> bk; std::vector<uint32_t> kf;
+    planCoarse(lengths, n, blocksPerKey, bk, kf);
+    if (kf.size() > cap) return FSGPU_E_ARG;
+    if (blkKey) std::copy(bk.begin(), bk.end(), blkKey);
+    if (keyFirst) std::copy(kf.begin(), kf.end(), keyFirst);
+    return (int) kf.size() - 1;
 }
 
 struct KmerScratch {
     DevBuf qs, posQuery, seqs, thrs, profiles, K, Kbase, listStart, listSize, listPos, listP, chunks,
-           rec, part, tmpA, tileL, binCount, segStart, cursor, segCand, candBase, segLast, candFlags, segLists, ckeys, cvals, kept, score, scrA, scrB, best,
+           rec, recKey, recA, ordA, tileL, cntA, colA, grpSum, segCnt, segStart, tiles, candKey, candVal, candKey2, candVal2, candCount, ckeys, cvals, kept, score, scrA, scrB, best,
            ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand, kept0, qSlot, truncHist, trunc;
-    PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc;
+    PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc, hTiles;
     hipEvent_t ev[14] = {};
     bool evInit = false;
 };
@@ -99,13 +100,13 @@ struct KmerScratch {
 void fsgpu_kmer_free_scratch(KmerScratch *s) {
     if (!s) return;
     DevBuf *d[] = {&s->qs, &s->posQuery, &s->seqs, &s->thrs, &s->profiles, &s->K, &s->Kbase, &s->listStart, &s->listSize, &s->listPos, &s->listP,
-                   &s->chunks, &s->rec, &s->part, &s->tmpA, &s->tileL, &s->binCount, &s->segStart, &s->cursor, &s->segCand, &s->candBase, &s->segLast, &s->candFlags, &s->segLists,
-                   &s->ckeys, &s->cvals, &s->kept, &s->score,
+                   &s->chunks, &s->rec, &s->recKey, &s->recA, &s->ordA, &s->tileL, &s->cntA, &s->colA, &s->grpSum, &s->segCnt, &s->segStart, &s->tiles,
+                   &s->candKey, &s->candVal, &s->candKey2, &s->candVal2, &s->candCount, &s->ckeys, &s->cvals, &s->kept, &s->score,
                    &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand,
                    &s->kept0, &s->qSlot, &s->truncHist, &s->trunc};
     for (DevBuf *b : d) if (b->p) (void) hipFree(b->p);
     PinBuf *h[] = {&s->hQs, &s->hPosQuery, &s->hSeqs, &s->hThrs, &s->hProfiles, &s->hChunks, &s->hEc, &s->hRounds, &s->hResSize, &s->hThr,
-                   &s->hOutCount, &s->hOut, &s->hMisc};
+                   &s->hOutCount, &s->hOut, &s->hMisc, &s->hTiles};
     for (PinBuf *b : h) if (b->p) (void) hipHostFree(b->p);
     if (s->evInit) for (hipEvent_t e : s->ev) (void) hipEventDestroy(e);
     delete s;
@@ -160,7 +161,8 @@ static int scanExclusive32to64(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *in, 
     RPCHK(rocprim::exclusive_scan(tmp.p, bytes, it, out, (uint64_t) 0, n, rocprim::plus<uint64_t>(), ctx->stream));
     return FSGPU_OK;
 }
-static int sortPairs(fsgpu_ctx *ctx, DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout, size_t n, int bits) {
+template <class K, class V>
+static int sortPairs(fsgpu_ctx *ctx, DevBuf &tmp, const K *kin, K *kout, const V *vin, V *vout, size_t n, int bits) {
     size_t bytes = 0;
     RPCHK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, ctx->stream));
     int rc = ensureK(ctx, tmp, bytes);
@@ -278,40 +280,30 @@ int fsgpu_kmer_index_build(fsgpu_ctx *ctx, const fsgpu_kmer_index_params *p, con
     IXCHK(hipMalloc((void **) &ix->bitmap, (tableSize / 32) * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_kmer_bitmap, dim3(gridFor(tableSize / 32, 256)), dim3(256), 0, ctx->stream, ix->offsets, (uint32_t) (tableSize / 32), ix->bitmap);
     IXCHK(hipGetLastError());
-    // bin levels of the hit-stream partition
+    // coarse-key levels of the hit-stream partition
     {
         ix->residues = R;
-        if ((n + 1023) / 1024 > (uint64_t) kMaxBins || (n + 65535) / 65536 > (uint64_t) kMaxCoarse) {
-            ctx->err = "k-mer prefilter: more than " + std::to_string((uint64_t) kMaxCoarse * 65536) + " targets are not supported by the device hit-stream partition";
+        if ((n + 1023) / 1024 > (uint64_t) kMaxCoarse * kCoarseBlocks) {
+            ctx->err = "k-mer prefilter: more than " + std::to_string((uint64_t) kMaxCoarse * kCoarseBlocks * 1024) + " targets are not supported by the device hit-stream partition";
             cleanup(); return FSGPU_E_UNSUPPORTED;
         }
-        std::vector<uint32_t> bk, bf;
-        uint64_t resCap0 = 16384;                              // levels that cannot fit kMaxBins bins are not worth planning
-        while (R / resCap0 > (uint64_t) kPlanBins / 2) resCap0 *= 2;
-        uint32_t prevNb = 0;
-        for (uint64_t resCap = resCap0; ; resCap *= 2) {
-            planBins(db.hLengths.data(), n, resCap, bk, bf);
-            const uint32_t nb = (uint32_t) bf.size() - 1;
-            if (nb == prevNb) break;                           // one bin per block everywhere: no coarser level exists
-            prevNb = nb;
-            std::vector<uint16_t> bc; std::vector<uint32_t> cf;
-            planCoarse(bk, nb, bc, cf);
-            if (nb <= (uint32_t) kMaxBins && cf.size() - 1 <= (size_t) kMaxCoarse) {
-                ix->levels.emplace_back();                     // owned by the index from here on (freed by its destructor)
-                KmerIndex::BinLevel &lv = ix->levels.back();
-                lv.resCap = resCap; lv.nBins = nb; lv.nBlk = (uint32_t) bk.size(); lv.nCoarse = (uint32_t) cf.size() - 1;
-                IXCHK(hipMalloc((void **) &lv.blk, std::max<size_t>(bk.size(), 1) * sizeof(uint32_t)));
-                IXCHK(hipMalloc((void **) &lv.blkCoarse, std::max<size_t>(bc.size(), 1) * sizeof(uint16_t)));
-                IXCHK(hipMalloc((void **) &lv.coarseFirst, cf.size() * sizeof(uint32_t)));
-                IXCHK(hipMalloc((void **) &lv.binFirst, (size_t) (nb + 1) * sizeof(uint32_t)));
-                IXCHK(hipMemcpy(lv.blk, bk.data(), bk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-                IXCHK(hipMemcpy(lv.blkCoarse, bc.data(), bc.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-                IXCHK(hipMemcpy(lv.coarseFirst, cf.data(), cf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-                IXCHK(hipMemcpy(lv.binFirst, bf.data(), (size_t) (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-            }
-            if (resCap >= (1ull << 40) || ix->levels.size() >= 8) break;
+        std::vector<uint16_t> bk; std::vector<uint32_t> kf;
+        uint32_t prevKeys = 0;
+        for (uint32_t bpk : {0u, 1u, 2u, 4u, 8u, 16u, 32u, 64u}) {
+            planCoarse(db.hLengths.data(), n, bpk, bk, kf);
+            const uint32_t nk = (uint32_t) kf.size() - 1;
+            if (nk > (uint32_t) kMaxCoarse || (bpk > 1 && nk == prevKeys)) continue;           // (a coarser level with the same keys is the same level)
+            prevKeys = bpk ? nk : 0;
+            ix->levels.emplace_back();                         // owned by the index from here on (freed by its destructor)
+            KmerIndex::CoarseLevel &lv = ix->levels.back();
+            lv.nKeys = nk; lv.nBlk = (uint32_t) bk.size(); lv.blocksPerKey = bpk;
+            for (uint32_t k = 0; k < nk; k++) lv.maxIds = std::max(lv.maxIds, kf[k + 1] - kf[k]);
+            IXCHK(hipMalloc((void **) &lv.blkKey, bk.size() * sizeof(uint16_t)));
+            IXCHK(hipMalloc((void **) &lv.keyFirst, kf.size() * sizeof(uint32_t)));
+            IXCHK(hipMemcpy(lv.blkKey, bk.data(), bk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            IXCHK(hipMemcpy(lv.keyFirst, kf.data(), kf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
-        if (ix->levels.empty()) { ctx->err = "k-mer prefilter: no bin level fits the device partition"; cleanup(); return FSGPU_E_UNSUPPORTED; }
+        if (ix->levels.empty()) { ctx->err = "k-mer prefilter: no coarse-key level fits the device partition"; cleanup(); return FSGPU_E_UNSUPPORTED; }
     }
     IXCHK(hipStreamSynchronize(ctx->stream));
     cleanup();
@@ -695,162 +687,141 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     // ones, a first call with many queries) is split here, where its size is known and none of the 24-bytes-per-hit scratch exists yet
     if (nq > 1 && (double) nHits > 2.0 * kKmerHitBudget) return 1;
     const KmerChunks *hck = (const KmerChunks *) S.hChunks.p;
-    // ---- stage 2: hit stream -> (query, bin) segments -> double-diagonal candidates (k_kmer.hpp) ---------------------
-    KmerDupArgs da{};
-    uint32_t nSeg = 0;
-    KmerSegLists segLists{};
-    uint32_t *candList = nullptr;
+    // ---- stage 2: hit stream -> (query, key) runs in arrival order -> double-diagonal candidates (k_kmer.hpp) ---------------------
     if (nHits) {
-        // coarsest bin level whose largest expected segment (hits of the heaviest query x the bin's share of the residues) stays well
-        // inside the LDS path; hit density per residue is what the batch just measured
-        // coarsest bin level whose AVERAGE segment (hits of a query x the bin's share of the residues) is about a third of what a 256-thread
-        // workgroup resolves in LDS -- heavier segments (long queries, bins of long targets) take the 1024-thread variant, so the heaviest
-        // query's expected segment should still fit that one
+        // tiles: every databaseHits chunk of every query is cut into tiles of kTileA consecutive hits (the chunk starts came back with the lists)
+        uint32_t nVq = 0, nT = 0;
         uint64_t maxQ = 0;
-        for (int q = 0; q < nq; q++) maxQ = std::max<uint64_t>(maxQ, (q + 1 < nq ? hq[q + 1].hitBase : nHits) - hq[q].hitBase);
-        const double perResMax = (double) maxQ / (double) std::max<uint64_t>(ix.residues, 1);
-        const double perResAvg = (double) nHits / (double) nq / (double) std::max<uint64_t>(ix.residues, 1);
-        // LDS of the group kernels: 16-bit per-target counters x 2, the query's chunk starts, 9 bytes per hit (two 32-bit stream-position arrays and the
-        // sorted 8-bit diagonals; + 2 for the flag prefix where it cannot live in the cursor array) + the rank loop's slack entries
-        const size_t ldsCnt16 = (size_t) 2 * (kDupCounters + 4) * sizeof(uint16_t) + (kMaxChunks + 1) * sizeof(uint32_t) + 8 + 64;
-        const size_t ldsCnt32 = (size_t) 2 * (kDupCounters + 4) * sizeof(uint32_t) + (kMaxChunks + 1) * sizeof(uint32_t) + 8 + 64;
-        const size_t ldsDynMax = 160 * 1024 - 1024;            // the kernel's static LDS (wave sums) counts against the CU's 160 KB too
-        uint32_t capLarge = (uint32_t) std::min<size_t>(kDupCapLarge, ((ldsDynMax - ldsCnt16) / 12) & ~(size_t) 63);
-        if (const char *e = getenv("FSGPU_KMER_CAP_LARGE")) capLarge = (uint32_t) std::min<long>(capLarge, std::max<long>(kDupCap, atol(e)));   // tests: push groups into the global-scratch variant
-        // coarsest bin level whose AVERAGE segment is at most a third of a workgroup's capacity (segments are grouped up to about two thirds
-        // of it, k_kmer_groups) and whose heaviest query's expected segment still fits the 1024-thread variant
-        const KmerIndex::BinLevel *lv = &ix.levels.front();
-        for (const KmerIndex::BinLevel &l : ix.levels)
-            if (perResAvg * (double) l.resCap <= 0.35 * kDupCap && perResMax * (double) l.resCap <= 0.6 * capLarge) lv = &l;
+        for (int q = 0; q < nq; q++) {
+            nVq += hck[q].nChunks;
+            for (uint32_t c = 0; c < hck[q].nChunks; c++) nT += (uint32_t) ((hck[q].start[c + 1] - hck[q].start[c] + kTileA - 1) / kTileA);
+            maxQ = std::max<uint64_t>(maxQ, hck[q].total);
+        }
+        // [tileStart nT+1 | qTile0 nq+1 | vqTile0 nVq+1] as u32, then [vqQ nVq | vqChunk nVq] as u16
+        const size_t tilesWords = (size_t) nT + 1 + nq + 1 + nVq + 1, tilesBytes = tilesWords * sizeof(uint32_t) + (size_t) nVq * 2 * sizeof(uint16_t);
+        CHK(ensurePinned(ctx, S.hTiles, tilesBytes));
+        CHK(ensureK(ctx, S.tiles, tilesBytes));
+        {
+            uint32_t *tileStart = (uint32_t *) S.hTiles.p, *qTile0 = tileStart + nT + 1, *vqTile0 = qTile0 + nq + 1;
+            uint16_t *vqQ = (uint16_t *) (vqTile0 + nVq + 1), *vqChunk = vqQ + nVq;
+            uint32_t T = 0, v = 0;
+            for (int q = 0; q < nq; q++) {
+                qTile0[q] = T;
+                for (uint32_t c = 0; c < hck[q].nChunks; c++, v++) {
+                    vqTile0[v] = T; vqQ[v] = (uint16_t) q; vqChunk[v] = (uint16_t) c;
+                    for (uint64_t o = hck[q].start[c]; o < hck[q].start[c + 1]; o += kTileA) tileStart[T++] = (uint32_t) (hq[q].hitBase + o);
+                }
+            }
+            qTile0[nq] = T; vqTile0[nVq] = T; tileStart[T] = (uint32_t) nHits;
+            if (T != nT || v != nVq) { ctx->err = "k-mer search: inconsistent tile table"; return FSGPU_E_HIP; }
+        }
+        RPCHK(hipMemcpyAsync(S.tiles.p, S.hTiles.p, tilesBytes, hipMemcpyHostToDevice, st));
+        KmerTiles tl{};
+        tl.tileStart = (const uint32_t *) S.tiles.p; tl.qTile0 = tl.tileStart + nT + 1; tl.vqTile0 = tl.qTile0 + nq + 1;
+        tl.vqQ = (const uint16_t *) (tl.vqTile0 + nVq + 1); tl.vqChunk = tl.vqQ + nVq; tl.nT = nT; tl.nVq = nVq;
+        // granularity of the coarse keys: levels[0] (about 128 residue-balanced keys) unless its (query, chunk, key) runs would average fewer than
+        // 1024 hits -- the many-queries-few-hits batches of an all-vs-all search -- then the coarsest level of at most 16 blocks per key
+        const KmerIndex::CoarseLevel *lv = &ix.levels.front();
+        if ((double) nHits / ((double) nVq * lv->nKeys) < 1024.0)
+            for (const KmerIndex::CoarseLevel &l : ix.levels) if (l.blocksPerKey >= 1 && l.blocksPerKey <= 16 && l.nKeys <= lv->nKeys) lv = &l;
         if (const char *e = getenv("FSGPU_KMER_BIN_LEVEL")) lv = &ix.levels[std::min<size_t>(ix.levels.size() - 1, (size_t) std::max(0, atoi(e)))];   // tests: force a level
-        // hits per bincount / binscatter workgroup: about 16 per bin (128-byte runs per segment and tile, one reservation atomic per 16 hits),
-        // but no fewer than 4 tiles per CU
-        // ... and sized so that the tiles fill whole rounds of the device's workgroup slots (four bincount workgroups fit a CU's LDS): 2180 tiles on
-        // 1024 slots ran three rounds, the last one 13 % full
-        uint64_t hitTile = std::max<uint64_t>(16384, ((uint64_t) lv->nBins * 16 + 4095) / 4096 * 4096);
+        const uint32_t nKeys = lv->nKeys;
+        const bool blkInLds = (size_t) lv->nBlk * sizeof(uint16_t) <= 16 * 1024;
+        const KmerCoarse co{lv->blkKey, lv->keyFirst, lv->nBlk, nKeys, (uint32_t) bitsFor(nKeys), lv->maxIds};
+        const size_t nCells = (size_t) nT * nKeys, nSegs = (size_t) nq * nKeys;
+        const int gBits = bitsFor(maxQ + 1), qtBits = tbits + bitsFor((uint64_t) std::max(nq, 2));
+        CHK(ensureK(ctx, S.rec, nHits * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.recKey, nHits * sizeof(uint16_t)));
+        CHK(ensureK(ctx, S.recA, nHits * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.ordA, nHits * sizeof(uint16_t)));
+        CHK(ensureK(ctx, S.cntA, std::max<size_t>(nCells, 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.colA, std::max<size_t>(nCells, 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.grpSum, nSegs * kColGroups * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.segCnt, (nSegs + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.segStart, (nSegs + 1) * sizeof(uint32_t)));
+        CHK(ensureK(ctx, S.candCount, 64));
+        RPCHK(hipMemsetAsync(S.cntA.p, 0, nCells * sizeof(uint32_t), st));
+        RPCHK(hipMemsetAsync((uint32_t *) S.segCnt.p + nSegs, 0, sizeof(uint32_t), st));
         {
-            const uint64_t slots = (uint64_t) ctx->numCU * 4, rounds = std::max<uint64_t>(1, (nHits + slots * hitTile - 1) / (slots * hitTile));
-            hitTile = std::max<uint64_t>(16384, ((nHits + rounds * slots - 1) / (rounds * slots) + 4095) / 4096 * 4096);
-        }
-        // k_kmer_bincount's dynamic LDS: the bin counters, and behind them the block table while both fit what fitted before round 5 (64 KB: four
-        // workgroups per CU); databases of more than 16 M targets have more bins than that and run one workgroup per CU with up to 141 KB of counters
-        const bool blkInLds = ((size_t) lv->nBins + lv->nBlk) * sizeof(uint32_t) <= 64 * 1024 - 256;
-        if ((size_t) lv->nBins * sizeof(uint32_t) > 64 * 1024 - 256 && !ctx->kmerBincountAttr) {        // the attribute belongs to the device: once per context
-            RPCHK(hipFuncSetAttribute((const void *) k_kmer_bincount, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxBins * (int) sizeof(uint32_t)));
-            ctx->kmerBincountAttr = true;
-        }
-        const KmerBins bins{lv->blk, lv->blkCoarse, lv->coarseFirst, lv->binFirst, lv->nBlk, lv->nBins, lv->nCoarse, (uint32_t) hitTile, blkInLds ? 1u : 0u};
-        const size_t ldsBins = ((size_t) lv->nBins + (blkInLds ? lv->nBlk : 0)) * sizeof(uint32_t);
-        const uint32_t nOwners = (uint32_t) nq * lv->nCoarse;
-        nSeg = (uint32_t) nq * lv->nBins;
-        CHK(ensureK(ctx, S.rec, nHits * sizeof(uint64_t)));
-        CHK(ensureK(ctx, S.part, nHits * sizeof(uint64_t)));
-        CHK(ensureK(ctx, S.tmpA, nHits * sizeof(uint64_t)));            // level-A output; afterwards the big groups' position / flag arrays
-        CHK(ensureK(ctx, S.binCount, ((size_t) nSeg + 1) * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.segStart, ((size_t) nSeg + 1) * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.cursor, ((size_t) nSeg + 1) * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.segCand, ((size_t) nSeg + 1) * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.candBase, ((size_t) nSeg + 1) * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.segLast, ((size_t) nOwners + 2) * 2 * sizeof(uint32_t)));       // coarse segment starts + level-A cursors
-        CHK(ensureK(ctx, S.candFlags, ((size_t) nSeg + 1) * 2 * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.segLists, (size_t) nSeg * (4 * sizeof(KmerGroup) + sizeof(uint32_t)) + 64));
-        segLists.small = (KmerGroup *) S.segLists.p; segLists.wg = segLists.small + nSeg; segLists.large = segLists.wg + nSeg; segLists.big = segLists.large + nSeg;
-        candList = (uint32_t *) (segLists.big + nSeg);
-        segLists.counts = candList + nSeg;
-        RPCHK(hipMemsetAsync(S.binCount.p, 0, ((size_t) nSeg + 1) * sizeof(uint32_t), st));
-        RPCHK(hipMemsetAsync(segLists.counts, 0, 16 * sizeof(uint32_t), st));
-        const unsigned nTiles = gridFor(nHits, hitTile);
-        {
-            const uint32_t nEmitTiles = gridFor(nHits, kEmitTile);
-            CHK(ensureK(ctx, S.tileL, (size_t) nEmitTiles * 2 * sizeof(uint32_t)));
-            hipLaunchKernelGGL(k_kmer_tile_lists, dim3(gridFor((uint64_t) nEmitTiles * 2, 256)), dim3(256), 0, st, (const uint64_t *) S.listP.p, nLists, nHits, nEmitTiles, (uint32_t *) S.tileL.p);
+            const uint32_t nEmit = nT * kSubTiles;
+            CHK(ensureK(ctx, S.tileL, (size_t) nEmit * 2 * sizeof(uint32_t)));
+            hipLaunchKernelGGL(k_kmer_tile_lists, dim3(gridFor((uint64_t) nEmit * 2, 256)), dim3(256), 0, st, (const uint64_t *) S.listP.p, nLists, tl.tileStart, nT, (uint32_t *) S.tileL.p);
+            const size_t ldsEmit = blkInLds ? (size_t) lv->nBlk * sizeof(uint16_t) : 0;
             if (ix.posBits)
-                hipLaunchKernelGGL(k_kmer_emit<uint32_t>, dim3(nEmitTiles), dim3(256), 0, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
-                                   (const uint32_t *) S.listPos.p, (const uint32_t *) S.tileL.p, (const uint32_t *) ix.entries32, ix.posBits, nHits, (uint64_t *) S.rec.p);
+                hipLaunchKernelGGL(k_kmer_emit<uint32_t>, dim3(nEmit), dim3(256), ldsEmit, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
+                                   (const uint32_t *) S.listPos.p, (const uint32_t *) S.tileL.p, (const uint32_t *) ix.entries32, ix.posBits, tl.tileStart, co, blkInLds ? 1 : 0,
+                                   (uint32_t *) S.cntA.p, (uint32_t *) S.rec.p, (uint16_t *) S.recKey.p);
             else
-                hipLaunchKernelGGL(k_kmer_emit<uint64_t>, dim3(nEmitTiles), dim3(256), 0, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
-                                   (const uint32_t *) S.listPos.p, (const uint32_t *) S.tileL.p, (const uint64_t *) ix.entries, 16, nHits, (uint64_t *) S.rec.p);
+                hipLaunchKernelGGL(k_kmer_emit<uint64_t>, dim3(nEmit), dim3(256), ldsEmit, st, nLists, (const uint64_t *) S.listP.p, (const uint32_t *) S.listStart.p,
+                                   (const uint32_t *) S.listPos.p, (const uint32_t *) S.tileL.p, (const uint64_t *) ix.entries, 16, tl.tileStart, co, blkInLds ? 1 : 0,
+                                   (uint32_t *) S.cntA.p, (uint32_t *) S.rec.p, (uint16_t *) S.recKey.p);
         }
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[3], st));
-        hipLaunchKernelGGL(k_kmer_bincount, dim3(nTiles), dim3(256), ldsBins, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.rec.p, nHits, bins,
-                           (uint32_t *) S.binCount.p);
-        RPCHK(hipGetLastError());
-        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.binCount.p, (uint32_t *) S.segStart.p, (size_t) nSeg + 1));
-        RPCHK(hipMemcpyAsync(S.cursor.p, S.segStart.p, (size_t) nSeg * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        uint32_t *coarseStart = (uint32_t *) S.segLast.p, *cursorA = coarseStart + nOwners + 2;
-        hipLaunchKernelGGL(k_kmer_coarse_starts, dim3(gridFor((uint64_t) nOwners + 1, 256)), dim3(256), 0, st, (const uint32_t *) S.segStart.p, (const uint32_t *) lv->coarseFirst,
-                           lv->nBins, lv->nCoarse, nOwners, coarseStart);
-        RPCHK(hipMemcpyAsync(cursorA, coarseStart, (size_t) nOwners * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        // two staged levels: stream order -> (query, coarse bin) in the gaux buffers' place (tmpA), -> (query, bin) in part
-        uint64_t *tmpA = (uint64_t *) S.tmpA.p;
-        // (round 5: persistent workgroups that prefetch their next tile into registers were measured and dropped -- 80 to 128 VGPRs for 4 to 6 workgroups
-        // per CU: coarse 1.12 -> 1.21 ms, fine 0.91 -> 1.03 ms per 1.6 x 10^8 hits; the kernels are not bound by the latency of their tile loads)
-        hipLaunchKernelGGL(k_kmer_scatter_coarse, dim3(gridFor(nHits, kScTile)), dim3(256), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.rec.p, nHits, bins, cursorA, tmpA);
-        hipLaunchKernelGGL(k_kmer_scatter_fine, dim3(gridFor(nHits, kScTile)), dim3(256), 0, st, (const uint32_t *) coarseStart, nOwners, (const uint64_t *) tmpA, nHits, bins,
-                           (uint32_t *) S.cursor.p, (uint64_t *) S.part.p);
+        // where every (tile, key) run starts: column sums -> segment starts -> column prefixes (in place of the counts)
+        const dim3 colGrid((unsigned) nq, (nKeys + 63) / 64);
+        hipLaunchKernelGGL(k_kmer_col_sums, colGrid, dim3(64 * kColGroups), 0, st, (const uint32_t *) S.cntA.p, tl.qTile0, nKeys, (uint32_t *) S.grpSum.p, (uint32_t *) S.segCnt.p);
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.segCnt.p, (uint32_t *) S.segStart.p, nSegs + 1));
+        hipLaunchKernelGGL(k_kmer_col_offsets, colGrid, dim3(64 * kColGroups), 0, st, (uint32_t *) S.cntA.p, tl.qTile0, nKeys, (const uint32_t *) S.grpSum.p,
+                           (const uint32_t *) S.segStart.p, (uint32_t *) S.colA.p);
+        hipLaunchKernelGGL(k_kmer_scatter_stable, dim3(nT), dim3(kScThreads), 0, st, (const uint32_t *) S.rec.p, (const uint16_t *) S.recKey.p, tl.tileStart, (const uint32_t *) S.cntA.p,
+                           nKeys, (int) co.keyBits, (uint32_t *) S.recA.p, (uint16_t *) S.ordA.p);
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[4], st));
-        // ---- stage 3: per segment, the double-diagonal rule in arrival order ------------------------------------------------
-        da.qs = (const KmerQ *) S.qs.p; da.chunks = (const KmerChunks *) S.chunks.p; da.segStart = (const uint32_t *) S.segStart.p;
-        da.binFirst = lv->binFirst; da.nBins = lv->nBins; da.part = (uint64_t *) S.part.p; da.segCand = (uint32_t *) S.segCand.p;
-        da.gbucket = (uint64_t *) S.rec.p;         // the emit records are dead after the scatter: their buffer is the big groups' bucket array
-        da.gaux = (uint32_t *) S.tmpA.p; da.gaux2 = da.gaux + nHits;            // the level-A buffer is dead after the fine scatter
-        hipLaunchKernelGGL(k_kmer_groups, dim3(gridFor(nSeg, 256)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const KmerChunks *) S.chunks.p, (const uint32_t *) S.segStart.p,
-                           (const uint32_t *) lv->binFirst, lv->nBins, nSeg, segLists, capLarge, (uint32_t *) S.segCand.p);
-        static_assert(kDupCap <= kDupCounters + 4 && sizeof(uint16_t) == 2, "the flag prefix of the 512-thread variant lives in the cursor array");
-        const size_t ldsWg = ldsCnt16 + ((size_t) kDupCap + 8) * 9 + 16;
-        const size_t ldsLarge = ldsCnt16 + ((size_t) capLarge + 8) * 11 + 16;
-        const unsigned gridSmall = (unsigned) std::min<uint64_t>(gridFor(nSeg, 4), (uint64_t) ctx->numCU * 16);
-        const unsigned gridWg = (unsigned) std::min<uint64_t>(nSeg, (uint64_t) ctx->numCU * 8);
-        const unsigned gridLarge = (unsigned) std::min<uint64_t>(nSeg, (uint64_t) ctx->numCU);
-        // heaviest groups first: the one-CU workgroups start while the small ones fill the rest of the device
-        {
-            static const hipError_t attr = hipFuncSetAttribute((const void *) k_kmer_dup_wg<false, 1024, kDupCapLarge / 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-            if (attr != hipSuccess) { ctx->err = std::string("hipFuncSetAttribute(k_kmer_dup_wg): ") + hipGetErrorString(attr); return FSGPU_E_HIP; }
-            hipLaunchKernelGGL((k_kmer_dup_wg<false, 1024, kDupCapLarge / 1024>), dim3(gridLarge), dim3(1024), ldsLarge, st, da, (const KmerGroup *) segLists.large, (const uint32_t *) segLists.counts + 2, capLarge);
+        // ---- stage 3: the double-diagonal rule, run by run in arrival order ------------------------------------------------
+        KmerDupStream da{};
+        da.recA = (const uint32_t *) S.recA.p; da.ordA = (const uint16_t *) S.ordA.p; da.offA = (const uint32_t *) S.cntA.p; da.colA = (const uint32_t *) S.colA.p;
+        da.segStart = (const uint32_t *) S.segStart.p; da.tl = tl; da.qs = (const KmerQ *) S.qs.p; da.keyFirst = lv->keyFirst; da.nKeys = nKeys;
+        da.tbits = tbits; da.gBits = gBits; da.candCount = (uint32_t *) S.candCount.p; da.ecCount = (uint32_t *) S.ec.p;
+        const size_t ldsDup = ((size_t) lv->maxIds / 2 + 1) * sizeof(uint32_t);
+        if (ldsDup > 48 * 1024 && !ctx->kmerDupAttr) {          // the attribute belongs to the device: once per context
+            RPCHK(hipFuncSetAttribute((const void *) k_kmer_dup_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (kCoarseBlocks * 1024 / 2 + 1) * (int) sizeof(uint32_t)));
+            ctx->kmerDupAttr = true;
         }
-        hipLaunchKernelGGL((k_kmer_dup_wg<true, 1024, 1>), dim3(std::min<unsigned>(gridWg, (unsigned) ctx->numCU * 2)), dim3(1024), ldsCnt32, st, da, (const KmerGroup *) segLists.big, (const uint32_t *) segLists.counts + 3, 0u);
-        hipLaunchKernelGGL((k_kmer_dup_wg<false, 512, kDupCap / 512>), dim3(gridWg), dim3(512), ldsWg, st, da, (const KmerGroup *) segLists.wg, (const uint32_t *) segLists.counts + 1, (uint32_t) kDupCap);
-        hipLaunchKernelGGL(k_kmer_dup_small, dim3(gridSmall), dim3(256), 0, st, da, (const KmerGroup *) segLists.small, (const uint32_t *) segLists.counts + 0);
-        RPCHK(hipGetLastError());
-        RPCHK(hipMemsetAsync((uint32_t *) S.segCand.p + nSeg, 0, sizeof(uint32_t), st));
-        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.segCand.p, (uint32_t *) S.candBase.p, (size_t) nSeg + 1));
-        uint32_t *candFlag = (uint32_t *) S.candFlags.p, *candFlagScan = candFlag + nSeg + 1;
-        hipLaunchKernelGGL(k_kmer_candflags, dim3(gridFor((uint64_t) nSeg + 1, 256)), dim3(256), 0, st, (const uint32_t *) S.segCand.p, nSeg, candFlag);
-        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) candFlag, candFlagScan, (size_t) nSeg + 1));
-        hipLaunchKernelGGL(k_kmer_candlist, dim3(gridFor((uint64_t) nSeg + 1, 256)), dim3(256), 0, st, (const uint32_t *) S.segCand.p, (const uint32_t *) candFlagScan, nSeg, candList, segLists.counts + 4);
-        RPCHK(hipGetLastError());
-        RPCHK(hipMemcpyAsync(S.nCand.p, (uint32_t *) S.candBase.p + nSeg, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        RPCHK(hipMemcpyAsync(&misc[2], (uint32_t *) S.candBase.p + nSeg, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        RPCHK(hipMemcpyAsync(&misc[3], segLists.counts, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        CHK(syncStream(ctx));
-        nCand = (uint32_t) misc[2];
+        // the candidate array holds an eighth of the hits (2-3 % are flagged on protein-sized inputs); a batch that flags more is counted to the end
+        // and the launch repeated with an array of that size
+        uint64_t candCap = std::max<uint64_t>(nHits / 8, 1u << 16);
+        for (int attempt = 0; ; attempt++) {
+            CHK(ensureK(ctx, S.candKey, candCap * sizeof(uint64_t)));
+            CHK(ensureK(ctx, S.candVal, candCap * sizeof(uint32_t)));
+            da.candKey = (uint64_t *) S.candKey.p; da.candVal = (uint32_t *) S.candVal.p; da.candCap = (uint32_t) std::min<uint64_t>(candCap, 0xFFFFFFFFull);
+            RPCHK(hipMemsetAsync(S.candCount.p, 0, 64, st));
+            if (attempt) RPCHK(hipMemsetAsync(S.ec.p, 0, (size_t) nq * kMaxChunks * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_kmer_dup_stream, dim3((unsigned) ((uint64_t) nVq * nKeys)), dim3(kDupRound), ldsDup, st, da);
+            RPCHK(hipGetLastError());
+            RPCHK(hipMemcpyAsync(&misc[2], S.candCount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            CHK(syncStream(ctx));
+            nCand = (uint32_t) misc[2];
+            if (nCand <= candCap) break;
+            if (attempt) { ctx->err = "k-mer search: candidate count changed between two runs of the duplicate stage"; return FSGPU_E_HIP; }
+            candCap = nCand;
+        }
         mark("emit..dup+sync");
-        {   // [0] one wave, [1] LDS (256- and 1024-thread workgroups), [2] global scratch, [3] with candidates, [4] all, [5] bins
-            const uint32_t *c = (const uint32_t *) &misc[3];
-            ctx->kmerSegs[0] = c[0]; ctx->kmerSegs[1] = c[1] + c[2]; ctx->kmerSegs[2] = c[3]; ctx->kmerSegs[3] = c[4];
-            ctx->kmerSegs[4] = nSeg; ctx->kmerSegs[5] = lv->nBins; ctx->kmerSegs[6] = c[2];         // [0..3] count GROUPS of segments
+        ctx->kmerSegs[0] = 0; ctx->kmerSegs[1] = nVq * nKeys; ctx->kmerSegs[2] = 0; ctx->kmerSegs[3] = nT;
+        ctx->kmerSegs[4] = nVq * nKeys; ctx->kmerSegs[5] = nKeys; ctx->kmerSegs[6] = lv->maxIds;
+        if (nCand) {
+            // (query, target, arrival) order: one radix sort over the flagged hits only
+            CHK(ensureK(ctx, S.candKey2, (size_t) nCand * sizeof(uint64_t)));
+            CHK(ensureK(ctx, S.candVal2, (size_t) nCand * sizeof(uint32_t)));
+            CHK(ensureK(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
+            CHK(ensureK(ctx, S.cvals, (size_t) nCand * sizeof(uint64_t)));
+            CHK((sortPairs<uint64_t, uint32_t>(ctx, S.tmp, (const uint64_t *) S.candKey.p, (uint64_t *) S.candKey2.p, (const uint32_t *) S.candVal.p, (uint32_t *) S.candVal2.p,
+                                               nCand, std::min(64, gBits + qtBits))));
+            hipLaunchKernelGGL(k_kmer_cand_unpack, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint64_t *) S.candKey2.p, (const uint32_t *) S.candVal2.p, nCand, gBits,
+                               (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p);
+            RPCHK(hipGetLastError());
+            RPCHK(hipMemcpyAsync(S.nCand.p, S.candCount.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         }
     }
     if (!nHits) { RPCHK(hipEventRecord(S.ev[3], st)); RPCHK(hipEventRecord(S.ev[4], st)); }   // keep every stage event recorded
     RPCHK(hipEventRecord(S.ev[5], st));
     if (nCand) {
-        CHK(ensureK(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.cvals, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.kept, (size_t) nCand));
         CHK(ensureK(ctx, S.score, (size_t) nCand * sizeof(int32_t)));
         CHK(ensureK(ctx, S.scrA, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.scrB, (size_t) nCand * sizeof(uint64_t)));
         CHK(ensureK(ctx, S.best, (size_t) nCand * sizeof(KmerBest)));
         CHK(ensureK(ctx, S.out, (size_t) nCand * sizeof(KmerOut)));
-        {
-            const uint32_t nCandSegs = ctx->kmerSegs[3];
-            const unsigned gridEx = (unsigned) std::min<uint64_t>(gridFor(nCandSegs, 64), (uint64_t) ctx->numCU * 16);
-            hipLaunchKernelGGL(k_kmer_expand, dim3(gridEx), dim3(256), 0, st, da, (const uint32_t *) S.candBase.p, (const uint32_t *) candList,
-                               (const uint32_t *) segLists.counts + 4, tbits, (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p, (uint32_t *) S.ec.p);
-        }
-        RPCHK(hipGetLastError());
         if (sp.kmerScoreOnly) {
             // --diag-score 0: the score of a target is the number of its candidates, no diagonal is scored; a query that refilled databaseHits has
             // the reference's merge of the per-refill counts replayed per (query, id >> shift) group (k_kmer_merge_heads)

@@ -6,10 +6,11 @@
 //                   diagonal scoring (UngappedAlignment.cpp:45-57,430-443), per-target replay of the overflow rounds
 //                   (mergeElements / keepMaxScoreElementOnly), score histogram + cut (QueryMatcher.h:211-221).
 //
-// All of it is integer / byte work bound by HBM latency and bandwidth (random 8-byte index-table probes, 8-byte
-// entry gathers, 12 B/hit through the radix sort); no MFMA.  The reference's arrival-order rules are kept exact by
-// giving every hit its stream position g and sorting the hit stream by (query, target) with a STABLE radix sort,
-// after which every order-dependent rule of the reference becomes a per-target, neighbour-only rule.
+// All of it is integer / byte work bound by HBM latency and bandwidth (random index-table probes, 4-byte entry gathers,
+// 6-byte hit records through one order-preserving scatter); no MFMA.  The reference's arrival-order rules are kept exact:
+// the hit stream is partitioned STABLY into (query, target range) runs, the double-diagonal rule walks every run in arrival
+// order over the reference's own byte-per-target array (in LDS), and the 2-3 % of the hits it flags get their stream
+// position back, after which every later order-dependent rule is a per-target, neighbour-only rule.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -551,68 +552,58 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// search, stage 2: the hit stream -> double-diagonal candidates, without a global sort.
+// search, stage 2: the hit stream -> double-diagonal candidates (round 6: a STABLE partition of narrow records).
 //
 // The reference decides "is this hit a double-diagonal hit" with a byte per target that remembers the 8-bit diagonal of
 // the PREVIOUS hit of that target in arrival order (findDuplicates, CacheFriendlyOperations.cpp:188-283); to make that
-// byte array fit its L2 it first scatters the hits into bins by target id (hashElements, :285-311).  Same idea here, one
-// level up the memory hierarchy: the hit stream is scattered into (query, bin) segments, a bin being a contiguous range
-// of target ids with a bounded number of targets AND of residues (so a segment's hits fit a workgroup's LDS), and every
-// segment is then resolved inside LDS:
-//   k_kmer_emit        output-balanced gather of the index entries; one 8-byte record (bin, target-in-bin, diagonal)
-//                      per hit at its stream position o, (query, bin) histogram in LDS -> binCount
-//   (exclusive scan)   segStart[query][bin]
-//   k_kmer_binscatter  record o -> its segment (order inside a segment is arbitrary: the record carries o)
-//   k_kmer_dup_*       per segment: group the hits by target (LDS counting sort on the target-in-bin), find every hit's
-//                      predecessor = the hit of the same target with the largest smaller o (rank scan inside the target's
-//                      bucket), flag it when the 8-bit diagonals agree (same databaseHits chunk, else the byte array was
-//                      reset: compare with 0), and write the flagged hits back IN (target, o) ORDER
-//   k_kmer_expand      candidates of all segments -> (key = query|target, value = g|diag16|chunk) arrays, in (query,
-//                      target, arrival) order: exactly what the stable sort used to deliver, for 2-3 % of the hits only.
-// Bytes per hit: 8 written by emit, 8 read + 8 written by the scatter, 8 read by the segment kernels (the global radix
-// sort moved 24 B four times).  Nothing here depends on the order in which atomics are served.
+// byte array fit its L2 it first scatters the hits into bins by target id (hashElements, :285-311), and it zeroes the
+// array whenever databaseHits is flushed (QueryMatcher.cpp:311-346).  The same here, one level up the memory hierarchy:
+//   k_kmer_emit            output-balanced gather of the index entries.  One 4-byte record (target id & 0xffff, 16-bit
+//                          diagonal) + its 2-byte COARSE KEY per hit at the hit's stream position, and the number of
+//                          hits per (tile, key) -- a tile = up to 16384 consecutive hits of ONE databaseHits chunk of
+//                          one query.  A coarse key is a run of blocks of 1024 target ids (at most 64: the low 16 bits
+//                          of an id are unique inside it), about 128 keys per database.
+//   k_kmer_col_sums / _offsets   per (query, key) column over the query's tiles: where the run of (tile, key) starts
+//   k_kmer_scatter_stable  records -> (query, key) segments, ORDER PRESERVING: inside a segment the hits stand in
+//                          arrival order, so no record has to carry its stream position (rounds 3-5 moved 8-byte
+//                          records twice through two unordered scatters and ranked every target's hits by their
+//                          32-bit stream positions afterwards).  What identifies a hit later travels beside it as
+//                          a 16-bit position inside its tile.
+//   k_kmer_dup_stream      one workgroup per (query, chunk, key): the reference's byte array itself, in LDS (16 bits per
+//                          target of the key: last diagonal + a counter), walked in arrival order 256 hits at a time;
+//                          hits of one round that share a target are resolved among themselves by their position in
+//                          the round.  Flagged hits (2-3 %) get their stream position back (tile of their run + the
+//                          16-bit position) and leave as (query | target | stream position, diagonal | chunk).
+//   radix sort + k_kmer_cand_unpack   the candidates in (query, target, arrival) order: the arrays the scoring and
+//                          replay stages read.
+// Bytes per hit: 6 written by emit, 6 read + 6 written by the scatter, 4 (+ 2 for the flagged ones) read by the
+// duplicate stage.  Nothing here depends on the order in which atomics are served.
 // --------------------------------------------------------------------------------------------------------------
 constexpr int kEmitTile = 2048;               // hits per workgroup of k_kmer_emit
-constexpr int kEmitStage = 6144;              // list prefixes of an emit tile staged in LDS (24 KB -> 6 workgroups per CU)
+constexpr int kEmitStage = 6144;              // list prefixes of an emit tile staged in LDS
 static_assert(kEmitStage < 8192, "k_kmer_emit searches the staged prefixes with 13 halving steps");
-constexpr int kDupCap = 2560;                 // hits of a segment group resolved in LDS by a 512-thread workgroup (four of them per CU)
-constexpr int kDupCapLarge = 12288;           // ... by a 1024-thread workgroup that owns the CU's LDS; beyond: global scratch
-constexpr int kDupSmall = 64;                 // ... at most this many: one wave, all-pairs in registers (k_kmer_dup_small)
-constexpr int kDupWindow = 2048;              // a group's bins start inside one window of this many target ids ...
-constexpr int kBinTargets = 1024;             // ... and a bin holds at most this many targets: a group spans fewer than kDupWindow + kBinTargets targets
-constexpr int kDupCounters = kDupWindow + kBinTargets;
-constexpr int kMaxBins = 36000;               // LDS counters of k_kmer_bincount: 4 B per bin, 141 KB of a CU's 160 KB (a block of 1024 target ids is at least one bin:
-                                              // 36.8 M targets; the 512 coarse bins of a query, one per 65536 ids at least, stop at 33.5 M)
-constexpr int kPlanBins = 16000;              // bin levels are planned for at most this many bins where the residues allow it (64 KB of counters: four workgroups per CU)
+constexpr int kTileA = 16384;                 // hits per counting tile (a position inside it fits 16 bits)
+constexpr int kSubTiles = kTileA / kEmitTile; // emit workgroups per tile
+constexpr int kMaxCoarse = 512;               // coarse keys per database (LDS counters of emit and of the scatter)
+constexpr int kCoarseBlocks = 64;             // blocks of 1024 ids per key at most
+constexpr int kScStage = 4096;                // records per LDS pass of the stable scatter
+constexpr int kScThreads = 512;
+constexpr int kDupRound = 256;                // hits per round of k_kmer_dup_stream = its workgroup size
+constexpr int kCandStage = 3 * kDupRound;     // flagged hits staged in LDS; flushed from 2 * kDupRound on
+constexpr int kColGroups = 16;                // tile groups of the column kernels
 
-// Bins are power-of-two aligned id ranges inside blocks of 1024 target ids: bin(t) = base[t >> 10] + ((t & 1023) >> shift[t >> 10]), the shift
-// chosen per block from its residue count (fsgpu_kmer_plan_bins) -- a table of n / 1024 words that lives in LDS, so the per-hit bin
-// look-up costs no memory request (a per-target table did: one 64-byte L2 request per hit and pass, the scatter's limit).
-struct KmerBins {
-    const uint32_t *blk;          // [ceil(n / 1024)] first bin of the block << 8 | shift
-    const uint16_t *blkCoarse;    // [ceil(n / 1024)] coarse bin of the block: runs of blocks with at most kCoarseKeys bins, inside one 65536-id block
-    const uint32_t *coarseFirst;  // [nCoarse + 1] first (fine) bin of a coarse bin
-    const uint32_t *binFirst;     // [nBins + 1] first target id of a bin
-    uint32_t nBlk, nBins, nCoarse;
-    uint32_t hitTile;             // hits per workgroup of k_kmer_bincount (about 16 per bin: one flush atomic per 16 hits)
-    uint32_t blkInLds;            // bincount: the block table is staged behind the bin counters
+struct KmerCoarse {
+    const uint16_t *blkKey;       // [nBlk] key of every block of 1024 target ids
+    const uint32_t *keyFirst;     // [nKeys + 1] first target id of a key
+    uint32_t nBlk, nKeys, keyBits, maxIds;
 };
-__device__ __forceinline__ uint32_t kmerBinOf(const uint32_t *blk, uint32_t t) {
-    const uint32_t e = blk[t >> 10];
-    return (e >> 8) + ((t & 1023u) >> (e & 0xffu));
-}
-constexpr int kCoarseKeys = 128;              // fine bins per coarse bin (a block of 1024 ids has at most 128 bins: shift >= 3) and coarse bins per query
-constexpr int kMaxCoarse = 512;               // coarse bins per query (LDS counters of the staged scatter)
-constexpr int kScTile = 2048;                 // hits per workgroup pass of the staged scatters (16 KB of LDS staging)
-
-// hit record at stream position o (k_kmer_emit -> k_kmer_bincount / k_kmer_binscatter): target << 16 | 16-bit diagonal
-__host__ __device__ inline uint64_t recPack(uint32_t t, uint32_t d16) { return ((uint64_t) t << 16) | (d16 & 0xffffu); }
-// hit record inside a segment: ordered as a u64 by (target id & 0xffff, o)
-__host__ __device__ inline uint64_t partPack(uint32_t tloc, uint32_t o, uint32_t d16) { return ((uint64_t) tloc << 48) | ((uint64_t) o << 16) | (d16 & 0xffffu); }
-__host__ __device__ inline uint32_t partTloc(uint64_t r) { return (uint32_t) (r >> 48); }
-__host__ __device__ inline uint32_t partO(uint64_t r) { return (uint32_t) (r >> 16); }
-__host__ __device__ inline uint32_t partD16(uint64_t r) { return (uint32_t) r & 0xffffu; }
-__host__ __device__ inline uint32_t partD8(uint64_t r) { return (uint32_t) r & 0xffu; }
+struct KmerTiles {
+    const uint32_t *tileStart;    // [nT + 1] first stream position of a tile (tiles follow the stream; tileStart[nT] = hits of the batch)
+    const uint32_t *qTile0;       // [nq + 1] first tile of a query
+    const uint32_t *vqTile0;      // [nVq + 1] first tile of a (query, chunk) pair
+    const uint16_t *vqQ, *vqChunk;// [nVq]
+    uint32_t nT, nVq;
+};
 
 // list that holds stream position o: the last l with listP[l] <= o (empty lists share their prefix with the successor, so that list is non-empty)
 __device__ inline uint64_t kmerListOf(const uint64_t *listP, uint64_t nLists, uint64_t o) {
@@ -620,35 +611,41 @@ __device__ inline uint64_t kmerListOf(const uint64_t *listP, uint64_t nLists, ui
     while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (listP[mid] <= o) lo = mid; else hi = mid; }
     return lo;
 }
-// first and last list of every emit tile, one thread per tile.  (Until round 5 two threads of every emit workgroup ran these searches themselves: 27
-// dependent global loads before the tile's 256 threads could start -- more than the tile's own work takes.)
-__global__ void k_kmer_tile_lists(const uint64_t *listP, uint64_t nLists, uint64_t nHits, uint32_t nTiles, uint32_t *tileL /*[2 * nTiles]*/) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * nTiles) return;
-    const uint64_t o0 = (uint64_t) (t >> 1) * kEmitTile;
-    const uint64_t o = (t & 1u) ? min(nHits, o0 + kEmitTile) - 1 : o0;
-    tileL[t] = (uint32_t) kmerListOf(listP, nLists, o);          // list slots of a batch fit 32 bits (listStart / listSize / listPos are indexed by them)
+// first and last list of every emit workgroup (sub-tile s of tile T covers kEmitTile stream positions from tileStart[T] + s * kEmitTile on), one thread per
+// bound.  (Until round 5 two threads of every emit workgroup ran these searches themselves: 27 dependent global loads before the other 254 could start.)
+__global__ void k_kmer_tile_lists(const uint64_t *listP, uint64_t nLists, const uint32_t *tileStart, uint32_t nT, uint32_t *tileL /*[2 * nT * kSubTiles]*/) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2u * nT * kSubTiles) return;
+    const uint32_t b = i >> 1, T = b / kSubTiles, s = b % kSubTiles;
+    const uint64_t o0 = (uint64_t) tileStart[T] + (uint64_t) s * kEmitTile, tEnd = tileStart[T + 1];
+    if (o0 >= tEnd) { tileL[i] = 0; return; }
+    const uint64_t o = (i & 1u) ? min(tEnd, o0 + kEmitTile) - 1 : o0;
+    tileL[i] = (uint32_t) kmerListOf(listP, nLists, o);          // list slots of a batch fit 32 bits (listStart / listSize / listPos are indexed by them)
 }
 
 // Output-balanced gather: one thread per hit, list found by binary search over the staged list prefixes.
 // E = uint64_t: entries seqId << 16 | position; E = uint32_t: seqId << posBits | position (k_kmer_compact_entries32)
 template <class E>
 __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64_t *listP, const uint32_t *listStart, const uint32_t *listPos /* query << 16 | position */,
-                                                   const uint32_t *tileL, const E *entries, int posBits, uint64_t nHits, uint64_t *rec) {
+                                                   const uint32_t *tileL, const E *entries, int posBits, const uint32_t *tileStart, KmerCoarse co, int blkInLds,
+                                                   uint32_t *cntA /*[nT][nKeys]*/, uint32_t *rec, uint16_t *recKey) {
     // list prefixes relative to the tile's first stream position, clamped below at 0 (only the tile's first list can start before the tile): < kEmitTile,
     // 16 bits each -- 12 KB instead of 24, so the workgroups per CU are bounded by their waves, not by LDS
     __shared__ uint16_t rel[kEmitStage + 1];
-    const uint64_t o0 = (uint64_t) blockIdx.x * kEmitTile;
-    if (o0 >= nHits) return;
-    const uint64_t o1 = min(nHits, o0 + kEmitTile);
+    __shared__ uint32_t hist[kMaxCoarse];
+    extern __shared__ uint16_t sblk[];        // [nBlk] when blkInLds
+    const uint32_t T = blockIdx.x / kSubTiles, sub = blockIdx.x % kSubTiles;
+    const uint64_t o0 = (uint64_t) tileStart[T] + (uint64_t) sub * kEmitTile, tEnd = tileStart[T + 1];
+    if (o0 >= tEnd) return;
+    const uint64_t o1 = min(tEnd, o0 + kEmitTile);
     const uint64_t l0 = tileL[2 * blockIdx.x], l1 = tileL[2 * blockIdx.x + 1];
     const uint64_t p0 = listP[l0];
     const int nl = (int) min<uint64_t>(l1 - l0 + 1, (uint64_t) kEmitStage + 1);
     const bool staged = l1 - l0 + 1 <= (uint64_t) kEmitStage;
-    if (staged) {
-        for (int i = threadIdx.x; i < nl; i += 256) { const uint64_t lp = listP[l0 + i]; rel[i] = (uint16_t) (lp > o0 ? lp - o0 : 0); }
-        __syncthreads();
-    }
+    for (uint32_t i = threadIdx.x; i < co.nKeys; i += 256) hist[i] = 0;
+    if (blkInLds) for (uint32_t i = threadIdx.x; i < co.nBlk; i += 256) sblk[i] = co.blkKey[i];
+    if (staged) for (int i = threadIdx.x; i < nl; i += 256) { const uint64_t lp = listP[l0 + i]; rel[i] = (uint16_t) (lp > o0 ? lp - o0 : 0); }
+    __syncthreads();
     // 8 outputs per thread, handled phase by phase so that the dependent loads of all 8 are in flight together
     constexpr int U = kEmitTile / 256;
     uint64_t l[U];
@@ -689,62 +686,20 @@ __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64
     }
     const int pb = sizeof(E) == 8 ? 16 : posBits;
     const uint32_t pmask = (1u << pb) - 1u;
+    uint32_t key[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t b = (uint32_t) (e[u] >> pb) >> 10; key[u] = blkInLds ? (uint32_t) sblk[b] : (uint32_t) co.blkKey[b]; }      // (entry 0 -> block 0: harmless)
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint64_t o = o0 + threadIdx.x + 256 * u;
         if (o >= o1) continue;
-        const uint32_t posj = (uint32_t) e[u] & pmask;
-        rec[o] = recPack((uint32_t) (e[u] >> pb), ((p[u] & 0xffffu) - posj) & 0xffffu);
-    }
-}
-
-__device__ __forceinline__ bool o_valid(uint64_t ob, int u, uint64_t t1) { return ob + threadIdx.x + 256 * u < t1; }
-
-// the query that owns hit t0 (the last one whose hitBase is <= t0) and where its hits end
-__device__ inline void kmerTileQuery(const KmerQ *qs, int nq, uint64_t t0, uint64_t nHits, uint32_t &q0, uint64_t &end0) {
-    int lo = 0, hi = nq;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qs[mid].hitBase <= t0) lo = mid; else hi = mid; }
-    q0 = (uint32_t) lo;
-    end0 = lo + 1 < nq ? qs[lo + 1].hitBase : nHits;
-}
-
-// hits per (query, bin): LDS counters for the tile's first query, one fire-and-forget global atomic per (tile, non-empty bin)
-__global__ __launch_bounds__(256) void k_kmer_bincount(const KmerQ *qs, int nq, const uint64_t *rec, uint64_t nHits, KmerBins bins, uint32_t *binCount /*[nq][nBins]*/) {
-    extern __shared__ uint32_t shCnt[];       // [nBins]
-    __shared__ uint32_t q0s;
-    __shared__ uint64_t end0s;
-    const uint64_t t0 = (uint64_t) blockIdx.x * bins.hitTile;
-    if (t0 >= nHits) return;
-    const uint64_t t1 = min(nHits, t0 + bins.hitTile);
-    if (threadIdx.x == 0) { uint32_t q; uint64_t e; kmerTileQuery(qs, nq, t0, nHits, q, e); q0s = q; end0s = e; }
-    for (uint32_t i = threadIdx.x; i < bins.nBins; i += 256) shCnt[i] = 0;
-    const uint32_t *blk = bins.blk;
-    if (bins.blkInLds) { uint32_t *sb = shCnt + bins.nBins; for (uint32_t i = threadIdx.x; i < bins.nBlk; i += 256) sb[i] = bins.blk[i]; blk = sb; }
-    __syncthreads();
-    const uint32_t q0 = q0s;
-    const uint64_t end0 = end0s;
-    constexpr int U = 16;                     // loads in flight per thread
-    for (uint64_t ob = t0; ob < t1; ob += 256 * U) {
-        uint64_t r[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { const uint64_t o = ob + threadIdx.x + 256 * u; r[u] = o < t1 ? rec[o] : 0; }
-        uint32_t bn[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) bn[u] = o_valid(ob, u, t1) ? kmerBinOf(blk, (uint32_t) (r[u] >> 16)) : 0u;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint64_t o = ob + threadIdx.x + 256 * u;
-            if (o >= t1) continue;
-            if (o < end0) atomicAdd(&shCnt[bn[u]], 1u);
-            else {                            // the tile runs into the next queries
-                uint32_t q = q0 + 1;
-                while (q + 1 < (uint32_t) nq && qs[q + 1].hitBase <= o) q++;
-                atomicAdd(&binCount[(size_t) q * bins.nBins + bn[u]], 1u);
-            }
-        }
+        const uint32_t posj = (uint32_t) e[u] & pmask, t = (uint32_t) (e[u] >> pb);
+        rec[o] = (t << 16) | (((p[u] & 0xffffu) - posj) & 0xffffu);
+        recKey[o] = (uint16_t) key[u];
+        atomicAdd(&hist[key[u]], 1u);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < bins.nBins; i += 256) { const uint32_t c = shCnt[i]; if (c) atomicAdd(&binCount[(size_t) q0 * bins.nBins + i], c); }
+    for (uint32_t i = threadIdx.x; i < co.nKeys; i += 256) { const uint32_t c = hist[i]; if (c) atomicAdd(&cntA[(size_t) T * co.nKeys + i], c); }
 }
 
 // block-wide in-place scan (NT threads) over an array in LDS or global memory: every thread owns a contiguous run (one block scan over the
@@ -768,503 +723,250 @@ __device__ inline uint32_t kmerBlockScan(T *v, uint32_t n, uint32_t *wsum /*[NT 
     return total;
 }
 
-// Staged scatter, the building block of both levels: up to kScTile records of ONE owner (a query for level A, a (query, coarse bin)
-// segment for level B) are counted per key in LDS, every key reserves its run in the owner's output with one global atomic, the records
-// are ordered by key inside LDS and written out run by run -- consecutive lanes write consecutive addresses, every global write is a full
-// line (an 8-byte store per hit into thousands of open segments costs a read-modify-write of its line once the lines fall out of L2).
-struct KmerStage {
-    uint64_t rec[kScTile];
-    uint16_t key[kScTile];
-    uint32_t hist[kMaxCoarse], lbase[kMaxCoarse], gbase[kMaxCoarse];
-    uint32_t wsum[4];
-};
-template <class KeyOf, class Conv>
-__device__ inline void kmerStagedScatter(KmerStage &S, const uint64_t *in, uint64_t a, uint32_t n, uint32_t nKeys, uint32_t *cursorRow, uint64_t *out, KeyOf keyOf, Conv conv) {
-    constexpr int U = kScTile / 256;
-    for (uint32_t i = threadIdx.x; i < nKeys; i += 256) S.hist[i] = 0;
+// Column kernels: cnt[T][key] -> where the run of (T, key) starts in the output of the stable scatter.  The output is laid out (query, key, tile), so
+// the prefix runs DOWN a column of the query's rows.  A workgroup = one query x 64 keys x kColGroups groups of consecutive tiles: pass 1 sums every
+// group (-> segment sizes: one scan over the (query, key) pairs of the batch in between), pass 2 walks the groups again and leaves the starts in
+// place of the counts, plus a transposed copy (column-contiguous) in which k_kmer_dup_stream looks a position's tile up.
+__global__ __launch_bounds__(64 * kColGroups) void k_kmer_col_sums(const uint32_t *cntA, const uint32_t *qTile0, uint32_t nKeys, uint32_t *grpSum /*[nq][kColGroups][nKeys]*/,
+                                                                    uint32_t *segCnt /*[nq * nKeys]*/) {
+    __shared__ uint32_t sh[kColGroups][64];
+    const uint32_t q = blockIdx.x, kx = threadIdx.x & 63u, g = threadIdx.x >> 6, key = blockIdx.y * 64u + kx;
+    const uint32_t T0 = qTile0[q], T1 = qTile0[q + 1], per = (T1 - T0 + kColGroups - 1) / kColGroups;
+    const uint32_t a = min(T1, T0 + g * per), b = min(T1, a + per);
+    uint32_t s = 0;
+    if (key < nKeys) for (uint32_t T = a; T < b; T++) s += cntA[(size_t) T * nKeys + key];
+    sh[g][kx] = s;
     __syncthreads();
-    uint64_t r[U];
-    uint32_t k[U], rk[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) { const uint32_t e = threadIdx.x + 256 * u; r[u] = e < n ? in[a + e] : 0; }
-#pragma unroll
-    for (int u = 0; u < U; u++) { const uint32_t e = threadIdx.x + 256 * u; k[u] = e < n ? keyOf(r[u]) : 0u; r[u] = conv(r[u], a + e); }
-#pragma unroll
-    for (int u = 0; u < U; u++) { const uint32_t e = threadIdx.x + 256 * u; rk[u] = e < n ? atomicAdd(&S.hist[k[u]], 1u) : 0u; }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nKeys; i += 256) {
-        const uint32_t c = S.hist[i];
-        S.lbase[i] = c;
-        S.gbase[i] = c ? atomicAdd(&cursorRow[i], c) : 0u;
-    }
-    __syncthreads();
-    kmerBlockScan<uint32_t, false, 256>(S.lbase, nKeys, S.wsum);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const uint32_t e = threadIdx.x + 256 * u;
-        if (e < n) { const uint32_t p = S.lbase[k[u]] + rk[u]; S.rec[p] = r[u]; S.key[p] = (uint16_t) k[u]; }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t kk = S.key[i];
-        out[S.gbase[kk] + (i - S.lbase[kk])] = S.rec[i];
-    }
-    __syncthreads();
+    if (key >= nKeys) return;
+    grpSum[((size_t) q * kColGroups + g) * nKeys + key] = s;
+    if (g == 0) { uint32_t tot = 0; for (int i = 0; i < kColGroups; i++) tot += sh[i][kx]; segCnt[(size_t) q * nKeys + key] = tot; }
 }
-
-// level A: hit records at their stream positions -> the (query, coarse bin) segments, as segment records (target id & 0xffff, o, diagonal)
-__global__ __launch_bounds__(256) void k_kmer_scatter_coarse(const KmerQ *qs, int nq, const uint64_t *rec, uint64_t nHits, KmerBins bins,
-                                                             uint32_t *cursorA /*[nq][nCoarse]*/, uint64_t *tmpA) {
-    __shared__ KmerStage S;
-    __shared__ uint32_t q0s;
-    __shared__ uint64_t end0s;
-    const uint64_t t0 = (uint64_t) blockIdx.x * kScTile;
-    if (t0 >= nHits) return;
-    const uint64_t t1 = min(nHits, t0 + kScTile);
-    const uint16_t *blkCoarse = bins.blkCoarse;
-    uint64_t pos = t0;
-    while (pos < t1) {                        // one pass per query the tile touches (almost always one)
-        if (threadIdx.x == 0) { uint32_t q; uint64_t e; kmerTileQuery(qs, nq, pos, nHits, q, e); q0s = q; end0s = e; }
-        __syncthreads();
-        const uint32_t q = q0s;
-        const uint64_t end = min(t1, end0s);
-        kmerStagedScatter(S, rec, pos, (uint32_t) (end - pos), bins.nCoarse, cursorA + (size_t) q * bins.nCoarse, tmpA,
-                          [&](uint64_t raw) { return (uint32_t) blkCoarse[(uint32_t) (raw >> 26)]; },                      // raw = target << 16 | diagonal: block = target >> 10
-                          [&](uint64_t raw, uint64_t o) { return partPack((uint32_t) (raw >> 16) & 0xffffu, (uint32_t) o, (uint32_t) raw & 0xffffu); });
-        pos = end;                            // (the helper ends with a barrier: q0s / end0s can be rewritten)
+__global__ __launch_bounds__(64 * kColGroups) void k_kmer_col_offsets(uint32_t *cntA /* in: counts, out: run starts */, const uint32_t *qTile0, uint32_t nKeys, const uint32_t *grpSum,
+                                                                       const uint32_t *segStart /*[nq * nKeys + 1]*/, uint32_t *colA /*[qTile0[q] * nKeys + key * tiles(q) + tile]*/) {
+    const uint32_t q = blockIdx.x, kx = threadIdx.x & 63u, g = threadIdx.x >> 6, key = blockIdx.y * 64u + kx;
+    if (key >= nKeys) return;
+    const uint32_t T0 = qTile0[q], T1 = qTile0[q + 1], nTq = T1 - T0, per = (nTq + kColGroups - 1) / kColGroups;
+    const uint32_t a = min(T1, T0 + g * per), b = min(T1, a + per);
+    uint32_t base = segStart[(size_t) q * nKeys + key];
+    for (uint32_t i = 0; i < g; i++) base += grpSum[((size_t) q * kColGroups + i) * nKeys + key];
+    uint32_t *col = colA + (size_t) T0 * nKeys + (size_t) key * nTq;
+    for (uint32_t T = a; T < b; T++) {
+        const uint32_t c = cntA[(size_t) T * nKeys + key];
+        cntA[(size_t) T * nKeys + key] = base;
+        col[T - T0] = base;
+        base += c;
     }
 }
 
-// level B: inside every (query, coarse bin) segment, records -> their (query, bin) segments.  coarseStart[query][coarse] (+ the total at
-// the end) delimits the owners; a tile that runs over several of them makes one pass per owner.
-__global__ __launch_bounds__(256) void k_kmer_scatter_fine(const uint32_t *coarseStart /*[nq * nCoarse + 1]*/, uint32_t nOwners, const uint64_t *tmpA, uint64_t nHits, KmerBins bins,
-                                                           uint32_t *cursor /*[nq][nBins]*/, uint64_t *part) {
-    __shared__ KmerStage S;
-    __shared__ uint32_t own, ownEnd;
-    const uint64_t t0 = (uint64_t) blockIdx.x * kScTile;
-    if (t0 >= nHits) return;
-    const uint64_t t1 = min(nHits, t0 + kScTile);
-    const uint32_t *blk = bins.blk;
-    uint64_t pos = t0;
-    while (pos < t1) {
-        if (threadIdx.x == 0) {
-            uint32_t lo = 0, hi = nOwners;    // last owner whose start is <= pos: it is non-empty and contains pos
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coarseStart[mid] <= pos) lo = mid; else hi = mid; }
-            own = lo; ownEnd = coarseStart[lo + 1];
+// Stable scatter: one workgroup per tile, kScStage records per pass through LDS.  A wave owns a contiguous eighth of the pass and ranks its
+// records in lane order: the lanes of a wave instruction that share a key find each other with one ballot per key bit, the lowest of them
+// takes the group's places from the wave's private counter of that key (plain read + write: one lane per key and instruction, and a wave's
+// LDS accesses execute in order), everybody's rank = that base + its position among the group's lower lanes.  A cross-wave prefix per key
+// and a scan over the keys turn the ranks into LDS positions; the runs leave LDS key by key as consecutive 4-byte stores into the
+// (tile, key) runs of the output, whose starts the column kernels computed.
+__global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32_t *rec, const uint16_t *recKey, const uint32_t *tileStart, const uint32_t *offA, uint32_t nKeys, int keyBits,
+                                                                     uint32_t *out, uint16_t *ordOut) {
+    constexpr int NW = kScThreads / 64, U = kScStage / kScThreads, PW = kScStage / NW;
+    __shared__ uint32_t srec[kScStage];
+    __shared__ uint16_t skey[kScStage], sord[kScStage];
+    __shared__ uint16_t whist[NW][kMaxCoarse];
+    __shared__ uint32_t lbase[kMaxCoarse + 1], gcur[kMaxCoarse];
+    __shared__ uint32_t wsum[NW];
+    const uint32_t T = blockIdx.x;
+    const uint32_t a = tileStart[T], n = tileStart[T + 1] - a;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t k = threadIdx.x; k < nKeys; k += kScThreads) {
+        gcur[k] = offA[(size_t) T * nKeys + k];
+#pragma unroll
+        for (int w = 0; w < NW; w++) whist[w][k] = 0;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t sp0 = 0; sp0 < n; sp0 += kScStage) {
+        const uint32_t m = min((uint32_t) kScStage, n - sp0);
+        uint32_t r[U], k[U], rk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
+            r[u] = e < m ? rec[a + sp0 + e] : 0u;
+            k[u] = e < m ? (uint32_t) recKey[a + sp0 + e] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
+            const bool valid = e < m;
+            unsigned long long peers = __ballot(valid);
+            for (int bit = 0; bit < keyBits; bit++) {
+                const bool s = (k[u] >> bit) & 1u;
+                const unsigned long long mb = __ballot(valid && s);
+                peers &= s ? mb : ~mb;
+            }
+            uint32_t prev = 0;
+            int leader = lane;
+            if (valid) {
+                leader = __ffsll((long long) peers) - 1;
+                if (lane == leader) { prev = whist[wave][k[u]]; whist[wave][k[u]] = (uint16_t) (prev + (uint32_t) __popcll(peers)); }
+            }
+            prev = (uint32_t) __shfl((int) prev, leader);
+            rk[u] = prev + (uint32_t) __popcll(peers & lt);
         }
         __syncthreads();
-        const uint32_t o = own;
-        const uint64_t end = min<uint64_t>(t1, ownEnd);
-        const uint32_t q = o / bins.nCoarse, A = o - q * bins.nCoarse;
-        const uint32_t fine0 = bins.coarseFirst[A], nKeys = bins.coarseFirst[A + 1] - fine0;
-        const uint32_t idBlock = bins.binFirst[fine0] & ~0xffffu;          // a coarse bin lies inside one block of 65536 ids
-        kmerStagedScatter(S, tmpA, pos, (uint32_t) (end - pos), nKeys, cursor + (size_t) q * bins.nBins + fine0, part,
-                          [&](uint64_t r) { return kmerBinOf(blk, idBlock + partTloc(r)) - fine0; },
-                          [&](uint64_t r, uint64_t) { return r; });
-        pos = end;
+        for (uint32_t kk = threadIdx.x; kk < nKeys; kk += kScThreads) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) { const uint32_t c = whist[w][kk]; whist[w][kk] = (uint16_t) run; run += c; }
+            lbase[kk] = run;
+        }
+        if (threadIdx.x == 0) lbase[nKeys] = 0;
+        __syncthreads();
+        kmerBlockScan<uint32_t, false, kScThreads>(lbase, nKeys + 1, wsum);          // lbase[key] = first LDS position of the key, lbase[nKeys] = m
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
+            if (e < m) { const uint32_t p = lbase[k[u]] + whist[wave][k[u]] + rk[u]; srec[p] = r[u]; skey[p] = (uint16_t) k[u]; sord[p] = (uint16_t) e; }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += kScThreads) {
+            const uint32_t kk = skey[i];
+            const uint32_t dst = gcur[kk] + (i - lbase[kk]);
+            out[dst] = srec[i];
+            ordOut[dst] = (uint16_t) (sp0 + sord[i]);
+        }
+        __syncthreads();
+        for (uint32_t kk = threadIdx.x; kk < nKeys; kk += kScThreads) {
+            gcur[kk] += lbase[kk + 1] - lbase[kk];
+#pragma unroll
+            for (int w = 0; w < NW; w++) whist[w][kk] = 0;
+        }
+        __syncthreads();
     }
 }
 
-// coarseStart[query][coarse] = segStart[query][first bin of the coarse bin] (+ the batch total at the end)
-__global__ void k_kmer_coarse_starts(const uint32_t *segStart, const uint32_t *coarseFirst, uint32_t nBins, uint32_t nCoarse, uint32_t nOwners, uint32_t *coarseStart) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > nOwners) return;
-    if (i == nOwners) { coarseStart[i] = segStart[(size_t) (nOwners / nCoarse) * nBins]; return; }
-    const uint32_t q = i / nCoarse, A = i - q * nCoarse;
-    coarseStart[i] = segStart[(size_t) q * nBins + coarseFirst[A]];
-}
-
-// Segments -> groups.  A (query, bin) segment of average size fills a third of a workgroup's LDS capacity (the spread over bins and queries
-// is wide), and a workgroup pays ~10 latency-bound phases per pass whatever the fill.  So consecutive segments of one query are resolved
-// TOGETHER: a group = the run of (small) segments whose first hit falls into the same window of kDupCap / 2 stream positions of the query and whose
-// bins start inside the same window of kDupWindow target ids (so the group spans fewer than kDupCounters targets and, bins never
-// straddling a 65536-id block, one block).  Both keys are functions of the segment alone: heads are found independently, the head's thread
-// walks to the group's last segment.  A group is to the kernels below what a segment is -- a contiguous range of `part` holding ALL hits of
-// its targets -- with a wider target range; it is classed by its hit count.
-struct KmerGroup {
-    uint32_t s0, m;               // the group's hits: part[s0 .. s0 + m)
-    uint32_t seg;                 // head segment (query * nBins + bin): where the group's candidate count goes
-    uint32_t tBase, T;            // first target id & 0xffff, number of targets spanned
-    uint32_t q, hb, nCh;          // query, its first stream position, its databaseHits chunks
-};
-struct KmerSegLists { KmerGroup *small, *wg, *large, *big; uint32_t *counts; /* [5]: small, wg, large, big groups, (expand: groups with candidates) */ };
-__global__ void k_kmer_groups(const KmerQ *qs, const KmerChunks *chunks, const uint32_t *segStart, const uint32_t *binFirst, uint32_t nBins, uint32_t nSeg,
-                              KmerSegLists L, uint32_t capLarge, uint32_t *segCand) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nSeg) return;
-    segCand[s] = 0;                           // heads with candidates overwrite theirs (stream order: the dup kernels run after this one)
-    const uint32_t q = s / nBins, b = s - q * nBins;
-    const uint32_t qBase = segStart[q * nBins];
-    constexpr uint32_t C = kDupCap / 2;
-    // hit-window key of a segment; a segment of more than C / 2 hits stands alone (its key is its own), so a merged group holds at most
-    // C + C / 2 hits and never spills into the 1024-thread variant because of its last member
-    auto keyOf = [&](uint32_t seg) { const uint32_t st = segStart[seg], mm = segStart[seg + 1] - st; return mm > C / 2 ? 0x80000000u | seg : (st - qBase) / C; };
-    const uint32_t start = segStart[s];
-    const uint32_t keyH = keyOf(s), keyT = binFirst[b] / (uint32_t) kDupWindow;
-    if (b > 0 && keyOf(s - 1) == keyH && binFirst[b - 1] / (uint32_t) kDupWindow == keyT) return;      // not a head
-    uint32_t last = s;
-    while (last + 1 < (q + 1) * nBins && keyOf(last + 1) == keyH && binFirst[b + (last + 1 - s)] / (uint32_t) kDupWindow == keyT) last++;
-    const uint32_t m = segStart[last + 1] - start;
-    if (m == 0) return;
-    KmerGroup g;
-    g.s0 = start; g.m = m; g.seg = s; g.tBase = binFirst[b] & 0xffffu; g.T = binFirst[b + (last + 1 - s)] - binFirst[b];
-    g.q = q; g.hb = (uint32_t) qs[q].hitBase; g.nCh = chunks[q].nChunks;
-    const int cls = m <= (uint32_t) kDupSmall ? 0 : m <= (uint32_t) kDupCap ? 1 : m <= capLarge ? 2 : 3;
-    // one atomic per (wave, class): a hundred thousand single appends to one counter serialise in L2
-    const int lane = (int) (threadIdx.x & 63);
-    for (int c = 0; c < 4; c++) {
-        const unsigned long long mk = __ballot(cls == c);             // only the lanes that got here take part
-        if (cls != c || !mk) continue;
-        const int leader = __ffsll((long long) mk) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&L.counts[c], (uint32_t) __popcll(mk));
-        base = (uint32_t) __shfl((int) base, leader);
-        KmerGroup *dst = c == 0 ? L.small : c == 1 ? L.wg : c == 2 ? L.large : L.big;
-        dst[base + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))] = g;
-    }
-}
-
-struct KmerDupArgs {
+// The double-diagonal rule on a (query, chunk, key) run of the scatter's output: `tab` holds 16 bits per target of the key, two targets per
+// dword -- bits 0-7 / 8-15 the last 8-bit diagonal of the even / odd target, bits 16-23 / 24-31 how many hits of the CURRENT round fall on it.
+// A round = 256 consecutive hits, one per thread:
+//   A  every hit adds 1 to its target's counter (atomic add on the dword) and takes the diagonal byte out of the returned word -- no diagonal
+//      byte is written in this phase, so that IS the byte the round found;
+//   B  counter == 1: the hit is alone on its target this round.  Otherwise it joins the round's conflict list (target, thread, diagonal);
+//   C  a conflicting hit looks for the nearest earlier list member of its target (its predecessor: then that one's diagonal replaces the
+//      byte) and whether a later one exists; flag = diagonal equals the byte (findDuplicates: currDiagonal == prevDiagonal).  Every hit
+//      takes its count back and -- when it is the round's last hit of its target -- replaces the byte, in ONE atomic add of the difference
+//      (additions commute: whatever order the lanes are served in, the dword ends as count 0 + the new bytes; a counter that wraps in
+//      between -- 256 hits on one target, or a carry into the neighbour's counter -- only sends hits through the list, which is exact).
+// Flagged hits are staged in LDS and leave in blocks of 512 or more: one reservation in the batch's candidate array per block.
+struct KmerDupStream {
+    const uint32_t *recA; const uint16_t *ordA;
+    const uint32_t *offA, *colA, *segStart;
+    KmerTiles tl;
     const KmerQ *qs;
-    const KmerChunks *chunks;
-    const uint32_t *segStart;     // [nSeg + 1]
-    const uint32_t *binFirst;
-    uint32_t nBins;
-    uint64_t *part;               // in: the group's hits in any order; out: its candidates in (target, o) order at the group's start
-    uint32_t *segCand;            // [nSeg] candidates per group, at its head segment
-    uint64_t *gbucket;            // big groups: bucket array (same indexing as part)
-    uint32_t *gaux, *gaux2;       // big groups: sorted position | flag, flag prefix
+    const uint32_t *keyFirst;
+    uint32_t nKeys;
+    int tbits, gBits;
+    uint64_t *candKey; uint32_t *candVal; uint32_t candCap;
+    uint32_t *candCount;          // candidates of the batch (may run past candCap: the host then repeats the launch with a larger array)
+    uint32_t *ecCount;            // [nq][kMaxChunks] candidates per (query, chunk)
 };
-
-// chunk (databaseHits refill round) of stream position g: start[] ascending, start[0] = 0; binary search (LDS or registers' worth of loads)
-template <class T>
-__device__ inline uint32_t kmerChunkOf(const T *start, uint32_t nChunks, uint32_t g) {
-    uint32_t lo = 0, hi = nChunks;            // last c with start[c] <= g
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t) start[mid] <= g) lo = mid; else hi = mid; }
-    return lo;
-}
-
-// per-wave LDS copy of a query's chunk starts (stream positions relative to the query's first hit fit 32 bits: a batch has < 2^32 hits)
-__device__ inline void kmerStageChunks(uint32_t *cst, const KmerChunks &ck, uint32_t nCh, int lane) {
-    for (uint32_t i = (uint32_t) lane; i <= nCh; i += 64) cst[i] = (uint32_t) ck.start[i];
-}
-
-// groups of at most 64 hits: one wave, every hit looks at every other one through v_readlane
-__global__ __launch_bounds__(256) void k_kmer_dup_small(KmerDupArgs a, const KmerGroup *list, const uint32_t *countPtr) {
-    __shared__ uint32_t cstAll[4][kMaxChunks + 1];
-    const uint32_t n = *countPtr;
-    const int lane = threadIdx.x & 63;
-    uint32_t *cst = cstAll[threadIdx.x >> 6];
-    // everything that identifies the group is wave-uniform: keep it in SGPRs (scalar loop control, v_readlane indices)
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nWaves = gridDim.x * 4u;
-    uint32_t qStaged = 0xffffffffu;
-    for (uint32_t it = wave; it < n; it += nWaves) {
-        const KmerGroup &g = list[it];
-        const uint32_t seg = __builtin_amdgcn_readfirstlane(g.seg), s0 = __builtin_amdgcn_readfirstlane(g.s0), m = __builtin_amdgcn_readfirstlane(g.m);
-        const uint32_t q = __builtin_amdgcn_readfirstlane(g.q), hb = __builtin_amdgcn_readfirstlane(g.hb), nCh = __builtin_amdgcn_readfirstlane(g.nCh);
-        const KmerChunks &ck = a.chunks[q];
-        if (nCh > 1 && q != qStaged) { kmerStageChunks(cst, ck, nCh, lane); qStaged = q; }     // same wave writes and reads: no barrier needed
-        const bool live = (uint32_t) lane < m;
-        const uint64_t r = live ? a.part[s0 + lane] : ~0ull;
-        uint64_t pred = 0;
-        bool has = false;
-        for (uint32_t j = 0; j < m; j++) {
-            const uint64_t x = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (r >> 32), (int) j) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) r, (int) j);
-            if (live && x < r && (x >> 48) == (r >> 48)) { has = true; pred = x > pred ? x : pred; }
-        }
-        uint32_t prevD8 = 0;
-        if (has) {
-            bool same = true;
-            if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, partO(r) - hb); same = partO(pred) - hb >= cst[c]; }
-            if (same) prevD8 = partD8(pred);
-        }
-        const bool flag = live && partD8(r) == prevD8;
-        unsigned long long fm = __ballot(flag);
-        const uint32_t nc = (uint32_t) __popcll(fm);
-        uint32_t slot = 0;
-        while (fm) {
-            const int j = __ffsll((long long) fm) - 1;
-            fm &= fm - 1;
-            const uint64_t x = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (r >> 32), j) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) r, j);
-            slot += x < r ? 1u : 0u;
-        }
-        if (flag) a.part[s0 + slot] = r;      // every lane holds its record in a register: the group's range can be overwritten
-        if (lane == 0) a.segCand[seg] = nc;
-    }
-}
-
-// per-target counters of a group.  In LDS as 16-bit halves (a group resolved in LDS has fewer than 65536 hits; two counters per dword, the
-// atomic adds 1 << 16 for the odd one -- no carry can reach the neighbour), 32-bit for the global-scratch variant whose groups can be larger.
-template <bool WIDE> struct KmerCnt;
-template <> struct KmerCnt<false> {
-    typedef uint16_t T;
-    static __device__ __forceinline__ uint32_t add(T *a, uint32_t i) {        // returns the counter's value before the add
-        const uint32_t sh = (i & 1u) * 16u;
-        return (atomicAdd(reinterpret_cast<uint32_t *>(a) + (i >> 1), 1u << sh) >> sh) & 0xffffu;
-    }
-};
-template <> struct KmerCnt<true> {
-    typedef uint32_t T;
-    static __device__ __forceinline__ uint32_t add(T *a, uint32_t i) { return atomicAdd(a + i, 1u); }
-};
-
-// a group descriptor is the same for every lane: keep it in scalar registers
-__device__ __forceinline__ KmerGroup kmerLoadGroup(const KmerGroup *list, uint32_t i) {
-    const KmerGroup g = list[i];
-    KmerGroup s;
-    s.s0 = __builtin_amdgcn_readfirstlane(g.s0); s.m = __builtin_amdgcn_readfirstlane(g.m); s.seg = __builtin_amdgcn_readfirstlane(g.seg);
-    s.tBase = __builtin_amdgcn_readfirstlane(g.tBase); s.T = __builtin_amdgcn_readfirstlane(g.T); s.q = __builtin_amdgcn_readfirstlane(g.q);
-    s.hb = __builtin_amdgcn_readfirstlane(g.hb); s.nCh = __builtin_amdgcn_readfirstlane(g.nCh);
-    return s;
-}
-
-// one workgroup (NT threads) per group.  The hits are counted per target (LDS counters), the counters scanned into bucket starts, and
-// every hit gets its place in (target, stream position) order: bucket start + its rank among the bucket's stream positions.  The
-// predecessor of a hit (previous hit of the same target) is then the entry before it, and the double-diagonal rule one compare.
-// BIG = false: up to `cap` = NT * PER hits, read from global memory once.  LDS holds the entries grouped by target as two 32-bit arrays
-// (stream position; target | diagonal), filled through atomic cursors in any order inside a bucket; the rank loop reads the stream
-// positions only -- one 8-byte LDS read and two compare + add-with-carry per two bucket entries -- and the sorted stream positions
-// then replace the grouped ones.  The kernel is VALU-issue bound: what counts is instructions per hit.
-// BIG = true: any size, bucket / position arrays in global scratch, records re-read (the per-target counters stay in LDS).
-// The next group's descriptor is fetched while the current one is being resolved.
-template <bool BIG, int NT, int PER>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 8 : 4))) void k_kmer_dup_wg(KmerDupArgs a, const KmerGroup *list, const uint32_t *countPtr, uint32_t cap) {
-    typedef KmerCnt<BIG> Cnt;
-    typedef typename Cnt::T CT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char shDup[];
-    __shared__ uint32_t wsum[NT / 64];
-    __shared__ uint32_t needCnt;              // hits of the current group whose flag needs their databaseHits chunk
-    // byte offsets into the dynamic LDS block (plain pointer arithmetic on shDup: an integer round trip would turn every access below into
-    // a flat_* instruction -- address-space inference stops at ptrtoint -- and flat accesses to LDS go through the vector memory pipe)
-    constexpr uint32_t kCntBytes = (uint32_t) ((kDupCounters + 4) * sizeof(CT));
-    constexpr uint32_t kCstOff = 2 * kCntBytes, kBucketOff = (kCstOff + (kMaxChunks + 1) * 4 + 7) & ~7u;
-    CT *off = (CT *) shDup;                              // [kDupCounters + 4] bucket starts (off[t] .. off[t + 1])
-    CT *cur = (CT *) (shDup + kCntBytes);                // [kDupCounters + 4] scatter cursors
-    uint32_t *cst = (uint32_t *) (shDup + kCstOff);      // [kMaxChunks + 1] chunk starts of the query, stream positions relative to its first hit
-    uint32_t *ao = (uint32_t *) (shDup + kBucketOff);                        // [cap + 8] stream positions, grouped by target (any order inside a bucket)
-    uint32_t *so = ao;                                                       // ... and, once every rank is known, the same in sorted order
-    uint32_t *at = (uint32_t *) (shDup + kBucketOff + (cap + 8) * 4);        // [cap + 8] (target & 0xffff) << 16 | 16-bit diagonal of the grouped entry
-    uint8_t *sd = shDup + kBucketOff + (cap + 8) * 8;                        // [cap + 8] 8-bit diagonal at the sorted position
-    // [cap] flag at sorted position -> exclusive prefix.  The 256- / 512-thread variant keeps it in the scatter cursors' place (dead once the
-    // buckets are filled, and cap <= kDupCounters there): 36 KB per workgroup, four of them per CU
-    uint16_t *lpfx = (!BIG && NT <= 512) ? (uint16_t *) cur : (uint16_t *) (shDup + kBucketOff + (cap + 8) * 9 + ((cap + 8) & 1u));
-    const uint32_t n = *countPtr;
-    if (blockIdx.x >= n) return;
-    // software pipeline over the workgroup's groups: the descriptor is fetched two groups ahead and the records one group ahead, so the
-    // global round trips of group i + 1 run under the LDS phases of group i (a group is a dozen dependent LDS phases: latency, not issue,
-    // bounds the small variant)
-    KmerGroup g = kmerLoadGroup(list, blockIdx.x), gNext = g;
-    if (blockIdx.x + gridDim.x < n) gNext = kmerLoadGroup(list, blockIdx.x + gridDim.x);
-    uint64_t rNext[PER];
-    if (!BIG) {
-#pragma unroll
-        for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; rNext[u] = e < g.m ? a.part[g.s0 + e] : 0; }
-    }
-    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
-        const uint32_t seg = g.seg, s0 = g.s0, m = g.m, tBase = g.tBase, T = g.T, nCh = g.nCh, hb = g.hb;
-        const KmerChunks &ck = a.chunks[g.q];
-        uint64_t *gb = a.gbucket + s0;       // BIG only; the two variants index different address spaces, so no common pointer
-        uint64_t r[PER];
-#pragma unroll
-        for (int u = 0; u < PER; u++) r[u] = BIG ? 0 : rNext[u];
-        uint32_t cstv[(kMaxChunks + NT) / NT];
-#pragma unroll
-        for (int u = 0; u < (kMaxChunks + NT) / NT; u++) { const uint32_t i = threadIdx.x + NT * u; cstv[u] = i <= nCh ? (uint32_t) ck.start[i] : 0u; }
-        g = gNext;
-        if (!BIG && it + gridDim.x < n) {     // the next group's records (its range is disjoint from this group's: nothing below writes there)
-#pragma unroll
-            for (int u = 0; u < PER; u++) { const uint32_t e = threadIdx.x + NT * u; rNext[u] = e < g.m ? a.part[g.s0 + e] : 0; }
-        }
-        if (it + 2 * gridDim.x < n) gNext = kmerLoadGroup(list, it + 2 * gridDim.x);
-        if (threadIdx.x == 0) needCnt = 0;
-        for (uint32_t i = threadIdx.x; i < (T + 2) / 2 + 1; i += NT) {       // zero as dwords (both counter widths)
-            if (BIG) { off[2 * i] = 0; off[2 * i + 1] = 0; } else reinterpret_cast<uint32_t *>(off)[i] = 0;
-        }
-#pragma unroll
-        for (int u = 0; u < (kMaxChunks + NT) / NT; u++) { const uint32_t i = threadIdx.x + NT * u; if (i <= nCh) cst[i] = cstv[u]; }
+__global__ __launch_bounds__(kDupRound) void k_kmer_dup_stream(KmerDupStream a) {
+    extern __shared__ uint32_t tab[];         // [maxIds / 2 + 1]
+    __shared__ uint32_t clist[kDupRound];
+    __shared__ uint32_t stPos[kCandStage], stRec[kCandStage];
+    __shared__ uint32_t nConf, nStage, flushBase, unitCand;
+    const uint32_t vq = blockIdx.x / a.nKeys, A = blockIdx.x - vq * a.nKeys;
+    const uint32_t q = a.tl.vqQ[vq], chunk = a.tl.vqChunk[vq];
+    const uint32_t T0 = a.tl.vqTile0[vq], T1 = a.tl.vqTile0[vq + 1], qT0 = a.tl.qTile0[q], qT1 = a.tl.qTile0[q + 1];
+    if (T0 == T1) return;
+    const uint32_t segEnd = a.segStart[(size_t) q * a.nKeys + A + 1];
+    const uint32_t p0 = a.offA[(size_t) T0 * a.nKeys + A], p1 = T1 < qT1 ? a.offA[(size_t) T1 * a.nKeys + A] : segEnd;
+    if (p0 >= p1) return;
+    const uint32_t first = a.keyFirst[A], ids = a.keyFirst[A + 1] - first, lowFirst = first & 0xffffu;
+    for (uint32_t i = threadIdx.x; i < ids / 2 + 1; i += kDupRound) tab[i] = 0;
+    if (threadIdx.x == 0) { nConf = 0; nStage = 0; unitCand = 0; }
+    __syncthreads();
+    const uint32_t nTq = qT1 - qT0;
+    const uint32_t *col = a.colA + (size_t) qT0 * a.nKeys + (size_t) A * nTq;
+    const uint32_t hb = (uint32_t) a.qs[q].hitBase;
+    const uint64_t keyHi = ((uint64_t) q << a.tbits) | first;
+    auto flush = [&]() {                       // called by all threads, between barriers
+        const uint32_t n = nStage;
+        if (threadIdx.x == 0) { flushBase = atomicAdd(a.candCount, n); unitCand += n; }
         __syncthreads();
-        if (BIG) {
-            for (uint32_t e = threadIdx.x; e < m; e += NT) Cnt::add(off, partTloc(a.part[s0 + e]) - tBase + 1);
-        } else {
-#pragma unroll
-            for (int u = 0; u < PER; u++) if (threadIdx.x + NT * u < m) Cnt::add(off, partTloc(r[u]) - tBase + 1);
+        const uint32_t fb = flushBase;
+        for (uint32_t k = threadIdx.x; k < n; k += kDupRound) {
+            const uint32_t pos = stPos[k], rr = stRec[k];
+            uint32_t lo = T0 - qT0, hi = T1 - qT0;          // last tile of the chunk whose run starts at or before pos (empty runs share their start with the next one)
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (col[mid] <= pos) lo = mid; else hi = mid; }
+            const uint32_t g = a.tl.tileStart[qT0 + lo] + (uint32_t) a.ordA[pos] - hb;
+            const uint32_t dst = fb + k;
+            if (dst < a.candCap) {
+                a.candKey[dst] = ((keyHi + (rr >> 16)) << a.gBits) | g;
+                a.candVal[dst] = (rr & 0xffffu) | (chunk << 16);
+            }
         }
         __syncthreads();
-        kmerBlockScan<CT, true, NT>(off + 1, T, wsum);            // off[t + 1] = end of target t's bucket, off[0] = 0
-        for (uint32_t i = threadIdx.x; i < T; i += NT) cur[i] = off[i];
+        if (threadIdx.x == 0) nStage = 0;
         __syncthreads();
-        uint32_t nc;
-        if constexpr (BIG) {
-            for (uint32_t e = threadIdx.x; e < m; e += NT) { const uint64_t x = a.part[s0 + e]; gb[Cnt::add(cur, partTloc(x) - tBase)] = x; }
+    };
+    constexpr int R = 4;                      // rounds per load phase
+    for (uint32_t base = p0; base < p1; base += R * kDupRound) {
+        uint32_t rr[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) { const uint32_t pos = base + k * kDupRound + threadIdx.x; rr[k] = pos < p1 ? a.recA[pos] : 0u; }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t rbase = base + k * kDupRound;
+            if (rbase >= p1) break;            // uniform
+            const uint32_t pos = rbase + threadIdx.x;
+            const bool valid = pos < p1;
+            const uint32_t t = ((rr[k] >> 16) - lowFirst) & 0xffffu, d = rr[k] & 0xffu;
+            const uint32_t sh = (t & 1u) * 8u, inc = 0x10000u << sh, w = t >> 1;
+            uint32_t old = 0;
+            if (valid) old = (atomicAdd(&tab[w], inc) >> sh) & 0xffu;
             __syncthreads();
-            for (uint32_t p = threadIdx.x; p < m; p += NT) {
-                const uint64_t x0 = gb[p];
-                const uint32_t t = partTloc(x0) - tBase, lo = off[t], hi = off[t + 1];
-                uint64_t pred = 0;
-                uint32_t rank = 0;
-                for (uint32_t j = lo; j < hi; j++) { const uint64_t x = gb[j]; if (x < x0) { rank++; pred = x > pred ? x : pred; } }
-                uint32_t prevD8 = 0;
-                if (rank) {
-                    bool same = true;
-                    if (nCh > 1) { const uint32_t c = kmerChunkOf(cst, nCh, partO(x0) - hb); same = partO(pred) - hb >= cst[c]; }
-                    if (same) prevD8 = partD8(pred);
-                }
-                const uint32_t flag = partD8(x0) == prevD8 ? 1u : 0u, sp = lo + rank;
-                a.gaux[s0 + p] = sp | (flag << 31); a.gaux2[s0 + sp] = flag;
+            bool conflict = false;
+            if (valid) {
+                conflict = ((tab[w] >> (16u + sh)) & 0xffu) != 1u;
+                if (conflict) clist[atomicAdd(&nConf, 1u)] = (t << 16) | (threadIdx.x << 8) | d;
             }
             __syncthreads();
-            nc = kmerBlockScan<uint32_t, false, NT>(a.gaux2 + s0, m, wsum);
-            for (uint32_t p = threadIdx.x; p < m; p += NT) {
-                const uint32_t sx = a.gaux[s0 + p];
-                if (sx >> 31) a.part[s0 + a.gaux2[s0 + (sx & 0x7fffffffu)]] = gb[p];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < PER; u++)
-                if (threadIdx.x + NT * u < m) {
-                    const uint32_t pos = Cnt::add(cur, partTloc(r[u]) - tBase);
-                    ao[pos] = partO(r[u]); at[pos] = (uint32_t) (r[u] >> 32 & 0xffff0000u) | partD16(r[u]);
-                }
-            __syncthreads();
-            // from here on a thread works on the entries at bucket positions threadIdx.x + NT * u: neighbouring lanes sit in the same bucket,
-            // so the rank loops of a wave have (nearly) the same trip count and their LDS reads are broadcasts
-            uint32_t o0[PER], td[PER], sp[PER], blo[PER];
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                o0[u] = 0; td[u] = 0; sp[u] = 0; blo[u] = 0;
-                const uint32_t p = threadIdx.x + NT * u;
-                if (p < m) {
-                    o0[u] = ao[p]; td[u] = at[p];
-                    const uint32_t t = (td[u] >> 16) - tBase, lo = off[t], hi = off[t + 1], x = o0[u];
-                    // entries are read in aligned pairs from the even index at or below lo to the even index at or above hi; the (at most two)
-                    // entries outside [lo, hi) that this touches are taken out again afterwards
-                    const uint32_t hiE = (hi + 1) & ~1u;
-                    uint32_t j = lo & ~1u, rank = 0;
-                    for (; j + 8 <= hiE; j += 8) {
-                        const uint2 x0 = *reinterpret_cast<const uint2 *>(ao + j), x1 = *reinterpret_cast<const uint2 *>(ao + j + 2);
-                        const uint2 x2 = *reinterpret_cast<const uint2 *>(ao + j + 4), x3 = *reinterpret_cast<const uint2 *>(ao + j + 6);
-                        rank += (x0.x < x) + (x0.y < x) + (x1.x < x) + (x1.y < x) + (x2.x < x) + (x2.y < x) + (x3.x < x) + (x3.y < x);
+            if (valid) {
+                uint32_t prev = old;
+                bool writer = true;
+                if (conflict) {
+                    const uint32_t nC = nConf;
+                    int predI = -1;
+                    for (uint32_t x = 0; x < nC; x++) {
+                        const uint32_t e = clist[x];
+                        if ((e >> 16) != t) continue;
+                        const int ix = (int) ((e >> 8) & 0xffu);
+                        if (ix < (int) threadIdx.x && ix > predI) { predI = ix; prev = e & 0xffu; }
+                        if (ix > (int) threadIdx.x) writer = false;
                     }
-                    for (; j < hiE; j += 2) { const uint2 y = *reinterpret_cast<const uint2 *>(ao + j); rank += (y.x < x) + (y.y < x); }
-                    if (lo & 1u) rank -= ao[lo - 1] < x ? 1u : 0u;
-                    if (hi & 1u) rank -= ao[hi] < x ? 1u : 0u;
-                    sp[u] = lo + rank; blo[u] = lo;
                 }
-            }
-            __syncthreads();                  // every rank is known: the grouped stream positions can be overwritten by the sorted ones
-#pragma unroll
-            for (int u = 0; u < PER; u++)
-                if (threadIdx.x + NT * u < m) { so[sp[u]] = o0[u]; sd[sp[u]] = (uint8_t) td[u]; }
-            __syncthreads();
-            // The rule: a hit is flagged when its 8-bit diagonal equals that of its predecessor (previous hit of the target) if both lie in the same
-            // databaseHits chunk, and equals 0 otherwise.  With eq = "equals the predecessor's" and z = "is 0" the chunk only matters when eq != z --
-            // one hit in thirty -- and finding it is a binary search over the query's chunk starts, a third of this phase's instructions when every
-            // lane runs it.  Those hits are set aside (their sorted position + the two bits, in the dead target | diagonal array) and a few threads
-            // look their chunks up afterwards; everybody reads its flag back from the prefix array.
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                if (threadIdx.x + NT * u < m) {
-                    const bool has = sp[u] > blo[u];
-                    const uint32_t d8 = td[u] & 0xffu;
-                    const bool z = d8 == 0, eq = has && d8 == (uint32_t) sd[sp[u] - (has ? 1u : 0u)];
-                    uint32_t f;
-                    if (!has) f = z ? 1u : 0u;
-                    else if (nCh <= 1 || eq == z) f = eq ? 1u : 0u;
-                    else { f = 0; at[atomicAdd(&needCnt, 1u)] = sp[u] | (eq ? 1u << 30 : 0u) | (z ? 1u << 31 : 0u); }
-                    lpfx[sp[u]] = (uint16_t) f;
+                uint32_t delta = 0u - inc;
+                if (writer) delta += (d - old) << sh;
+                atomicAdd(&tab[w], delta);
+                if (prev == d) {
+                    const uint32_t slot = atomicAdd(&nStage, 1u);
+                    stPos[slot] = pos; stRec[slot] = (t << 16) | (rr[k] & 0xffffu);
                 }
             }
             __syncthreads();
-            if (nCh > 1) {
-                const uint32_t nNeed = needCnt;
-                for (uint32_t k = threadIdx.x; k < nNeed; k += NT) {
-                    const uint32_t e = at[k], spk = e & 0x3fffffffu;
-                    const uint32_t c = kmerChunkOf(cst, nCh, so[spk] - hb);
-                    const bool same = so[spk - 1] - hb >= cst[c];
-                    if (same ? (e >> 30) & 1u : e >> 31) lpfx[spk] = 1;
-                }
-                __syncthreads();
-            }
-            nc = kmerBlockScan<uint16_t, false, NT>(lpfx, m, wsum);
-#pragma unroll
-            for (int u = 0; u < PER; u++)
-                if (threadIdx.x + NT * u < m) {
-                    const uint32_t at0 = lpfx[sp[u]], at1 = sp[u] + 1 < m ? (uint32_t) lpfx[sp[u] + 1] : nc;
-                    if (at1 != at0) a.part[s0 + at0] = partPack(td[u] >> 16, o0[u], td[u] & 0xffffu);   // the group's range can be overwritten: it was read into registers
-                }
+            if (threadIdx.x == 0) nConf = 0;   // (the next append follows the next round's first barrier)
+            if (nStage >= 2 * kDupRound) flush();
         }
-        if (threadIdx.x == 0) a.segCand[seg] = nc;
-        __syncthreads();                      // LDS arrays are reused by the next group
     }
+    if (nStage) flush();
+    if (threadIdx.x == 0 && unitCand) atomicAdd(&a.ecCount[(size_t) q * kMaxChunks + chunk], unitCand);
 }
 
-// groups that produced candidates, in segment order (flag -> exclusive scan -> list), so that neighbouring list entries belong to one query
-__global__ void k_kmer_candflags(const uint32_t *segCand, uint32_t nSeg, uint32_t *flags) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s <= nSeg) flags[s] = s < nSeg && segCand[s] ? 1u : 0u;
-}
-__global__ void k_kmer_candlist(const uint32_t *segCand, const uint32_t *flagScan, uint32_t nSeg, uint32_t *list, uint32_t *count) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nSeg && segCand[s]) list[flagScan[s]] = s;
-    if (s == nSeg) *count = flagScan[nSeg];
-}
-
-// candidates of a group (already in (target, o) order) -> the candidate arrays of the scoring / replay stages at candBase[head segment]:
-// key = query << tbits | target, value = (g, 16-bit diagonal, chunk); per-(query, chunk) candidate counts for the host's
-// findDuplicates capacity test, collected in LDS for the workgroup's first query (64 consecutive list entries per workgroup).
-__global__ __launch_bounds__(256) void k_kmer_expand(KmerDupArgs a, const uint32_t *candBase, const uint32_t *list, const uint32_t *countPtr, int tbits,
-                                                     uint32_t *ckeys, uint64_t *cvals, uint32_t *ecCount /*[nq][kMaxChunks]*/) {
-    __shared__ uint32_t cstAll[4][kMaxChunks + 1];
-    __shared__ uint32_t h[kMaxChunks];
-    __shared__ uint32_t q0s;
-    const uint32_t n = *countPtr;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *cst = cstAll[wv];
-    for (uint32_t blk = blockIdx.x; blk * 64u < n; blk += gridDim.x) {
-        const uint32_t i0 = blk * 64u, i1 = min(n, i0 + 64u);
-        h[threadIdx.x] = 0;
-        if (threadIdx.x == 0) q0s = list[i0] / a.nBins;
-        __syncthreads();
-        const uint32_t q0 = q0s;
-        uint32_t qStaged = 0xffffffffu;
-        for (uint32_t it = i0 + wv; it < i1; it += 4) {
-            const uint32_t seg = __builtin_amdgcn_readfirstlane(list[it]);
-            const uint32_t s0 = __builtin_amdgcn_readfirstlane(a.segStart[seg]), nc = __builtin_amdgcn_readfirstlane(a.segCand[seg]), cb = __builtin_amdgcn_readfirstlane(candBase[seg]);
-            const uint32_t q = seg / a.nBins, b = seg - q * a.nBins;
-            const uint32_t tBlock = a.binFirst[b] & ~0xffffu;
-            const KmerChunks &ck = a.chunks[q];
-            const uint32_t nCh = __builtin_amdgcn_readfirstlane(ck.nChunks);
-            const uint32_t hb = (uint32_t) a.qs[q].hitBase;
-            if (nCh > 1 && q != qStaged) { kmerStageChunks(cst, ck, nCh, lane); qStaged = q; }
-            for (uint32_t k0 = 0; k0 < nc; k0 += 64) {
-                const uint32_t k = k0 + lane;
-                const bool live = k < nc;
-                uint32_t c = 0;
-                if (live) {
-                    const uint64_t r = a.part[s0 + k];
-                    const uint32_t g = partO(r) - hb;
-                    c = nCh > 1 ? kmerChunkOf(cst, nCh, g) : 0u;
-                    ckeys[cb + k] = (q << tbits) | (tBlock + partTloc(r));
-                    cvals[cb + k] = hitPack(g, partD16(r), c);
-                }
-                // one atomic per (wave, chunk): same-address atomics serialise
-                unsigned long long pending = __ballot(live);
-                while (pending) {
-                    const int leader = __ffsll((long long) pending) - 1;
-                    const uint32_t cl = (uint32_t) __shfl((int) c, leader);
-                    const unsigned long long grp = __ballot(live && c == cl);
-                    if (lane == leader) {
-                        if (q == q0) atomicAdd(&h[cl], (uint32_t) __popcll(grp));
-                        else atomicAdd(&ecCount[(size_t) q * kMaxChunks + cl], (uint32_t) __popcll(grp));
-                    }
-                    pending &= ~grp;
-                }
-            }
-        }
-        __syncthreads();
-        if (h[threadIdx.x]) atomicAdd(&ecCount[(size_t) q0 * kMaxChunks + threadIdx.x], h[threadIdx.x]);
-        __syncthreads();
-    }
+// sorted (query | target | stream position, diagonal | chunk) pairs -> the candidate arrays of the scoring / replay stages
+__global__ void k_kmer_cand_unpack(const uint64_t *key, const uint32_t *val, uint32_t n, int gBits, uint32_t *ckeys, uint64_t *cvals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    const uint32_t v = val[i];
+    ckeys[i] = (uint32_t) (k >> gBits);
+    cvals[i] = hitPack(k & ((1ull << gBits) - 1ull), v & 0xffffu, v >> 16);
 }
 
 // findDuplicates pass 2 (collapse runs of equal 8-bit diagonals among the candidates of one target and chunk) fused

@@ -342,14 +342,16 @@ void fsgpu_kmer_last_counts(const fsgpu_ctx *ctx, uint64_t *out4);
  * the index hits per query the previous call saw.  A low-sensitivity prefilter (clustering: ~10^4 hits per query) needs hundreds of queries
  * per batch to fill the device, the sensitive search default (~10^7 hits per query at 1M targets) fills it with 32. */
 int fsgpu_kmer_batch_hint(const fsgpu_ctx *ctx);
-/* Segment accounting of the last batch's hit-stream partition: [0] (query, bin) segments resolved by one wave (<= 64 hits), [1] in a
- * workgroup's LDS, [2] through global scratch (larger than the LDS capacity), [3] groups with candidates, [4] all segments, [5] bins,
- * [6] of [1]: those that needed the 1024-thread variant.  [0..3] count GROUPS of consecutive segments (k_kmer_groups). */
+/* Accounting of the last batch's hit-stream partition (round 6: one order-preserving scatter into (query, key) runs, a key = a run of blocks
+ * of 1024 target ids): [1] = [4] (query, databaseHits chunk, key) runs walked by the duplicate stage, [3] tiles of the scatter, [5] coarse keys
+ * of the level the batch used, [6] target ids of its widest key (16 bits of LDS each in k_kmer_dup_stream); [0] = [2] = 0. */
 void fsgpu_kmer_last_segments(const fsgpu_ctx *ctx, uint32_t *out7);
-/* The target bins of that partition (host-only planning, also used by the index build): every block of 1024 target ids is cut into 2^k equal
- * id ranges so that a bin's share of the block's residues stays at or below resCap; bin(t) = (blk[t >> 10] >> 8) + ((t & 1023) >> (blk[t >> 10] & 255)).
- * Fills blk[ceil(n / 1024)] / binFirst[bins + 1] (either may be NULL) and returns the number of bins, or FSGPU_E_ARG when cap is too small. */
-int fsgpu_kmer_plan_bins(const int32_t *lengths, uint64_t n, uint64_t resCap, uint32_t *blk, uint32_t *binFirst, uint32_t cap);
+/* The coarse keys of that partition (host-only planning, also used by the index build): consecutive blocks of 1024 target ids joined into keys.
+ * blocksPerKey = 1..64: that many blocks per key; 0: about 128 keys of equal residue count, none longer than twice the average number of blocks
+ * nor than 64.  key(t) = blkKey[t >> 10]; keyFirst[key] .. keyFirst[key + 1] are its target ids (at most 65536: the low 16 bits of an id are unique
+ * inside a key).  Fills blkKey[max(1, ceil(n / 1024))] / keyFirst[keys + 1] (either may be NULL) and returns the number of keys (<= 512 up to
+ * 33.5 M targets), or FSGPU_E_ARG when cap is too small. */
+int fsgpu_kmer_plan_coarse(const int32_t *lengths, uint64_t n, uint32_t blocksPerKey, uint16_t *blkKey, uint32_t *keyFirst, uint32_t cap);
 
 /* ---- instrumentation -------------------------------------------------------------------------------------- */
 /* Device time (ms, HIP events on the context stream) of the dominant kernel of the last _finish()ed call:

@@ -209,15 +209,16 @@ def test_bench_usable_cores():
         assert n <= len(os.sched_getaffinity(0))
 
 
-def test_kmer_bin_table_planner():
-    """fsgpu_kmer_plan_bins (host only): the arithmetic target-bin table of the k-mer hit-stream partition.  Invariants: bin(t) =
-    (blk[t >> 10] >> 8) + ((t & 1023) >> (blk[t >> 10] & 255)) is monotone in t, maps every target into [0, bins), binFirst is its inverse,
-    every block of 1024 ids is cut into equal power-of-two id ranges of at least 8 ids, and a block is only cut finer while a bin's
-    share of the block's residues exceeds resCap"""
+def test_kmer_coarse_key_planner():
+    """fsgpu_kmer_plan_coarse (host only): the coarse keys of the k-mer hit-stream partition.  Invariants: key(t) = blkKey[t >> 10] is monotone in t and
+    maps every target into [0, keys), keyFirst is its inverse, a key is a run of whole blocks of 1024 ids, at most 64 of them (the low 16 bits of an id
+    are unique inside a key), at most 512 keys; with blocksPerKey > 0 every key but the last holds exactly that many blocks; the balanced plan (0) aims at
+    128 keys of equal residue count: a key is only closed early because the next block would take it beyond a 128th of the residues, or at twice the
+    average number of blocks"""
     L = api.lib()
     rng = np.random.default_rng(21)
     for trial in range(30):
-        n = int(rng.integers(1, 40000))
+        n = int(rng.integers(1, 400000)) if trial % 5 else int(rng.integers(1, 3000))
         kind = trial % 3
         if kind == 0:
             lens = np.clip(np.rint(rng.gamma(2.0, 175.0, size=n)), 1, 3000).astype(np.int32)
@@ -225,23 +226,33 @@ def test_kmer_bin_table_planner():
             lens = np.sort(np.clip(np.rint(rng.gamma(2.0, 175.0, size=n)), 1, 3000).astype(np.int32))[::-1].copy()      # length-sorted DB
         else:
             lens = np.full(n, int(rng.integers(1, 2000)), np.int32)
-        res_cap = int(rng.choice([500, 5000, 40000, 10**7]))
-        nblk = (n + 1023) // 1024
-        blk = np.zeros(nblk, np.uint32)
-        cap = nblk * 128 + 2
-        first = np.zeros(cap, np.uint32)
-        bins = L.fsgpu_kmer_plan_bins(lens.ctypes.data, n, res_cap, blk.ctypes.data, first.ctypes.data, cap)
-        assert bins >= nblk and bins <= nblk * 128
-        assert L.fsgpu_kmer_plan_bins(lens.ctypes.data, n, res_cap, None, None, cap) == bins           # sizes only
-        assert L.fsgpu_kmer_plan_bins(lens.ctypes.data, n, res_cap, blk.ctypes.data, first.ctypes.data, bins) < 0   # cap too small: bins + 1 needed
-        t = np.arange(n, dtype=np.int64)
-        shift = (blk[t >> 10] & 255).astype(np.int64)
-        b = (blk[t >> 10] >> 8).astype(np.int64) + ((t & 1023) >> shift)
-        assert b[0] == 0 and (np.diff(b) >= 0).all() and (np.diff(b) <= 1).all() and b[-1] == bins - 1
-        assert first[bins] == n and (first[b] <= t).all() and (t < first[b + 1]).all()
-        assert ((blk & 255) >= 3).all() and ((blk & 255) <= 10).all()
-        for k in range(nblk):
-            sh = int(blk[k] & 255)
-            res = int(lens[k * 1024:(k + 1) * 1024].sum())
-            assert sh == 3 or (res >> (10 - sh)) <= res_cap                       # fine enough, or at the finest cut
-            assert sh == 10 or (res >> (10 - (sh + 1))) > res_cap                 # not finer than needed
+        nblk = max(1, (n + 1023) // 1024)
+        for bpk in (0, 1, 2, 16, 64):
+            blk = np.zeros(nblk, np.uint16)
+            cap = nblk + 2
+            first = np.zeros(cap, np.uint32)
+            keys = L.fsgpu_kmer_plan_coarse(lens.ctypes.data, n, bpk, blk.ctypes.data, first.ctypes.data, cap)
+            assert 1 <= keys <= min(nblk, 512), (n, bpk, keys)
+            assert L.fsgpu_kmer_plan_coarse(lens.ctypes.data, n, bpk, None, None, cap) == keys           # sizes only
+            assert L.fsgpu_kmer_plan_coarse(lens.ctypes.data, n, bpk, blk.ctypes.data, first.ctypes.data, keys) < 0   # cap too small: keys + 1 needed
+            t = np.arange(n, dtype=np.int64)
+            k = blk[t >> 10].astype(np.int64)
+            assert k[0] == 0 and (np.diff(k) >= 0).all() and (np.diff(k) <= 1).all() and k[-1] == keys - 1
+            assert first[0] == 0 and first[keys] == n and (first[k] <= t).all() and (t < first[k + 1]).all()
+            assert (first[:keys] % 1024 == 0).all()
+            blocks = np.bincount(blk.astype(np.int64), minlength=keys)
+            assert blocks.min() >= 1 and blocks.max() <= 64 and (np.diff(first[:keys + 1].astype(np.int64)) <= 65536).all()
+            if bpk:
+                assert (blocks[:-1] == bpk).all() and blocks[-1] <= bpk
+            else:
+                res = np.add.reduceat(lens.astype(np.int64), np.arange(0, n, 1024))
+                target = max(1, -(-int(lens.sum()) // 128))
+                capb = min(64, max(1, 2 * -(-nblk // 128)))
+                assert blocks.max() <= capb
+                kres = np.bincount(blk.astype(np.int64), weights=res, minlength=keys)
+                for j in range(keys - 1):           # closed because full, or because the next block did not fit
+                    nxt = int(res[int(first[j + 1]) >> 10])
+                    assert blocks[j] == capb or kres[j] + nxt > target, (j, blocks[j], kres[j], nxt, target)
+                assert (kres[blocks > 1] <= target).all()                                  # only a single over-long block exceeds the target
+    assert L.fsgpu_kmer_plan_coarse(None, 0, 0, None, None, 4) == 1                        # an empty database still has one (empty) key
+    assert L.fsgpu_kmer_plan_coarse(lens.ctypes.data, n, 65, None, None, 4) < 0

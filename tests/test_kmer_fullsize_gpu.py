@@ -125,10 +125,10 @@ def test_equals_compiled_reference_at_1M_targets():
 
 
 def test_equals_compiled_reference_beyond_16M_targets():
-    """More targets than the hit-stream partition took until round 5 (16.4 M: one LDS counter per bin, a block of 1024 target ids is at least one bin): 17 M
+    """More targets than the hit-stream partition took until round 5 (16.4 M): 17 M
     short structures (30 .. 64 residues, 0.6 G residues; 25 id bits, so a device batch holds 128 queries and the index entries stay 4 bytes), four
     queries with planted homologs against the compiled reference's QueryMatcher over the same sequences.  The limit that remains is 33.5 M targets
-    (512 coarse bins of at most 65536 ids) and 2^32 residues (k = 6), include/fsgpu.h."""
+    (512 coarse keys of at most 65536 ids) and 2^32 residues (k = 6), include/fsgpu.h."""
     R = K.load_ref()
     if R is None:
         pytest.skip("oracle/_ref not built")
@@ -145,7 +145,7 @@ def test_equals_compiled_reference_beyond_16M_targets():
     ident[2] = 16999999
     res, status, stats = ctx.kmer_search(prep, identity=ident, max_res=1000, l2_cache_size=l2, want_stats=True)
     assert (status >= 0).all()
-    assert ctx.kmer_segments()[5] > 16000                                 # more bins than the old LDS limit
+    assert ctx.kmer_segments()[5] >= 17000000 // 65536                     # coarse keys hold at most 64 blocks of 1024 ids
     r = K.RefKpf.from_padded(R, db, threads=16)
     rr, rs, _ = r.run(q3, ident, threads=4)
     r.close()

@@ -97,33 +97,29 @@ def test_hit_lists(world, kw):
 
 @pytest.mark.parametrize("kw", [dict(), dict(maxResListLen=300, maxDbMatches=5000, foundDiagonalsSize=40000)])
 def test_every_bin_level_gives_the_same_hits(world, kw, monkeypatch):
-    """the hit-stream partition may use any granularity of target bins (and groups the segments it gets): fine levels leave groups of a few
-    hits to single waves, coarse ones fill the LDS variants, and with the 1024-thread variant switched off the largest groups go through the
-    global-scratch path of k_kmer_dup_wg<true>; results (incl. the databaseHits refill rounds of the second parameter set) do not depend on it"""
+    """the hit-stream partition may cut the targets into coarse keys of any granularity (the residue-balanced default, or 1 / 2 / 4 ... blocks of
+    1024 ids per key): the (query, chunk, key) runs change, the hits do not (incl. the databaseHits refill rounds of the second parameter set)"""
     o, q3, ctx = world["o"], world["q3"], world["ctx"]
     base = dict(maxResListLen=1000, bins=0, maxDbMatches=0, foundDiagonalsSize=0, compBias=1, minDiagScoreThr=30)
     base.update(kw)
     o.set(**base)
-    qs = list(q3) + [q3[0][:11], q3[1][5:18]]          # two queries of 2 and 4 k-mer positions: a few dozen hits, groups one wave resolves
+    qs = list(q3) + [q3[0][:11], q3[1][5:18]]          # two queries of 2 and 4 k-mer positions: a few dozen hits
     orr, _ = o.run(qs, None)
     seen = set()
-    for level in (0, 1, 2, 3, 4, 99, 100):
+    for level in (0, 1, 2, 3, 4, 99):
         monkeypatch.setenv("FSGPU_KMER_BIN_LEVEL", str(level))
-        if level == 100:                                  # coarsest level again, 1024-thread LDS variant switched off: larger groups take the global-scratch path
-            monkeypatch.setenv("FSGPU_KMER_CAP_LARGE", "0")
         res, status, _ = run_gpu(world, kw, qs, None)
         seg = ctx.kmer_segments()
-        assert seg[0] + seg[1] + seg[2] <= seg[4] == len(qs) * seg[5] and seg[3] <= seg[0] + seg[1] + seg[2]
-        seen.update(i for i in range(3) if seg[i] > 0)
+        assert seg[1] == seg[4] and seg[4] % seg[5] == 0 and seg[4] // seg[5] >= len(qs) and 1 <= seg[6] <= 65536, seg
+        seen.add(int(seg[5]))
         for q in range(len(qs)):
             assert status[q] == 0 and len(res[q]) == len(orr[q]) and (res[q] == orr[q]).all(), (level, q, seg)
     monkeypatch.delenv("FSGPU_KMER_BIN_LEVEL")
-    monkeypatch.delenv("FSGPU_KMER_CAP_LARGE")
-    assert {1, 2} <= seen, seen               # LDS and global-scratch groups occurred (one-wave groups: test_tiny_database_one_wave_groups)
+    assert len(seen) >= 2, seen               # more than one granularity occurred
 
 
-def test_tiny_database_one_wave_groups():
-    """60 short targets, short queries: a query's hits number a few dozen, every group of segments is resolved by one wave (k_kmer_dup_small)"""
+def test_tiny_database_one_key_one_round():
+    """60 short targets, short queries: a query's hits number a few dozen -- one coarse key, one tile and one round of k_kmer_dup_stream per query"""
     O = K.load_ora()
     q3, qa = synth.make_queries(5, seed=11, mean_len=30, lo=12, hi=40)
     db = synth.make_db(60, (q3, qa), seed=12, homologs_per_query=3, mean_len=40, lo=12, hi=80)
@@ -138,7 +134,7 @@ def test_tiny_database_one_wave_groups():
     prep = [api.kmer_query_prepare(m8, m2, q, kmer_thr=100) for q in q3]
     res, status = ctx.kmer_search(prep, max_res=20, min_diag=15, l2_cache_size=2 << 20)
     seg = ctx.kmer_segments()
-    assert seg[0] > 0 and seg[1] == seg[2] == 0, seg
+    assert seg[5] == 1 and seg[4] == len(q3) and seg[3] <= len(q3) and seg[6] == 60, seg
     want, _ = o.run(q3, None)
     for q in range(len(q3)):
         assert status[q] == 0 and len(res[q]) == len(want[q]) and (res[q] == want[q]).all(), q
@@ -154,7 +150,7 @@ def test_large_batches_equal_small_ones(world):
     qs = [q3[i % NQ][: len(q3[i % NQ]) - (i // NQ) % 5] for i in range(150)]
     ident = np.array([(-1 if i % 3 else (i * 7) % N) for i in range(150)], np.int64)
     big, st_big, _ = run_gpu(world, dict(maxResListLen=200), qs, ident)
-    assert world["ctx"].kmer_segments()[4] == 150 * world["ctx"].kmer_segments()[5]
+    assert world["ctx"].kmer_segments()[4] >= 150 * world["ctx"].kmer_segments()[5]              # every query in ONE device batch (runs = (query, chunk) pairs x keys)
     for b in range(0, 150, 7):
         small, st, _ = run_gpu(world, dict(maxResListLen=200), qs[b:b + 7], ident[b:b + 7])
         for k in range(len(small)):

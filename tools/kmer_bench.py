@@ -18,7 +18,7 @@ for rep in range(REPS):
         stages += np.array(ctx.kmer_stage_ms()); hits += stats[:, 1].sum(); counts += np.array(ctx.kmer_counts(), dtype=np.float64)
         assert (status >= 0).all()
     dt = time.time() - t
-    print("segments of the last batch [wave, LDS, global, with candidates, all, bins, of LDS: 1024-thread]:", ctx.kmer_segments() if hasattr(ctx, "kmer_segments") else None)
+    print("partition of the last batch [-, runs, -, tiles, runs, coarse keys, ids of the widest key]:", ctx.kmer_segments() if hasattr(ctx, "kmer_segments") else None)
     print("rep %d: %.3f ms/query wall, device %.3f ms/query; stage ms/query %s; hits/query %.0f; prefilter residues/s %.3e" % (
         rep, dt / NQ * 1e3, stages[0] / NQ, ["%.3f" % (x / NQ) for x in stages[1:]], hits / NQ, NQ * db.residues / dt), flush=True)
     print("COUNTS " + __import__("json").dumps({"targets": N, "queries": NQ, "similar_kmers": counts[0], "index_hits": counts[1], "candidates": counts[2],

@@ -1,17 +1,17 @@
 #!/bin/bash
-# Round-5 evidence (counters never combined with tracing, MI355X_MICROARCH.md):
-#   r05_profile.sh emu TAG    bench.py --emulate-rank-share 8, weak and strong scaling: what ONE rank of an 8-rank node runs, on one GPU with that rank's 2 cores
-#   r05_profile.sh pmc TAG    separate --pmc passes over a short bench run (k_gapless, k_sw3), over ONE k-mer prefilter batch of 32 queries at 1M
+# Round-6 evidence (counters never combined with tracing, MI355X_MICROARCH.md):
+#   r06_profile.sh emu TAG    bench.py --emulate-rank-share 8, weak and strong scaling: what ONE rank of an 8-rank node runs, on one GPU with that rank's 2 cores
+#   r06_profile.sh pmc TAG    separate --pmc passes over a short bench run (k_gapless, k_sw3), over ONE k-mer prefilter batch of 32 queries at 1M
 #                             targets, and over a short all-vs-all run (configs[4], 200k family DB)
-#   r05_profile.sh bench TAG  default bench line, rocprofv3 kernel traces of the default command and of three k-mer batches
-# Output: gpurun_out/r05_prof/.  tools/pmc_to_traffic.py turns the pmc files into profiles/pmc_traffic*.json.
+#   r06_profile.sh bench TAG  default bench line, rocprofv3 kernel traces of the default command and of three k-mer batches
+# Output: gpurun_out/r06_prof/.  tools/pmc_to_traffic.py turns the pmc files into profiles/pmc_traffic*.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r05_prof
+O=$R/gpurun_out/r06_prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-bench}
 TAG=${2:-x}
-#   r05_profile.sh pmck TAG   the k-mer and all-vs-all passes of `pmc` alone (the scan kernel's sources did not change: its pass of tag PREV=... is reused)
+#   r06_profile.sh pmck TAG   the k-mer and all-vs-all passes of `pmc` alone (the scan kernel's sources did not change: its pass of tag PREV=... is reused)
 if [ "$MODE" = emu ]; then
 python $R/bench.py --emulate-rank-share 8 --scaling weak > $O/${TAG}_bench_emulate_rank_share8_weak.json 2> $O/${TAG}_emu_weak.err
 python $R/bench.py --emulate-rank-share 8 --scaling strong --steps 20 > $O/${TAG}_bench_emulate_rank_share8_strong.json 2> $O/${TAG}_emu_strong.err
