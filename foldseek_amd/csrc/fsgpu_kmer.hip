@@ -90,7 +90,7 @@ extern "C" int fsgpu_kmer_plan_coarse(const int32_t *lengths, uint64_t n, uint32
 
 struct KmerScratch {
     DevBuf qs, posQuery, seqs, thrs, profiles, K, Kbase, listStart, listSize, listPos, listP, chunks,
-           rec, recKey, recA, ordA, tileL, cntA, colA, grpSum, segCnt, segStart, tiles, candKey, candVal, candKey2, candVal2, candCount, ckeys, cvals, kept, score, scrA, scrB, best,
+           rec, recKey, recA, ordA, tileL, cntA, colA, grpSum, segCnt, segStart, tiles, candKey, candVal, candCount, ckeys, cvals, kept, score, scrA, scrB, best,
            ec, rounds, resSize, hist, thr, outCount, out, tmp, nCand, kept0, qSlot, truncHist, trunc;
     PinBuf hQs, hPosQuery, hSeqs, hThrs, hProfiles, hChunks, hEc, hRounds, hResSize, hThr, hOutCount, hOut, hMisc, hTiles;
     hipEvent_t ev[14] = {};
@@ -101,7 +101,7 @@ void fsgpu_kmer_free_scratch(KmerScratch *s) {
     if (!s) return;
     DevBuf *d[] = {&s->qs, &s->posQuery, &s->seqs, &s->thrs, &s->profiles, &s->K, &s->Kbase, &s->listStart, &s->listSize, &s->listPos, &s->listP,
                    &s->chunks, &s->rec, &s->recKey, &s->recA, &s->ordA, &s->tileL, &s->cntA, &s->colA, &s->grpSum, &s->segCnt, &s->segStart, &s->tiles,
-                   &s->candKey, &s->candVal, &s->candKey2, &s->candVal2, &s->candCount, &s->ckeys, &s->cvals, &s->kept, &s->score,
+                   &s->candKey, &s->candVal, &s->candCount, &s->ckeys, &s->cvals, &s->kept, &s->score,
                    &s->scrA, &s->scrB, &s->best, &s->ec, &s->rounds, &s->resSize, &s->hist, &s->thr, &s->outCount, &s->out, &s->tmp, &s->nCand,
                    &s->kept0, &s->qSlot, &s->truncHist, &s->trunc};
     for (DevBuf *b : d) if (b->p) (void) hipFree(b->p);
@@ -691,37 +691,38 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     if (nHits) {
         // tiles: every databaseHits chunk of every query is cut into tiles of kTileA consecutive hits (the chunk starts came back with the lists)
         uint32_t nVq = 0, nT = 0;
-        uint64_t maxQ = 0;
         for (int q = 0; q < nq; q++) {
             nVq += hck[q].nChunks;
             for (uint32_t c = 0; c < hck[q].nChunks; c++) nT += (uint32_t) ((hck[q].start[c + 1] - hck[q].start[c] + kTileA - 1) / kTileA);
-            maxQ = std::max<uint64_t>(maxQ, hck[q].total);
         }
-        // [tileStart nT+1 | qTile0 nq+1 | vqTile0 nVq+1] as u32, then [vqQ nVq | vqChunk nVq] as u16
-        const size_t tilesWords = (size_t) nT + 1 + nq + 1 + nVq + 1, tilesBytes = tilesWords * sizeof(uint32_t) + (size_t) nVq * 2 * sizeof(uint16_t);
+        // [tileStart nT+1 | qTile0 nq+1 | vqTile0 nVq+1 | qVq0 nq+1] as u32, then [vqQ nVq] as u16
+        const size_t tilesWords = (size_t) nT + 1 + nq + 1 + nVq + 1 + nq + 1, tilesBytes = tilesWords * sizeof(uint32_t) + (size_t) nVq * sizeof(uint16_t);
         CHK(ensurePinned(ctx, S.hTiles, tilesBytes));
         CHK(ensureK(ctx, S.tiles, tilesBytes));
         {
-            uint32_t *tileStart = (uint32_t *) S.hTiles.p, *qTile0 = tileStart + nT + 1, *vqTile0 = qTile0 + nq + 1;
-            uint16_t *vqQ = (uint16_t *) (vqTile0 + nVq + 1), *vqChunk = vqQ + nVq;
+            uint32_t *tileStart = (uint32_t *) S.hTiles.p, *qTile0 = tileStart + nT + 1, *vqTile0 = qTile0 + nq + 1, *qVq0 = vqTile0 + nVq + 1;
+            uint16_t *vqQ = (uint16_t *) (qVq0 + nq + 1);
             uint32_t T = 0, v = 0;
             for (int q = 0; q < nq; q++) {
-                qTile0[q] = T;
+                qTile0[q] = T; qVq0[q] = v;
                 for (uint32_t c = 0; c < hck[q].nChunks; c++, v++) {
-                    vqTile0[v] = T; vqQ[v] = (uint16_t) q; vqChunk[v] = (uint16_t) c;
+                    vqTile0[v] = T; vqQ[v] = (uint16_t) q;
                     for (uint64_t o = hck[q].start[c]; o < hck[q].start[c + 1]; o += kTileA) tileStart[T++] = (uint32_t) (hq[q].hitBase + o);
                 }
             }
-            qTile0[nq] = T; vqTile0[nVq] = T; tileStart[T] = (uint32_t) nHits;
+            qTile0[nq] = T; qVq0[nq] = v; vqTile0[nVq] = T; tileStart[T] = (uint32_t) nHits;
             if (T != nT || v != nVq) { ctx->err = "k-mer search: inconsistent tile table"; return FSGPU_E_HIP; }
         }
         RPCHK(hipMemcpyAsync(S.tiles.p, S.hTiles.p, tilesBytes, hipMemcpyHostToDevice, st));
         KmerTiles tl{};
         tl.tileStart = (const uint32_t *) S.tiles.p; tl.qTile0 = tl.tileStart + nT + 1; tl.vqTile0 = tl.qTile0 + nq + 1;
-        tl.vqQ = (const uint16_t *) (tl.vqTile0 + nVq + 1); tl.vqChunk = tl.vqQ + nVq; tl.nT = nT; tl.nVq = nVq;
-        // granularity of the coarse keys: levels[0] (about 128 residue-balanced keys) unless its (query, chunk, key) runs would average fewer than
-        // 1024 hits -- the many-queries-few-hits batches of an all-vs-all search -- then the coarsest level of at most 16 blocks per key
-        const KmerIndex::CoarseLevel *lv = &ix.levels.front();
+        tl.qVq0 = tl.vqTile0 + nVq + 1; tl.vqQ = (const uint16_t *) (tl.qVq0 + nq + 1); tl.nT = nT; tl.nVq = nVq;
+        // granularity of the coarse keys: at most 256 keys of 1, 2, 4 ... blocks of 1024 ids (245 keys of 4096 ids at 1M targets: measured best there -- more
+        // keys shorten the scatter's runs, fewer widen the duplicate stage's tables and thin out its waves); when the (query, chunk, key) runs would
+        // average fewer than 1024 hits -- the many-queries-few-hits batches of an all-vs-all search -- the coarsest level of at most 16 blocks per key
+        const KmerIndex::CoarseLevel *lv = nullptr;
+        for (const KmerIndex::CoarseLevel &l : ix.levels) if (l.blocksPerKey >= 1 && (lv == nullptr || lv->nKeys > 256)) lv = &l;
+        if (lv == nullptr) lv = &ix.levels.front();
         if ((double) nHits / ((double) nVq * lv->nKeys) < 1024.0)
             for (const KmerIndex::CoarseLevel &l : ix.levels) if (l.blocksPerKey >= 1 && l.blocksPerKey <= 16 && l.nKeys <= lv->nKeys) lv = &l;
         if (const char *e = getenv("FSGPU_KMER_BIN_LEVEL")) lv = &ix.levels[std::min<size_t>(ix.levels.size() - 1, (size_t) std::max(0, atoi(e)))];   // tests: force a level
@@ -729,7 +730,7 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         const bool blkInLds = (size_t) lv->nBlk * sizeof(uint16_t) <= 16 * 1024;
         const KmerCoarse co{lv->blkKey, lv->keyFirst, lv->nBlk, nKeys, (uint32_t) bitsFor(nKeys), lv->maxIds};
         const size_t nCells = (size_t) nT * nKeys, nSegs = (size_t) nq * nKeys;
-        const int gBits = bitsFor(maxQ + 1), qtBits = tbits + bitsFor((uint64_t) std::max(nq, 2));
+        const int qtBits = tbits + bitsFor((uint64_t) std::max(nq, 2));
         CHK(ensureK(ctx, S.rec, nHits * sizeof(uint32_t)));
         CHK(ensureK(ctx, S.recKey, nHits * sizeof(uint16_t)));
         CHK(ensureK(ctx, S.recA, nHits * sizeof(uint32_t)));
@@ -739,7 +740,6 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(ensureK(ctx, S.grpSum, nSegs * kColGroups * sizeof(uint32_t)));
         CHK(ensureK(ctx, S.segCnt, (nSegs + 1) * sizeof(uint32_t)));
         CHK(ensureK(ctx, S.segStart, (nSegs + 1) * sizeof(uint32_t)));
-        CHK(ensureK(ctx, S.candCount, 64));
         RPCHK(hipMemsetAsync(S.cntA.p, 0, nCells * sizeof(uint32_t), st));
         RPCHK(hipMemsetAsync((uint32_t *) S.segCnt.p + nSegs, 0, sizeof(uint32_t), st));
         {
@@ -770,47 +770,40 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         RPCHK(hipEventRecord(S.ev[4], st));
         // ---- stage 3: the double-diagonal rule, run by run in arrival order ------------------------------------------------
         KmerDupStream da{};
-        da.recA = (const uint32_t *) S.recA.p; da.ordA = (const uint16_t *) S.ordA.p; da.offA = (const uint32_t *) S.cntA.p; da.colA = (const uint32_t *) S.colA.p;
+        da.recA = (const uint32_t *) S.recA.p; da.ordA = (const uint16_t *) S.ordA.p; da.note = (uint32_t *) S.rec.p; da.offA = (const uint32_t *) S.cntA.p; da.colA = (const uint32_t *) S.colA.p;
         da.segStart = (const uint32_t *) S.segStart.p; da.tl = tl; da.qs = (const KmerQ *) S.qs.p; da.keyFirst = lv->keyFirst; da.nKeys = nKeys;
-        da.tbits = tbits; da.gBits = gBits; da.candCount = (uint32_t *) S.candCount.p; da.ecCount = (uint32_t *) S.ec.p;
-        const size_t ldsDup = ((size_t) lv->maxIds / 2 + 1) * sizeof(uint32_t);
-        if (ldsDup > 48 * 1024 && !ctx->kmerDupAttr) {          // the attribute belongs to the device: once per context
-            RPCHK(hipFuncSetAttribute((const void *) k_kmer_dup_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (kCoarseBlocks * 1024 / 2 + 1) * (int) sizeof(uint32_t)));
+        da.tbits = tbits; da.ecCount = (uint32_t *) S.ec.p;
+        const uint32_t nRuns = nVq * nKeys;
+        CHK(ensureK(ctx, S.candCount, ((size_t) nRuns + 1) * 2 * sizeof(uint32_t)));            // [runCand nRuns + 1 | runBase nRuns + 1]
+        da.runCand = (uint32_t *) S.candCount.p; da.runBase = da.runCand + nRuns + 1;
+        RPCHK(hipMemsetAsync(S.candCount.p, 0, ((size_t) nRuns + 1) * sizeof(uint32_t), st));
+        const size_t ldsDup = ((size_t) lv->maxIds / 4 + 1) * sizeof(uint32_t);           // one byte per target id of the widest key
+        if (ldsDup > 60 * 1024 && !ctx->kmerDupAttr) {          // the attribute belongs to the device: once per context
+            RPCHK(hipFuncSetAttribute((const void *) k_kmer_dup_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (kCoarseBlocks * 1024 / 4 + 1) * (int) sizeof(uint32_t)));
             ctx->kmerDupAttr = true;
         }
-        // the candidate array holds an eighth of the hits (2-3 % are flagged on protein-sized inputs); a batch that flags more is counted to the end
-        // and the launch repeated with an array of that size
-        uint64_t candCap = std::max<uint64_t>(nHits / 8, 1u << 16);
-        for (int attempt = 0; ; attempt++) {
-            CHK(ensureK(ctx, S.candKey, candCap * sizeof(uint64_t)));
-            CHK(ensureK(ctx, S.candVal, candCap * sizeof(uint32_t)));
-            da.candKey = (uint64_t *) S.candKey.p; da.candVal = (uint32_t *) S.candVal.p; da.candCap = (uint32_t) std::min<uint64_t>(candCap, 0xFFFFFFFFull);
-            RPCHK(hipMemsetAsync(S.candCount.p, 0, 64, st));
-            if (attempt) RPCHK(hipMemsetAsync(S.ec.p, 0, (size_t) nq * kMaxChunks * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_kmer_dup_stream, dim3((unsigned) ((uint64_t) nVq * nKeys)), dim3(kDupRound), ldsDup, st, da);
-            RPCHK(hipGetLastError());
-            RPCHK(hipMemcpyAsync(&misc[2], S.candCount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            CHK(syncStream(ctx));
-            nCand = (uint32_t) misc[2];
-            if (nCand <= candCap) break;
-            if (attempt) { ctx->err = "k-mer search: candidate count changed between two runs of the duplicate stage"; return FSGPU_E_HIP; }
-            candCap = nCand;
-        }
+        hipLaunchKernelGGL(k_kmer_dup_stream, dim3(nRuns), dim3(64), ldsDup, st, da);
+        RPCHK(hipGetLastError());
+        CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) da.runCand, (uint32_t *) da.runBase, (size_t) nRuns + 1));
+        RPCHK(hipMemcpyAsync(&misc[2], da.runBase + nRuns, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        CHK(syncStream(ctx));
+        nCand = (uint32_t) misc[2];
         mark("emit..dup+sync");
         ctx->kmerSegs[0] = 0; ctx->kmerSegs[1] = nVq * nKeys; ctx->kmerSegs[2] = 0; ctx->kmerSegs[3] = nT;
         ctx->kmerSegs[4] = nVq * nKeys; ctx->kmerSegs[5] = nKeys; ctx->kmerSegs[6] = lv->maxIds;
         if (nCand) {
-            // (query, target, arrival) order: one radix sort over the flagged hits only
-            CHK(ensureK(ctx, S.candKey2, (size_t) nCand * sizeof(uint64_t)));
-            CHK(ensureK(ctx, S.candVal2, (size_t) nCand * sizeof(uint32_t)));
+            // (query, target, arrival) order: the gathered candidates stand in (query, key) blocks with ascending stream positions, one STABLE radix sort by
+            // (query | target) over the flagged hits finishes it
+            CHK(ensureK(ctx, S.candKey, (size_t) nCand * sizeof(uint32_t)));
+            CHK(ensureK(ctx, S.candVal, (size_t) nCand * sizeof(uint64_t)));
             CHK(ensureK(ctx, S.ckeys, (size_t) nCand * sizeof(uint32_t)));
             CHK(ensureK(ctx, S.cvals, (size_t) nCand * sizeof(uint64_t)));
-            CHK((sortPairs<uint64_t, uint32_t>(ctx, S.tmp, (const uint64_t *) S.candKey.p, (uint64_t *) S.candKey2.p, (const uint32_t *) S.candVal.p, (uint32_t *) S.candVal2.p,
-                                               nCand, std::min(64, gBits + qtBits))));
-            hipLaunchKernelGGL(k_kmer_cand_unpack, dim3(gridFor(nCand, 256)), dim3(256), 0, st, (const uint64_t *) S.candKey2.p, (const uint32_t *) S.candVal2.p, nCand, gBits,
-                               (uint32_t *) S.ckeys.p, (uint64_t *) S.cvals.p);
+            da.candKey = (uint32_t *) S.candKey.p; da.candVal = (uint64_t *) S.candVal.p;
+            hipLaunchKernelGGL(k_kmer_cand_gather, dim3((nRuns + 3) / 4), dim3(256), 0, st, da, nRuns);
             RPCHK(hipGetLastError());
-            RPCHK(hipMemcpyAsync(S.nCand.p, S.candCount.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            CHK((sortPairs<uint32_t, uint64_t>(ctx, S.tmp, (const uint32_t *) S.candKey.p, (uint32_t *) S.ckeys.p, (const uint64_t *) S.candVal.p, (uint64_t *) S.cvals.p,
+                                               nCand, std::min(32, qtBits))));
+            RPCHK(hipMemcpyAsync(S.nCand.p, da.runBase + nRuns, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         }
     }
     if (!nHits) { RPCHK(hipEventRecord(S.ev[3], st)); RPCHK(hipEventRecord(S.ev[4], st)); }   // keep every stage event recorded

@@ -569,13 +569,13 @@ __global__ void k_kmer_chunks(const KmerQ *qs, int nq, const uint64_t *Kbase, co
 //                          records twice through two unordered scatters and ranked every target's hits by their
 //                          32-bit stream positions afterwards).  What identifies a hit later travels beside it as
 //                          a 16-bit position inside its tile.
-//   k_kmer_dup_stream      one workgroup per (query, chunk, key): the reference's byte array itself, in LDS (16 bits per
-//                          target of the key: last diagonal + a counter), walked in arrival order 256 hits at a time;
-//                          hits of one round that share a target are resolved among themselves by their position in
-//                          the round.  Flagged hits (2-3 %) get their stream position back (tile of their run + the
-//                          16-bit position) and leave as (query | target | stream position, diagonal | chunk).
-//   radix sort + k_kmer_cand_unpack   the candidates in (query, target, arrival) order: the arrays the scoring and
-//                          replay stages read.
+//   k_kmer_dup_stream      one wave per (query, chunk, key): the reference's byte array itself, in LDS (a byte per target
+//                          of the key), walked in arrival order 64 hits at a time; hits of one step that share a
+//                          target take their turn in lane order.  Flagged hits (2-3 %) get their stream position back
+//                          (tile of their run + the 16-bit position) and leave as (query | target | stream position,
+//                          diagonal | chunk).
+//   k_kmer_cand_gather + a stable radix sort by (query | target)   the candidates in (query, target, arrival)
+//                          order: the arrays the scoring and replay stages read.
 // Bytes per hit: 6 written by emit, 6 read + 6 written by the scatter, 4 (+ 2 for the flagged ones) read by the
 // duplicate stage.  Nothing here depends on the order in which atomics are served.
 // --------------------------------------------------------------------------------------------------------------
@@ -588,8 +588,6 @@ constexpr int kMaxCoarse = 512;               // coarse keys per database (LDS c
 constexpr int kCoarseBlocks = 64;             // blocks of 1024 ids per key at most
 constexpr int kScStage = 4096;                // records per LDS pass of the stable scatter
 constexpr int kScThreads = 512;
-constexpr int kDupRound = 256;                // hits per round of k_kmer_dup_stream = its workgroup size
-constexpr int kCandStage = 3 * kDupRound;     // flagged hits staged in LDS; flushed from 2 * kDupRound on
 constexpr int kColGroups = 16;                // tile groups of the column kernels
 
 struct KmerCoarse {
@@ -601,7 +599,8 @@ struct KmerTiles {
     const uint32_t *tileStart;    // [nT + 1] first stream position of a tile (tiles follow the stream; tileStart[nT] = hits of the batch)
     const uint32_t *qTile0;       // [nq + 1] first tile of a query
     const uint32_t *vqTile0;      // [nVq + 1] first tile of a (query, chunk) pair
-    const uint16_t *vqQ, *vqChunk;// [nVq]
+    const uint32_t *qVq0;         // [nq + 1] first (query, chunk) pair of a query
+    const uint16_t *vqQ;          // [nVq]
     uint32_t nT, nVq;
 };
 
@@ -782,14 +781,21 @@ __global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32
     }
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t r[U], k[U], rn[U], kn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
+        r[u] = e < n ? rec[a + e] : 0u;
+        k[u] = e < n ? (uint32_t) recKey[a + e] : 0u;
+    }
     for (uint32_t sp0 = 0; sp0 < n; sp0 += kScStage) {
         const uint32_t m = min((uint32_t) kScStage, n - sp0);
-        uint32_t r[U], k[U], rk[U];
+        uint32_t rk[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
-            r[u] = e < m ? rec[a + sp0 + e] : 0u;
-            k[u] = e < m ? (uint32_t) recKey[a + sp0 + e] : 0u;
+        for (int u = 0; u < U; u++) {          // the next pass's records are in flight while this pass goes through LDS
+            const uint32_t e = sp0 + kScStage + (uint32_t) (wave * PW + u * 64 + lane);
+            rn[u] = e < n ? rec[a + e] : 0u;
+            kn[u] = e < n ? (uint32_t) recKey[a + e] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -838,135 +844,148 @@ __global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32
 #pragma unroll
             for (int w = 0; w < NW; w++) whist[w][kk] = 0;
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) { r[u] = rn[u]; k[u] = kn[u]; }
         __syncthreads();
     }
 }
 
-// The double-diagonal rule on a (query, chunk, key) run of the scatter's output: `tab` holds 16 bits per target of the key, two targets per
-// dword -- bits 0-7 / 8-15 the last 8-bit diagonal of the even / odd target, bits 16-23 / 24-31 how many hits of the CURRENT round fall on it.
-// A round = 256 consecutive hits, one per thread:
-//   A  every hit adds 1 to its target's counter (atomic add on the dword) and takes the diagonal byte out of the returned word -- no diagonal
-//      byte is written in this phase, so that IS the byte the round found;
-//   B  counter == 1: the hit is alone on its target this round.  Otherwise it joins the round's conflict list (target, thread, diagonal);
-//   C  a conflicting hit looks for the nearest earlier list member of its target (its predecessor: then that one's diagonal replaces the
-//      byte) and whether a later one exists; flag = diagonal equals the byte (findDuplicates: currDiagonal == prevDiagonal).  Every hit
-//      takes its count back and -- when it is the round's last hit of its target -- replaces the byte, in ONE atomic add of the difference
-//      (additions commute: whatever order the lanes are served in, the dword ends as count 0 + the new bytes; a counter that wraps in
-//      between -- 256 hits on one target, or a carry into the neighbour's counter -- only sends hits through the list, which is exact).
-// Flagged hits are staged in LDS and leave in blocks of 512 or more: one reservation in the batch's candidate array per block.
+// The double-diagonal rule on a (query, chunk, key) run of the scatter's output: `tab` IS the reference's duplicateBitArray for the targets of the
+// key -- one byte per target, the 8-bit diagonal of its last hit, zero at the start of a chunk -- and a hit is flagged when its diagonal equals
+// the byte it finds (findDuplicates: currDiagonal == prevDiagonal).  ONE WAVE walks a run in arrival order, 64 hits a step, with no barrier
+// anywhere (a wave's LDS accesses execute in order):
+//   old = tab[t];  tab[t] = lane;  back = tab[t];
+// -- the table itself tells whether two hits of the step share a target: then one of them reads the other's lane back.  No such lane (most
+// steps): flag = old == d, tab[t] = d.  Otherwise the lanes that read a foreign lane and the lanes they read are set aside, everybody else
+// proceeds as before (their targets are theirs alone), the set-aside lanes put the old byte back and then take their turn one after the other
+// in lane = arrival order: read the byte, compare, replace -- the reference's loop, literally, for the two to four hits concerned.
+// About 20 wave instructions per 64 hits on the common path.  What bounds the kernel is the chain of four LDS round trips per step times the
+// steps of a run, hidden by the other waves of the CU: the number of concurrent runs is what LDS holds tables for (a byte per target id of the
+// key + 1.5 KB per wave).
+// Flagged hits (2-3 %) are noted as 4-byte positions in the run's own range of the emit records' buffer (dead since the scatter; a run has
+// room for every one of its hits), the run's count goes to runCand.  No atomics: a reservation in a batch-wide candidate array per 64 flagged
+// hits was 67 k atomic adds on one address per batch, which is what the kernel then waited for (1.08 ms against 0.41 ms without them); one per
+// run still cost a third of the kernel.  k_kmer_cand_gather turns the notes into candidates at the scanned offsets.
 struct KmerDupStream {
     const uint32_t *recA; const uint16_t *ordA;
+    uint32_t *note;               // [hits of the batch] positions of the flagged hits of a run, at the run's own range
     const uint32_t *offA, *colA, *segStart;
     KmerTiles tl;
     const KmerQ *qs;
     const uint32_t *keyFirst;
     uint32_t nKeys;
-    int tbits, gBits;
-    uint64_t *candKey; uint32_t *candVal; uint32_t candCap;
-    uint32_t *candCount;          // candidates of the batch (may run past candCap: the host then repeats the launch with a larger array)
+    int tbits;
+    uint32_t *runCand;            // [runs] flagged hits of every run (zeroed by the caller: an empty run returns early)
+    const uint32_t *runBase;      // [runs + 1] their exclusive prefix: k_kmer_cand_gather
+    uint32_t *candKey; uint64_t *candVal;
     uint32_t *ecCount;            // [nq][kMaxChunks] candidates per (query, chunk)
 };
-__global__ __launch_bounds__(kDupRound) void k_kmer_dup_stream(KmerDupStream a) {
-    extern __shared__ uint32_t tab[];         // [maxIds / 2 + 1]
-    __shared__ uint32_t clist[kDupRound];
-    __shared__ uint32_t stPos[kCandStage], stRec[kCandStage];
-    __shared__ uint32_t nConf, nStage, flushBase, unitCand;
-    const uint32_t vq = blockIdx.x / a.nKeys, A = blockIdx.x - vq * a.nKeys;
-    const uint32_t q = a.tl.vqQ[vq], chunk = a.tl.vqChunk[vq];
-    const uint32_t T0 = a.tl.vqTile0[vq], T1 = a.tl.vqTile0[vq + 1], qT0 = a.tl.qTile0[q], qT1 = a.tl.qTile0[q + 1];
-    if (T0 == T1) return;
-    const uint32_t segEnd = a.segStart[(size_t) q * a.nKeys + A + 1];
-    const uint32_t p0 = a.offA[(size_t) T0 * a.nKeys + A], p1 = T1 < qT1 ? a.offA[(size_t) T1 * a.nKeys + A] : segEnd;
-    if (p0 >= p1) return;
-    const uint32_t first = a.keyFirst[A], ids = a.keyFirst[A + 1] - first, lowFirst = first & 0xffffu;
-    for (uint32_t i = threadIdx.x; i < ids / 2 + 1; i += kDupRound) tab[i] = 0;
-    if (threadIdx.x == 0) { nConf = 0; nStage = 0; unitCand = 0; }
-    __syncthreads();
-    const uint32_t nTq = qT1 - qT0;
-    const uint32_t *col = a.colA + (size_t) qT0 * a.nKeys + (size_t) A * nTq;
-    const uint32_t hb = (uint32_t) a.qs[q].hitBase;
-    const uint64_t keyHi = ((uint64_t) q << a.tbits) | first;
-    auto flush = [&]() {                       // called by all threads, between barriers
-        const uint32_t n = nStage;
-        if (threadIdx.x == 0) { flushBase = atomicAdd(a.candCount, n); unitCand += n; }
-        __syncthreads();
-        const uint32_t fb = flushBase;
-        for (uint32_t k = threadIdx.x; k < n; k += kDupRound) {
-            const uint32_t pos = stPos[k], rr = stRec[k];
-            uint32_t lo = T0 - qT0, hi = T1 - qT0;          // last tile of the chunk whose run starts at or before pos (empty runs share their start with the next one)
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (col[mid] <= pos) lo = mid; else hi = mid; }
-            const uint32_t g = a.tl.tileStart[qT0 + lo] + (uint32_t) a.ordA[pos] - hb;
-            const uint32_t dst = fb + k;
-            if (dst < a.candCap) {
-                a.candKey[dst] = ((keyHi + (rr >> 16)) << a.gBits) | g;
-                a.candVal[dst] = (rr & 0xffffu) | (chunk << 16);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) nStage = 0;
-        __syncthreads();
-    };
-    constexpr int R = 4;                      // rounds per load phase
-    for (uint32_t base = p0; base < p1; base += R * kDupRound) {
-        uint32_t rr[R];
+// the run of workgroup / wave `unit`: false when it is empty.  Runs are numbered (query, key, chunk): the flagged hits of all runs, one run after
+// the other, then stand in (query, key) blocks with the stream positions ascending inside a block -- a STABLE sort by (query, target) is all that
+// separates them from the order the scoring and replay stages need
+struct KmerRun { uint32_t q, chunk, A, T0, nTc, p0, p1, first, lowFirst; const uint32_t *col; };
+__device__ inline bool kmerRunOf(const KmerDupStream &a, uint32_t unit, KmerRun &r) {
+    r.q = a.tl.vqQ[unit / a.nKeys];           // the runs of a query are numbered from (its first chunk pair) x keys on, whatever their order inside
+    const uint32_t vq0 = a.tl.qVq0[r.q], nCh = a.tl.qVq0[r.q + 1] - vq0, local = unit - vq0 * a.nKeys;
+    r.A = local / nCh; r.chunk = local - r.A * nCh;
+    const uint32_t vq = vq0 + r.chunk;
+    const uint32_t T0 = a.tl.vqTile0[vq], T1 = a.tl.vqTile0[vq + 1], qT0 = a.tl.qTile0[r.q], qT1 = a.tl.qTile0[r.q + 1];
+    if (T0 == T1) return false;
+    r.T0 = T0; r.nTc = T1 - T0;
+    r.p0 = a.offA[(size_t) T0 * a.nKeys + r.A];
+    r.p1 = T1 < qT1 ? a.offA[(size_t) T1 * a.nKeys + r.A] : a.segStart[(size_t) r.q * a.nKeys + r.A + 1];
+    r.first = a.keyFirst[r.A]; r.lowFirst = r.first & 0xffffu;
+    r.col = a.colA + (size_t) qT0 * a.nKeys + (size_t) r.A * (qT1 - qT0) + (T0 - qT0);          // run starts of the chunk's tiles in this key
+    return r.p0 < r.p1;
+}
+constexpr int kDupColStage = 128;             // tiles of a chunk whose column slice is staged in LDS (a chunk of 2 x 10^6 hits has 123)
+constexpr int kDupAhead = 8;                  // steps whose records are in flight
+__global__ __launch_bounds__(64) void k_kmer_dup_stream(KmerDupStream a) {
+    extern __shared__ uint32_t tabWords[];    // [maxIds / 4 + 1]: one byte per target id of the key
+    uint8_t *tab = reinterpret_cast<uint8_t *>(tabWords);
+    // what a lane reads back from a byte it has just written is what ANOTHER lane may have written there: the compiler must not forward the stored
+    // value to the load (a volatile pointer would do that too, but turns the accesses into flat_* instructions)
+#define FS_LDS_REREAD() asm volatile("" ::: "memory")
+    KmerRun run;
+    if (!kmerRunOf(a, blockIdx.x, run)) return;
+    const uint32_t p0 = run.p0, p1 = run.p1, lowFirst = run.lowFirst;
+    const uint32_t ids = a.keyFirst[run.A + 1] - run.first;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < ids / 4 + 1; i += 64) tabWords[i] = 0;
+    uint32_t nSt = 0;                          // flagged hits so far (wave-uniform)
+    constexpr int R = kDupAhead;
+    uint32_t cur[R], nxt[R];
 #pragma unroll
-        for (int k = 0; k < R; k++) { const uint32_t pos = base + k * kDupRound + threadIdx.x; rr[k] = pos < p1 ? a.recA[pos] : 0u; }
+    for (int k = 0; k < R; k++) { const uint32_t pos = p0 + k * 64 + lane; cur[k] = pos < p1 ? a.recA[pos] : 0u; }
+    for (uint32_t base = p0; base < p1; base += R * 64) {
+#pragma unroll
+        for (int k = 0; k < R; k++) { const uint32_t pos = base + (R + k) * 64 + lane; nxt[k] = pos < p1 ? a.recA[pos] : 0u; }
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const uint32_t rbase = base + k * kDupRound;
-            if (rbase >= p1) break;            // uniform
-            const uint32_t pos = rbase + threadIdx.x;
+            const uint32_t sbase = base + k * 64;
+            if (sbase >= p1) break;            // uniform
+            const uint32_t pos = sbase + lane;
             const bool valid = pos < p1;
-            const uint32_t t = ((rr[k] >> 16) - lowFirst) & 0xffffu, d = rr[k] & 0xffu;
-            const uint32_t sh = (t & 1u) * 8u, inc = 0x10000u << sh, w = t >> 1;
-            uint32_t old = 0;
-            if (valid) old = (atomicAdd(&tab[w], inc) >> sh) & 0xffu;
-            __syncthreads();
-            bool conflict = false;
-            if (valid) {
-                conflict = ((tab[w] >> (16u + sh)) & 0xffu) != 1u;
-                if (conflict) clist[atomicAdd(&nConf, 1u)] = (t << 16) | (threadIdx.x << 8) | d;
-            }
-            __syncthreads();
-            if (valid) {
-                uint32_t prev = old;
-                bool writer = true;
-                if (conflict) {
-                    const uint32_t nC = nConf;
-                    int predI = -1;
-                    for (uint32_t x = 0; x < nC; x++) {
-                        const uint32_t e = clist[x];
-                        if ((e >> 16) != t) continue;
-                        const int ix = (int) ((e >> 8) & 0xffu);
-                        if (ix < (int) threadIdx.x && ix > predI) { predI = ix; prev = e & 0xffu; }
-                        if (ix > (int) threadIdx.x) writer = false;
-                    }
+            const uint32_t t = ((cur[k] >> 16) - lowFirst) & 0xffffu, d = cur[k] & 0xffu;
+            uint32_t old = 0, back = lane;
+            if (valid) { old = tab[t]; tab[t] = (uint8_t) lane; FS_LDS_REREAD(); back = tab[t]; }
+            const unsigned long long losers = __ballot(back != lane);
+            bool flag = false;
+            if (losers == 0ull) {
+                if (valid) { flag = old == d; tab[t] = (uint8_t) d; }
+            } else {
+                unsigned long long inv = losers, m = losers;
+                while (m) { const int j = __ffsll((long long) m) - 1; m &= m - 1ull; inv |= 1ull << (uint32_t) __builtin_amdgcn_readlane((int) back, j); }
+                const bool involved = (inv >> lane) & 1ull;
+                if (valid && !involved) { flag = old == d; tab[t] = (uint8_t) d; }
+                if (involved) tab[t] = (uint8_t) old;
+                m = inv;
+                while (m) {
+                    const int j = __ffsll((long long) m) - 1; m &= m - 1ull;
+                    FS_LDS_REREAD();
+                    if ((int) lane == j) { const uint32_t p = tab[t]; flag = p == d; tab[t] = (uint8_t) d; }
                 }
-                uint32_t delta = 0u - inc;
-                if (writer) delta += (d - old) << sh;
-                atomicAdd(&tab[w], delta);
-                if (prev == d) {
-                    const uint32_t slot = atomicAdd(&nStage, 1u);
-                    stPos[slot] = pos; stRec[slot] = (t << 16) | (rr[k] & 0xffffu);
-                }
+                FS_LDS_REREAD();
             }
-            __syncthreads();
-            if (threadIdx.x == 0) nConf = 0;   // (the next append follows the next round's first barrier)
-            if (nStage >= 2 * kDupRound) flush();
+            const unsigned long long fm = __ballot(flag);
+            if (fm) {
+                if (flag) a.note[p0 + nSt + (uint32_t) __popcll(fm & ((1ull << lane) - 1ull))] = pos;
+                nSt += (uint32_t) __popcll(fm);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < R; k++) cur[k] = nxt[k];
     }
-    if (nStage) flush();
-    if (threadIdx.x == 0 && unitCand) atomicAdd(&a.ecCount[(size_t) q * kMaxChunks + chunk], unitCand);
+    if (lane == 0 && nSt) { a.runCand[blockIdx.x] = nSt; atomicAdd(&a.ecCount[(size_t) run.q * kMaxChunks + run.chunk], nSt); }
+#undef FS_LDS_REREAD
 }
 
-// sorted (query | target | stream position, diagonal | chunk) pairs -> the candidate arrays of the scoring / replay stages
-__global__ void k_kmer_cand_unpack(const uint64_t *key, const uint32_t *val, uint32_t n, int gBits, uint32_t *ckeys, uint64_t *cvals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = key[i];
-    const uint32_t v = val[i];
-    ckeys[i] = (uint32_t) (k >> gBits);
-    cvals[i] = hitPack(k & ((1ull << gBits) - 1ull), v & 0xffffu, v >> 16);
+// the flagged hits of all runs -> (query | target) keys and (stream position, diagonal, chunk) values at the runs' places in the candidate array (exclusive
+// scan of runCand).  One wave per run; the stream position of a hit = first position of the tile whose run holds it (search over the chunk's slice of the key's
+// column, staged in LDS) + its 16-bit position inside the tile.
+__global__ __launch_bounds__(256) void k_kmer_cand_gather(KmerDupStream a, uint32_t nRuns) {
+    __shared__ uint32_t colAll[4][kDupColStage];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, unit = blockIdx.x * 4u + wv;
+    if (unit >= nRuns) return;
+    const uint32_t n = a.runCand[unit];
+    if (n == 0) return;
+    KmerRun run;
+    if (!kmerRunOf(a, unit, run)) return;
+    uint32_t *colS = colAll[wv];
+    const bool colStaged = run.nTc <= (uint32_t) kDupColStage;
+    if (colStaged) for (uint32_t i = lane; i < run.nTc; i += 64) colS[i] = run.col[i];           // (read by the same wave only: its LDS accesses execute in order)
+    const uint32_t hb = (uint32_t) a.qs[run.q].hitBase, fb = a.runBase[unit];
+    const uint32_t keyHi = (run.q << a.tbits) | run.first;
+    for (uint32_t k = lane; k < n; k += 64) {
+        const uint32_t pos = a.note[run.p0 + k];
+        const uint32_t rr = a.recA[pos];
+        uint32_t lo = 0, hi = run.nTc;          // last tile of the chunk whose run starts at or before pos (empty runs share their start with the next one)
+        if (colStaged) { while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (colS[mid] <= pos) lo = mid; else hi = mid; } }
+        else { while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run.col[mid] <= pos) lo = mid; else hi = mid; } }
+        const uint32_t g = a.tl.tileStart[run.T0 + lo] + (uint32_t) a.ordA[pos] - hb;
+        a.candKey[fb + k] = keyHi + (((rr >> 16) - run.lowFirst) & 0xffffu);
+        a.candVal[fb + k] = hitPack(g, rr & 0xffffu, run.chunk);
+    }
 }
 
 // findDuplicates pass 2 (collapse runs of equal 8-bit diagonals among the candidates of one target and chunk) fused
