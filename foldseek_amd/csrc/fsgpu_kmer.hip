@@ -764,8 +764,15 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         CHK(scanExclusive<uint32_t>(ctx, S.tmp, (const uint32_t *) S.segCnt.p, (uint32_t *) S.segStart.p, nSegs + 1));
         hipLaunchKernelGGL(k_kmer_col_offsets, colGrid, dim3(64 * kColGroups), 0, st, (uint32_t *) S.cntA.p, tl.qTile0, nKeys, (const uint32_t *) S.grpSum.p,
                            (const uint32_t *) S.segStart.p, (uint32_t *) S.colA.p);
-        hipLaunchKernelGGL(k_kmer_scatter_stable, dim3(nT), dim3(kScThreads), 0, st, (const uint32_t *) S.rec.p, (const uint16_t *) S.recKey.p, tl.tileStart, (const uint32_t *) S.cntA.p,
-                           nKeys, (int) co.keyBits, (uint32_t *) S.recA.p, (uint16_t *) S.ordA.p);
+        {
+#define FS_SCATTER(KB) hipLaunchKernelGGL(k_kmer_scatter_stable<KB>, dim3(nT), dim3(kScThreads), 0, st, (const uint32_t *) S.rec.p, (const uint16_t *) S.recKey.p, tl.tileStart, \
+                                          (const uint32_t *) S.cntA.p, nKeys, (uint32_t *) S.recA.p, (uint16_t *) S.ordA.p)
+            switch (co.keyBits) {          // ballots per record = key bits: unrolled per width
+                case 1: FS_SCATTER(1); break; case 2: FS_SCATTER(2); break; case 3: FS_SCATTER(3); break; case 4: FS_SCATTER(4); break; case 5: FS_SCATTER(5); break;
+                case 6: FS_SCATTER(6); break; case 7: FS_SCATTER(7); break; case 8: FS_SCATTER(8); break; default: FS_SCATTER(9); break;
+            }
+#undef FS_SCATTER
+        }
         RPCHK(hipGetLastError());
         RPCHK(hipEventRecord(S.ev[4], st));
         // ---- stage 3: the double-diagonal rule, run by run in arrival order ------------------------------------------------

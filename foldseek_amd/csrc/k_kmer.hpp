@@ -631,7 +631,8 @@ __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64
     // list prefixes relative to the tile's first stream position, clamped below at 0 (only the tile's first list can start before the tile): < kEmitTile,
     // 16 bits each -- 12 KB instead of 24, so the workgroups per CU are bounded by their waves, not by LDS
     __shared__ uint16_t rel[kEmitStage + 1];
-    __shared__ uint32_t hist[kMaxCoarse];
+    __shared__ __attribute__((aligned(16))) uint16_t owner[kEmitTile];       // list (relative to the tile's first) of every stream position of the tile
+    __shared__ uint32_t hist[kMaxCoarse], wmax[4];
     extern __shared__ uint16_t sblk[];        // [nBlk] when blkInLds
     const uint32_t T = blockIdx.x / kSubTiles, sub = blockIdx.x % kSubTiles;
     const uint64_t o0 = (uint64_t) tileStart[T] + (uint64_t) sub * kEmitTile, tEnd = tileStart[T + 1];
@@ -644,25 +645,45 @@ __global__ __launch_bounds__(256) void k_kmer_emit(uint64_t nLists, const uint64
     for (uint32_t i = threadIdx.x; i < co.nKeys; i += 256) hist[i] = 0;
     if (blkInLds) for (uint32_t i = threadIdx.x; i < co.nBlk; i += 256) sblk[i] = co.blkKey[i];
     if (staged) for (int i = threadIdx.x; i < nl; i += 256) { const uint64_t lp = listP[l0 + i]; rel[i] = (uint16_t) (lp > o0 ? lp - o0 : 0); }
+    constexpr int U = kEmitTile / 256;
+    static_assert(U == 8, "k_kmer_emit reads a thread's eight list owners as one 16-byte word");
+    reinterpret_cast<uint4 *>(owner)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     // 8 outputs per thread, handled phase by phase so that the dependent loads of all 8 are in flight together
-    constexpr int U = kEmitTile / 256;
     uint64_t l[U];
     if (staged) {
-        // the 8 searches of a thread advance in lockstep (fixed 13 halving steps, no data-dependent branch): 8 independent LDS reads per
-        // step instead of 8 x 13 dependent ones
-        uint32_t lo[U], ro[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { lo[u] = 0; ro[u] = (uint32_t) (min<uint64_t>(o0 + threadIdx.x + 256 * u, o1 - 1) - o0); }
-        for (uint32_t step = 4096; step >= 1; step >>= 1) {          // kEmitStage < 8192: last index with rel[index] <= ro
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t cand = lo[u] + step;
-                if (cand < (uint32_t) nl && (uint32_t) rel[cand] <= ro[u]) lo[u] = cand;
-            }
+        // The list of every stream position of the tile, WITHOUT a search per position (until round 6 every thread ran eight 13-step binary searches over the
+        // staged prefixes: 80 of the kernel's ~170 wave instructions per 64 hits, and the kernel is as close to its issue limit as to the HBM's): every
+        // non-empty list marks its first position with its index, a running maximum over the positions spreads it.  Thread t scans positions 8 t .. 8 t + 7, a
+        // wave scan and the four wave totals carry the maximum across; the result goes back through LDS because the gathers and the stores below keep the
+        // interleaved mapping (position = thread + 256 u: consecutive lanes, consecutive addresses).
+        const uint32_t tileLen = (uint32_t) (o1 - o0);
+        for (int i = threadIdx.x; i < nl; i += 256) {
+            const uint32_t sPos = rel[i], ePos = i + 1 < nl ? (uint32_t) rel[i + 1] : tileLen;
+            if (ePos > sPos) owner[sPos] = (uint16_t) i;
         }
+        __syncthreads();
+        const uint4 ow = reinterpret_cast<const uint4 *>(owner)[threadIdx.x];
+        uint32_t mx[U];
+        mx[0] = ow.x & 0xffffu; mx[1] = max(mx[0], ow.x >> 16);
+        mx[2] = max(mx[1], ow.y & 0xffffu); mx[3] = max(mx[2], ow.y >> 16);
+        mx[4] = max(mx[3], ow.z & 0xffffu); mx[5] = max(mx[4], ow.z >> 16);
+        mx[6] = max(mx[5], ow.w & 0xffffu); mx[7] = max(mx[6], ow.w >> 16);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t incl = mx[7];
 #pragma unroll
-        for (int u = 0; u < U; u++) l[u] = l0 + lo[u];
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t v = (uint32_t) __shfl_up((int) incl, dd); if (lane >= dd) incl = max(incl, v); }
+        uint32_t before = (uint32_t) __shfl_up((int) incl, 1);
+        if (lane == 0) before = 0;
+        if (lane == 63) wmax[wave] = incl;
+        __syncthreads();
+        for (int w = 0; w < wave; w++) before = max(before, wmax[w]);
+#pragma unroll
+        for (int u = 0; u < U; u++) mx[u] = max(mx[u], before);
+        reinterpret_cast<uint4 *>(owner)[threadIdx.x] = make_uint4(mx[0] | (mx[1] << 16), mx[2] | (mx[3] << 16), mx[4] | (mx[5] << 16), mx[6] | (mx[7] << 16));
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) l[u] = l0 + owner[min((uint32_t) (threadIdx.x + 256 * u), tileLen - 1u)];
     } else {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -758,12 +779,14 @@ __global__ __launch_bounds__(64 * kColGroups) void k_kmer_col_offsets(uint32_t *
 }
 
 // Stable scatter: one workgroup per tile, kScStage records per pass through LDS.  A wave owns a contiguous eighth of the pass and ranks its
-// records in lane order: the lanes of a wave instruction that share a key find each other with one ballot per key bit, the lowest of them
-// takes the group's places from the wave's private counter of that key (plain read + write: one lane per key and instruction, and a wave's
-// LDS accesses execute in order), everybody's rank = that base + its position among the group's lower lanes.  A cross-wave prefix per key
-// and a scan over the keys turn the ranks into LDS positions; the runs leave LDS key by key as consecutive 4-byte stores into the
-// (tile, key) runs of the output, whose starts the column kernels computed.
-__global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32_t *rec, const uint16_t *recKey, const uint32_t *tileStart, const uint32_t *offA, uint32_t nKeys, int keyBits,
+// records in lane order: the lanes of a wave instruction that share a key find each other with one ballot per key bit (KB of them, a template
+// parameter: the loop must unroll -- as a loop it cost 16 instructions per bit and made the kernel issue-bound at 209 wave instructions per 64
+// records), the lowest of them adds the group's size to the wave's private counter of that key (one lane per key and instruction, and a wave's
+// LDS accesses execute in order), everybody reads the counter back: rank = counter - group size + position among the group's lower lanes.
+// A cross-wave prefix per key and a scan over the keys turn the ranks into LDS positions; the runs leave LDS key by key as consecutive 4-byte
+// stores into the (tile, key) runs of the output, whose starts the column kernels computed.
+template <int KB>
+__global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32_t *rec, const uint16_t *recKey, const uint32_t *tileStart, const uint32_t *offA, uint32_t nKeys,
                                                                      uint32_t *out, uint16_t *ordOut) {
     constexpr int NW = kScThreads / 64, U = kScStage / kScThreads, PW = kScStage / NW;
     __shared__ uint32_t srec[kScStage];
@@ -780,7 +803,8 @@ __global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32
         for (int w = 0; w < NW; w++) whist[w][k] = 0;
     }
     __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t ltLo = lane < 32 ? (1u << lane) - 1u : 0xffffffffu, ltHi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+    uint16_t *myHist = whist[wave];
     uint32_t r[U], k[U], rn[U], kn[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -801,20 +825,19 @@ __global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32
         for (int u = 0; u < U; u++) {
             const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
             const bool valid = e < m;
-            unsigned long long peers = __ballot(valid);
-            for (int bit = 0; bit < keyBits; bit++) {
-                const bool s = (k[u] >> bit) & 1u;
-                const unsigned long long mb = __ballot(valid && s);
-                peers &= s ? mb : ~mb;
+            const unsigned long long vm = __ballot(valid);
+            uint32_t lo = (uint32_t) vm, hi = (uint32_t) (vm >> 32);            // lanes with this lane's key (an invalid lane's own set is not used)
+#pragma unroll
+            for (int bit = 0; bit < KB; bit++) {
+                const bool s = (k[u] & (1u << bit)) != 0u;
+                const unsigned long long mb = __ballot(s);
+                const uint32_t same = s ? 0u : 0xffffffffu;                       // set -> the lanes of mb, clear -> the others
+                lo &= (uint32_t) mb ^ same; hi &= (uint32_t) (mb >> 32) ^ same;
             }
-            uint32_t prev = 0;
-            int leader = lane;
-            if (valid) {
-                leader = __ffsll((long long) peers) - 1;
-                if (lane == leader) { prev = whist[wave][k[u]]; whist[wave][k[u]] = (uint16_t) (prev + (uint32_t) __popcll(peers)); }
-            }
-            prev = (uint32_t) __shfl((int) prev, leader);
-            rk[u] = prev + (uint32_t) __popcll(peers & lt);
+            const uint32_t below = (uint32_t) __popc(lo & ltLo) + (uint32_t) __popc(hi & ltHi), cnt = (uint32_t) __popc(lo) + (uint32_t) __popc(hi);
+            if (valid && below == 0u) myHist[k[u]] = (uint16_t) (myHist[k[u]] + cnt);
+            asm volatile("" ::: "memory");     // the counter is read back by the other lanes of the group
+            rk[u] = valid ? (uint32_t) myHist[k[u]] - cnt + below : 0u;
         }
         __syncthreads();
         for (uint32_t kk = threadIdx.x; kk < nKeys; kk += kScThreads) {
@@ -829,7 +852,7 @@ __global__ __launch_bounds__(kScThreads) void k_kmer_scatter_stable(const uint32
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t e = (uint32_t) (wave * PW + u * 64 + lane);
-            if (e < m) { const uint32_t p = lbase[k[u]] + whist[wave][k[u]] + rk[u]; srec[p] = r[u]; skey[p] = (uint16_t) k[u]; sord[p] = (uint16_t) e; }
+            if (e < m) { const uint32_t p = lbase[k[u]] + myHist[k[u]] + rk[u]; srec[p] = r[u]; skey[p] = (uint16_t) k[u]; sord[p] = (uint16_t) e; }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < m; i += kScThreads) {
