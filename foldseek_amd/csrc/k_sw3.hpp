@@ -213,7 +213,18 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
     readEntry();
 
     const Sw3LaneBase<R, HL> lb3(0u, l, lane), lbA((uint32_t) TBL, l, lane);
-    auto step = [&](const int s) {
+    // Software pipeline (round 6): the profile rows of step s + 1 are fetched while the DP of step s runs (their ring entry was read a step earlier still),
+    // into the buffer the step after next computes from -- until then every step began by waiting for its own 2 (4 with AA) row reads: at 3-4 waves per
+    // SIMD nobody covers an LDS round trip per step (PMC: 7.5 cycles per VALU instruction, 55 % of the wave cycles waiting).  The registers are free:
+    // the LDS image, not the VGPR count, bounds the waves per SIMD.
+    auto loadRows = [&](uint32_t (&PA)[D], uint32_t (&PB)[D], uint32_t (&QA)[D], uint32_t (&QB)[D]) {
+        sw3LoadRow<R, HL>(smem, lb3, t3A, PA);
+        sw3LoadRow<R, HL>(smem, lb3, t3B, PB);
+        if constexpr (HAS_AA) { sw3LoadRow<R, HL>(smem, lbA, tAA, QA); sw3LoadRow<R, HL>(smem, lbA, tAB, QB); }
+    };
+    // PAc .. QBc: rows of the column this step works on; PAn .. QBn: filled for the next step
+    auto step = [&](const int s, uint32_t (&PAc)[D], uint32_t (&PBc)[D], uint32_t (&QAc)[D], uint32_t (&QBc)[D],
+                    uint32_t (&PAn)[D], uint32_t (&PBn)[D], uint32_t (&QAn)[D], uint32_t (&QBn)[D]) {
         if ((s & (kSw3Chunk - 1)) == 0) {
             storeChunk(s + kSw3Chunk);
             loadChunk(s + 2 * kSw3Chunk);
@@ -222,28 +233,22 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
         const uint32_t fsegIn = wave_shr1(fsegOut);
         uint32_t ffullIn = wave_shr1(ffullOut);
         if constexpr (HL == 32) { hUpNew &= inMask; ffullIn &= inMask; }
-        const uint32_t r3A = t3A, r3B = t3B, rAA = tAA, rAB = tAB;
-        // the entry of the column this lane works on in the NEXT step
+        // the rows of the NEXT step's column (its entry is in t3A .. tAB), then the entry of the column after that
+        loadRows(PAn, PBn, QAn, QBn);
         ringAt = ((ringAt + EB) & (uint32_t) (RINGB - 1)) | ring;
         readEntry();
         const int col = s - l;
         // No lane is masked off (see k_sw2): a lane before its first column or past its target's end reads the "past the end" row, rows
         // beyond the query score 0 -- neither can set a new maximum.
         {
-            uint32_t PA[D], PB[D];
-            sw3LoadRow<R, HL>(smem, lb3, r3A, PA);
-            sw3LoadRow<R, HL>(smem, lb3, r3B, PB);
             if constexpr (HAS_AA) {
-                uint32_t QA[D], QB[D];
-                sw3LoadRow<R, HL>(smem, lbA, rAA, QA);
-                sw3LoadRow<R, HL>(smem, lbA, rAB, QB);
 #pragma unroll
-                for (int j = 0; j < D; j++) { PA[j] = A::add(QA[j], PA[j]); PB[j] = A::add(QB[j], PB[j]); }
+                for (int j = 0; j < D; j++) { PAc[j] = A::add(QAc[j], PAc[j]); PBc[j] = A::add(QBc[j], PBc[j]); }
             }
             uint32_t diag = hUpPrev, fseg = fsegIn, ffull = ffullIn, cm = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t sc = __builtin_amdgcn_perm(PB[r / 2], PA[r / 2], (r & 1) ? selOdd : selEven);
+                const uint32_t sc = __builtin_amdgcn_perm(PBc[r / 2], PAc[r / 2], (r & 1) ? selOdd : selEven);
                 uint32_t h = A::adds(diag, sc);
                 h = A::max(h, E[r]);
                 fseg &= segmask[r];
@@ -272,9 +277,15 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
         hUpPrev = hUpNew;
     };
     {
+        uint32_t PA0[D], PB0[D], QA0[D], QB0[D], PA1[D], PB1[D], QA1[D], QB1[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) { QA0[j] = QB0[j] = QA1[j] = QB1[j] = 0; }
+        loadRows(PA0, PB0, QA0, QB0);                                            // column of step 0
+        ringAt = ((ringAt + EB) & (uint32_t) (RINGB - 1)) | ring;
+        readEntry();                                                             // entry of step 1
         int s = 0;
-        for (; s + 1 < steps; s += 2) { step(s); step(s + 1); }
-        if (s < steps) step(s);
+        for (; s + 1 < steps; s += 2) { step(s, PA0, PB0, QA0, QB0, PA1, PB1, QA1, QB1); step(s + 1, PA1, PB1, QA1, QB1, PA0, PB0, QA0, QB0); }
+        if (s < steps) step(s, PA0, PB0, QA0, QB0, PA1, PB1, QA1, QB1);
     }
 
 #pragma unroll
