@@ -956,7 +956,7 @@ int fsmod_search(int argc, const char **argv) {
         return fail("usage: search <queryDB> <targetDB> <outAlnDB> [<outPrefDB>] [--prefilter-mode 0|1] [-s S] [--max-seqs N] [-e E] [--alignment-type 0|2] [-a] [--threads T] ...");
     std::string err;
     const double tStart = nowSec();
-    std::atomic<int64_t> usPrep(0), usPref(0), usAlign(0), usFormat(0), usAlnPrep(0), usAlnDev(0), usAlnGate(0), usAlnBack(0), nRev(0), nPairs(0);
+    std::atomic<int64_t> usPrep(0), usPref(0), usAlign(0), usFormat(0), usAlnPrep(0), usAlnDev(0), usAlnGate(0), usAlnBack(0), nRev(0), nPairs(0), nBtDev(0), nBtAll(0);
     DbReader qA, q3, tA, t3;
     if (!qA.open(o.pos[0], err) || !q3.open(dbPathWithSuffix(o.pos[0], "_ss"), err) || !tA.open(o.pos[1], err) || !t3.open(dbPathWithSuffix(o.pos[1], "_ss"), err)) return fail(err);
     if (qA.size() != q3.size()) return fail("query AA and 3Di databases differ in size");
@@ -1080,6 +1080,7 @@ int fsmod_search(int argc, const char **argv) {
                     fshost_search_stats(s, st);
                     usAlnPrep += (int64_t) (st[2] * 1e6); usAlnDev += (int64_t) (st[3] * 1e6); usAlnGate += (int64_t) (st[4] * 1e6); usAlnBack += (int64_t) (st[5] * 1e6);
                     nRev += (int64_t) st[7];
+                    { int64_t bd = 0, ba = 0; fshost_search_backtrace_counts(s, &bd, &ba); nBtDev += bd; nBtAll += ba; }
                 }
                 for (size_t k = 0; k < nb && !bad; k++) {
                     if (status[k] < 0) { if (!bad++) firstErr = "query " + std::to_string(q3.key(qid[k])) + ": hit buffers of the reference would overflow"; break; }
@@ -1146,6 +1147,7 @@ int fsmod_search(int argc, const char **argv) {
                 fshost_search_stats(s, st);
                 usAlnPrep += (int64_t) (st[2] * 1e6); usAlnDev += (int64_t) (st[3] * 1e6); usAlnGate += (int64_t) (st[4] * 1e6); usAlnBack += (int64_t) (st[5] * 1e6);
                 nRev += (int64_t) st[7];
+                { int64_t bd = 0, ba = 0; fshost_search_backtrace_counts(s, &bd, &ba); nBtDev += bd; nBtAll += ba; }
                 for (int x : lN) nPairs += x;
             }
             for (size_t j = 0; j < live.size(); j++) {
@@ -1173,8 +1175,8 @@ int fsmod_search(int argc, const char **argv) {
     if (!w.close(err) || (writePref && !wp.close(err))) return fail(err);
     if (moduleTiming())
         fprintf(stderr, "search timing: load %.2f s, device open + index %.2f s, query loop %.2f s (%d threads; summed over threads: prepare %.2f, prefilter %.2f, align %.2f [profiles %.2f, SW launches + waits %.2f, gates %.2f, "
-                "backtrace %.2f; %lld pairs, %lld reversed], format %.2f), close + write %.2f s\n", tLoaded - tStart, tDevice - tLoaded, tLoop - tDevice, nthreads, usPrep / 1e6, usPref / 1e6,
-                usAlign / 1e6, usAlnPrep / 1e6, usAlnDev / 1e6, usAlnGate / 1e6, usAlnBack / 1e6, (long long) nPairs.load(), (long long) nRev.load(), usFormat / 1e6, nowSec() - tLoop);
+                "backtrace %.2f (%lld of %lld on the device); %lld pairs, %lld reversed], format %.2f), close + write %.2f s\n", tLoaded - tStart, tDevice - tLoaded, tLoop - tDevice, nthreads, usPrep / 1e6, usPref / 1e6,
+                usAlign / 1e6, usAlnPrep / 1e6, usAlnDev / 1e6, usAlnGate / 1e6, usAlnBack / 1e6, (long long) nBtDev.load(), (long long) nBtAll.load(), (long long) nPairs.load(), (long long) nRev.load(), usFormat / 1e6, nowSec() - tLoop);
     return EXIT_SUCCESS;
 }
 
@@ -1210,6 +1212,7 @@ int fsmod_structurealign(int argc, const char **argv) {
     std::vector<std::string> results(pref.size());
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
+    std::atomic<int64_t> nBtDev(0), nBtAll(0);
     std::string firstErr;
     // each host thread takes groups of prefilter entries: their hit lists go through ONE multi-query SW launch
     // (fshost_search_align_batch), then gates / backtrace / formatting per query
@@ -1269,6 +1272,7 @@ int fsmod_structurealign(int argc, const char **argv) {
                 if (!bad++) firstErr = fshost_search_error(s);
                 break;
             }
+            { int64_t bd = 0, ba = 0; fshost_search_backtrace_counts(s, &bd, &ba); nBtDev += bd; nBtAll += ba; }
             for (size_t k = 0; k < m; k++) {
                 std::string &out = results[entry[k]];
                 for (int r = 0; r < nres[k]; r++)
@@ -1286,6 +1290,7 @@ int fsmod_structurealign(int argc, const char **argv) {
     if (bad) return fail("structurealign failed: " + firstErr);
     for (size_t id = 0; id < pref.size(); id++) w.write(pref.key(id), results[id].data(), results[id].size());
     if (!w.close(err)) return fail(err);
+    if (moduleTiming()) fprintf(stderr, "structurealign timing: backtrace 0.00 (%lld of %lld on the device)\n", (long long) nBtDev.load(), (long long) nBtAll.load());
     return EXIT_SUCCESS;
 }
 

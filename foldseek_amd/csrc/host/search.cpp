@@ -510,6 +510,37 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
 // Backtraces of every pair of the given queries that passes the score gates, computed by the host pool (the calling
 // thread takes part).  Only when the accept / reject limits cannot cut a query short (their defaults): otherwise gateAlign
 // computes them one by one, like the reference, and stops where the reference stops.
+// what the two aligners cost in this process (exponential averages; plain doubles behind a mutex: a few updates per batch)
+struct BtCalib {
+    std::mutex m;
+    double hostSecPerHitCore = 0, devSecFixed = 0, devSecPerHit = 0;     // 0 = not measured yet
+    long calls = 0;
+    static BtCalib &get() { static BtCalib c; return c; }
+    bool chooseDevice(double n, int cores) {
+        std::lock_guard<std::mutex> g(m);
+        const long c = calls++;
+        if (n < 64) return false;                                          // a handful of hits: the call overhead alone decides
+        if (hostSecPerHitCore == 0) return false;                          // measure the host first,
+        if (devSecPerHit == 0) return true;                                // then the device
+        const bool dev = devSecFixed + n * devSecPerHit < n * hostSecPerHitCore / (double) cores;
+        return (c % 64 == 63) ? !dev : dev;
+    }
+    void hostSample(double sec, double n, int cores) {
+        if (n < 64) return;
+        std::lock_guard<std::mutex> g(m);
+        const double v = sec * (double) cores / n;
+        hostSecPerHitCore = hostSecPerHitCore == 0 ? v : 0.75 * hostSecPerHitCore + 0.25 * v;
+    }
+    void devSample(double sec, double n) {
+        if (n < 64) return;
+        std::lock_guard<std::mutex> g(m);
+        // one call = fixed part + n x per-hit part; small calls move the fixed part, large ones the slope
+        if (devSecPerHit == 0) { devSecFixed = std::min(sec, 1.0e-3); devSecPerHit = std::max(1e-9, (sec - devSecFixed) / n); return; }
+        const double pred = devSecFixed + n * devSecPerHit, err = sec - pred;
+        if (n < 1024) devSecFixed = std::max(1e-4, devSecFixed + 0.25 * err);
+        else devSecPerHit = std::max(1e-9, devSecPerHit + 0.25 * err / n);
+    }
+};
 struct PreBacktrace {
     std::vector<BlockAlnOut> outs;
     std::vector<std::vector<int>> idx;       // [query][pair] -> outs index or -1
@@ -543,17 +574,16 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     // everything when it is switched off (FSGPU_DEVICE_BACKTRACE=0) or cannot run (database without AA sequences) goes to the host pool ----
     std::vector<int> hostTasks;
     // FSGPU_DEVICE_BACKTRACE = 1 / 0 forces the device / the host aligner (read per call: the tests switch it inside one process).  Unset: whichever is
-    // expected to answer the batch sooner, from what tools/btrace_probe.py measures on one MI355X and its 16-core host -- an alignment of two 350-residue
-    // structures is ~36 us of one host core (the pool spreads a batch over its workers + the caller) and ~1.5 ms of LATENCY in a wave, of which three
-    // thousand run at once: device 1.5 ms + 0.8 us per hit (50 hits 1.5 ms, 1 600 hits 3.2 ms, 12 800 hits 11.6 ms) against host 0.23 / 4.3 / 33 ms with
-    // 13 workers.  With the two cores one of eight ranks of a node gets, the host aligner is what a rank waits for (bench.py --emulate-rank-share 8).
+    // expected to answer the batch sooner -- from what THIS process has measured (BtCalib below): the host's seconds per hit and pool worker, the
+    // device's seconds per call and per hit.  Until both have been seen the first two batches of 64 hits or more take one path each; every 64th
+    // batch re-measures the path that is not being chosen (the balance shifts with the load of either side).  Round 5 decided from constants
+    // measured once on a 16-core box (36 us per hit on the host, 1.5 ms + 0.8 us on the device, the host given a factor of four), which on that
+    // box never picked the device and on no other box meant anything.
     const char *envDev = getenv("FSGPU_DEVICE_BACKTRACE");
     const double nTasks = (double) tasks.size();
-    // The host gets the benefit of the doubt (factor 4): pool workers of a 16-core job run while the feeders' other batches keep the device busy, and a
-    // device aligner that runs BESIDE a scan launch waits for issue slots -- 9.7 ms per 3 200-hit call on average, 45 ms at worst, in the traced bench run
-    // against 4 ms alone -- and costs the scan something too (bench.py at N = 1 with the device aligner on every large batch: headline -0.7 ... -1.0 %,
-    // all-vs-all leg +6 %, k-mer leg +3 %, module unchanged).  In practice: 16 cores -> host, up to four cores -> device from ~200 hits on.
-    const bool deviceOn = envDev ? atoi(envDev) != 0 : nTasks * 36e-6 / (double) (HostPool::get().workers() + 1) > 4.0 * (1.5e-3 + nTasks * 0.8e-6);
+    BtCalib &cal = BtCalib::get();
+    const bool deviceOn = envDev ? atoi(envDev) != 0 : cal.chooseDevice(nTasks, HostPool::get().workers() + 1);
+    const double tDevStart = nowSec();
     const fshost_params &par = s->par;
     bool onDevice = deviceOn && s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
     if (onDevice) {
@@ -577,9 +607,16 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
         for (int i = 0; i < nq; i++) { bq[i].qAA = aq[i].qAA; bq[i].q3Di = aq[i].q3di; bq[i].cbAA = aq[i].cbAA.data(); bq[i].cbSS = aq[i].cbSS.data(); bq[i].L = aq[i].L; bq[i].reserved = 0; }
         std::vector<fsgpu_bt_task> bt;
         std::vector<fsgpu_bt_res> br;
-        const size_t chunk = 16384;                       // tasks per device call: 60-120 KB of trace scratch each
-        for (size_t c0 = 0; c0 < tasks.size() && onDevice; c0 += chunk) {
-            const size_t c1 = std::min(tasks.size(), c0 + chunk);
+        // tasks per device call: at most 16384 and at most 1 GB of trace scratch (64 B per row and column of an alignment's prefixes: a call full of
+        // 2000-residue pairs would otherwise pin 6.7 GB per feeder context for good)
+        for (size_t c0 = 0, c1 = 0; c0 < tasks.size() && onDevice; c0 = c1) {
+            size_t traceBytes = 0;
+            for (c1 = c0; c1 < tasks.size() && c1 - c0 < 16384; c1++) {
+                const fsgpu_swres &f = fwd[tasks[c1].base + tasks[c1].k];
+                const size_t b = 64 * ((size_t) f.qEnd + (size_t) f.dbEnd + 2 + 256);
+                if (c1 > c0 && traceBytes + b > ((size_t) 1 << 30)) break;
+                traceBytes += b;
+            }
             bt.resize(c1 - c0); br.resize(c1 - c0);
             for (size_t t = c0; t < c1; t++) {
                 const Task &tk = tasks[t];
@@ -605,11 +642,14 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
         for (size_t t = 0; t < tasks.size(); t++) hostTasks.push_back((int) t);
     }
     pb.onDevice = tasks.size() - hostTasks.size();
+    if (onDevice && pb.onDevice > 0) cal.devSample(nowSec() - tDevStart, (double) tasks.size());
+    const double tHost0 = nowSec();
     HostPool::get().parallelFor((int) hostTasks.size(), [&](int h) {
         const int t = hostTasks[h];
         const Task &tk = tasks[t];
         pairBacktrace(s, aq[tk.q], targetIds[tk.q][tk.k], fwd[tk.base + tk.k], pb.outs[t]);
     });
+    if (hostTasks.size() == tasks.size()) cal.hostSample(nowSec() - tHost0, (double) tasks.size(), HostPool::get().workers() + 1);
     pb.seconds = nowSec() - t0;
 }
 

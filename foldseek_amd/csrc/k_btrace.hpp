@@ -3,13 +3,15 @@
 // M/lib/block-aligner: align_core scan_block.rs:120-630, place_block_3di :1302-1443, Trace / cigar :1726-2007, AVX2 configuration L = 16).
 //
 // The host restatement (host/block_aligner.cpp) is a lane-exact emulation of the crate's 16 x int16 vector code, because CIGARs depend on its
-// saturation corners, tie-breaks and block trajectory.  Here ONE WAVE RUNS ONE ALIGNMENT and a 16-lane DPP row IS the crate's vector: lane k of
-// a row holds lane k of every vector as a sign-extended int, each vector helper of the host file is the same expression on row shuffles
-// (simd_sl_i16 = row shift by one, simd_step = rotate by 8, the 128-bit-half quirks of the prefix scan as written there), and everything
-// align_core decides per block (direction, grow / shrink, x-drop, checkpoints) is wave-uniform scalar control flow -- no divergence.  The four
-// rows of a wave compute the same alignment (the work is latency bound: 30 k vector steps per alignment, thousands of alignments in flight);
-// only row 0's ballots and stores count.  Column / row state lives in LDS, the trace words and the block list of an alignment in global
-// scratch.  The block may grow to kBtMaxBlock rows; an alignment that wants a larger block, or does not reach the SW score with starting sizes
+// saturation corners, tie-breaks and block trajectory.  Here a 16-lane DPP ROW RUNS ONE ALIGNMENT -- four alignments per wave (round 6; round 5
+// ran one per wave with the four rows computing the same thing, and the kernel is bound by instruction issue: ~390 k wave instructions per
+// alignment) -- and the row IS the crate's vector: lane k of a row holds lane k of every vector as a sign-extended int, each vector helper of the
+// host file is the same expression on row shuffles (simd_sl_i16 = row shift by one, simd_step = rotate by 8, a lane broadcast = row_newbcast, the
+// 128-bit-half quirks of the prefix scan as written there).  What align_core decides per block (direction, grow / shrink, x-drop, checkpoints) is
+// uniform inside a row and differs between the rows of a wave: the rows share the instruction stream where they agree (right and down steps run
+// the same code on swapped operands) and take turns where they do not; the host hands the tasks over sorted by size so that the four alignments of
+// a wave are of similar length.  Column / row state lives in LDS (2.4 KB per row), the padded sequences, the trace words and the block list of an
+// alignment in global scratch.  The block may grow to kBtMaxBlock rows; an alignment that wants a larger block, or does not reach the SW score with starting sizes
 // 32 .. kBtMaxBlock, is handed back (status 0) and takes the host path -- same answers either way, which is what tests/test_btrace_gpu.py holds.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,10 +24,12 @@ constexpr int kBtZero = 1 << 14;         // avx2.rs:15
 constexpr int kBtMin = 0;                // avx2.rs:16
 constexpr int kBtStep = 8;               // scan_block.rs:813
 constexpr int kBtXDropIter = 2;          // scan_block.rs:814
-constexpr int kBtMaxBlock = 128;         // largest block size the device grows to (the crate: 4096)
-constexpr int kBtPad = kBtMaxBlock + 2 * kBtL + 16;      // readable bytes behind a sequence
+constexpr int kBtMaxBlock = 128;         // largest block size of the first pass (16 alignments per workgroup)
+constexpr int kBtMaxBlock2 = 512;        // ... of the second pass over what the first handed back (4 alignments per workgroup; the crate: 4096)
+constexpr int kBtPad = kBtMaxBlock2 + 2 * kBtL + 16;     // readable bytes behind a sequence
 constexpr int kBtNull = 26;              // AA_NULL: b'A' + 26 - b'A'
-constexpr int kBtSeqLds = 8192;          // per wave: the padded prefixes of an alignment live in LDS when they fit (two sequences of up to ~1000 residues), in global scratch otherwise
+constexpr int kBtRows = 16;               // alignments (rows of 16 lanes) per workgroup of the first pass
+constexpr int kBtRows2 = 4;               // ... of the second pass
 
 struct BtTask {                          // one accepted hit
     uint32_t query, target;              // index into the call's queries / target id in the resident DB
@@ -51,11 +55,11 @@ __device__ __forceinline__ int btSat(int x) { return min(max(x, -32768), 32767);
 __device__ __forceinline__ int btAdds(int a, int b) { return btSat(a + b); }
 __device__ __forceinline__ int btSubs(int a, int b) { return btSat(a - b); }
 // Row shuffles as DPP modifiers (a 16-lane DPP row is the vector; ds_bpermute costs an LDS round trip per shuffle and a block step is a chain of a dozen):
-// row_shr:n = 0x110 + n (lane i takes lane i - n, 0 where there is none), row_ror:n = 0x120 + n.  The four rows of a wave hold the same values, so a
-// broadcast of one lane is v_readlane of row 0's.
+// row_shr:n = 0x110 + n (lane i takes lane i - n, 0 where there is none), row_ror:n = 0x120 + n, row_newbcast:k = 0x150 + k (every lane of a row takes
+// the row's lane k).
 template <int CTRL> __device__ __forceinline__ int btDpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-__device__ __forceinline__ int btLane(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
-__device__ __forceinline__ int btSl1(int a, int b, int ln) { const int t = btDpp<0x111>(a), c = btLane(b, kBtL - 1); return ln == 0 ? c : t; }
+template <int K> __device__ __forceinline__ int btBcast(int v) { return btDpp<0x150 + K>(v); }
+__device__ __forceinline__ int btSl1(int a, int b, int ln) { const int t = btDpp<0x111>(a), c = btBcast<kBtL - 1>(b); return ln == 0 ? c : t; }
 __device__ __forceinline__ int btStep8(int a, int b, int ln) { const int xa = btDpp<0x128>(a), xb = btDpp<0x128>(b); return ln < 8 ? xb : xa; }
 template <int N> __device__ __forceinline__ int btSllz(int a, int ln) { const int t = btDpp<0x110 + N>(a); return (ln & 7) >= N ? t : 0; }
 template <int B> __device__ __forceinline__ int btSlli16(int a) { return (int) (int16_t) (uint16_t) ((uint32_t) a << B); }
@@ -68,7 +72,7 @@ __device__ __forceinline__ BtScanConsts btPrefixScanConsts(int gap, int ln) {
     const int shift1 = btAdds(btSllz<1>(gap, ln), gap);
     const int shift2 = btAdds(btSllz<2>(shift1, ln), shift1);
     const int shift4 = btAdds(btSllz<4>(shift2, ln), shift2);
-    const int s7 = btLane(shift4, 7);
+    const int s7 = btBcast<7>(shift4);
     BtScanConsts c;
     c.gapExtendAll = btAdds(ln < 8 ? 0 : s7, shift4);
     c.lane = shift4;
@@ -78,7 +82,7 @@ __device__ __forceinline__ int btPrefixScan(int Rmax, int gapCost, int gapCostLa
     const int shift1 = max(Rmax, btAdds(btSllz<1>(Rmax, ln), gapCost));
     const int shift2 = max(shift1, btAdds(btSllz<2>(shift1, ln), btSlli16<1>(gapCost)));
     const int shift4 = max(shift2, btAdds(btSllz<4>(shift2, ln), btSlli16<2>(gapCost)));
-    const int lowq = ln < 4 ? shift4 : btDpp<0x114>(shift4), s7 = btLane(shift4, 7);          // lanes 0..7 take lane (ln & 3)
+    const int lowq = ln < 4 ? shift4 : btDpp<0x114>(shift4), s7 = btBcast<7>(shift4);          // lanes 0..7 take lane (ln & 3)
     const int correct1 = btAdds(ln < 8 ? lowq : s7, gapCostLane);
     return max(shift4, correct1);
 }
@@ -87,24 +91,30 @@ __device__ __forceinline__ uint32_t btSpread16(uint32_t x) {
     x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
     return x;
 }
-// bit 2k <- lo lane k, bit 2k + 1 <- hi lane k (row 0 of the wave)
-__device__ __forceinline__ uint32_t btMask2(bool lo, bool hi) {
-    const uint32_t a = (uint32_t) __ballot(lo), b = (uint32_t) __ballot(hi);
+// bit 2k <- lo lane k, bit 2k + 1 <- hi lane k of this lane's row (sh = 16 x row of the wave; the rows that are not here with this one do not matter)
+__device__ __forceinline__ uint32_t btMask2(bool lo, bool hi, int sh) {
+    const uint32_t a = (uint32_t) (__ballot(lo) >> sh), b = (uint32_t) (__ballot(hi) >> sh);
     return btSpread16(a) | (btSpread16(b) << 1);
 }
 
 struct BtSeq { const uint8_t *aa, *ss; const int16_t *bias; int len; };      // padded: index 0 = AA_NULL, residues at 1 .. len, AA_NULL behind
 
-struct BtState {                       // per-wave LDS
-    int16_t Dcol[kBtMaxBlock + kBtL], Ccol[kBtMaxBlock + kBtL], Drow[kBtMaxBlock + kBtL], Rrow[kBtMaxBlock + kBtL];
-    int16_t DcolCk[kBtMaxBlock + kBtL], CcolCk[kBtMaxBlock + kBtL], DrowCk[kBtMaxBlock + kBtL], RrowCk[kBtMaxBlock + kBtL];
+template <int MAXB>
+struct BtState {                       // per-row LDS
+    static constexpr int kMaxBlock = MAXB;
+    int16_t Dcol[MAXB + kBtL], Ccol[MAXB + kBtL], Drow[MAXB + kBtL], Rrow[MAXB + kBtL];
+    int16_t DcolCk[MAXB + kBtL], CcolCk[MAXB + kBtL], DrowCk[MAXB + kBtL], RrowCk[MAXB + kBtL];
     int16_t tmp1[kBtL], tmp2[kBtL];
+    // the letters and biases of the block being placed (btPlaceBlock): the sequences live in global scratch, a vector step must not wait for them
+    int16_t wqb[MAXB], wrb[MAXB / 2];                          // (height <= MAXB; the reference window is refilled every MAXB / 2 columns)
+    uint8_t wqa[MAXB], wqs[MAXB], wra[MAXB / 2], wrs[MAXB / 2];
 };
 
-struct BtTrace {                       // wave-uniform scalars + the task's global arrays
+struct BtTrace {                       // row-uniform values + the task's global arrays
     uint32_t *trace, *trace2;
     uint4 *blocks;                     // {i, j, height | width << 16, right}
     uint32_t traceIdx, blockIdx, ckptTraceIdx, ckptBlockIdx;
+    uint32_t traceCap;                 // words of each of the two trace arrays
 };
 
 struct BtPB { int Dmax, argI, argJ; };
@@ -116,26 +126,37 @@ __device__ __forceinline__ void btWaveSync() {
 }
 
 // place_block_3di (scan_block.rs:1302-1443); `query` runs along the vector dimension
+template <class ST>
 __device__ __forceinline__ BtPB btPlaceBlock(const BtSeq &query, const BtSeq &reference, const int8_t *tblAA, const int8_t *tblSS, int gapOpen, int gapExtend,
                                              int startI, int startJ, int width, int height, int16_t *DcolP, int16_t *CcolP, int16_t *DrowP, int16_t *RrowP,
-                                             int Dcorner, BtTrace &tr, int ln, bool row0) {
+                                             int Dcorner, BtTrace &tr, ST &S, int ln, int sh) {
     const BtScanConsts sc = btPrefixScanConsts(gapExtend, ln);
     BtPB out; out.Dmax = kBtMin; out.argI = 0; out.argJ = 0;
     if (width == 0 || height == 0) return out;
     const int openMinusExt = btSubs(gapOpen, gapExtend);
+    // the block's letters into LDS: every global read of the block is in flight at once (width, height <= kBtMaxBlock)
+    for (int i = ln; i < height; i += kBtL) { S.wqa[i] = query.aa[startI + i]; S.wqs[i] = query.ss[startI + i]; S.wqb[i] = query.bias ? query.bias[startI + i] : (int16_t) 0; }
+    btWaveSync();
+    constexpr int kW = ST::kMaxBlock / 2;           // columns per fill of the reference window (the very first block of an attempt is minSize <= MAXB wide)
     for (int j = 0; j < width; j++) {
+        if ((j & (kW - 1)) == 0) {
+            for (int jj = ln; jj < kW && j + jj < width; jj += kBtL) {
+                S.wra[jj] = reference.aa[startJ + j + jj]; S.wrs[jj] = reference.ss[startJ + j + jj]; S.wrb[jj] = reference.bias ? reference.bias[startJ + j + jj] : (int16_t) 0;
+            }
+            btWaveSync();
+        }
         int R01 = kBtMin, D11 = kBtMin, R11 = kBtMin;
         bool prevTraceR = false;
-        const int c = reference.aa[startJ + j], c3 = reference.ss[startJ + j];
-        const int refBias = reference.bias ? (int) reference.bias[startJ + j] : 0;
+        const int c = S.wra[j & (kW - 1)], c3 = S.wrs[j & (kW - 1)];
+        const int refBias = S.wrb[j & (kW - 1)];
         for (int i = 0; i < height; i += kBtL) {
             const int D10 = DcolP[i + ln], C10 = CcolP[i + ln];
             const int D00 = btSl1(D10, Dcorner, ln);
             Dcorner = D10;
-            int scores = tblAA[c * 32 + (query.aa[startI + i + ln] & 31)];
+            int scores = tblAA[c * 32 + (S.wqa[i + ln] & 31)];
             {
-                const int s3 = tblSS[c3 * 32 + (query.ss[startI + i + ln] & 31)];
-                const int qBias = query.bias ? (int) query.bias[startI + i + ln] : 0;
+                const int s3 = tblSS[c3 * 32 + (S.wqs[i + ln] & 31)];
+                const int qBias = S.wqb[i + ln];
                 scores = btAdds(btAdds(scores, s3), btAdds(refBias, qBias));
             }
             D11 = btAdds(D00, scores);
@@ -145,18 +166,18 @@ __device__ __forceinline__ BtPB btPlaceBlock(const BtSeq &query, const BtSeq &re
             D11 = max(D11, C11);
             const int D11open = btAdds(D11, openMinusExt);
             R11 = btPrefixScan(D11open, gapExtend, sc.lane, ln);
-            R11 = max(R11, btAdds(btLane(R01, kBtL - 1), sc.gapExtendAll));
+            R11 = max(R11, btAdds(btBcast<kBtL - 1>(R01), sc.gapExtendAll));
             D11 = max(D11, R11);
             R01 = R11;
             {
-                const uint32_t t = btMask2(D11 == C11, D11 == R11);
+                const uint32_t t = btMask2(D11 == C11, D11 == R11, sh);
                 const bool tempTraceR = R11 == D11open;
                 // traceR = simd_sl_i16(tempTraceR, prevTraceR, 1)
-                const int up = btDpp<0x111>((int) tempTraceR), last = btLane((int) prevTraceR, kBtL - 1);
+                const int up = btDpp<0x111>((int) tempTraceR), last = btBcast<kBtL - 1>((int) prevTraceR);
                 const bool traceR = (ln == 0 ? last : up) != 0;
-                const uint32_t t2 = btMask2(C11 == C11open, traceR);
+                const uint32_t t2 = btMask2(C11 == C11open, traceR, sh);
                 prevTraceR = tempTraceR;
-                if (row0 && ln == 0) { tr.trace[tr.traceIdx] = t; tr.trace2[tr.traceIdx] = t2; }
+                if (ln == 0) { tr.trace[tr.traceIdx] = t; tr.trace2[tr.traceIdx] = t2; }
                 tr.traceIdx++;
             }
             out.Dmax = max(out.Dmax, D11);
@@ -179,7 +200,7 @@ __device__ __forceinline__ void btJustOffset(int blockSize, int16_t *b1, int16_t
 // shift_and_offset (scan_block.rs:1096-1123)
 __device__ __forceinline__ int btShiftAndOffset(int blockSize, int16_t *b1, int16_t *b2, const int16_t *t1, const int16_t *t2, int offAdd, int ln) {
     int curr1 = btAdds(b1[ln], offAdd);
-    const int Dcorner = btLane(curr1, kBtStep - 1);
+    const int Dcorner = btBcast<kBtStep - 1>(curr1);
     int curr2 = btAdds(b2[ln], offAdd);
     int i = 0;
     while (i < blockSize - kBtL) {
@@ -208,11 +229,13 @@ __device__ __forceinline__ int btClamp16(int x) { return btSat(x); }
 enum { kBtRight = 0, kBtDown = 1, kBtGrow = 2 };
 
 // align_core (scan_block.rs:120-630) with trace and x-drop.  Returns false when the block wants to grow beyond kBtMaxBlock.
-__device__ __forceinline__ bool btAlign(BtState &S, BtTrace &tr, const BtSeq &query, const BtSeq &reference, const int8_t *tblAA, const int8_t *tblSS, int gapOpen, int gapExtend,
-                                        int minSize, int maxSize, int xDropThr, int ln, bool row0, int &resScore, int &resQ, int &resR) {
+template <class ST>
+__device__ __forceinline__ bool btAlign(ST &S, BtTrace &tr, const BtSeq &query, const BtSeq &reference, const int8_t *tblAA, const int8_t *tblSS, int gapOpen, int gapExtend,
+                                        int minSize, int maxSize, int xDropThr, int ln, int sh, int &resScore, int &resQ, int &resR) {
     // clear
     tr.traceIdx = tr.blockIdx = tr.ckptTraceIdx = tr.ckptBlockIdx = 0;
-    for (int i = 0; i < kBtMaxBlock + kBtL; i += kBtL) {
+    constexpr int MAXB = ST::kMaxBlock;
+    for (int i = 0; i < MAXB + kBtL; i += kBtL) {
         S.Dcol[i + ln] = kBtMin; S.Ccol[i + ln] = kBtMin; S.Drow[i + ln] = kBtMin; S.Rrow[i + ln] = kBtMin;
         S.DcolCk[i + ln] = kBtMin; S.CcolCk[i + ln] = kBtMin; S.DrowCk[i + ln] = kBtMin; S.RrowCk[i + ln] = kBtMin;
     }
@@ -229,7 +252,7 @@ __device__ __forceinline__ bool btAlign(BtState &S, BtTrace &tr, const BtSeq &qu
     const int qLen = query.len, rLen = reference.len;
     const uint32_t blockCap = (uint32_t) (qLen + rLen + 12);
     auto addBlock = [&](int i, int j, int width, int height, int right) {
-        if (row0 && ln == 0 && tr.blockIdx < blockCap) tr.blocks[tr.blockIdx] = make_uint4((uint32_t) i, (uint32_t) j, (uint32_t) height | ((uint32_t) width << 16), (uint32_t) right);
+        if (ln == 0 && tr.blockIdx < blockCap) tr.blocks[tr.blockIdx] = make_uint4((uint32_t) i, (uint32_t) j, (uint32_t) height | ((uint32_t) width << 16), (uint32_t) right);
         tr.blockIdx++;
     };
     auto copyToCkpt = [&](int n) {
@@ -238,39 +261,38 @@ __device__ __forceinline__ bool btAlign(BtState &S, BtTrace &tr, const BtSeq &qu
     };
     for (;;) {
         if (tr.blockIdx + 2 >= blockCap) return false;            // cannot happen while the walk follows the crate (a block per 8 rows or columns); the host path answers
+        if (tr.traceIdx + (uint32_t) (3 * MAXB * MAXB / (4 * kBtL)) > tr.traceCap) return false;   // the largest step (a grow to MAXB: two blocks) must fit the task's slice
         prevOff = off;
         int growDmax = kBtMin, growArgI = 0, growArgJ = 0;
         BtPB pb;
         int rightMax, downMax;
-        if (dir == kBtRight) {
+        if (dir != kBtGrow) {
+            // a step to the right and a step down are the same code on swapped operands (scan_block.rs:237-330): the rows of a wave that step in
+            // different directions stay in one instruction stream
+            const bool rt = dir == kBtRight;
+            int16_t *c1 = rt ? S.Dcol : S.Drow, *c2 = rt ? S.Ccol : S.Rrow, *o1 = rt ? S.Drow : S.Dcol, *o2 = rt ? S.Rrow : S.Ccol;
+            BtSeq sa, sb;
+            sa.aa = rt ? query.aa : reference.aa; sa.ss = rt ? query.ss : reference.ss; sa.bias = rt ? query.bias : reference.bias; sa.len = rt ? query.len : reference.len;
+            sb.aa = rt ? reference.aa : query.aa; sb.ss = rt ? reference.ss : query.ss; sb.bias = rt ? reference.bias : query.bias; sb.len = rt ? reference.len : query.len;
             off = offMax;
             const int offAdd = btClamp16(prevOff - off);
-            addBlock(si, sj + blockSize - kBtStep, kBtStep, blockSize, 1);
-            btJustOffset(blockSize, S.Dcol, S.Ccol, offAdd, ln);
-            pb = btPlaceBlock(query, reference, tblAA, tblSS, gapOpen, gapExtend, si, sj + blockSize - kBtStep, kBtStep, blockSize, S.Dcol, S.Ccol, S.tmp1, S.tmp2,
-                              prevDir == kBtDown ? btAdds(Dcorner, offAdd) : kBtMin, tr, ln, row0);
-            rightMax = btPrefixHmax8(S.Dcol, ln);
-            Dcorner = btShiftAndOffset(blockSize, S.Drow, S.Rrow, S.tmp1, S.tmp2, offAdd, ln);
-            downMax = btPrefixHmax8(S.Drow, ln);
-        } else if (dir == kBtDown) {
-            off = offMax;
-            const int offAdd = btClamp16(prevOff - off);
-            addBlock(si + blockSize - kBtStep, sj, blockSize, kBtStep, 0);
-            btJustOffset(blockSize, S.Drow, S.Rrow, offAdd, ln);
-            pb = btPlaceBlock(reference, query, tblAA, tblSS, gapOpen, gapExtend, sj, si + blockSize - kBtStep, kBtStep, blockSize, S.Drow, S.Rrow, S.tmp1, S.tmp2,
-                              prevDir == kBtRight ? btAdds(Dcorner, offAdd) : kBtMin, tr, ln, row0);
-            downMax = btPrefixHmax8(S.Drow, ln);
-            Dcorner = btShiftAndOffset(blockSize, S.Dcol, S.Ccol, S.tmp1, S.tmp2, offAdd, ln);
-            rightMax = btPrefixHmax8(S.Dcol, ln);
+            addBlock(rt ? si : si + blockSize - kBtStep, rt ? sj + blockSize - kBtStep : sj, rt ? kBtStep : blockSize, rt ? blockSize : kBtStep, rt ? 1 : 0);
+            btJustOffset(blockSize, c1, c2, offAdd, ln);
+            pb = btPlaceBlock(sa, sb, tblAA, tblSS, gapOpen, gapExtend, rt ? si : sj, (rt ? sj : si) + blockSize - kBtStep, kBtStep, blockSize, c1, c2, S.tmp1, S.tmp2,
+                              prevDir == (rt ? kBtDown : kBtRight) ? btAdds(Dcorner, offAdd) : kBtMin, tr, S, ln, sh);
+            const int m1 = btPrefixHmax8(c1, ln);
+            Dcorner = btShiftAndOffset(blockSize, o1, o2, S.tmp1, S.tmp2, offAdd, ln);
+            const int m2 = btPrefixHmax8(o1, ln);
+            rightMax = rt ? m1 : m2; downMax = rt ? m2 : m1;
         } else {
             Dcorner = kBtMin;
             const int growStep = blockSize - prevSize;
             addBlock(si + prevSize, sj, prevSize, growStep, 0);
             const BtPB p1 = btPlaceBlock(reference, query, tblAA, tblSS, gapOpen, gapExtend, sj, si + prevSize, growStep, prevSize, S.Drow, S.Rrow, S.Dcol + prevSize,
-                                         S.Ccol + prevSize, kBtMin, tr, ln, row0);
+                                         S.Ccol + prevSize, kBtMin, tr, S, ln, sh);
             addBlock(si, sj + prevSize, growStep, blockSize, 1);
             pb = btPlaceBlock(query, reference, tblAA, tblSS, gapOpen, gapExtend, si, sj + prevSize, growStep, blockSize, S.Dcol, S.Ccol, S.Drow + prevSize,
-                              S.Rrow + prevSize, kBtMin, tr, ln, row0);
+                              S.Rrow + prevSize, kBtMin, tr, S, ln, sh);
             rightMax = btPrefixHmax8(S.Dcol, ln);
             downMax = btPrefixHmax8(S.Drow, ln);
             growDmax = p1.Dmax; growArgI = p1.argI; growArgJ = p1.argJ;
@@ -332,7 +354,7 @@ __device__ __forceinline__ bool btAlign(BtState &S, BtTrace &tr, const BtSeq &qu
         const int nextSize = blockSize * 2;
         if (nextSize <= maxSize) {
             if (yDropIter > (blockSize / kBtStep) - 1 || growNoMax) {
-                if (nextSize > kBtMaxBlock) return false;          // the host path continues where the device's LDS ends
+                if (nextSize > MAXB) return false;                 // the next pass / the host path continues where this pass's LDS ends
                 prevSize = blockSize;
                 blockSize = nextSize;
                 dir = kBtGrow;
@@ -421,17 +443,16 @@ __device__ __forceinline__ int btCigar(const BtTrace &tr, int i, int j, const ui
     return n;
 }
 
-// alignStartPosBacktraceBlock (StructureSmithWaterman.cpp:369-537) for a batch of accepted hits: one wave per task
-__global__ __launch_bounds__(256) void k_block_backtrace(BtArgs a) {
-    __shared__ BtState states[4];
-    __shared__ __attribute__((aligned(16))) uint8_t seqLds[4][kBtSeqLds];
+// alignStartPosBacktraceBlock (StructureSmithWaterman.cpp:369-537) for a batch of accepted hits: one 16-lane row per task
+template <int MAXB, int ROWS>
+__global__ __launch_bounds__(ROWS * kBtL) void k_block_backtrace(BtArgs a) {
+    __shared__ BtState<MAXB> states[ROWS];
     __shared__ int8_t tAA[27 * 32], tSS[27 * 32];
     for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) { tAA[i] = a.tblAA[i]; tSS[i] = a.tblSS[i]; }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & (kBtL - 1);
-    const bool row0 = lane < kBtL;
-    BtState &S = states[wave];
-    for (int task = blockIdx.x * 4 + wave; task < a.nTasks; task += gridDim.x * 4) {
+    const int row = threadIdx.x >> 4, ln = threadIdx.x & (kBtL - 1), sh = (int) (threadIdx.x & 48u);     // sh: first lane of the row inside its wave
+    BtState<MAXB> &S = states[row];
+    for (int task = blockIdx.x * ROWS + row; task < a.nTasks; task += gridDim.x * ROWS) {
         const BtTask tk = a.tasks[task];
         const BtQuery q = a.queries[tk.query];
         const int qn = tk.qEnd + 1, tn = tk.dbEnd + 1;
@@ -441,63 +462,50 @@ __global__ __launch_bounds__(256) void k_block_backtrace(BtArgs a) {
         const int16_t *qb = (const int16_t *) (a.qdata + q.off + 2 * (size_t) q.L);      // q.off is a multiple of 16
         const uint8_t *ta = a.dbAA + a.dbOff[tk.target], *t3 = a.dbSS + a.dbOff[tk.target];
         BtTrace tr;
-        const size_t traceWords = (size_t) (kBtMaxBlock / kBtL) * ((size_t) qn + tn + 2 * kBtMaxBlock);
-        tr.trace = a.trace + tk.traceOff; tr.trace2 = tr.trace + traceWords;
+        const size_t traceWords = (size_t) (MAXB / kBtL) * ((size_t) qn + tn + 2 * MAXB);
+        tr.trace = a.trace + tk.traceOff; tr.trace2 = tr.trace + traceWords; tr.traceCap = (uint32_t) traceWords;
         tr.blocks = a.blocks + tk.blockOff;
         BtRes r;
         r.status = 0; r.qStart = -1; r.dbStart = -1; r.identicalAA = 0; r.btLen = 0; r.blockSizes = 0;
-        // the same body twice, once per address space of the sequences (a pointer that may be LDS or global memory compiles to flat accesses)
-#define FS_BT_RUN(PQ, PQ3, PT, PT3, PB)                                                                                                                  \
-        {                                                                                                                                               \
-            for (int i = lane; i < (int) qStride; i += 64) {                                                                                            \
-                const int k = i - 1;                             /* reversed-prefix index */                                                           \
-                const bool in = k >= 0 && k < qn;                                                                                                       \
-                (PQ)[i] = in ? a.letAA[min((int) qa[tk.qEnd - k], 20)] : (uint8_t) kBtNull;                                                             \
-                (PQ3)[i] = in ? a.letSS[min((int) q3[tk.qEnd - k], 20)] : (uint8_t) kBtNull;                                                            \
-                (PB)[i] = in ? qb[tk.qEnd - k] : (int16_t) 0;                                                                                           \
-            }                                                                                                                                           \
-            for (int i = lane; i < (int) tStride; i += 64) {                                                                                            \
-                const int k = i - 1;                                                                                                                    \
-                const bool in = k >= 0 && k < tn;                                                                                                       \
-                (PT)[i] = in ? a.letAA[min((int) ta[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;                                                            \
-                (PT3)[i] = in ? a.letSS[min((int) t3[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;                                                           \
-            }                                                                                                                                           \
-            __threadfence_block();                                                                                                                      \
-            btWaveSync();                                                                                                                               \
-            const BtSeq qs{(PQ), (PQ3), (PB), qn}, rs{(PT), (PT3), nullptr, tn};                                                                        \
-            int score = -1000000000, rq = -1, rr = -1, sizes = 0;                                                                                       \
-            bool onDevice = true;                                                                                                                       \
-            for (int minSize = 32; minSize <= kBtMaxBlock && score < tk.score; minSize *= 2) {                                                          \
-                const int xDrop = -(minSize * a.gapExtend + a.gapOpen);                                                                                 \
-                onDevice = btAlign(S, tr, qs, rs, tAA, tSS, a.gapOpen, a.gapExtend, minSize, 4096, xDrop, ln, row0, score, rq, rr);                     \
-                sizes++;                                                                                                                                \
-                if (!onDevice) break;                                                                                                                   \
-            }                                                                                                                                           \
-            r.blockSizes = sizes;                                                                                                                       \
-            if (onDevice && score >= tk.score) {                                                                                                        \
-                /* reached (a larger starting size is never tried once the score is there); like the host: a score that differs from the SW score */  \
-                /* leaves the hit without start position, except at int16 saturation */                                                                \
-                if (!(score != tk.score && !(tk.score == 32767 && score >= tk.score))) {                                                                \
-                    __threadfence_block();                                                                                                              \
-                    btWaveSync();                                                                                                                       \
-                    int ident = 0;                                                                                                                      \
-                    const int n = btCigar(tr, rq, rr, (PQ), (PT), a.bt + tk.btOff, ident, row0 && ln == 0);                                             \
-                    if (n >= 0) { r.status = 1; r.qStart = (tk.qEnd + 1) - rq; r.dbStart = (tk.dbEnd + 1) - rr; r.identicalAA = ident; r.btLen = n; }  \
-                } else r.status = 2;                                                                                                                    \
-            }                                                                                                                                           \
+        uint8_t *pq = a.seq + tk.seqOff, *pq3 = pq + qStride, *pt = pq3 + qStride, *pt3 = pt + tStride;
+        int16_t *pb = (int16_t *) (pt3 + tStride);
+        for (int i = ln; i < (int) qStride; i += kBtL) {
+            const int k = i - 1;                             // reversed-prefix index
+            const bool in = k >= 0 && k < qn;
+            pq[i] = in ? a.letAA[min((int) qa[tk.qEnd - k], 20)] : (uint8_t) kBtNull;
+            pq3[i] = in ? a.letSS[min((int) q3[tk.qEnd - k], 20)] : (uint8_t) kBtNull;
+            pb[i] = in ? qb[tk.qEnd - k] : (int16_t) 0;
         }
-        if (4 * qStride + 2 * tStride <= (size_t) kBtSeqLds) {
-            uint8_t *base = seqLds[wave];
-            uint8_t *lq = base, *lq3 = lq + qStride, *lt = lq3 + qStride, *lt3 = lt + tStride;
-            int16_t *lb = (int16_t *) (lt3 + tStride);
-            FS_BT_RUN(lq, lq3, lt, lt3, lb)
-        } else {
-            uint8_t *pq = a.seq + tk.seqOff, *pq3 = pq + qStride, *pt = pq3 + qStride, *pt3 = pt + tStride;
-            int16_t *pb = (int16_t *) (pt3 + tStride);
-            FS_BT_RUN(pq, pq3, pt, pt3, pb)
+        for (int i = ln; i < (int) tStride; i += kBtL) {
+            const int k = i - 1;
+            const bool in = k >= 0 && k < tn;
+            pt[i] = in ? a.letAA[min((int) ta[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;
+            pt3[i] = in ? a.letSS[min((int) t3[tk.dbEnd - k], 20)] : (uint8_t) kBtNull;
         }
-#undef FS_BT_RUN
-        if (lane == 0) a.res[task] = r;
+        __threadfence_block();
+        btWaveSync();
+        const BtSeq qs{pq, pq3, pb, qn}, rs{pt, pt3, nullptr, tn};
+        int score = -1000000000, rq = -1, rr = -1, sizes = 0;
+        bool onDevice = true;
+        for (int minSize = 32; minSize <= MAXB && score < tk.score; minSize *= 2) {
+            const int xDrop = -(minSize * a.gapExtend + a.gapOpen);
+            onDevice = btAlign(S, tr, qs, rs, tAA, tSS, a.gapOpen, a.gapExtend, minSize, 4096, xDrop, ln, sh, score, rq, rr);
+            sizes++;
+            if (!onDevice) break;
+        }
+        r.blockSizes = sizes;
+        if (onDevice && score >= tk.score) {
+            // reached (a larger starting size is never tried once the score is there); like the host: a score that differs from the SW score
+            // leaves the hit without start position, except at int16 saturation
+            if (!(score != tk.score && !(tk.score == 32767 && score >= tk.score))) {
+                __threadfence_block();
+                btWaveSync();
+                int ident = 0;
+                const int n = btCigar(tr, rq, rr, pq, pt, a.bt + tk.btOff, ident, ln == 0);
+                if (n >= 0) { r.status = 1; r.qStart = (tk.qEnd + 1) - rq; r.dbStart = (tk.dbEnd + 1) - rr; r.identicalAA = ident; r.btLen = n; }
+            } else r.status = 2;
+        }
+        if (ln == 0) a.res[task] = r;
         btWaveSync();
     }
 }

@@ -6,6 +6,7 @@ What only shows up at this size: the column-segment work items and the atomic wo
 byte-wise atomicCAS max over a stripe's segments, 8-target stripes of up to 2000 columns, multi-query SW launches with
 tens of thousands of waves, several register classes in one launch.
 """
+import os
 import numpy as np
 import pytest
 
@@ -66,7 +67,18 @@ def test_gapless_scores_and_hit_lists_equal_reference_at_100k(world):
     s.close()
 
 
-def _align_against_reference(world, atype, go, ge, queries, max_hits):
+def _align_against_reference(world, atype, go, ge, queries, max_hits, device_backtrace=None):
+    """device_backtrace: None = the library's own choice, 0 / 1 = host / device block aligner (FSGPU_DEVICE_BACKTRACE): with 1 the CIGARs the
+    compiled reference's alignStructure wrote are met by k_block_backtrace directly, not through the host restatement"""
+    if device_backtrace is not None:
+        os.environ["FSGPU_DEVICE_BACKTRACE"] = str(device_backtrace)
+    try:
+        return _align_against_reference_body(world, atype, go, ge, queries, max_hits, device_backtrace)
+    finally:
+        os.environ.pop("FSGPU_DEVICE_BACKTRACE", None)
+
+
+def _align_against_reference_body(world, atype, go, ge, queries, max_hits, device_backtrace):
     ref, db, q3, qa = world["ref"], world["db"], world["q3"], world["qa"]
     par = api.default_params()
     par.alignmentType = atype
@@ -100,28 +112,35 @@ def _align_against_reference(world, atype, go, ge, queries, max_hits):
             assert r["eval"] == a["evalue"] and r["alnLength"] == a["alnLen"] and abs(r["seqId"] - a["seqId"]) == 0
             assert bt == cigs[k], (qi, k, go, ge)
         accepted += len(want)
+    on_device, total = s.backtrace_counts()
+    if device_backtrace == 1:
+        assert total > 0 and on_device >= 0.95 * total, (on_device, total)
+    elif device_backtrace == 0:
+        assert on_device == 0
     s.close()
     return accepted
 
 
+@pytest.mark.parametrize("dev", [0, 1])
 @pytest.mark.parametrize("atype", [0, 2])
-def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, atype):
+def test_structure_alignment_of_real_hit_lists_equals_reference_at_100k(world, atype, dev):
     """prefilter hit lists (1000 targets each, 50 planted homologs among them) through the batch path (k_sw2 forward over all
     pairs, reversed over the gate survivors, host gates, block-aligner backtrace): forward score / end positions of EVERY pair
     and the complete accepted records (scores, e-value bits, start/end, CIGAR, order) against the reference's alignStructure"""
     if world["ref"] is None:
         pytest.skip("oracle/_ref not built")
-    accepted = _align_against_reference(world, atype, 10, 1, list(range(len(world["q3"]))), 1000)
+    accepted = _align_against_reference(world, atype, 10, 1, list(range(len(world["q3"]))), 1000, dev)
     assert accepted >= 150            # the planted homologs are found and aligned, not just random pairs
 
 
+@pytest.mark.parametrize("dev", [0, 1])
 @pytest.mark.parametrize("go,ge", [(8, 2), (15, 3), (3, 1), (2, 1), (25, 1)])
-def test_structure_alignment_with_other_gap_costs_equals_reference(world, go, ge):
+def test_structure_alignment_with_other_gap_costs_equals_reference(world, go, ge, dev):
     """--gap-open / --gap-extend other than 10 / 1 (any gapOpen > gapExtend >= 1 is on the device path): the same comparison against the
     reference's alignStructure run with those costs -- SW kernels (single tile and the 777-residue row-tiled query), gates, backtraces"""
     if world["ref"] is None:
         pytest.skip("oracle/_ref not built")
-    accepted = _align_against_reference(world, 2, go, ge, [0, 1, 3], 300)
+    accepted = _align_against_reference(world, 2, go, ge, [0, 1, 3], 300, dev)
     assert accepted >= 60
 
 
@@ -242,12 +261,13 @@ def test_gapless_properties_at_1M_targets(world1m):
     s.close()
 
 
+@pytest.mark.parametrize("dev", [0, 1])
 @pytest.mark.parametrize("atype", [0, 2])
-def test_structure_alignment_of_real_hit_lists_equals_reference_at_1M(world1m, atype):
+def test_structure_alignment_of_real_hit_lists_equals_reference_at_1M(world1m, atype, dev):
     """configs[2] (--alignment-type 0) and configs[3] (--alignment-type 2, 3Di + AA) at their stated size: the 3 x 1000 prefilter hit lists of
     the 1M-target database through the batch path, the COMPLETE alignStructure records (forward / reverse scores, e-value bits, start / end
     positions, alignment length, identity, CIGAR, output order) against the compiled reference's alignStructure on the same pairs"""
     if world1m["ref"] is None:
         pytest.skip("oracle/_ref not built")
-    accepted = _align_against_reference(world1m, atype, 10, 1, [0, 1, 2], 1000)
+    accepted = _align_against_reference(world1m, atype, 10, 1, [0, 1, 2], 1000, dev)
     assert accepted >= 120            # the planted homologs are among the accepted records

@@ -18,6 +18,7 @@ oracle/ba_kat (vectors to run against the crate wherever cargo exists).
 import json
 import os
 import shutil
+import re
 import subprocess
 
 import pytest
@@ -95,12 +96,18 @@ def test_modules_refuse_what_they_do_not_implement(scop, module, args, needle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dev", [0, 1])
 @pytest.mark.parametrize("name", sorted(MANIFEST["runs"]))
-def test_module_equals_reference_result_db(scop, name):
+def test_module_equals_reference_result_db(scop, name, dev):
+    """dev: FSGPU_DEVICE_BACKTRACE -- with 1 the CIGARs of the frozen reference-binary outputs are met by the device block aligner (k_block_backtrace), with 0
+    by the host restatement; runs without backtraces (prefilter modules, rescorediagonal) are run once"""
     run = MANIFEST["runs"][name]
-    out = str(scop / ("mine_" + name))
+    if dev == 1 and run["module"] not in ("structurealign", "search"):
+        pytest.skip("no backtrace in this module")
+    out = str(scop / ("mine_%d_" % dev + name))
     cmd = [BIN, run["module"]] + [str(scop / p) for p in run["positional"]] + [out] + run["parameters"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    env = dict(os.environ, FSGPU_DEVICE_BACKTRACE=str(dev), FSGPU_MODULE_TIMING="1")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     if name in NOT_IMPLEMENTED:
         assert r.returncode == 1 and NOT_IMPLEMENTED[name] in r.stderr
         return
@@ -112,6 +119,9 @@ def test_module_equals_reference_result_db(scop, name):
     for k in sorted(want):
         assert got[k] == want[k], f"{name}: entry {k}\nwant {want[k][:300]!r}\ngot  {got[k][:300]!r}"
     assert sum(len(v) for v in want.values()) > 0
+    if dev == 1 and run["module"] == "structurealign" and "-a" in run["parameters"] and "--alt-ali" not in run["parameters"]:
+        m = re.search(r"backtrace [0-9.]+ \((\d+) of (\d+) on the device\)", r.stderr)
+        assert m and int(m.group(2)) > 0 and int(m.group(1)) >= 0.95 * int(m.group(2)), r.stderr[-400:]
 
 
 @pytest.mark.gpu
