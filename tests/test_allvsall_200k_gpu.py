@@ -71,9 +71,15 @@ def test_cascade_step_equals_the_reference_binary_at_200k(world, step):
     assert lines >= NQ + (NQ if step else 0), lines                           # the self match; from -s 4.5 on family members too
     apar = _aln_par()
     _run([FS, "structurealign", "q", "t", f"ref_p{step}", f"ref_a{step}"] + apar, w)
-    _run([BIN, "structurealign", "q", "t", f"ref_p{step}", f"mine_a{step}"] + apar, w)
+    # the accepted hits' backtraces on the device aligner in steps 0 and 2 (FSGPU_DEVICE_BACKTRACE=1: the reference binary's CIGARs are met by
+    # k_block_backtrace itself), on the host restatement in step 1
+    dev = "0" if step == 1 else "1"
+    out = _run([BIN, "structurealign", "q", "t", f"ref_p{step}", f"mine_a{step}"] + apar, w, env={"FSGPU_DEVICE_BACKTRACE": dev, "FSGPU_MODULE_TIMING": "1"})
     alines = _same(w, f"ref_a{step}", f"mine_a{step}")
     assert alines >= NQ, alines
+    import re
+    m = re.search(r"backtrace [0-9.]+ \((\d+) of (\d+) on the device\)", out)
+    assert m and int(m.group(2)) >= NQ and (int(m.group(1)) >= 0.95 * int(m.group(2)) if dev == "1" else int(m.group(1)) == 0), out[-300:]
     # the fused module, one feeder thread: device batches of up to 1024 queries (what the all-vs-all run submits; round 5: the limit of a device batch)
     s, maxseqs = CASCADE[step][1], CASCADE[step][3]
     fused = [BIN, "search", "q", "t", f"fused_a{step}", f"fused_p{step}", "--prefilter-mode", "0", "-s", s, "--max-seqs", maxseqs, "--diag-score", CASCADE[step][5],

@@ -32,9 +32,10 @@ MANIFEST = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(FS), reason="oracle/_ref_full/bin/foldseek not built")]
 
 
-def _run(cmd, cwd):
-    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+def _run(cmd, cwd, env=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, " ".join(cmd[:4]) + "\n" + r.stdout[-3000:]
+    return r.stdout
 
 
 def _par(name, threads, **over):
