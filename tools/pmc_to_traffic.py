@@ -67,10 +67,18 @@ for line in open(os.path.join(d, f"{tag}_pmc_kmer_1M_counts.txt")):
         cnt = json.loads(line[7:])
 hits, probes = cnt["index_hits"], cnt["similar_kmers"]
 fam = {n: (v["counters"].get("FETCH_SIZE", {}).get("total", 0.0), v["counters"].get("WRITE_SIZE", {}).get("total", 0.0)) for n, v in k.items()}
-# calibration on known byte counts in this access pattern (8 bytes per lane): k_kmer_bincount reads the hit records once (8 B per hit) and
-# writes only counters; k_kmer_scatter_coarse writes every record once (8 B per hit)
-fcal = 8.0 * hits / (fam["fs::k_kmer_bincount"][0] * 1024.0)
-wcal = 8.0 * hits / (fam["fs::k_kmer_scatter_coarse"][1] * 1024.0)
+# calibration on known byte counts in this pipeline's own access pattern.  Round 6 (stable partition of narrow records): k_kmer_scatter_stable
+# reads every record + its coarse key once, coalesced (4 + 2 B per hit; its per-(tile, key) offsets are < 0.5 % of that); k_kmer_emit writes them
+# once at the hit's stream position (4 + 2 B per hit; the (tile, key) counts beside them < 0.5 %).  Rounds 3-5 (8-byte records): k_kmer_bincount
+# read 8 B per hit, k_kmer_scatter_coarse wrote 8 B per hit.
+if "fs::k_kmer_scatter_stable" in fam:
+    fcal = 6.0 * hits / (fam["fs::k_kmer_scatter_stable"][0] * 1024.0)
+    wcal = 6.0 * hits / (fam["fs::k_kmer_emit"][1] * 1024.0)
+    calnote = ("(4-byte records + 2-byte keys, one per lane): k_kmer_scatter_stable fetches exactly 6 B per hit, k_kmer_emit writes exactly 6 B per hit")
+else:
+    fcal = 8.0 * hits / (fam["fs::k_kmer_bincount"][0] * 1024.0)
+    wcal = 8.0 * hits / (fam["fs::k_kmer_scatter_coarse"][1] * 1024.0)
+    calnote = "(8-byte records, one per lane): k_kmer_bincount fetches exactly 8 B per hit, k_kmer_scatter_coarse writes exactly 8 B per hit"
 rows, tot_raw, tot_cal = {}, 0.0, 0.0
 for n, (f, w) in sorted(fam.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
     stream = not any(x in n for x in ("k_kmer_lists", "k_kmer_count"))          # those two are random 4-8 byte probes: raw counter
@@ -90,7 +98,7 @@ tk["1000000"] = {
     "k_kmer_lists_bytes_per_probe": (lists["fetch_kb"] + lists["write_kb"] * wcal) * 1024.0 / probes,
     "per_kernel": rows,
     "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes. The counters are calibrated on known byte counts in this pipeline's own access pattern "
-            "(8-byte records, one per lane): k_kmer_bincount fetches exactly 8 B per hit, k_kmer_scatter_coarse writes exactly 8 B per hit; fetch_calibration / "
+            + calnote + "; fetch_calibration / "
             "write_calibration are bytes per reported byte (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a wide streaming read, other widths "
             "to be calibrated). The random 4-8 byte probes of k_kmer_count / k_kmer_lists keep the raw fetch counter.",
     "source": f"{prefix}_pmc_kmer_batch32_1M.txt (rocprofv3 --pmc passes of tools/kmer_bench.py 1000000 32 1; NOT collected in the run that prints it)",
