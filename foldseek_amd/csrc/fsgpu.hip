@@ -43,6 +43,17 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     ctx->numCU = prop.multiProcessorCount;
     if (const char *e2 = getenv("FSGPU_GAPLESS_BLOCKS_PER_CU")) ctx->gaplessBlocksPerCU = std::max(1, atoi(e2));
+    // FSGPU_SW_CUS=<n> (A/B measurement): a CU-mask split instead of stream priorities -- the batch SW's streams own the last n CUs of the
+    // mask (n / 8 per XCD where the mask interleaves them), the context's stream (scans, selection, k-mer batches) the others
+    const int swCUs = [] { const char *e = getenv("FSGPU_SW_CUS"); return e ? atoi(e) : 0; }();
+    if (swCUs > 0 && swCUs < ctx->numCU) {
+        const int words = (ctx->numCU + 31) / 32;
+        std::vector<uint32_t> mScan(words, 0), mSw(words, 0);
+        for (int c = 0; c < ctx->numCU; c++) (c < ctx->numCU - swCUs ? mScan : mSw)[c / 32] |= 1u << (c % 32);
+        if ((e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t) words, mScan.data())) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
+        if ((e = hipExtStreamCreateWithCUMask(&ctx->swHi, (uint32_t) words, mSw.data())) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
+        ctx->swCuMask = mSw;
+    } else {
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     {
         // the batch SW of a context runs on a stream of the highest priority: its launches are short and a host thread waits for them, while the
@@ -53,6 +64,7 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
             if (hipStreamCreateWithPriority(&ctx->swHi, hipStreamNonBlocking, hi) != hipSuccess) { ctx->swHi = nullptr; (void) hipGetLastError(); }
             ctx->swHiPrio = hi;
         }
+    }
     }
     for (int i = 0; i < 4; i++)
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
@@ -81,6 +93,11 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (ctx->swLong) (void) hipStreamSynchronize(ctx->swLong);
     if (ctx->swHi) (void) hipStreamSynchronize(ctx->swHi);          // the k_sw3 path runs here and on swAux: nothing may be in flight when its buffers go
     for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamSynchronize(ctx->swAux[i]);
+    if (ctx->swChainEv) {
+        if (ctx->db) { std::lock_guard<std::mutex> g(ctx->db->scanMutex); if (ctx->db->lastScanDone == ctx->swChainEv) ctx->db->lastScanDone = nullptr; }
+        (void) hipEventDestroy(ctx->swChainEv);
+        ctx->swChainEv = nullptr;
+    }
     if (ctx->scanDoneEv) {
         if (ctx->db) { std::lock_guard<std::mutex> g(ctx->db->scanMutex); if (ctx->db->lastScanDone == ctx->scanDoneEv) ctx->db->lastScanDone = nullptr; }
         (void) hipEventDestroy(ctx->scanDoneEv);
@@ -1745,6 +1762,20 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // (32 queries x 1000 random targets, forward pass alone on the device: thresholds 384 / 640 / 896 / none = 1.21 / 1.20 / 1.20 / 1.21 ms for 3Di,
     // 1.37 / 1.30 / 1.28 / 1.31 ms for 3Di + AA -- the split matters little once all classes share a launch; FSGPU_SW3_LONG overrides it)
     static const int longT = [] { const char *e = getenv("FSGPU_SW3_LONG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 896; }();
+    // Round 6: a third shape, 16 lanes per target pair (eight targets per wave, up to 24 rows per lane), for queries of up to 384 rows: least
+    // fill / drain, bookkeeping and row padding per cell, but twice the run time per target column of the 32-lane shape -- it takes the pairs
+    // whose target has at most FSGPU_SW3_MID columns (0 switches the shape off).
+    // Measured (tools/sw2_probe.py N, forward pass alone, fraction of the issue bound without / with the 16-lane shape): N = 32 queries x 1000 targets
+    // 0.57 / 0.49, 64: 0.67 / 0.59, 128: 0.69 / 0.72, 256: 0.72 / 0.75 (3Di; 3Di + AA the same picture) -- its waves are half as many and twice as
+    // long, which a launch of one or two rounds of waves pays for in its tail.  All-vs-all's lists of ~8 pairs per query want the opposite: the LDS
+    // image of a query (34-45 KB with AA) admits three workgroups per CU whatever the shape, so the shape with the MOST waves per pair keeps the SIMDs
+    // busiest (a batch of 1024 queries solo: 16 lanes 1.42 ms, 32 lanes 1.03 ms, 64 lanes 0.88 ms).  Hence the automatic rule: a query whose list is
+    // at most 16 pairs long runs with 64 lanes per pair; the 16-lane shape is taken when the call holds at least 100 000 pairs.
+    // FSGPU_SW3_MID=<columns> forces the 16-lane shape for every query (0: never), FSGPU_SW3_SHORT=<pairs> moves the short-list limit (0: off).
+    const int midEnv = [] { const char *e = getenv("FSGPU_SW3_MID"); return e && *e ? atoi(e) : -1; }();      // read per call: the tests switch shapes inside one process
+    const int midT = midEnv >= 0 ? midEnv : 512;
+    const int shortList = [] { const char *e = getenv("FSGPU_SW3_SHORT"); return e && *e ? atoi(e) : 16; }();
+    static const int maxR16 = [] { const char *e = getenv("FSGPU_SW3_MAXR16"); const int v = e ? atoi(e) : 0; return v > 0 && v <= kSw3MaxR16 ? v : kSw3MaxR16; }();
     auto nSel = [&](int i) { return cR[i] > 0 ? nSelAll(i) : 0; };
     for (int i = 0; i < nq; i++) sbase[i + 1] = sbase[i] + (size_t) nSel(i);
     const size_t total = sbase[nq];
@@ -1763,10 +1794,12 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         return FSGPU_OK;
     }
     const std::vector<int32_t> &len = ctx->db->hLengths;
-    // target ids of the pass, longest first inside a query (neighbours share a wave), and the split into the two shapes
+    // target ids of the pass, longest first inside a query (neighbours share a wave), and the split into the three shapes:
+    // pairs [0, nLong) of a query's sorted list run with 64 lanes, [nLong, nLong + nMid) with 32, the rest with 16
     if ((rc = ensurePinned(ctx, ctx->hS3pass, total * 4 + 64)) != FSGPU_OK) return rc;      // grown below once the descriptors are counted
     std::vector<uint32_t> perm(total);
-    std::vector<int> nLong(nq, 0);
+    std::vector<int> nLong(nq, 0), nMid(nq, 0);
+    const size_t total16 = total;
     {
         std::vector<uint64_t> lkey;
         for (int i = 0; i < nq; i++) {
@@ -1777,13 +1810,16 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
             lkey.resize(ns);
             for (int k = 0; k < ns; k++) { const int j = selIdx(i, k); lkey[k] = ((uint64_t) (0xFFFFFF - len[ids[j]]) << 32) | (uint32_t) j; }
             std::sort(lkey.begin(), lkey.end());
-            int nl = 0;
-            for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; if (len[ids[p[k]]] > longT) nl++; }
-            nLong[i] = q[i].L > 32 * kSw3MaxR ? ns : nl;
+            int nl = 0, nm = 0;
+            for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; const int lt = len[ids[p[k]]]; if (lt > longT) nl++; else if (lt > midT) nm++; }
+            nLong[i] = (q[i].L > 32 * kSw3MaxR || ns <= shortList) ? ns : nl;
+            const bool shape16 = q[i].L <= 16 * maxR16 && midT > 0 && (midEnv >= 0 || total16 >= 100000);
+            nMid[i] = nLong[i] == ns ? 0 : shape16 ? nm : ns - nLong[i];
         }
     }
-    auto need64 = [&](int i) { return nLong[i] > 0; };
-    auto need32 = [&](int i) { return nSel(i) - nLong[i] > 0; };
+    constexpr int kShapeHL[3] = {16, 32, 64};
+    auto nShape = [&](int i, int shape) { return shape == 2 ? nLong[i] : shape == 1 ? nMid[i] : nSel(i) - nLong[i] - nMid[i]; };
+    auto firstOfShape = [&](int i, int shape) { return shape == 2 ? 0 : shape == 1 ? nLong[i] : nLong[i] + nMid[i]; };
     // images: built once per set of queries (the reversed call of a forward call finds them in place)
     uint64_t sig = 0xcbf29ce484222325ull ^ (uint64_t) nq ^ ((uint64_t) hasAA << 40);
     sig = hashWords(sig, mat3Di, kAlphabet * kAlphabet);
@@ -1797,22 +1833,22 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         for (int c = 0; c < 4; c++) { if (cbs[c]) sig = hashWords(sig, cbs[c], L); else sig = (sig ^ 0x55) * 0x100000001B3ull; }
     }
     if (!sig) sig = 1;
-    bool haveImages = ctx->s3Sig == sig && (int) ctx->s3ImgOff.size() == 2 * nq;
+    bool haveImages = ctx->s3Sig == sig && (int) ctx->s3ImgOff.size() == 3 * nq;
     for (int i = 0; i < nq && haveImages; i++)
-        if ((need32(i) && ctx->s3ImgOff[2 * i] == 0xffffffffu) || (need64(i) && ctx->s3ImgOff[2 * i + 1] == 0xffffffffu)) haveImages = false;
+        for (int shape = 0; shape < 3; shape++) if (nShape(i, shape) > 0 && ctx->s3ImgOff[3 * i + shape] == 0xffffffffu) haveImages = false;
     if (!haveImages) {
         ctx->s3Sig = 0;
-        ctx->s3ImgOff.assign((size_t) 2 * nq, 0xffffffffu);       // [2 i]: 32-lane image of query i, [2 i + 1]: 64-lane image
+        ctx->s3ImgOff.assign((size_t) 3 * nq, 0xffffffffu);       // [3 i + shape]: image of query i for 16 / 32 / 64 lanes per target pair
         size_t imgDw = 0, dataBytes = 0;
         int nImg = 0, maxDw = 0;
         for (int i = 0; i < nq; i++) {
             if (nSel(i) == 0) continue;
-            for (int shape = 0; shape < 2; shape++) {
-                if (!(shape == 0 ? need32(i) : need64(i))) continue;
-                const int HL = shape == 0 ? 32 : 64, R = (q[i].L + HL - 1) / HL;
+            for (int shape = 0; shape < 3; shape++) {
+                if (nShape(i, shape) == 0) continue;
+                const int HL = kShapeHL[shape], R = (q[i].L + HL - 1) / HL;
                 const size_t one = (size_t) 2 * sw3ImageBytes(R, HL, hasAA) / 4;
                 if (imgDw + one >= (1ull << 32)) { ctx->err = "fsgpu_sw_multi_dir_c: images of one call exceed 16 GiB"; return FSGPU_E_NOMEM; }
-                ctx->s3ImgOff[2 * i + shape] = (uint32_t) imgDw; imgDw += one; maxDw = std::max(maxDw, (int) one);
+                ctx->s3ImgOff[3 * i + shape] = (uint32_t) imgDw; imgDw += one; maxDw = std::max(maxDw, (int) one);
                 nImg++;
             }
             dataBytes += ((size_t) 6 * q[i].L + 15) / 16 * 16;
@@ -1830,10 +1866,10 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         for (int i = 0; i < nq; i++) {
             if (nSel(i) == 0) continue;
             const size_t L = (size_t) q[i].L;
-            for (int shape = 0; shape < 2; shape++) {
-                if (ctx->s3ImgOff[2 * i + shape] == 0xffffffffu) continue;
-                const int HL = shape == 0 ? 32 : 64;
-                hd[k].imgOff = ctx->s3ImgOff[2 * i + shape]; hd[k].dataOff = (uint32_t) (dpos - dataOff0); hd[k].L = (uint32_t) L;
+            for (int shape = 0; shape < 3; shape++) {
+                if (ctx->s3ImgOff[3 * i + shape] == 0xffffffffu) continue;
+                const int HL = kShapeHL[shape];
+                hd[k].imgOff = ctx->s3ImgOff[3 * i + shape]; hd[k].dataOff = (uint32_t) (dpos - dataOff0); hd[k].L = (uint32_t) L;
                 hd[k].R = (uint16_t) ((L + HL - 1) / HL); hd[k].HL = (uint16_t) HL;
                 k++;
             }
@@ -1859,20 +1895,23 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // launch is that of its largest R: a query of 9 rows per lane must not take the 106 KB of one with 16 and lose its second workgroup per CU)
     // (a class whose largest member still fits three workgroups per CU shares its launch with the smaller ones: the register classes of a
     // search batch then run as one or two launches, each with a single long-target tail)
-    auto occOf = [&](int HL, int R) { return std::min(3, (160 * 1024) / sw3LdsBytes(std::min(kSw3MaxR, (R + 3) / 4 * 4), HL, hasAA, 4)); };
-    auto keyOf = [&](int HL, int R) { return (HL == 64 ? 8 : 0) + (R > 8 ? 4 : 0) + occOf(HL, R); };
+    auto occOf = [&](int HL, int R) { return std::min(3, (160 * 1024) / sw3LdsBytes(std::min(sw3MaxR(HL), (R + 3) / 4 * 4), HL, hasAA, 4)); };
+    auto keyOf = [&](int shape, int R, int) { return shape * 12 + ((R - 1) / 8) * 4 + occOf(kShapeHL[shape], R); };
     for (int i = 0; i < nq; i++) {
-        const int ns = nSel(i);
-        if (ns == 0) continue;
-        const int R64 = (q[i].L + 63) / 64, R32 = (q[i].L + 31) / 32;
-        if (nLong[i] > 0) parts.push_back({i, keyOf(64, R64), R64, 0, nLong[i]});
-        if (ns - nLong[i] > 0) parts.push_back({i, keyOf(32, R32), R32, nLong[i], ns - nLong[i]});
+        if (nSel(i) == 0) continue;
+        for (int shape = 2; shape >= 0; shape--) {
+            if (nShape(i, shape) == 0) continue;
+            const int R = (q[i].L + kShapeHL[shape] - 1) / kShapeHL[shape];
+            parts.push_back({i, keyOf(shape, R, nShape(i, shape)), R, firstOfShape(i, shape), nShape(i, shape)});
+        }
     }
     struct Group { int key, HL, rlo, maxR, waves, lds; size_t blk0, nblk; };
     std::vector<Group> groups;
     size_t nBlocks = 0;
-    for (int key = 15; key >= 0; key--) {           // the 64-lane groups (the long targets) first
-        Group g{key, key >= 8 ? 64 : 32, (key & 4) ? 9 : 1, 0, 0, 0, nBlocks, 0};
+    // (workgroups of one or two waves for lists that fit them -- all-vs-all's ~8 pairs per query -- were measured and lost: 1.30 against 1.08 ms per
+    // batch of 1024 solo; the 34 KB image of a workgroup then arrives through 64 lanes, and the extra launch groups queue behind each other)
+    for (int key = 35; key >= 0; key--) {           // the 64-lane groups (the long targets) first
+        Group g{key, kShapeHL[key / 12], ((key % 12) / 4) * 8 + 1, 0, 0, 0, nBlocks, 0};
         for (const Part &pt : parts) if (pt.key == key) g.maxR = std::max(g.maxR, pt.R);
         if (g.maxR == 0) continue;
         g.waves = sw3Waves(g.maxR, g.HL, hasAA);
@@ -1903,7 +1942,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
                 const int i = pt.q, L = q[i].L, lanes = (L + pt.R - 1) / pt.R;
                 for (int p0 = 0; p0 < pt.n; p0 += ppb) {
                     SwBlockDesc &d = hBlk[bp++];
-                    d.imgOff = ctx->s3ImgOff[2 * i + (g.HL == 64 ? 1 : 0)]; d.firstPair = (uint32_t) (sbase[i] + pt.first + p0); d.nPairs = (uint16_t) std::min(ppb, pt.n - p0);
+                    d.imgOff = ctx->s3ImgOff[3 * i + g.key / 12]; d.firstPair = (uint32_t) (sbase[i] + pt.first + p0); d.nPairs = (uint16_t) std::min(ppb, pt.n - p0);
                     d.rowsInTile = (uint16_t) L; d.segLen = (uint32_t) ((L + 15) / 16);
                 }
                 // accounting in the units of the kernel's roofline: DP cells and the VALU wave-instructions its waves issue (a wave runs
@@ -1923,13 +1962,23 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         ctx->swDirCells[slot] = clCells + cells * nDirs; ctx->swDirPairs[slot] = clPairs + pairs * nDirs; ctx->swDirWaveSteps[slot] = clSteps + winsts * nDirs;
     }
     HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, S));
+    // FSGPU_SW_EXCLUSIVE=1 (A/B measurement): the pass takes its turn in the database's chain of scan batches (DbStore::lastScanDone) --
+    // it starts when the scan batch enqueued before it is done and the next scan batch starts behind it -- instead of co-running with them from a
+    // high-priority stream.  Uploads and the image build above stay outside the chain.
+    static const bool swExclusive = [] { const char *e = getenv("FSGPU_SW_EXCLUSIVE"); return e && atoi(e) != 0; }();
+    std::unique_lock<std::mutex> chain(ctx->db->scanMutex, std::defer_lock);
+    if (swExclusive) {
+        if (!ctx->swChainEv) HIPCHK(hipEventCreateWithFlags(&ctx->swChainEv, hipEventDisableTiming));
+        chain.lock();
+        if (ctx->db->lastScanDone && ctx->db->lastScanDone != ctx->swChainEv) HIPCHK(hipStreamWaitEvent(S, ctx->db->lastScanDone, 0));
+    }
     if (slot == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], S));
     HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot], S));
     // every launch group gets a stream: their long-target tails overlap instead of queueing up
     const size_t nStreams = std::min<size_t>(groups.size(), 6);
     if (nStreams > 1) {
         if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
-        for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) { if (ctx->swHi) HIPCHK(hipStreamCreateWithPriority(&ctx->swAux[k], hipStreamNonBlocking, ctx->swHiPrio)); else HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking)); }
+        for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) { if (!ctx->swCuMask.empty()) HIPCHK(hipExtStreamCreateWithCUMask(&ctx->swAux[k], (uint32_t) ctx->swCuMask.size(), ctx->swCuMask.data())); else if (ctx->swHi) HIPCHK(hipStreamCreateWithPriority(&ctx->swAux[k], hipStreamNonBlocking, ctx->swHiPrio)); else HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking)); }
         HIPCHK(hipEventRecord(ctx->swAuxEv[6], S));
         for (size_t k = 1; k < nStreams; k++) HIPCHK(hipStreamWaitEvent(ctx->swAux[k], ctx->swAuxEv[6], 0));
     }
@@ -1954,6 +2003,11 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     for (size_t k = 1; k < nStreams; k++) { HIPCHK(hipEventRecord(ctx->swAuxEv[k], ctx->swAux[k])); HIPCHK(hipStreamWaitEvent(S, ctx->swAuxEv[k], 0)); }
     HIPCHK(hipEventRecord(ctx->ev[3], S));
     HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot + 1], S));
+    if (swExclusive) {
+        HIPCHK(hipEventRecord(ctx->swChainEv, S));
+        ctx->db->lastScanDone = ctx->swChainEv;
+        chain.unlock();
+    }
     ctx->swDirValid[slot] = true;
     ctx->evValid[1] = true;
     HIPCHK(hipMemcpyAsync(ctx->hS3res.p, ctx->s3res.p, total * 16 * nDirs, hipMemcpyDeviceToHost, S));

@@ -100,6 +100,7 @@ struct fsgpu_ctx {
     PinBuf hMqPssm, hMqRec, hMqMeta, hMqOutId, hMqOutScore, hMqIdent;
     int mqLaunches = 0, mqQueries = 0;          // scan kernel launches / queries of the last batch
     double mqScanMs = -1.0;                     // >= 0: scan time of the last multi-query call incl. its row-tiled queries
+    hipEvent_t swChainEv = nullptr;             // FSGPU_SW_EXCLUSIVE=1: recorded behind a k_sw3 pass that took its turn in the scan chain
     hipEvent_t scanDoneEv = nullptr;            // recorded after the last scan launch of a batch (chained through DbStore::lastScanDone)
     uint64_t mqScoreStride = 0;
     std::vector<int> mqSlot;                    // query index of the last call -> slice of mqScores (-1: went through the single-query path)
@@ -107,6 +108,7 @@ struct fsgpu_ctx {
     // sw scratch
     hipStream_t swHi = nullptr;                 // highest-priority stream of the batch SW (fsgpu_sw_multi_dir_c); null: ctx->stream
     int swHiPrio = 0;
+    std::vector<uint32_t> swCuMask;             // FSGPU_SW_CUS: the CU mask of the batch SW's streams (empty: priorities)
     hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
     hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf img, tids, res0, res1, border0, border1, keys;

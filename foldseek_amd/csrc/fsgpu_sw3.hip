@@ -30,12 +30,15 @@ int launchT(fsgpu_ctx *ctx, const Sw3Args &sa, int nBlocks, int waves, int lds, 
 
 } // namespace
 
-// rlo: 1 (queries with 1..8 rows per lane) or 9 (9..16); lds: dynamic LDS of the largest class among the launch's workgroups
+// rlo: 1 (queries with 1..8 rows per lane), 9 (9..16) or -- 16 lanes per target pair only -- 17 (17..24); lds: dynamic LDS of the largest class among the launch's workgroups
 #if FS_SW3_AA
 int fsgpuLaunchSw3AA(fsgpu_ctx *ctx, int rlo, int HL, const Sw3Args &sa, int nBlocks, int waves, int lds, hipStream_t stream) {
 #else
 int fsgpuLaunchSw3NA(fsgpu_ctx *ctx, int rlo, int HL, const Sw3Args &sa, int nBlocks, int waves, int lds, hipStream_t stream) {
 #endif
+    if (HL == 16 && rlo == 1) return launchT<16, 1>(ctx, sa, nBlocks, waves, lds, stream);
+    if (HL == 16 && rlo == 9) return launchT<16, 9>(ctx, sa, nBlocks, waves, lds, stream);
+    if (HL == 16 && rlo == 17) return launchT<16, 17>(ctx, sa, nBlocks, waves, lds, stream);
     if (HL == 32 && rlo == 1) return launchT<32, 1>(ctx, sa, nBlocks, waves, lds, stream);
     if (HL == 32 && rlo == 9) return launchT<32, 9>(ctx, sa, nBlocks, waves, lds, stream);
     if (HL == 64 && rlo == 1) return launchT<64, 1>(ctx, sa, nBlocks, waves, lds, stream);

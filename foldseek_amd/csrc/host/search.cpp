@@ -288,13 +288,14 @@ void materializeProfiles(const fshost_search *s, AlignQuery &aq) {
 }
 
 // structurealign.cpp:322-347: e-value network + the biases of the forward / reversed-query profiles (+ the profiles themselves on request)
-int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, std::vector<uint8_t> &r3Di, bool withProfiles = true) {
+int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, std::vector<uint8_t> &r3Di, bool withProfiles = true, std::string *errOut = nullptr) {
     const fshost_params &par = s->par;
+    std::string &serr = errOut ? *errOut : s->err;          // callers that run queries in parallel collect the message themselves
     // the block aligner takes NEGATIVE gap costs with open < extend (block-aligner scan_block.rs: "Gap costs must be negative!"; the
     // reference process dies in that assertion with --gap-extend 0) and the device SW reproduces the striped kernel for open > extend:
     // refuse here, with a message, instead of aborting in the backtrace
     if (!(par.gapExtend >= 1 && par.gapOpen > par.gapExtend && par.gapOpen < 32768)) {
-        s->err = "gap costs must satisfy gapOpen > gapExtend >= 1 (got " + std::to_string(par.gapOpen) + " / " + std::to_string(par.gapExtend) + ")";
+        serr = "gap costs must satisfy gapOpen > gapExtend >= 1 (got " + std::to_string(par.gapOpen) + " / " + std::to_string(par.gapExtend) + ")";
         return FSGPU_E_UNSUPPORTED;
     }
     const int A = s->mat3Di.n, L = aq.L;
@@ -309,7 +310,7 @@ int prepareAlign(fshost_search *s, AlignQuery &aq, std::vector<uint8_t> &rAA, st
     if (rc == FSGPU_OK)
         rc = alignProfiles(s->matAA, s->mat3Di, rAA.data(), r3Di.data(), L, par.compBiasCorrection != 0, par.alnCompBiasScale,
                            nullptr, nullptr, aq.cbAAr.data(), aq.cbSSr.data());
-    if (rc != FSGPU_OK) { s->err = "bad query residue code"; return rc; }
+    if (rc != FSGPU_OK) { serr = "bad query residue code"; return rc; }
     if (withProfiles) materializeProfiles(s, aq);
     return rc;
 }
@@ -700,11 +701,25 @@ int fshost_search_align_batch(fshost_search *s, int nq, const uint8_t *const *qA
     std::vector<AlignQuery> aq(nq);
     std::vector<fsgpu_sw_cquery> dq(nq);
     size_t total = 0;
+    for (int i = 0; i < nq; i++) if (!qAA[i] || !q3di[i] || L[i] <= 0 || n[i] < 0) return FSGPU_E_ARG;
+    {
+        // e-value network + the two composition-bias passes of every query: 25-50 us each, 1024 of them per all-vs-all batch -- over the pool, in
+        // slices of 16 queries (round 5 ran them one after the other on the feeder thread: "profiles" in the module timing)
+        std::atomic<int> firstErr{FSGPU_OK};
+        std::mutex errM;
+        const int slice = 16, nSlices = (nq + slice - 1) / slice;
+        HostPool::get().parallelFor(nSlices, [&](int sl) {
+            static thread_local std::vector<uint8_t> rAA, r3Di;
+            for (int i = sl * slice; i < std::min(nq, (sl + 1) * slice); i++) {
+                aq[i].qAA = qAA[i]; aq[i].q3di = q3di[i]; aq[i].L = L[i];
+                std::string err;
+                const int rc = prepareAlign(s, aq[i], rAA, r3Di, par.altAlignment > 0, &err);      // --alt-ali re-aligns through the profile-based call
+                if (rc != FSGPU_OK) { std::lock_guard<std::mutex> g(errM); if (firstErr.load() == FSGPU_OK) { firstErr.store(rc); s->err = err; } }
+            }
+        });
+        if (firstErr.load() != FSGPU_OK) return firstErr.load();
+    }
     for (int i = 0; i < nq; i++) {
-        if (!qAA[i] || !q3di[i] || L[i] <= 0 || n[i] < 0) return FSGPU_E_ARG;
-        aq[i].qAA = qAA[i]; aq[i].q3di = q3di[i]; aq[i].L = L[i];
-        const int rc = prepareAlign(s, aq[i], s->rAA, s->r3Di, par.altAlignment > 0);      // --alt-ali re-aligns through the profile-based call
-        if (rc != FSGPU_OK) return rc;
         dq[i].qAA = qAA[i]; dq[i].q3Di = q3di[i];
         dq[i].cbAA_fwd = aq[i].cbAA.data(); dq[i].cb3Di_fwd = aq[i].cbSS.data(); dq[i].cbAA_rev = aq[i].cbAAr.data(); dq[i].cb3Di_rev = aq[i].cbSSr.data();
         dq[i].L = L[i]; dq[i].n = n[i]; dq[i].targetIds = targetIds[i];

@@ -7,6 +7,10 @@
 //     R <= 16 consecutive query rows.  Against 64 lanes x R/2 rows that halves the wavefront's fill / drain (HL - 1 steps per target
 //     instead of 63), halves the per-step bookkeeping per row, and cuts the row padding (rows are padded to HL * R: 352 instead of 384
 //     rows for a 350-residue query).  HL = 64 (one pair per wave) carries queries of 513..1024 rows in one piece.
+//     Round 6: HL = 16 (four pairs = eight targets per wave, R <= 24 rows per lane) for queries of up to 384 rows against targets of up to
+//     FSGPU_SW3_MID columns: per DP cell it halves the fill / drain again (15 steps), halves the per-step bookkeeping (ring, DPP moves, best
+//     tracking: ~18 instructions next to 15 R) and pads to 16 R rows (336 for a 330-residue query, 352 with 32 lanes); the lane that starts
+//     a pair takes zeros from the DPP row shift itself (row_shr:1 with bound_ctrl) instead of two v_and.
 //   * the target codes come from a ring in LDS (2 HL columns per target pair, per column the LDS row offsets of target A and target B in
 //     the 3Di table [and in the AA table]) that the wave refills 16 columns at a time, instead of riding a register conveyor of
 //     v_mov_dpp + v_readlane + v_cndmask per step and table; a lane fetches the entry of its NEXT column while it works on this one.
@@ -28,12 +32,14 @@ namespace fs {
 // The D dwords are fetched in chunks of 4 (a remainder of 3 is fetched as a chunk of 4 whose last dword is unused: same LDS footprint as a
 // 2 + 1 split, one address and two reads less), a remainder of 2 as one 8-byte read, a remainder of 1 as one 4-byte read.  A 4-dword chunk
 // k is a plane of HL lanes x 16 B, the 2-dword remainder a plane of HL x 8 B, the 1-dword remainder a plane of 64 x 4 B (for HL = 32 it
-// holds two copies: lanes 32..63 of the wave read the second one, a ds_read_b32 services all 64 lanes at once).  Every plane is a multiple
-// of 256 B and so is the row: the bank of an access depends on the lane only, although every lane reads a different profile row.
+// holds two copies: lanes 32..63 of the wave read the second one, a ds_read_b32 services all 64 lanes at once; for HL = 16 four copies, and
+// the 2-dword plane two: lanes 16..31 and 48..63 read the second).  Every plane is a multiple of 256 B and so is the row: the bank of an
+// access depends on the lane only, although every lane group reads a different profile row.
 __host__ __device__ constexpr int sw3Dw(int R) { return (R + 1) / 2; }
 __host__ __device__ constexpr int sw3Planes16(int R) { return sw3Dw(R) / 4 + ((sw3Dw(R) % 4) == 3 ? 1 : 0); }
-__host__ __device__ constexpr int sw3RowBytes(int R, int HL) { return sw3Planes16(R) * HL * 16 + ((sw3Dw(R) % 4) == 2 ? HL * 8 : 0) + ((sw3Dw(R) % 4) == 1 ? 256 : 0); }
-// dword index inside one profile row for (lane l of its target pair, dword j < D); the 1-dword plane's second copy (HL == 32) is at + 32
+__host__ __device__ constexpr int sw3Plane8Lanes(int HL) { return HL < 32 ? 32 : HL; }      // lanes (copies included) of the 2-dword plane
+__host__ __device__ constexpr int sw3RowBytes(int R, int HL) { return sw3Planes16(R) * HL * 16 + ((sw3Dw(R) % 4) == 2 ? sw3Plane8Lanes(HL) * 8 : 0) + ((sw3Dw(R) % 4) == 1 ? 256 : 0); }
+// dword index inside one profile row for (lane l of its target pair, dword j < D); copies of the remainder planes: sw3RemCopies / sw3RemCopyStride
 __host__ __device__ constexpr int sw3DwordIndex(int R, int HL, int l, int j) {
     const int in16 = sw3Planes16(R) * 4;
     if (j < in16) return (j / 4) * HL * 4 + l * 4 + (j % 4);
@@ -41,9 +47,16 @@ __host__ __device__ constexpr int sw3DwordIndex(int R, int HL, int l, int j) {
     if ((sw3Dw(R) % 4) == 2) return off + l * 2 + (j - in16);
     return off + l;
 }
-constexpr int kSw3MaxR = 16;
+// the remainder plane of a row (dwords j >= 4 * sw3Planes16) is stored sw3RemCopies times, sw3RemCopyStride dwords apart
+__host__ __device__ constexpr int sw3RemCopies(int R, int HL) { return (sw3Dw(R) % 4) == 2 ? sw3Plane8Lanes(HL) / HL : (sw3Dw(R) % 4) == 1 ? 64 / HL : 1; }
+__host__ __device__ constexpr int sw3RemCopyStride(int R, int HL) { return (sw3Dw(R) % 4) == 2 ? HL * 2 : HL; }
+constexpr int kSw3MaxR = 16;           // rows per lane of the 32- and 64-lane shapes
+constexpr int kSw3MaxR16 = 24;         // of the 16-lane shape
+__host__ __device__ constexpr int sw3MaxR(int HL) { return HL == 16 ? kSw3MaxR16 : kSw3MaxR; }
 constexpr int kSw3Chunk = 16;          // target columns per ring refill
-__host__ __device__ constexpr int sw3RingCols(int HL) { return 2 * HL; }     // columns of a target pair held in LDS
+// columns of a target pair held in LDS: the refill at step s (a multiple of 16) overwrites the slots of columns s + 16 - RING .. s + 31 - RING while
+// lane HL - 1 still reads column s + 2 - HL: RING >= HL + 29
+__host__ __device__ constexpr int sw3RingCols(int HL) { return HL < 32 ? 64 : 2 * HL; }
 __host__ __device__ constexpr int sw3TableBytes(int R, int HL) { return kSw2Rows * sw3RowBytes(R, HL); }
 __host__ __device__ constexpr int sw3ImageBytes(int R, int HL, bool hasAA) { return (hasAA ? 2 : 1) * sw3TableBytes(R, HL); }   // one direction
 __host__ __device__ constexpr int sw3RingBytes(int HL, bool hasAA) { return sw3RingCols(HL) * (hasAA ? 16 : 8); }
@@ -74,7 +87,7 @@ template <int R, int HL>
 struct Sw3LaneBase {
     uint32_t b16, brem;            // LDS byte addresses: 16-byte planes, the 8- or 4-byte remainder plane
     __device__ __forceinline__ Sw3LaneBase(uint32_t table, int l, int lane64)
-        : b16(table + l * 16), brem(table + sw3Planes16(R) * HL * 16 + ((sw3Dw(R) % 4) == 2 ? l * 8 : lane64 * 4)) {}
+        : b16(table + l * 16), brem(table + sw3Planes16(R) * HL * 16 + ((sw3Dw(R) % 4) == 2 ? (lane64 & (sw3Plane8Lanes(HL) - 1)) * 8 : lane64 * 4)) {}
 };
 // rowOff: byte offset of the profile row inside its table; P: the lane's D = ceil(R / 2) row-pair dwords
 template <int R, int HL>
@@ -99,6 +112,10 @@ __device__ __forceinline__ void sw3LoadRow(const unsigned char *smem, const Sw3L
     }
 }
 
+__device__ __forceinline__ uint32_t row_shr1(uint32_t x) {
+    return __builtin_amdgcn_update_dpp(0u, x, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+}
+
 template <int HL>
 __device__ __forceinline__ uint64_t groupMaxU64(uint64_t k) {
 #pragma unroll
@@ -114,7 +131,7 @@ __device__ __forceinline__ uint64_t groupMaxU64(uint64_t k) {
 template <int R, bool HAS_AA, int HL>
 __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd, unsigned char *smem) {
     using A = Pk16;
-    static_assert(HL == 32 || HL == 64, "lanes per target pair");
+    static_assert(HL == 16 || HL == 32 || HL == 64, "lanes per target pair");
     constexpr int ROWB = sw3RowBytes(R, HL);
     constexpr int TBL = kSw2Rows * ROWB;
     constexpr int IMG = (HAS_AA ? 2 : 1) * TBL;       // one direction
@@ -154,7 +171,8 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
     const int LtA = hasA ? a.lengths[tidA] : 0, LtB = hasB ? a.lengths[tidB] : 0;
     const uint64_t offA = a.offsets[tidA], offB = a.offsets[tidB];
     int LtW = LtA > LtB ? LtA : LtB;                   // longest target of the wave -> scalar loop bound
-    if constexpr (GPW == 2) { const int o = __shfl_xor(LtW, 32); LtW = o > LtW ? o : LtW; }
+    if constexpr (GPW == 4) { const int o = __shfl_xor(LtW, 16); LtW = o > LtW ? o : LtW; }
+    if constexpr (GPW >= 2) { const int o = __shfl_xor(LtW, 32); LtW = o > LtW ? o : LtW; }
     LtW = __builtin_amdgcn_readfirstlane(LtW);
     // The wavefront is a long dependent chain: the waves with the longest targets are the critical path of the launch, they win the issue
     // arbitration of their SIMD; every wave of this kernel stays above a co-running throughput kernel (the gapless scan of another query).
@@ -166,9 +184,15 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
     // merge selectors: {S0 = target B's dword (bytes 4..7), S1 = target A's dword (bytes 0..3)} -> (A | B << 16) of the even / odd row of a pair
     constexpr uint32_t selEven = 0x05040100u, selOdd = 0x07060302u;
 
-    uint32_t segmask[R];
+    // The striped reference kernel's F is local to a segment of segLen = ceil(L / 16) query rows (k_sw.hpp).  With 16 lanes per target pair
+    // R = ceil(L / 16) IS segLen: a lane's rows are exactly one segment, its segment-local F never leaves the lane -- no mask per row, no
+    // DPP move, 13 instead of 14 instructions per register row.
+    constexpr bool LANESEG = HL == 16;
+    uint32_t segmask[LANESEG ? 1 : R];
+    if constexpr (!LANESEG) {
 #pragma unroll
-    for (int r = 0; r < R; r++) segmask[r] = ((l * R + r) % segLen == 0) ? 0u : 0xffffffffu;
+        for (int r = 0; r < R; r++) segmask[r] = ((l * R + r) % segLen == 0) ? 0u : 0xffffffffu;
+    }
     uint32_t E[R], Hp[R], snap[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { E[r] = 0; Hp[r] = 0; snap[r] = 0; }
@@ -213,50 +237,51 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
     readEntry();
 
     const Sw3LaneBase<R, HL> lb3(0u, l, lane), lbA((uint32_t) TBL, l, lane);
-    // Software pipeline (round 6): the profile rows of step s + 1 are fetched while the DP of step s runs (their ring entry was read a step earlier still),
-    // into the buffer the step after next computes from -- until then every step began by waiting for its own 2 (4 with AA) row reads: at 3-4 waves per
-    // SIMD nobody covers an LDS round trip per step (PMC: 7.5 cycles per VALU instruction, 55 % of the wave cycles waiting).  The registers are free:
-    // the LDS image, not the VGPR count, bounds the waves per SIMD.
-    auto loadRows = [&](uint32_t (&PA)[D], uint32_t (&PB)[D], uint32_t (&QA)[D], uint32_t (&QB)[D]) {
-        sw3LoadRow<R, HL>(smem, lb3, t3A, PA);
-        sw3LoadRow<R, HL>(smem, lb3, t3B, PB);
-        if constexpr (HAS_AA) { sw3LoadRow<R, HL>(smem, lbA, tAA, QA); sw3LoadRow<R, HL>(smem, lbA, tAB, QB); }
-    };
-    // PAc .. QBc: rows of the column this step works on; PAn .. QBn: filled for the next step
-    auto step = [&](const int s, uint32_t (&PAc)[D], uint32_t (&PBc)[D], uint32_t (&QAc)[D], uint32_t (&QBc)[D],
-                    uint32_t (&PAn)[D], uint32_t (&PBn)[D], uint32_t (&QAn)[D], uint32_t (&QBn)[D]) {
+    auto step = [&](const int s) {
         if ((s & (kSw3Chunk - 1)) == 0) {
             storeChunk(s + kSw3Chunk);
             loadChunk(s + 2 * kSw3Chunk);
         }
-        uint32_t hUpNew = wave_shr1(hOut);
-        const uint32_t fsegIn = wave_shr1(fsegOut);
-        uint32_t ffullIn = wave_shr1(ffullOut);
+        // what the lane above hands down; the first lane of a pair takes zeros (16 lanes: a DPP row is a pair, the shift itself fills them in)
+        uint32_t hUpNew = HL == 16 ? row_shr1(hOut) : wave_shr1(hOut);
+        uint32_t fsegIn = 0;
+        if constexpr (!LANESEG) fsegIn = wave_shr1(fsegOut);
+        uint32_t ffullIn = HL == 16 ? row_shr1(ffullOut) : wave_shr1(ffullOut);
         if constexpr (HL == 32) { hUpNew &= inMask; ffullIn &= inMask; }
-        // the rows of the NEXT step's column (its entry is in t3A .. tAB), then the entry of the column after that
-        loadRows(PAn, PBn, QAn, QBn);
+        const uint32_t r3A = t3A, r3B = t3B, rAA = tAA, rAB = tAB;
+        // the entry of the column this lane works on in the NEXT step
         ringAt = ((ringAt + EB) & (uint32_t) (RINGB - 1)) | ring;
         readEntry();
         const int col = s - l;
         // No lane is masked off (see k_sw2): a lane before its first column or past its target's end reads the "past the end" row, rows
         // beyond the query score 0 -- neither can set a new maximum.
         {
+            uint32_t PA[D], PB[D];
+            sw3LoadRow<R, HL>(smem, lb3, r3A, PA);
+            sw3LoadRow<R, HL>(smem, lb3, r3B, PB);
             if constexpr (HAS_AA) {
+                uint32_t QA[D], QB[D];
+                sw3LoadRow<R, HL>(smem, lbA, rAA, QA);
+                sw3LoadRow<R, HL>(smem, lbA, rAB, QB);
 #pragma unroll
-                for (int j = 0; j < D; j++) { PAc[j] = A::add(QAc[j], PAc[j]); PBc[j] = A::add(QBc[j], PBc[j]); }
+                for (int j = 0; j < D; j++) { PA[j] = A::add(QA[j], PA[j]); PB[j] = A::add(QB[j], PB[j]); }
             }
             uint32_t diag = hUpPrev, fseg = fsegIn, ffull = ffullIn, cm = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t sc = __builtin_amdgcn_perm(PBc[r / 2], PAc[r / 2], (r & 1) ? selOdd : selEven);
+                const uint32_t sc = __builtin_amdgcn_perm(PB[r / 2], PA[r / 2], (r & 1) ? selOdd : selEven);
                 uint32_t h = A::adds(diag, sc);
                 h = A::max(h, E[r]);
-                fseg &= segmask[r];
-                h = A::max(h, fseg);
+                if constexpr (LANESEG) {
+                    if (r > 0) h = A::max(h, fseg);
+                } else {
+                    fseg &= segmask[r];
+                    h = A::max(h, fseg);
+                }
                 const uint32_t t = A::subus(h, a.go);
                 E[r] = A::max(A::subus(E[r], a.ge), t);
                 const uint32_t hf = A::max(h, ffull);
-                fseg = A::max(A::subus(fseg, a.ge), t);
+                fseg = (LANESEG && r == 0) ? t : A::max(A::subus(fseg, a.ge), t);
                 ffull = A::max(A::subus(ffull, a.ge), t);
                 diag = Hp[r];
                 Hp[r] = hf;
@@ -277,15 +302,9 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
         hUpPrev = hUpNew;
     };
     {
-        uint32_t PA0[D], PB0[D], QA0[D], QB0[D], PA1[D], PB1[D], QA1[D], QB1[D];
-#pragma unroll
-        for (int j = 0; j < D; j++) { QA0[j] = QB0[j] = QA1[j] = QB1[j] = 0; }
-        loadRows(PA0, PB0, QA0, QB0);                                            // column of step 0
-        ringAt = ((ringAt + EB) & (uint32_t) (RINGB - 1)) | ring;
-        readEntry();                                                             // entry of step 1
         int s = 0;
-        for (; s + 1 < steps; s += 2) { step(s, PA0, PB0, QA0, QB0, PA1, PB1, QA1, QB1); step(s + 1, PA1, PB1, QA1, QB1, PA0, PB0, QA0, QB0); }
-        if (s < steps) step(s, PA0, PB0, QA0, QB0, PA1, PB1, QA1, QB1);
+        for (; s + 1 < steps; s += 2) { step(s); step(s + 1); }
+        if (s < steps) step(s);
     }
 
 #pragma unroll
@@ -314,7 +333,7 @@ __device__ __forceinline__ void sw3Body(const Sw3Args &a, const SwBlockDesc &bd,
 // its descriptor and runs the body instantiated for R = ceil(L / HL).  (One kernel per R made a batch of mixed lengths a dozen small
 // launches, each with its own long-target tail; register allocation is that of R = RLO + 7.)
 template <bool HAS_AA, int HL, int RLO>
-__global__ __launch_bounds__(512) void k_sw3(Sw3Args a) {
+__global__ __launch_bounds__(512, (HL == 16 && RLO == 17) ? 3 : 1) void k_sw3(Sw3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SwBlockDesc bd = a.blocks[blockIdx.x];
     const int R = __builtin_amdgcn_readfirstlane(((int) bd.rowsInTile + HL - 1) / HL);
@@ -380,7 +399,10 @@ __global__ __launch_bounds__(256) void k_sw3_image(const Sw3ImgQuery *qs, const 
         uint32_t *dst = img + q.imgOff + (size_t) dt * kSw2Rows * rowDw + (size_t) a * rowDw;
         const int di = sw3DwordIndex(R, HL, l, j);
         dst[di] = v;
-        if (HL == 32 && (D % 4) == 1 && j == D - 1) dst[di + 32] = v;      // second copy of the 1-dword plane
+        if (j >= sw3Planes16(R) * 4) {                                       // the copies of the remainder plane
+            const int nc = sw3RemCopies(R, HL), st = sw3RemCopyStride(R, HL);
+            for (int c = 1; c < nc; c++) dst[di + c * st] = v;
+        }
     }
 }
 #endif

@@ -1,4 +1,4 @@
-"""k_sw3 (fsgpu_sw_multi_dir_c: compact queries, images built on the device, 32 / 64 lanes per target pair, target codes from an LDS ring)
+"""k_sw3 (fsgpu_sw_multi_dir_c: compact queries, images built on the device, 16 / 32 / 64 lanes per target pair, target codes from an LDS ring)
 against k_sw (fsgpu_sw_batch: word profiles from the host, one pair per wave, both directions) and the C oracle."""
 import numpy as np
 import pytest
@@ -41,8 +41,24 @@ LENGTHS = [1, 20, 33, 64, 65, 97, 129, 161, 193, 225, 257, 289, 321, 350, 353, 3
 PAIRS = [1, 2, 3, 4, 5, 7, 9, 16, 17, 33, 64, 31, 120, 250, 6, 11, 13, 66, 15, 130, 1, 3, 5, 8, 19, 34, 4, 2, 70, 9]
 
 
+# which lanes-per-pair shape a pair takes is a launch decision (fsgpu.hip sw3MultiImpl): the automatic rule (lists of <= 16 pairs with 64 lanes, the
+# 16-lane shape only in calls of >= 100 000 pairs), the 16-lane shape forced for targets of up to 512 / 896 columns, and the short-list rule off --
+# every (shape, rows-per-lane) class must give the per-pair kernel's records
+SHAPES = {"auto": {}, "mid512": {"FSGPU_SW3_MID": "512"}, "mid896_noshort": {"FSGPU_SW3_MID": "896", "FSGPU_SW3_SHORT": "0"},
+          "no16_noshort": {"FSGPU_SW3_MID": "0", "FSGPU_SW3_SHORT": "0"}}
+
+
+@pytest.fixture(params=list(SHAPES))
+def shape(request, monkeypatch):
+    for k in ("FSGPU_SW3_MID", "FSGPU_SW3_SHORT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in SHAPES[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
 @pytest.mark.parametrize("atype", [0, 2])
-def test_sw3_every_class_equals_the_per_pair_kernel(env, atype):
+def test_sw3_every_class_equals_the_per_pair_kernel(env, atype, shape):
     rng, db, ctx, seeds = env
     rng = np.random.default_rng(500 + atype)
     mA, m3 = api.Matrix(1, 1.4 if atype == 2 else 0.0), api.Matrix(0, 2.1)
@@ -102,7 +118,7 @@ def test_sw3_every_class_equals_the_per_pair_kernel(env, atype):
         _same(got[i], (want_r[1:] + want_r[:1])[i], (atype, "other queries, reversed first", LENGTHS[(i + 1) % len(LENGTHS)]))
 
 
-def test_sw3_gap_costs_and_int16_saturation(env):
+def test_sw3_gap_costs_and_int16_saturation(env, shape):
     """other gap costs; position biases large enough to saturate int16: those pairs are re-run in int32 like alignScoreEndPos does"""
     rng, db, ctx, seeds = env
     rng = np.random.default_rng(9)
@@ -136,7 +152,7 @@ def test_sw3_gap_costs_and_int16_saturation(env):
         _same(both[d][0], want[d], ("saturated, one submission", d))
 
 
-def test_sw3_large_batch_of_small_hit_lists(env):
+def test_sw3_large_batch_of_small_hit_lists(env, shape):
     """the all-vs-all shape: hundreds of queries with a handful of pairs each, many classes in one call"""
     rng, db, ctx, seeds = env
     rng = np.random.default_rng(31)

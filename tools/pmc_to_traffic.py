@@ -37,27 +37,48 @@ print(f"k_gapless: FETCH {e['fetch_size_kb']:.1f} KB x2 + WRITE {e['write_size_k
 # (timed queries x hits per query x (1 + reversed fraction)) scaled by (steps + warm-up) / steps: the counters also cover the warm-up step; the eight
 # single-query solo probes run k_sw and are not in the k_sw3 family.  An estimate to a few per cent, said so in the entry.
 SW_FILES = ["k_sw3.hpp", "k_sw.hpp", "fsgpu_sw3.hip", "fs_kernels.h"]
-lp = os.path.join(d, f"{tag}_pmc_bench_1M_benchline.json")
-if "fs::k_sw3" in b and os.path.exists(lp):
-    line = json.load(open(lp))
-    sw = b["fs::k_sw3"]["counters"]
-    im = b.get("fs::k_sw3_image", {}).get("counters", {})
-    nq = line["config"]["queries_total"]
-    pairs = nq * line["hits_per_query"] * (1.0 + line["align_leg"]["reverse_pass_fraction"]) * (line["steps"] + line["warmup"] + 1) / line["steps"]
+hash_sw_box = open(os.path.join(d, f"{tag}_csrc_hash_sw.txt")).read().strip()
+
+
+def sw_entry(counters_json, line_json, key, what, allvsall=False):
+    """one entry of profiles/pmc_traffic_sw.json (key = '<targets>:<alignment type>') from a counter summary and the bench line of the SAME run"""
+    if not (os.path.exists(counters_json) and os.path.exists(line_json)):
+        return
+    bb = json.load(open(counters_json))
+    if "fs::k_sw3" not in bb:
+        return
+    line = json.load(open(line_json))
+    sw = bb["fs::k_sw3"]["counters"]
+    im = bb.get("fs::k_sw3_image", {}).get("counters", {})
+    if allvsall:
+        # pairs of every batch the counters saw: timed + warm-up + the five solo repetitions, each a forward + reversed pass pair
+        at = "2"
+        pairs = line["align_roofline"]["pairs_per_pass_pair"] * (line["steps"] + line["warmup"] + 5)
+    else:
+        at = line["config"]["workload"].split("--alignment-type ")[1][:1]
+        nq = line["config"]["queries_total"]
+        pairs = nq * line["hits_per_query"] * (1.0 + line["align_leg"]["reverse_pass_fraction"]) * (line["steps"] + line["warmup"] + 1) / line["steps"]
     fkb = sw["FETCH_SIZE"]["total"] + im.get("FETCH_SIZE", {}).get("total", 0.0)
     wkb = sw["WRITE_SIZE"]["total"] + im.get("WRITE_SIZE", {}).get("total", 0.0)
     ps = os.path.join(ROOT, "profiles", "pmc_traffic_sw.json")
     ts = json.load(open(ps)) if os.path.exists(ps) else {}
-    ts["1000000"] = {"kernel": "k_sw3 + k_sw3_image (batch structure SW, both passes)", "fetch_size_kb": fkb, "write_size_kb": wkb, "fetch_correction": 2.0,
-                     "pairs_estimate": pairs, "bytes_per_pair": (2.0 * fkb + wkb) * 1024.0 / max(pairs, 1.0), "alignment_type": line["config"]["workload"].split("--alignment-type ")[1][:1],
-                     "note": "pairs = queries_total x hits_per_query x (1 + reverse_pass_fraction) of the pass's own bench line x (steps + warm-up + the solo batch) / steps; "
-                             "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (wide reads: the LDS images and the target codes). Algorithmic bytes of a pair: its target's codes "
-                             "(1 B per residue and table) + 16 B of result; the rest is the workgroups' LDS images (30-106 KB per workgroup of 8-32 pairs, mostly L2 hits)",
-                     "source": f"{prefix}_pmc_bench_1M_steps3.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT collected in the run that prints it)",
-                     "csrc_hash": csrc_hash(SW_FILES) if open(os.path.join(d, f"{tag}_csrc_hash_sw.txt")).read().strip() == csrc_hash(SW_FILES) else open(os.path.join(d, f"{tag}_csrc_hash_sw.txt")).read().strip(),
-                     "csrc_files": SW_FILES}
+    ts[key] = {"kernel": "k_sw3 + k_sw3_image (batch structure SW, both passes)", "fetch_size_kb": fkb, "write_size_kb": wkb, "fetch_correction": 2.0,
+               "pairs_estimate": pairs, "bytes_per_pair": (2.0 * fkb + wkb) * 1024.0 / max(pairs, 1.0), "alignment_type": at,
+               "note": "pairs = what the pass's own bench line reports (queries x hits per query x (1 + reversed fraction), scaled to the batches the counters saw: "
+                       "timed + warm-up + solo); hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (wide reads: the LDS images and the target codes). Algorithmic bytes of a "
+                       "pair: its target's codes (1 B per residue and table) + 16 B of result; the rest is the workgroups' LDS images (17-106 KB per workgroup of "
+                       "8-64 pairs, mostly L2 hits). An estimate to a few per cent.",
+               "source": f"{prefix}_{what} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT collected in the run that prints it)",
+               "csrc_hash": hash_sw_box, "csrc_files": SW_FILES}
     json.dump(ts, open(ps, "w"), indent=1)
-    print(f"k_sw3: FETCH {fkb:.0f} KB x2 + WRITE {wkb:.0f} KB over ~{pairs:.0f} pairs = {ts['1000000']['bytes_per_pair']:.0f} B per pair")
+    print(f"k_sw3 [{key}]: FETCH {fkb:.0f} KB x2 + WRITE {wkb:.0f} KB over ~{pairs:.0f} pairs = {ts[key]['bytes_per_pair']:.0f} B per pair")
+
+
+if hash_sw_box != csrc_hash(SW_FILES):
+    print(f"WARNING: the SW kernel sources changed since the pass was collected ({hash_sw_box} on the box, {csrc_hash(SW_FILES)} here): bench.py will report traffic null", file=sys.stderr)
+sw_entry(os.path.join(d, f"{tag}_pmc_bench_1M.json"), os.path.join(d, f"{tag}_pmc_bench_1M_benchline.json"), "1000000:0", "pmc_bench_1M_steps3.txt")
+sw_entry(os.path.join(d, f"{tag}_pmc_bench_1M_t2.json"), os.path.join(d, f"{tag}_pmc_bench_1M_t2_benchline.json"), "1000000:2", "pmc_bench_1M_t2_steps3.txt")
+sw_entry(os.path.join(d, f"{tag}_pmc_allvsall_200k.json"), os.path.join(d, f"{tag}_pmc_allvsall_200k_benchline.json"), "200000:2", "pmc_allvsall_200k.txt", allvsall=True)
 
 # --- k-mer prefilter: every kernel of one 32-query batch, per index hit
 k = json.load(open(os.path.join(d, f"{tag}_pmc_kmer_1M.json")))
