@@ -19,6 +19,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 
 using namespace fsh;
 
@@ -65,6 +66,11 @@ namespace {
 int usableCores() {
     int n = (int) std::thread::hardware_concurrency();
     if (n <= 0) n = 1;
+    {   // the CPU set this process may run on (a rank pinned to its share of the node's cores)
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+    }
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
         char q[64]; long long period = 0;
         if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, atoll(q) / period));
@@ -508,40 +514,9 @@ int gateAlign(fshost_search *s, const AlignQuery &aq, int64_t identityId, const 
     return nres;
 }
 
-// Backtraces of every pair of the given queries that passes the score gates, computed by the host pool (the calling
-// thread takes part).  Only when the accept / reject limits cannot cut a query short (their defaults): otherwise gateAlign
-// computes them one by one, like the reference, and stops where the reference stops.
-// what the two aligners cost in this process (exponential averages; plain doubles behind a mutex: a few updates per batch)
-struct BtCalib {
-    std::mutex m;
-    double hostSecPerHitCore = 0, devSecFixed = 0, devSecPerHit = 0;     // 0 = not measured yet
-    long calls = 0;
-    static BtCalib &get() { static BtCalib c; return c; }
-    bool chooseDevice(double n, int cores) {
-        std::lock_guard<std::mutex> g(m);
-        const long c = calls++;
-        if (n < 64) return false;                                          // a handful of hits: the call overhead alone decides
-        if (hostSecPerHitCore == 0) return false;                          // measure the host first,
-        if (devSecPerHit == 0) return true;                                // then the device
-        const bool dev = devSecFixed + n * devSecPerHit < n * hostSecPerHitCore / (double) cores;
-        return (c % 64 == 63) ? !dev : dev;
-    }
-    void hostSample(double sec, double n, int cores) {
-        if (n < 64) return;
-        std::lock_guard<std::mutex> g(m);
-        const double v = sec * (double) cores / n;
-        hostSecPerHitCore = hostSecPerHitCore == 0 ? v : 0.75 * hostSecPerHitCore + 0.25 * v;
-    }
-    void devSample(double sec, double n) {
-        if (n < 64) return;
-        std::lock_guard<std::mutex> g(m);
-        // one call = fixed part + n x per-hit part; small calls move the fixed part, large ones the slope
-        if (devSecPerHit == 0) { devSecFixed = std::min(sec, 1.0e-3); devSecPerHit = std::max(1e-9, (sec - devSecFixed) / n); return; }
-        const double pred = devSecFixed + n * devSecPerHit, err = sec - pred;
-        if (n < 1024) devSecFixed = std::max(1e-4, devSecFixed + 0.25 * err);
-        else devSecPerHit = std::max(1e-9, devSecPerHit + 0.25 * err / n);
-    }
-};
+// Backtraces of every pair of the given queries that passes the score gates, computed ahead of gateAlign by the host pool (the calling
+// thread takes part) and the device aligner together.  Only when the accept / reject limits cannot cut a query short (their defaults):
+// otherwise gateAlign computes them one by one, like the reference, and stops where the reference stops.
 struct PreBacktrace {
     std::vector<BlockAlnOut> outs;
     std::vector<std::vector<int>> idx;       // [query][pair] -> outs index or -1
@@ -571,23 +546,96 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     }
     pb.outs.resize(tasks.size());
     const double t0 = nowSec();
-    // ---- device path (round 5): one wave per accepted hit runs the block aligner (k_btrace.hpp); what it hands back (blocks beyond 128 rows) and
-    // everything when it is switched off (FSGPU_DEVICE_BACKTRACE=0) or cannot run (database without AA sequences) goes to the host pool ----
-    std::vector<int> hostTasks;
-    // FSGPU_DEVICE_BACKTRACE = 1 / 0 forces the device / the host aligner (read per call: the tests switch it inside one process).  Unset: whichever is
-    // expected to answer the batch sooner -- from what THIS process has measured (BtCalib below): the host's seconds per hit and pool worker, the
-    // device's seconds per call and per hit.  Until both have been seen the first two batches of 64 hits or more take one path each; every 64th
-    // batch re-measures the path that is not being chosen (the balance shifts with the load of either side).  Round 5 decided from constants
-    // measured once on a 16-core box (36 us per hit on the host, 1.5 ms + 0.8 us on the device, the host given a factor of four), which on that
-    // box never picked the device and on no other box meant anything.
+    // ---- who answers a hit.  FSGPU_DEVICE_BACKTRACE = 1 / 0 forces the device aligner (k_btrace.hpp; what it hands back goes to the host) / the host
+    // aligner (read per call: the tests switch it inside one process).  2: BOTH, sharing one list -- the pool's threads take hits from its front one at
+    // a time, a helper thread feeds the device aligner chunks from its back (each at most half of what is left, at least kDevMin hits: the kernel's
+    // latency is that of its longest alignment, ~5-20 ms, whatever the chunk), until the two meet.  (Round 5 chose one side per batch from constants of
+    // one box, the first version of round 6 from per-hit costs measured in the process; both sent next to nothing to the device on 16 cores.)
     const char *envDev = getenv("FSGPU_DEVICE_BACKTRACE");
-    const double nTasks = (double) tasks.size();
-    BtCalib &cal = BtCalib::get();
-    const bool deviceOn = envDev ? atoi(envDev) != 0 : cal.chooseDevice(nTasks, HostPool::get().workers() + 1);
-    const double tDevStart = nowSec();
+    // Measured (all-vs-all, 606 k accepted hits; profiles/r06_backtrace_modes.txt).  16 cores, 8 feeder threads, module query loop: host only 2.45 s,
+    // shared 3.95 s with 294 k hits on the device -- k_block_backtrace keeps every SIMD issuing for the 10-20 ms of a chunk, and the k-mer batches'
+    // chains of short kernels and the SW passes of the other feeders queue behind it (their waits doubled).  One rank's 2 cores of an 8-rank node
+    // (bench.py --emulate-rank-share 8): host only 19.1 k queries/s, shared 30.1 k, device only 48.3 k -- two cores have no time to give.
+    // Hence the default by the cores this process may use: <= 4 -> the device aligner (1), more -> the host aligner (0); 2 = shared on request.
+    const int envMode = envDev && *envDev ? atoi(envDev) : -1;
+    const int mode = envMode == 0 || envMode == 1 || envMode == 2 ? envMode : (usableCores() <= 4 ? 1 : 0);          // 0 host, 1 device, 2 shared
     const fshost_params &par = s->par;
-    bool onDevice = deviceOn && s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
-    if (onDevice) {
+    const bool deviceCan = s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
+    // hits from which a batch is shared (FSGPU_BT_SHARE_MIN; the tests lower it), smallest / largest device chunk
+    const size_t kShareMin = [] { const char *e = getenv("FSGPU_BT_SHARE_MIN"); const long v = e && *e ? atol(e) : 0; return (size_t) (v > 0 ? v : 1024); }();
+    const size_t kDevMin = std::min<size_t>(512, kShareMin / 2), kDevMax = 8192;
+    // (a handful of hits: the device call's fixed cost alone decides, unless the device was asked for)
+    const bool useDevice = deviceCan && ((mode == 1 && (envMode == 1 || tasks.size() >= 64)) || (mode == 2 && tasks.size() >= kShareMin));
+    // the shared list: [lo, hi) not taken yet
+    std::atomic<uint64_t> range{(uint64_t) tasks.size()};          // lo << 32 | hi
+    auto popFront = [&](size_t &t) {
+        uint64_t r = range.load(std::memory_order_relaxed);
+        for (;;) {
+            const uint64_t lo = r >> 32, hi = r & 0xffffffffu;
+            if (lo >= hi) return false;
+            if (range.compare_exchange_weak(r, ((lo + 1) << 32) | hi, std::memory_order_acq_rel)) { t = (size_t) lo; return true; }
+        }
+    };
+    auto popBack = [&](size_t &c0, size_t &c1, size_t traceBudget) {
+        uint64_t r = range.load(std::memory_order_relaxed);
+        for (;;) {
+            const uint64_t lo = r >> 32, hi = r & 0xffffffffu;
+            const uint64_t left = hi > lo ? hi - lo : 0;
+            uint64_t take = mode == 1 ? std::min<uint64_t>(left, 16384) : std::min<uint64_t>(kDevMax, left / 2);
+            if (take == 0 || (mode == 2 && take < kDevMin)) return false;
+            // at most 1 GB of trace scratch per device call (64 B per row and column of an alignment's prefixes: a call full of 2000-residue pairs
+            // would otherwise pin 6.7 GB per feeder context for good)
+            size_t bytes = 0; uint64_t fit = 0;
+            for (uint64_t t = hi; t > hi - take; t--) {
+                const fsgpu_swres &f = fwd[tasks[t - 1].base + tasks[t - 1].k];
+                const size_t bb = 64 * ((size_t) f.qEnd + (size_t) f.dbEnd + 2 + 256);
+                if (fit > 0 && bytes + bb > traceBudget) break;
+                bytes += bb; fit++;
+            }
+            take = fit;
+            if (range.compare_exchange_weak(r, (lo << 32) | (hi - take), std::memory_order_acq_rel)) { c0 = (size_t) (hi - take); c1 = (size_t) hi; return true; }
+        }
+    };
+    std::vector<int> handedBack;          // device: status 0 (block beyond its limit, trace slice too small, ...)
+    std::mutex handedM;
+    std::atomic<size_t> devDone{0};
+    std::atomic<bool> devBroken{false};
+    auto deviceLoop = [&]() {
+        fshost_search *ms = const_cast<fshost_search *>(s);
+        std::vector<fsgpu_bt_query> bq(nq);
+        for (int i = 0; i < nq; i++) { bq[i].qAA = aq[i].qAA; bq[i].q3Di = aq[i].q3di; bq[i].cbAA = aq[i].cbAA.data(); bq[i].cbSS = aq[i].cbSS.data(); bq[i].L = aq[i].L; bq[i].reserved = 0; }
+        std::vector<fsgpu_bt_task> bt;
+        std::vector<fsgpu_bt_res> br;
+        size_t c0, c1;
+        while (!devBroken.load() && popBack(c0, c1, (size_t) 1 << 30)) {
+            bt.resize(c1 - c0); br.resize(c1 - c0);
+            for (size_t t = c0; t < c1; t++) {
+                const Task &tk = tasks[t];
+                const fsgpu_swres &f = fwd[tk.base + tk.k];
+                bt[t - c0] = fsgpu_bt_task{(uint32_t) tk.q, targetIds[tk.q][tk.k], f.qEnd, f.dbEnd, f.score};
+            }
+            const char *btBase = nullptr;
+            if (fsgpu_block_backtrace(s->ctx, ms->btTblAA.data(), ms->btTbl3.data(), ms->btLetAA.data(), ms->btLet3.data(), bq.data(), nq, bt.data(), (int) bt.size(),
+                                      par.gapOpen, par.gapExtend, br.data(), &btBase) != FSGPU_OK) {
+                // (scratch did not fit, ...): the host answers this chunk and the device takes no more
+                std::lock_guard<std::mutex> g(handedM);
+                for (size_t t = c0; t < c1; t++) handedBack.push_back((int) t);
+                devBroken.store(true);
+                break;
+            }
+            size_t ok = 0;
+            for (size_t t = c0; t < c1; t++) {
+                const fsgpu_bt_res &r = br[t - c0];
+                BlockAlnOut &o = pb.outs[t];
+                o = BlockAlnOut();
+                if (r.status == 1) { o.ok = true; o.qStart = r.qStart; o.dbStart = r.dbStart; o.identicalAA = (unsigned int) r.identicalAA; o.backtrace.assign(btBase + r.btOff, (size_t) r.btLen); ok++; }
+                else if (r.status == 2) ok++;
+                else { std::lock_guard<std::mutex> g(handedM); handedBack.push_back((int) t); }
+            }
+            devDone.fetch_add(ok);
+        }
+    };
+    if (useDevice) {
         fshost_search *ms = const_cast<fshost_search *>(s);
         if (ms->btTblAA.empty()) {
             // the two AAMatrix tables exactly as blockBacktrace fills them (block_set_aamatrix per letter pair, StructureSmithWaterman.cpp:428-447)
@@ -604,53 +652,26 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
             for (int a = 0; a < std::min(21, s->matAA.n); a++) ms->btLetAA[a] = letterIdx(s->matAA.letters[a]);
             for (int a = 0; a < std::min(21, s->mat3Di.n); a++) ms->btLet3[a] = letterIdx(s->mat3Di.letters[a]);
         }
-        std::vector<fsgpu_bt_query> bq(nq);
-        for (int i = 0; i < nq; i++) { bq[i].qAA = aq[i].qAA; bq[i].q3Di = aq[i].q3di; bq[i].cbAA = aq[i].cbAA.data(); bq[i].cbSS = aq[i].cbSS.data(); bq[i].L = aq[i].L; bq[i].reserved = 0; }
-        std::vector<fsgpu_bt_task> bt;
-        std::vector<fsgpu_bt_res> br;
-        // tasks per device call: at most 16384 and at most 1 GB of trace scratch (64 B per row and column of an alignment's prefixes: a call full of
-        // 2000-residue pairs would otherwise pin 6.7 GB per feeder context for good)
-        for (size_t c0 = 0, c1 = 0; c0 < tasks.size() && onDevice; c0 = c1) {
-            size_t traceBytes = 0;
-            for (c1 = c0; c1 < tasks.size() && c1 - c0 < 16384; c1++) {
-                const fsgpu_swres &f = fwd[tasks[c1].base + tasks[c1].k];
-                const size_t b = 64 * ((size_t) f.qEnd + (size_t) f.dbEnd + 2 + 256);
-                if (c1 > c0 && traceBytes + b > ((size_t) 1 << 30)) break;
-                traceBytes += b;
-            }
-            bt.resize(c1 - c0); br.resize(c1 - c0);
-            for (size_t t = c0; t < c1; t++) {
-                const Task &tk = tasks[t];
-                const fsgpu_swres &f = fwd[tk.base + tk.k];
-                bt[t - c0] = fsgpu_bt_task{(uint32_t) tk.q, targetIds[tk.q][tk.k], f.qEnd, f.dbEnd, f.score};
-            }
-            const char *base = nullptr;
-            if (fsgpu_block_backtrace(s->ctx, ms->btTblAA.data(), ms->btTbl3.data(), ms->btLetAA.data(), ms->btLet3.data(), bq.data(), nq, bt.data(), (int) bt.size(),
-                                      par.gapOpen, par.gapExtend, br.data(), &base) != FSGPU_OK) {
-                for (size_t t = c0; t < tasks.size(); t++) hostTasks.push_back((int) t);      // (scratch did not fit, ...): the host path answers the rest
-                onDevice = false;
-                break;
-            }
-            for (size_t t = c0; t < c1; t++) {
-                const fsgpu_bt_res &r = br[t - c0];
-                BlockAlnOut &o = pb.outs[t];
-                o = BlockAlnOut();
-                if (r.status == 1) { o.ok = true; o.qStart = r.qStart; o.dbStart = r.dbStart; o.identicalAA = (unsigned int) r.identicalAA; o.backtrace.assign(base + r.btOff, (size_t) r.btLen); }
-                else if (r.status != 2) hostTasks.push_back((int) t);
-            }
-        }
-    } else {
-        for (size_t t = 0; t < tasks.size(); t++) hostTasks.push_back((int) t);
     }
-    pb.onDevice = tasks.size() - hostTasks.size();
-    if (onDevice && pb.onDevice > 0) cal.devSample(nowSec() - tDevStart, (double) tasks.size());
-    const double tHost0 = nowSec();
-    HostPool::get().parallelFor((int) hostTasks.size(), [&](int h) {
-        const int t = hostTasks[h];
+    auto hostOne = [&](size_t t) {
         const Task &tk = tasks[t];
         pairBacktrace(s, aq[tk.q], targetIds[tk.q][tk.k], fwd[tk.base + tk.k], pb.outs[t]);
-    });
-    if (hostTasks.size() == tasks.size()) cal.hostSample(nowSec() - tHost0, (double) tasks.size(), HostPool::get().workers() + 1);
+    };
+    if (useDevice && mode == 1) {
+        deviceLoop();                          // everything the device takes; what it cannot take or hands back follows below
+    } else if (useDevice) {
+        std::thread helper(deviceLoop);        // sleeps in the device call's stream wait almost all of its time
+        const int slots = HostPool::get().workers() + 1;
+        HostPool::get().parallelFor(slots, [&](int) { size_t t; while (popFront(t)) hostOne(t); });
+        helper.join();
+    }
+    {
+        // the host's part where nothing was shared, plus whatever the device left or handed back
+        size_t t;
+        while (popFront(t)) handedBack.push_back((int) t);
+        HostPool::get().parallelFor((int) handedBack.size(), [&](int h) { hostOne((size_t) handedBack[h]); });
+    }
+    pb.onDevice = devDone.load();
     pb.seconds = nowSec() - t0;
 }
 

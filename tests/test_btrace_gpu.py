@@ -30,7 +30,13 @@ def _run(world, atype, go, ge, device):
     par.alignmentType = atype
     par.addBacktrace = 1
     par.gapOpen, par.gapExtend = go, ge
-    os.environ["FSGPU_DEVICE_BACKTRACE"] = "1" if device else "0"
+    os.environ.pop("FSGPU_DEVICE_BACKTRACE", None)
+    os.environ.pop("FSGPU_BT_SHARE_MIN", None)
+    if device is None:
+        os.environ["FSGPU_DEVICE_BACKTRACE"] = "2"        # host pool and device share the batch's list (the default on hosts with <= 4 cores; from 1024 hits on, here from 128)
+        os.environ["FSGPU_BT_SHARE_MIN"] = "128"
+    else:
+        os.environ["FSGPU_DEVICE_BACKTRACE"] = "1" if device else "0"
     try:
         pre = api.Search(world["ctx"])
         hits = [pre.prefilter(q)["id"][:300] for q in world["q3"]]
@@ -41,7 +47,21 @@ def _run(world, atype, go, ge, device):
         s.close()
     finally:
         os.environ.pop("FSGPU_DEVICE_BACKTRACE", None)
+        os.environ.pop("FSGPU_BT_SHARE_MIN", None)
     return res, bts, counts
+
+
+@pytest.mark.parametrize("atype", [0, 2])
+def test_shared_backtrace_equals_host_backtrace(world, atype):
+    """FSGPU_DEVICE_BACKTRACE=2 (the default where cores are few): the pool's threads take hits from the front of the batch's list, the device aligner chunks from its back;
+    both must have answered hits, and the records must be the host aligner's"""
+    rs, bs, (on_dev, total) = _run(world, atype, 10, 1, None)
+    rh, bh, (on_dev_h, total_h) = _run(world, atype, 10, 1, False)
+    assert on_dev_h == 0 and total_h == total and total >= 400
+    assert 0 < on_dev < total, (on_dev, total)
+    for q in range(len(rs)):
+        assert rs[q].tobytes() == rh[q].tobytes(), q
+        assert bs[q] == bh[q], q
 
 
 @pytest.mark.parametrize("atype,go,ge", [(0, 10, 1), (2, 10, 1), (2, 8, 2), (2, 3, 1), (0, 15, 3)])
