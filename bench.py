@@ -222,8 +222,10 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
         na = sum(len(a) for a in aln)
         ta = time.perf_counter() - ta
         swms = kctx[t].kernel_ms(1)
+        btc = ksearch[t].backtrace_counts()
         if timed:
             with lock:
+                stat["bt_device"] = stat.get("bt_device", 0) + btc[0]; stat["bt_all"] = stat.get("bt_all", 0) + btc[1]
                 stat["dev"].append(ms[0]); stat["lists"].append(ms[10]); stat["counts"].append(cnt); stat.setdefault("sw", []).append(swms)
                 stat["hits"] += sum(len(r) for r in res); stat["aln"] += na; stat["t_pref"] += tp; stat["t_aln"] += ta
                 stat["bad"] = stat.get("bad", 0) + int((status < 0).sum())
@@ -302,6 +304,7 @@ def kmer_section(args, api, synth, ctx0, search0, par, db, rank, world, dev, fdi
            "similar_kmers_per_query": float(reg_cnt[0]) / 32, "index_hits_per_query": float(reg_cnt[1]) / 32,
            "candidates_per_query": float(reg_cnt[2]) / 32,
            "hits_per_query": stat["hits"] / nqk, "alignments_per_query": stat["aln"] / nqk, "unsupported_queries": stat.get("bad", 0),
+           "backtraces_on_device": [int(stat.get("bt_device", 0)), int(stat.get("bt_all", 0))],
            "stage_ms_per_batch32_solo": {k: solo_ms[i] for i, k in enumerate(["device_total", "count", "lists", "emit", "partition", "dup", "score", "replay", "select", "host_tail", "k_kmer_lists"])},
            "segments_solo": {k: int(v) for k, v in zip(["unused0", "runs", "unused2", "tiles", "runs_all", "coarse_keys", "ids_of_widest_key"], kctx[0].kmer_segments()) if not k.startswith("unused")},
            # kernel_ms: mean over the batches of the timed region (the host threads overlap their batches and the SW launches);
@@ -516,9 +519,11 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
         tw2 = time.perf_counter()
         ms, cnt = ctxs[t].kmer_stage_ms(), ctxs[t].kmer_counts()
         swp = ctxs[t].sw_last_passes()
+        btc = searches[t].backtrace_counts()
         if count:
             sec = r["seconds"]
             with lock:
+                stat["bt_device"] = stat.get("bt_device", 0) + btc[0]; stat["bt_all"] = stat.get("bt_all", 0) + btc[1]
                 stat["hits"] += int(r["nkept"].sum()); stat["aln"] += int(r["nres"].sum()); stat["q"] += len(bb)
                 stat["res"] += int(ls.sum()); stat["dev"] += ms[0]; stat["bad"] += int((r["status"] < 0).sum())
                 stat["stage"] += np.array(ms[:11]); stat["cnt"] += np.array(cnt, float); stat["nb"] += 1; stat["swp"].append(swp)
@@ -610,6 +615,7 @@ def allvsall_run(args, api, synth, fdist, dev, rank, world, local_rank, targets,
                "queries_per_s": nq / dt, "ms_per_query": 1e3 * dt / max(1, nq / world), "hits_per_query": sum(x["hits"] for x in tot) / max(1, nq),
                "alignments_per_query": sum(x["aln"] for x in tot) / max(1, nq), "prefilter_device_ms_per_query": s0["dev"] / max(1, s0["q"]),
                "unsupported_queries": sum(x["bad"] for x in tot), "index_build_s": t_index, "db_generation_s": t_gen,
+               "backtraces_on_device": [int(sum(x.get("bt_device", 0) for x in tot)), int(sum(x.get("bt_all", 0) for x in tot))],
                "projected_full_all_vs_all_s": db.n / max(1e-9, nq / dt),
                "queries_per_batch": AB, "stage_ms_per_batch": {k: s0["stage"][i] / nb0 for i, k in enumerate(names)},
                # wall time of one feeder thread per batch (KT threads run their batches concurrently), all inside ONE fshost_search_kmer_batch call since round 5:
@@ -711,7 +717,7 @@ def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev
     import torch.distributed as dist
     nthreads = len(ctxs)
     rec = {"kms": [], "sms": [], "counts": [0, 0], "swp": [], "trace": [],
-           "host": {"backtrace_s": 0.0, "rev_pairs": 0.0, "gates_s": 0.0, "profiles_s": 0.0, "sw_wait_s": 0.0}}
+           "host": {"backtrace_s": 0.0, "rev_pairs": 0.0, "gates_s": 0.0, "profiles_s": 0.0, "sw_wait_s": 0.0, "bt_device": 0, "bt_all": 0}}
     lock = threading.Lock()
     ready = threading.Barrier(nthreads + 1)
     go = threading.Barrier(nthreads + 1)
@@ -754,6 +760,7 @@ def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev
             hl, rs, km = step(t, b)
             st = searches[t].stats()
             swp = ctxs[t].sw_last_passes()
+            btc = searches[t].backtrace_counts()
             with lock:
                 if os.environ.get("FS_BENCH_TRACE"):
                     rec["trace"].append((t, tg - t_go[0], time.perf_counter() - tg))
@@ -761,6 +768,7 @@ def search_region(api, ctxs, searches, q3, qa, warm_batches, batches, world, dev
                 rec["counts"][0] += sum(len(h) for h in hl); rec["counts"][1] += sum(len(r) for r in rs)
                 h = rec["host"]
                 h["profiles_s"] += st[2]; h["sw_wait_s"] += st[3]; h["gates_s"] += st[4]; h["backtrace_s"] += st[5]; h["rev_pairs"] += st[7]
+                h["bt_device"] += btc[0]; h["bt_all"] += btc[1]
 
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
     for th in ths:
@@ -1078,6 +1086,9 @@ def main():
             # rank 0's host-side accounting of the align leg (sums over its feeder threads, per query)
             "align_leg": {"reverse_pass_fraction": mine["rev_pairs"] / max(1, tot[0][0]),
                           "host_backtrace_ms_per_query": 1e3 * mine["backtrace_s"] / max(1, n_mine),
+                          # accepted hits whose start position + CIGAR came from the device block aligner / all accepted hits (rank 0's feeders);
+                          # the default is by the cores the process may use: <= 4 device, more host (profiles/r06_backtrace_modes.txt)
+                          "backtraces_on_device": [int(mine["bt_device"]), int(mine["bt_all"])],
                           "host_gates_ms_per_query": 1e3 * mine["gates_s"] / max(1, n_mine),
                           "host_profiles_ms_per_query": 1e3 * mine["profiles_s"] / max(1, n_mine),
                           "sw_call_wall_ms_per_query": 1e3 * mine["sw_wait_s"] / max(1, n_mine),
@@ -1125,6 +1136,7 @@ def main():
                        "queries_per_s": n2t / dt2, "ms_per_query": 1e3 * dt2 / max(1, n2t / world), "mean_query_len": float(np.mean(lq2)),
                        "hits_per_query": sum(x[0] for x in tot2) / max(1, n2t), "alignments_per_query": sum(x[1] for x in tot2) / max(1, n2t),
                        "sw_kernels_ms_per_query": float(np.mean(rec2["sms"])),
+                       "backtraces_on_device": [int(rec2["host"]["bt_device"]), int(rec2["host"]["bt_all"])],
                        "roofline": gapless_roofline(rec2["kms"], lq2), "align_roofline": sw_roofline(rec2["swp"], True, solo2, args.targets)}
                 if not args.no_cpu_baseline and world == 1:
                     hits, _ = step1(0, n_warm, searches2)

@@ -12,7 +12,10 @@ cd /tmp && export TMPDIR=/tmp
 MODE=${1:-bench}
 TAG=${2:-x}
 #   r06_profile.sh pmck TAG   the k-mer and all-vs-all passes of `pmc` alone (the scan kernel's sources did not change: its pass of tag PREV=... is reused)
-if [ "$MODE" = emu ]; then
+#   r06_profile.sh sw TAG     the batch SW alone: tools/sw2_probe.py for 16 .. 256 queries x 1000 targets without / with the 16-lane shape
+if [ "$MODE" = sw ]; then
+for n in 16 32 64 128 256; do for v in "FSGPU_SW3_MID=0" "FSGPU_SW3_MID=512"; do echo "== $n queries, $v"; env $v python $R/tools/sw2_probe.py $n 2>&1 | grep "alignment-type"; done; done > $O/${TAG}_sw_probe_batch_scaling.txt
+elif [ "$MODE" = emu ]; then
 python $R/bench.py --emulate-rank-share 8 --scaling weak > $O/${TAG}_bench_emulate_rank_share8_weak.json 2> $O/${TAG}_emu_weak.err
 python $R/bench.py --emulate-rank-share 8 --scaling strong --steps 20 > $O/${TAG}_bench_emulate_rank_share8_strong.json 2> $O/${TAG}_emu_strong.err
 elif [ "$MODE" = pmc ] || [ "$MODE" = pmck ]; then
@@ -28,6 +31,12 @@ pass FETCH_SIZE
 pass WRITE_SIZE
 python $R/tools/pmc_family.py /tmp/pmc_SQ_WAVES /tmp/pmc_SQ_LDS_BANK_CONFLICT /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE --json $O/${TAG}_pmc_bench_1M.json > $O/${TAG}_pmc_bench_1M_steps3.txt 2>&1
 grep -h "^{" /tmp/pmc_SQ_WAVES.log | tail -1 > $O/${TAG}_pmc_bench_1M_benchline.json
+# the same short run with --alignment-type 2 (configs[3]): FETCH / WRITE of k_sw3 with the AA table -> align_type2's align_roofline.traffic
+pass2() { rm -rf /tmp/pmc2_$1; rocprofv3 --pmc "$@" -d /tmp/pmc2_$1 -o p --output-format csv -- python $R/bench.py $SHORT --alignment-type 2 > /tmp/pmc2_$1.log 2>&1; }
+pass2 FETCH_SIZE
+pass2 WRITE_SIZE
+python $R/tools/pmc_family.py /tmp/pmc2_FETCH_SIZE /tmp/pmc2_WRITE_SIZE --json $O/${TAG}_pmc_bench_1M_t2.json > $O/${TAG}_pmc_bench_1M_t2_steps3.txt 2>&1
+grep -h "^{" /tmp/pmc2_FETCH_SIZE.log | tail -1 > $O/${TAG}_pmc_bench_1M_t2_benchline.json
 else
 cp $R/profiles/${PREV:-r04_z}_pmc_bench_1M.json $O/${TAG}_pmc_bench_1M.json
 fi
