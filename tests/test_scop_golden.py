@@ -95,15 +95,16 @@ def test_modules_refuse_what_they_do_not_implement(scop, module, args, needle):
     assert not os.path.exists(scop / "out.index")
 
 
+# every frozen run with the host block aligner; the runs of the modules that compute backtraces once more with the device block aligner
+_RUNS = [(n, 0) for n in sorted(MANIFEST["runs"])] + [(n, 1) for n in sorted(MANIFEST["runs"]) if MANIFEST["runs"][n]["module"] in ("structurealign", "search")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dev", [0, 1])
-@pytest.mark.parametrize("name", sorted(MANIFEST["runs"]))
+@pytest.mark.parametrize("name,dev", _RUNS)
 def test_module_equals_reference_result_db(scop, name, dev):
     """dev: FSGPU_DEVICE_BACKTRACE -- with 1 the CIGARs of the frozen reference-binary outputs are met by the device block aligner (k_block_backtrace), with 0
     by the host restatement; runs without backtraces (prefilter modules, rescorediagonal) are run once"""
     run = MANIFEST["runs"][name]
-    if dev == 1 and run["module"] not in ("structurealign", "search"):
-        pytest.skip("no backtrace in this module")
     out = str(scop / ("mine_%d_" % dev + name))
     cmd = [BIN, run["module"]] + [str(scop / p) for p in run["positional"]] + [out] + run["parameters"]
     env = dict(os.environ, FSGPU_DEVICE_BACKTRACE=str(dev), FSGPU_MODULE_TIMING="1")

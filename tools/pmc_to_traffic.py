@@ -136,7 +136,7 @@ if os.path.exists(pa):
     a = json.load(open(pa))
     line = json.load(open(os.path.join(d, f"{tag}_pmc_allvsall_200k_benchline.json")))
     nq = line["queries_per_s"] * line["ms_per_step"] * 1e-3 * line["steps"]            # timed queries; the counters also cover the warm-up batches
-    nb_all = line["steps"] + line["warmup"] + 3                                          # + the three solo repetitions
+    nb_all = line["steps"] + line["warmup"] + 5                                          # + the five solo repetitions (three until round 5)
     ahits = line["index_hits_per_query"] * line["queries_per_batch"] * nb_all
     tot = 0.0
     arows = {}
@@ -153,7 +153,7 @@ if os.path.exists(pa):
     tav["200000"] = {"kernel": "k_kmer_* + the scans of the all-vs-all prefilter batches", "index_hits": ahits, "batches": nb_all,
                      "k_kmer_all_bytes_per_index_hit": tot / max(ahits, 1.0), "per_kernel": arows,
                      "workload": f"bench.py --workload allvsall --targets 200000 --steps {line['steps']} --warmup {line['warmup']} --kmer-threads 1 (family DB, batches of {line['queries_per_batch']})",
-                     "note": "index hits = index_hits_per_query of the line x queries per batch x (timed + warm-up + three solo batches); fetch / write calibrations of the 1M k-mer batch pass",
+                     "note": "index hits = index_hits_per_query of the line x queries per batch x (timed + warm-up + five solo batches); fetch / write calibrations of the 1M k-mer batch pass",
                      "source": f"{prefix}_pmc_allvsall_200k.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT collected in the run that prints it)",
                      "csrc_hash": hash_k, "csrc_files": KMER_FILES}
     json.dump(tav, open(pav, "w"), indent=1)
