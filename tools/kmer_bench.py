@@ -5,6 +5,7 @@ from foldseek_amd import api, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 32          # queries per fsgpu_kmer_search call
 q3, qa = synth.make_queries(NQ, seed=1)
 db = synth.make_db(N, (q3[:32], qa[:32]))
 ctx = api.Context(0); ctx.load_db(db)
@@ -13,8 +14,8 @@ t = time.time(); ctx.kmer_index_build(m8, kmer_thr=78); print("index build %.3fs
 t = time.time(); prep = [api.kmer_query_prepare(m8, m2, q) for q in q3]; print("host prepare %.3f ms/query" % ((time.time() - t) / NQ * 1e3))
 for rep in range(REPS):
     stages = np.zeros(11); t = time.time(); hits = 0; counts = np.zeros(4)
-    for b in range(0, NQ, 32):
-        res, status, stats = ctx.kmer_search(prep[b:b + 32], max_res=1000, want_stats=True)
+    for b in range(0, NQ, BATCH):
+        res, status, stats = ctx.kmer_search(prep[b:b + BATCH], max_res=1000, want_stats=True)
         stages += np.array(ctx.kmer_stage_ms()); hits += stats[:, 1].sum(); counts += np.array(ctx.kmer_counts(), dtype=np.float64)
         assert (status >= 0).all()
     dt = time.time() - t
