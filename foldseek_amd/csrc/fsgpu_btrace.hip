@@ -9,6 +9,7 @@
 
 #include "fsgpu_ctx.h"
 #include "k_btrace.hpp"
+#include "../../include/fshost.h"
 
 namespace {
 inline size_t up16(size_t x) { return (x + 15) & ~(size_t) 15; }
@@ -33,6 +34,12 @@ struct BtDrain {
     hipStream_t st; bool armed = false;
     ~BtDrain() { if (armed) { (void) hipStreamSynchronize(st); (void) hipGetLastError(); } }
 };
+}
+
+extern "C" int fsgpu_block_backtrace_footprint(fsgpu_ctx *ctx, int workgroupsPerCU) {
+    if (!ctx || workgroupsPerCU < 0 || workgroupsPerCU > 16) return FSGPU_E_ARG;
+    ctx->btWgPerCU = workgroupsPerCU;
+    return FSGPU_OK;
 }
 
 extern "C" int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const int8_t *tbl3Di, const uint8_t *letterAA, const uint8_t *letter3Di,
@@ -124,12 +131,21 @@ extern "C" int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const 
         a.gapOpen = -gapOpen; a.gapExtend = -gapExtend;
         a.seq = (uint8_t *) ctx->btSeq.p; a.trace = (uint32_t *) ctx->btTrace.p; a.blocks = (uint4 *) ctx->btBlocks.p;
         a.bt = (char *) ctx->btOut.p; a.res = (BtRes *) ((char *) ctx->btOut.p + btBytes);
-        if (maxBlock == kBtMaxBlock) {
-            const unsigned grid = (unsigned) std::min<size_t>(((size_t) n + kBtRows - 1) / kBtRows, (size_t) ctx->numCU * 4);
+        const size_t wgCU = ctx->btWgPerCU > 0 ? (size_t) ctx->btWgPerCU : 4;
+        // fewer alignments than wave slots (3 waves per SIMD): one alignment per wave (latency form); FSGPU_BT_SPREAD = 0 / 1 forces a form of the first pass
+        static const int spreadEnv = [] { const char *e = getenv("FSGPU_BT_SPREAD"); return e && *e ? atoi(e) : -1; }();
+        const bool spread1 = spreadEnv >= 0 ? spreadEnv != 0 : (size_t) n <= (size_t) ctx->numCU * 12;
+        if (maxBlock == kBtMaxBlock && spread1) {
+            const unsigned grid = (unsigned) std::min<size_t>(((size_t) n + 3) / 4, (size_t) ctx->numCU * wgCU);
+            hipLaunchKernelGGL((k_block_backtrace<kBtMaxBlock, 4, true>), dim3(grid), dim3(4 * 64), 0, st, a);
+        } else if (maxBlock == kBtMaxBlock) {
+            const unsigned grid = (unsigned) std::min<size_t>(((size_t) n + kBtRows - 1) / kBtRows, (size_t) ctx->numCU * wgCU);
             hipLaunchKernelGGL((k_block_backtrace<kBtMaxBlock, kBtRows>), dim3(grid), dim3(kBtRows * kBtL), 0, st, a);
         } else {
-            const unsigned grid = (unsigned) std::min<size_t>(((size_t) n + kBtRows2 - 1) / kBtRows2, (size_t) ctx->numCU * 8);
-            hipLaunchKernelGGL((k_block_backtrace<kBtMaxBlock2, kBtRows2>), dim3(grid), dim3(kBtRows2 * kBtL), 0, st, a);
+            // the second pass sees a fraction of the call's alignments (those whose block wants more than 128 rows) and restarts each from the smallest block:
+            // always one per wave
+            const unsigned grid = (unsigned) std::min<size_t>(((size_t) n + kBtRows2 - 1) / kBtRows2, (size_t) ctx->numCU * 2 * wgCU);
+            hipLaunchKernelGGL((k_block_backtrace<kBtMaxBlock2, kBtRows2, true>), dim3(grid), dim3(kBtRows2 * 64), 0, st, a);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ctx->hBtOut.p, ctx->btOut.p, btBytes + (size_t) nt * sizeof(BtRes), hipMemcpyDeviceToHost, st));
@@ -150,7 +166,12 @@ extern "C" int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const 
     for (int t = 0; t < nt; t++) todo[t] = t;
     if ((rc = runPass(todo, kBtMaxBlock)) != FSGPU_OK) return rc;
     // (the backtraces of the first pass sit in the pinned buffer; the second pass copies the whole device buffer again: its own slices are added, the others unchanged)
-    if ((rc = runPass(todo, kBtMaxBlock2)) != FSGPU_OK) return rc;
+    // The second pass is a 3-5 ms kernel whatever it is given (the latency of its longest alignment, restarted from the smallest block): a handful of
+    // alignments are back from the host's aligner sooner (36 us each on a core) -- it runs for 64 alignments per usable core or more (FSGPU_BT_PASS2 = 1 / 0:
+    // always / never); what it does not take stays at status 0 and the caller's host path answers.
+    const int pass2Env = [] { const char *e = getenv("FSGPU_BT_PASS2"); return e && *e ? atoi(e) : -1; }();          // per call: the tests switch it
+    const bool pass2 = pass2Env >= 0 ? pass2Env != 0 : todo.size() >= (size_t) 64 * (size_t) std::max(1, fshost_usable_cores());
+    if (pass2 && (rc = runPass(todo, kBtMaxBlock2)) != FSGPU_OK) return rc;
     *btBase = (const char *) ctx->hBtOut.p;
     return FSGPU_OK;
 }

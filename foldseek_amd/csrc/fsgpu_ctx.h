@@ -132,6 +132,7 @@ struct fsgpu_ctx {
     uint64_t s3Sig = 0;
     std::vector<uint32_t> s3ImgOff;                // per query of the call the images were built for: dword offset of its images
     PinBuf hRes0, hRes1;                           // pinned result staging
+    int btWgPerCU = 0;                          // fsgpu_block_backtrace_footprint: workgroups per CU of k_block_backtrace (0: default)
     DevBuf btSeq, btTrace, btBlocks, btOut, btIn;  // fsgpu_block_backtrace (k_btrace.hpp): padded reversed prefixes, trace words, block lists, [backtraces | results], inputs
     PinBuf hBtIn, hBtOut;
     struct {

@@ -660,10 +660,19 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     if (useDevice && mode == 1) {
         deviceLoop();                          // everything the device takes; what it cannot take or hands back follows below
     } else if (useDevice) {
-        std::thread helper(deviceLoop);        // sleeps in the device call's stream wait almost all of its time
+        // one batch at a time shares its list with the device (the feeders' batches overlap: eight aligner calls in flight were what doubled the other
+        // kernels' waits), and with ONE workgroup per CU: the aligner's workgroups live for the whole call and hold 48 KB of LDS each
+        static std::mutex deviceAlignerBusy;
+        std::unique_lock<std::mutex> mine(deviceAlignerBusy, std::try_to_lock);
+        std::thread helper;
+        if (mine.owns_lock()) {
+            static const int fp = [] { const char *e = getenv("FSGPU_BT_SHARED_WG_PER_CU"); const int v = e && *e ? atoi(e) : 1; return v >= 0 && v <= 16 ? v : 1; }();
+            (void) fsgpu_block_backtrace_footprint(s->ctx, fp);
+            helper = std::thread(deviceLoop);  // sleeps in the device call's stream wait almost all of its time
+        }
         const int slots = HostPool::get().workers() + 1;
         HostPool::get().parallelFor(slots, [&](int) { size_t t; while (popFront(t)) hostOne(t); });
-        helper.join();
+        if (helper.joinable()) { helper.join(); (void) fsgpu_block_backtrace_footprint(s->ctx, 0); }
     }
     {
         // the host's part where nothing was shared, plus whatever the device left or handed back

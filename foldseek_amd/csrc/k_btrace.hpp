@@ -444,13 +444,18 @@ __device__ __forceinline__ int btCigar(const BtTrace &tr, int i, int j, const ui
 }
 
 // alignStartPosBacktraceBlock (StructureSmithWaterman.cpp:369-537) for a batch of accepted hits: one 16-lane row per task
-template <int MAXB, int ROWS>
-__global__ __launch_bounds__(ROWS * kBtL) void k_block_backtrace(BtArgs a) {
+// SPREAD = false: the ROWS alignments of a workgroup sit four to a wave (throughput form: rows that disagree about the next piece of code take turns).
+// SPREAD = true: ONE alignment per wave, in its first 16 lanes (latency form, for calls with fewer alignments than the device has wave slots and for the
+// second pass: what an alignment waits for is then its own dependent chain only -- round 5's shape, 2.7 ms per 1 600 alignments against ~9 ms four to a wave).
+template <int MAXB, int ROWS, bool SPREAD = false>
+__global__ __launch_bounds__(SPREAD ? ROWS * 64 : ROWS * kBtL) void k_block_backtrace(BtArgs a) {
     __shared__ BtState<MAXB> states[ROWS];
     __shared__ int8_t tAA[27 * 32], tSS[27 * 32];
     for (int i = threadIdx.x; i < 27 * 32; i += blockDim.x) { tAA[i] = a.tblAA[i]; tSS[i] = a.tblSS[i]; }
     __syncthreads();
-    const int row = threadIdx.x >> 4, ln = threadIdx.x & (kBtL - 1), sh = (int) (threadIdx.x & 48u);     // sh: first lane of the row inside its wave
+    if (SPREAD && (threadIdx.x & 63u) >= (unsigned) kBtL) return;          // (no workgroup barrier below this line)
+    const int row = SPREAD ? (int) (threadIdx.x >> 6) : (int) (threadIdx.x >> 4), ln = threadIdx.x & (kBtL - 1);
+    const int sh = SPREAD ? 0 : (int) (threadIdx.x & 48u);                 // sh: first lane of the row inside its wave
     BtState<MAXB> &S = states[row];
     for (int task = blockIdx.x * ROWS + row; task < a.nTasks; task += gridDim.x * ROWS) {
         const BtTask tk = a.tasks[task];

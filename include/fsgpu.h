@@ -260,6 +260,10 @@ typedef struct { int32_t status, qStart, dbStart, identicalAA, btLen, blockSizes
 int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const int8_t *tbl3Di, const uint8_t *letterAA, const uint8_t *letter3Di,
                           const fsgpu_bt_query *queries, int nq, const fsgpu_bt_task *tasks, int nt, int gapOpen, int gapExtend,
                           fsgpu_bt_res *res, const char **btBase);
+/* Workgroups of the block aligner per compute unit for the following fsgpu_block_backtrace calls of this context (0: the default, 4 -- every CU's LDS
+ * and three waves per SIMD for the 10-20 ms of a call).  1 leaves two thirds of a CU's LDS and most issue slots to the kernels of other contexts: what a
+ * caller that shares a batch between its host threads and the device asks for (fshost_search_align_batch with FSGPU_DEVICE_BACKTRACE=2). */
+int fsgpu_block_backtrace_footprint(fsgpu_ctx *ctx, int workgroupsPerCU);
 
 /* ---- prefilter: k-mer matching with double-diagonal hits + ungapped diagonal scoring ------------------------- */
 /* Index parameters == the subset of Prefiltering's members that shape IndexTable / SequenceLookup.  Sequence-

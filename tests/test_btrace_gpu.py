@@ -110,6 +110,7 @@ def test_long_gapped_pairs_fall_back_and_still_agree(world):
     out = []
     for dev in (True, False):
         os.environ["FSGPU_DEVICE_BACKTRACE"] = "1" if dev else "0"
+        os.environ["FSGPU_BT_PASS2"] = "1"          # the second pass (blocks of up to 512 rows) takes what the first hands back, however few
         try:
             s = api.Search(ctx, par)
             res, bts = s.align_batch([qa], [q3], [np.arange(db.n, dtype=np.uint32)], with_backtrace=True)
@@ -117,6 +118,7 @@ def test_long_gapped_pairs_fall_back_and_still_agree(world):
             s.close()
         finally:
             os.environ.pop("FSGPU_DEVICE_BACKTRACE", None)
+            os.environ.pop("FSGPU_BT_PASS2", None)
     ctx.close()
     (rd, bd, cd), (rh, bh, ch) = out
     assert rd.tobytes() == rh.tobytes() and bd == bh
