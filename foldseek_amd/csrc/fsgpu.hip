@@ -1769,8 +1769,8 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // 0.57 / 0.49, 64: 0.67 / 0.59, 128: 0.69 / 0.72, 256: 0.72 / 0.75 (3Di; 3Di + AA the same picture) -- its waves are half as many and twice as
     // long, which a launch of one or two rounds of waves pays for in its tail.  All-vs-all's lists of ~8 pairs per query want the opposite: the LDS
     // image of a query (34-45 KB with AA) admits three workgroups per CU whatever the shape, so the shape with the MOST waves per pair keeps the SIMDs
-    // busiest (a batch of 1024 queries solo: 16 lanes 1.42 ms, 32 lanes 1.03 ms, 64 lanes 0.88 ms).  Hence the automatic rule: a query whose list is
-    // at most 16 pairs long runs with 64 lanes per pair; the 16-lane shape is taken when the call holds at least 100 000 pairs.
+    // busiest (a batch of 1024 queries solo: 16 lanes 1.42 ms, 32 lanes 1.03 ms, 64 lanes 0.88 ms).  Hence the automatic rule: a call whose lists
+    // hold at most 16 pairs on average runs with 64 lanes per pair throughout; the 16-lane shape is taken when the call holds at least 100 000 pairs.
     // FSGPU_SW3_MID=<columns> forces the 16-lane shape for every query (0: never), FSGPU_SW3_SHORT=<pairs> moves the short-list limit (0: off).
     const int midEnv = [] { const char *e = getenv("FSGPU_SW3_MID"); return e && *e ? atoi(e) : -1; }();      // read per call: the tests switch shapes inside one process
     const int midT = midEnv >= 0 ? midEnv : 512;
@@ -1800,6 +1800,11 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     std::vector<uint32_t> perm(total);
     std::vector<int> nLong(nq, 0), nMid(nq, 0);
     const size_t total16 = total;
+    // the short-list rule is per CALL (mean pairs per query of the call): a per-query rule left all-vs-all's batches with 64-lane groups for the short
+    // lists AND 32-lane groups for the others -- 1.29 ms per batch against 0.88 ms with one shape for the whole call
+    size_t nActive = 0;
+    for (int i = 0; i < nq; i++) if (nSel(i) > 0) nActive++;
+    const bool callShort = shortList > 0 && nActive > 0 && total <= (size_t) shortList * nActive;
     {
         std::vector<uint64_t> lkey;
         for (int i = 0; i < nq; i++) {
@@ -1812,7 +1817,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
             std::sort(lkey.begin(), lkey.end());
             int nl = 0, nm = 0;
             for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; const int lt = len[ids[p[k]]]; if (lt > longT) nl++; else if (lt > midT) nm++; }
-            nLong[i] = (q[i].L > 32 * kSw3MaxR || ns <= shortList) ? ns : nl;
+            nLong[i] = (q[i].L > 32 * kSw3MaxR || callShort) ? ns : nl;
             const bool shape16 = q[i].L <= 16 * maxR16 && midT > 0 && (midEnv >= 0 || total16 >= 100000);
             nMid[i] = nLong[i] == ns ? 0 : shape16 ? nm : ns - nLong[i];
         }
