@@ -79,6 +79,38 @@ def test_device_backtrace_equals_host_backtrace(world, atype, go, ge):
     assert n >= 400
 
 
+def test_default_choice_follows_the_cores_the_process_may_use(world):
+    """FSGPU_DEVICE_BACKTRACE unset: a process that may run on at most 4 CPUs (a rank pinned to its share of the node's cores) gets its backtraces from the
+    device aligner, one with more from the host pool (precomputeBacktraces; measured in profiles/r06_backtrace_modes.txt)"""
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity on this platform")
+    cpus = sorted(os.sched_getaffinity(0))
+    os.environ.pop("FSGPU_DEVICE_BACKTRACE", None)
+    par = api.default_params()
+    par.alignmentType = 2
+    par.addBacktrace = 1
+    pre = api.Search(world["ctx"])
+    hits = [pre.prefilter(q)["id"][:300] for q in world["q3"]]
+    pre.close()
+    out = {}
+    try:
+        for name, mask in (("two", set(cpus[:2])), ("all", set(cpus))):
+            os.sched_setaffinity(0, mask)
+            s = api.Search(world["ctx"], par)
+            res, bts = s.align_batch(world["qa"], world["q3"], hits, with_backtrace=True)
+            out[name] = (res, bts, s.backtrace_counts())
+            s.close()
+    finally:
+        os.sched_setaffinity(0, set(cpus))
+    (r2, b2, (dev2, tot2)), (ra, ba, (deva, tota)) = out["two"], out["all"]
+    assert tot2 == tota and tot2 >= 400
+    assert dev2 >= 0.8 * tot2, (dev2, tot2)                     # two CPUs: the device aligner
+    if len(cpus) > 4 and api.lib().fshost_usable_cores() > 4:
+        assert deva == 0, (deva, tota)                          # the box's cores: the host pool
+    for q in range(len(r2)):
+        assert r2[q].tobytes() == ra[q].tobytes() and b2[q] == ba[q], q
+
+
 def test_long_gapped_pairs_fall_back_and_still_agree(world):
     """targets with a long insertion: the aligner's block grows beyond what the device keeps in LDS; those hits come back through the host path, the
     records stay identical"""
