@@ -1961,8 +1961,17 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
                 }
                 pairs += pt.n;
             }
-            // first pair of a workgroup is its longest: longest workgroups first
-            std::stable_sort(hBlk + g.blk0, hBlk + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return len[hTids[x.firstPair]] > len[hTids[y.firstPair]]; });
+            // first pair of a workgroup is its longest: the workgroups with the most work per wave first (steps x instructions per step: a query of 15
+            // rows per lane runs twice the instructions per column of one with 7; FSGPU_SW3_LPT=0: by target length alone, as until round 5)
+            static const bool byWork = [] { const char *e = getenv("FSGPU_SW3_LPT"); return !(e && atoi(e) == 0); }();
+            const int hl = g.HL;
+            auto work = [&](const SwBlockDesc &x) {
+                const long lt = len[hTids[x.firstPair]];
+                if (!byWork) return lt;
+                const long R = ((long) x.rowsInTile + hl - 1) / hl;
+                return (lt + hl) * (15 * R + 18);
+            };
+            std::stable_sort(hBlk + g.blk0, hBlk + g.blk0 + g.nblk, [&](const SwBlockDesc &x, const SwBlockDesc &y) { return work(x) > work(y); });
         }
         ctx->swDirCells[slot] = clCells + cells * nDirs; ctx->swDirPairs[slot] = clPairs + pairs * nDirs; ctx->swDirWaveSteps[slot] = clSteps + winsts * nDirs;
     }

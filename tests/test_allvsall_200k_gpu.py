@@ -74,7 +74,7 @@ def test_cascade_step_equals_the_reference_binary_at_200k(world, step):
     # the accepted hits' backtraces on the device aligner in steps 0 and 2 (FSGPU_DEVICE_BACKTRACE=1: the reference binary's CIGARs are met by
     # k_block_backtrace itself), on the host restatement in step 1
     dev = "0" if step == 1 else "1"
-    out = _run([BIN, "structurealign", "q", "t", f"ref_p{step}", f"mine_a{step}"] + apar, w, env={"FSGPU_DEVICE_BACKTRACE": dev, "FSGPU_MODULE_TIMING": "1"})
+    out = _run([BIN, "structurealign", "q", "t", f"ref_p{step}", f"mine_a{step}"] + apar, w, env={"FSGPU_DEVICE_BACKTRACE": dev, "FSGPU_BT_PASS2": "1", "FSGPU_MODULE_TIMING": "1"})      # PASS2: the 512-row pass takes whatever the first hands back
     alines = _same(w, f"ref_a{step}", f"mine_a{step}")
     assert alines >= NQ, alines
     import re

@@ -72,10 +72,12 @@ def _align_against_reference(world, atype, go, ge, queries, max_hits, device_bac
     compiled reference's alignStructure wrote are met by k_block_backtrace directly, not through the host restatement"""
     if device_backtrace is not None:
         os.environ["FSGPU_DEVICE_BACKTRACE"] = str(device_backtrace)
+        os.environ["FSGPU_BT_PASS2"] = "1"          # the device's second pass (blocks of up to 512 rows) runs however few hits reach it
     try:
         return _align_against_reference_body(world, atype, go, ge, queries, max_hits, device_backtrace)
     finally:
         os.environ.pop("FSGPU_DEVICE_BACKTRACE", None)
+        os.environ.pop("FSGPU_BT_PASS2", None)
 
 
 def _align_against_reference_body(world, atype, go, ge, queries, max_hits, device_backtrace):

@@ -178,3 +178,38 @@ def test_sw3_large_batch_of_small_hit_lists(env, shape):
         f, r = ctx.sw_batch(_profiles(tA, qa, cba_f), _profiles(t3, q3, cb3_f), _profiles(tA, qa, cba_r, True), _profiles(t3, q3, cb3_r, True), ids)
         _same(got_f[k], f, ("fwd", k, len(q3)))
         _same(got_r[k], r, ("rev", k, len(q3)))
+
+
+@pytest.mark.parametrize("atype", [0, 2])
+def test_sw3_call_of_100k_pairs_takes_the_16_lane_shape_by_itself(env, atype, monkeypatch):
+    """the automatic rule: a call of >= 100 000 pairs runs its queries of up to 384 rows with 16 lanes per pair (targets of up to 512 columns) -- the records
+    must be those of the same call with the shape switched off, and a sample of them the per-pair kernel's"""
+    rng, db, ctx, seeds = env
+    rng = np.random.default_rng(4100 + atype)
+    mA, m3 = api.Matrix(1, 1.4 if atype == 2 else 0.0), api.Matrix(0, 2.1)
+    t3, tA = _tiny(m3), _tiny(mA)
+    use_aa = atype == 2
+    queries = []
+    for k in range(104):
+        L = int(rng.integers(40, 500))                 # rows-per-lane classes 3 .. 24 of the 16-lane shape, and queries beyond 384 rows in the same call
+        q3, qa = rng.choice(20, size=L).astype(np.uint8), rng.choice(20, size=L).astype(np.uint8)
+        _, _, cba_f, cb3_f = api.align_profiles(mA, m3, qa, q3, True, 0.5)
+        _, _, cba_r, cb3_r = api.align_profiles(mA, m3, qa[::-1].copy(), q3[::-1].copy(), True, 0.5)
+        ids = rng.choice(db.n, size=1000, replace=False).astype(np.uint32)
+        queries.append((qa if use_aa else None, q3, cba_f if use_aa else None, cb3_f, cba_r if use_aa else None, cb3_r, ids))
+    assert sum(len(q[6]) for q in queries) >= 100000
+    for k in ("FSGPU_SW3_MID", "FSGPU_SW3_SHORT"):
+        monkeypatch.delenv(k, raising=False)
+    auto_f = ctx.sw_multi_dir_c(t3, tA if use_aa else None, queries, 0)
+    auto_r = ctx.sw_multi_dir_c(t3, tA if use_aa else None, queries, 1)
+    monkeypatch.setenv("FSGPU_SW3_MID", "0")
+    off_f = ctx.sw_multi_dir_c(t3, tA if use_aa else None, queries, 0)
+    off_r = ctx.sw_multi_dir_c(t3, tA if use_aa else None, queries, 1)
+    for k in range(len(queries)):
+        assert auto_f[k].tobytes() == off_f[k].tobytes() and auto_r[k].tobytes() == off_r[k].tobytes(), k
+    for k in (0, 17, 55, 103):
+        qa, q3, cba_f, cb3_f, cba_r, cb3_r, ids = queries[k]
+        pAf, pAr = (_profiles(tA, qa, cba_f), _profiles(tA, qa, cba_r, True)) if use_aa else (None, None)
+        f, r = ctx.sw_batch(pAf, _profiles(t3, q3, cb3_f), pAr, _profiles(t3, q3, cb3_r, True), ids[:64])
+        _same(auto_f[k][:64], f, ("fwd", k, len(q3)))
+        _same(auto_r[k][:64], r, ("rev", k, len(q3)))
