@@ -71,11 +71,17 @@ int usableCores() {
         CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
     }
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[64]; long long period = 0;
-        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, atoll(q) / period));
-        fclose(f);
-    }
+    // the cgroup's CPU quota, read once (usableCores() is asked per batch since round 6)
+    static const long long quota = [] {
+        long long v = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64]; long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) v = std::max<long long>(1, atoll(q) / period);
+            fclose(f);
+        }
+        return v;
+    }();
+    if (quota > 0) n = (int) std::min<long long>(n, quota);
     return std::max(1, n);
 }
 

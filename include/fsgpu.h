@@ -244,7 +244,7 @@ typedef struct {
 int fsgpu_diag_rescore(fsgpu_ctx *ctx, const uint8_t *qAA, const uint8_t *q3Di, const uint64_t *qOffsets, const int32_t *qLengths,
                        int nq, const int16_t *mat3Di, const int16_t *matAA, const fsgpu_diag_pair *pairs, int64_t n, fsgpu_diag_res *out);
 
-/* ---- start position + backtrace of accepted hits on the device (round 5) ------------------------------------------------
+/* ---- start position + backtrace of accepted hits on the device (rounds 5-6) ------------------------------------------------
  * StructureSmithWaterman::alignStartPosBacktraceBlock (F/src/commons/StructureSmithWaterman.cpp:369-537) over the block-aligner crate's align_3di
  * (M/lib/block-aligner/src/scan_block.rs:120-630, 1302-1443, 1844-2007) for a batch of hits: the reversed prefixes query[0..qEnd], target[0..dbEnd] are
  * aligned from their ends with starting block sizes 32, 64, 128 until the SW score is reproduced.  tblAA / tbl3Di: the crate's AAMatrix of the two
@@ -252,8 +252,10 @@ int fsgpu_diag_rescore(fsgpu_ctx *ctx, const uint8_t *qAA, const uint8_t *q3Di, 
  * letter3Di [21]: residue code -> letter - 'A'.  cbAA / cbSS: the query's forward composition bias (int8 per residue, StructureSmithWaterman.cpp:1566-1640).
  * status 1: qStart / dbStart / identicalAA and btLen characters ('M', 'I', 'D', query start to end) at *btBase + btOff (valid until the next call on this
  * context); status 2: the aligner's score differs from the SW score -- the reference leaves such a hit without start position and backtrace
- * (structurealign.cpp:83); status 0: the alignment needs a block of more than 128 rows (the crate grows to 4096): not computed here, the caller runs
- * its host path (fshost_block_backtrace) -- same answer either way.  Needs a database loaded WITH AA sequences. */
+ * (structurealign.cpp:83); status 0: not computed here -- the alignment needs a block of more than 128 rows and the second pass (blocks of up to 512 rows;
+ * the crate grows to 4096) did not run for it (it runs when at least 64 such hits per usable host core have come back from the first pass, or with
+ * FSGPU_BT_PASS2=1) or could not finish it either: the caller runs its host path (fshost_block_backtrace) -- same answer either way.
+ * Needs a database loaded WITH AA sequences. */
 typedef struct { const uint8_t *qAA, *q3Di; const int8_t *cbAA, *cbSS; int32_t L; int32_t reserved; } fsgpu_bt_query;
 typedef struct { uint32_t query, target; int32_t qEnd, dbEnd, score; } fsgpu_bt_task;
 typedef struct { int32_t status, qStart, dbStart, identicalAA, btLen, blockSizes; uint64_t btOff; } fsgpu_bt_res;
