@@ -982,6 +982,10 @@ def main():
     # host pool for the per-hit backtraces: the cores this rank may use beyond its feeder threads (cgroup quota / local ranks)
     if "FSGPU_HOST_WORKERS" not in os.environ:
         api.set_host_workers(max(0, min(8, usable_cores() // local_world - nthreads)))
+    # ... and what the library divides when it picks the host or the device block aligner for the backtraces (<= 4 cores per GPU: device): the quota and
+    # the affinity mask a rank sees are the whole job's
+    if local_world > 1 and "FSGPU_CORES_PER_GPU" not in os.environ:
+        os.environ["FSGPU_CORES_PER_GPU"] = str(max(1, usable_cores() // local_world))
     ctx0 = api.Context(local_rank)
     ctx0.adopt_device_db(tensors[0].data_ptr(), tensors[1].data_ptr(), tensors[2].data_ptr(), tensors[3].data_ptr(), db.n, db.data3di.size)
     ctx0._keep = (np.ascontiguousarray(db.data3di), np.ascontiguousarray(db.dataaa), np.ascontiguousarray(db.offsets, np.uint64),

@@ -21,6 +21,17 @@ static thread_local std::string g_createError;
 
 extern "C" {
 
+// devices with at least one live context in this process (fsgpu_live_devices: the host side divides the process's cores by it)
+static std::mutex g_liveM;
+static int g_liveCtx[64] = {0};
+static void liveAdd(int device, int d) { std::lock_guard<std::mutex> g(g_liveM); if (device >= 0 && device < 64) g_liveCtx[device] += d; }
+int fsgpu_live_devices(void) {
+    std::lock_guard<std::mutex> g(g_liveM);
+    int n = 0;
+    for (int i = 0; i < 64; i++) if (g_liveCtx[i] > 0) n++;
+    return n;
+}
+
 int fsgpu_create(int device, fsgpu_ctx **out) {
     if (!out) return FSGPU_E_ARG;
     *out = nullptr;
@@ -43,7 +54,7 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     ctx->numCU = prop.multiProcessorCount;
     if (const char *e2 = getenv("FSGPU_GAPLESS_BLOCKS_PER_CU")) ctx->gaplessBlocksPerCU = std::max(1, atoi(e2));
-    // FSGPU_SW_CUS=<n> (A/B measurement, DESIGN 4.4): a CU-mask split instead of stream priorities -- the batch SW's streams own the last n CUs of the
+    // FSGPU_SW_CUS=<n> (A/B measurement, DESIGN 4.3b): a CU-mask split instead of stream priorities -- the batch SW's streams own the last n CUs of the
     // mask (n / 8 per XCD where the mask interleaves them), the context's stream (scans, selection, k-mer batches) the others
     const int swCUs = [] { const char *e = getenv("FSGPU_SW_CUS"); return e ? atoi(e) : 0; }();
     if (swCUs > 0 && swCUs < ctx->numCU) {
@@ -71,6 +82,7 @@ int fsgpu_create(int device, fsgpu_ctx **out) {
     if ((e = hipMalloc((void **) &ctx->dMeta, sizeof(SelMeta))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc((void **) &ctx->queue, 256)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc((void **) &ctx->hMeta, sizeof(SelMeta))) != hipSuccess) return fail("hipHostMalloc", e);
+    liveAdd(device, +1);
     *out = ctx;
     return FSGPU_OK;
 }
@@ -88,6 +100,7 @@ int fsgpu_clone(const fsgpu_ctx *src, fsgpu_ctx **out) {
 
 void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (!ctx) return;
+    liveAdd(ctx->device, -1);
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->swLong) (void) hipStreamSynchronize(ctx->swLong);
@@ -1799,7 +1812,6 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     if ((rc = ensurePinned(ctx, ctx->hS3pass, total * 4 + 64)) != FSGPU_OK) return rc;      // grown below once the descriptors are counted
     std::vector<uint32_t> perm(total);
     std::vector<int> nLong(nq, 0), nMid(nq, 0);
-    const size_t total16 = total;
     // the short-list rule is per CALL (mean pairs per query of the call): a per-query rule left all-vs-all's batches with 64-lane groups for the short
     // lists AND 32-lane groups for the others -- 1.29 ms per batch against 0.88 ms with one shape for the whole call
     size_t nActive = 0;
@@ -1818,7 +1830,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
             int nl = 0, nm = 0;
             for (int k = 0; k < ns; k++) { p[k] = (uint32_t) lkey[k]; const int lt = len[ids[p[k]]]; if (lt > longT) nl++; else if (lt > midT) nm++; }
             nLong[i] = (q[i].L > 32 * kSw3MaxR || callShort) ? ns : nl;
-            const bool shape16 = q[i].L <= 16 * maxR16 && midT > 0 && (midEnv >= 0 || total16 >= 100000);
+            const bool shape16 = q[i].L <= 16 * maxR16 && midT > 0 && (midEnv >= 0 || total >= 100000);
             nMid[i] = nLong[i] == ns ? 0 : shape16 ? nm : ns - nLong[i];
         }
     }
@@ -1901,13 +1913,13 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // (a class whose largest member still fits three workgroups per CU shares its launch with the smaller ones: the register classes of a
     // search batch then run as one or two launches, each with a single long-target tail)
     auto occOf = [&](int HL, int R) { return std::min(3, (160 * 1024) / sw3LdsBytes(std::min(sw3MaxR(HL), (R + 3) / 4 * 4), HL, hasAA, 4)); };
-    auto keyOf = [&](int shape, int R, int) { return shape * 12 + ((R - 1) / 8) * 4 + occOf(kShapeHL[shape], R); };
+    auto keyOf = [&](int shape, int R) { return shape * 12 + ((R - 1) / 8) * 4 + occOf(kShapeHL[shape], R); };
     for (int i = 0; i < nq; i++) {
         if (nSel(i) == 0) continue;
         for (int shape = 2; shape >= 0; shape--) {
             if (nShape(i, shape) == 0) continue;
             const int R = (q[i].L + kShapeHL[shape] - 1) / kShapeHL[shape];
-            parts.push_back({i, keyOf(shape, R, nShape(i, shape)), R, firstOfShape(i, shape), nShape(i, shape)});
+            parts.push_back({i, keyOf(shape, R), R, firstOfShape(i, shape), nShape(i, shape)});
         }
     }
     struct Group { int key, HL, rlo, maxR, waves, lds; size_t blk0, nblk; };
@@ -1976,7 +1988,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         ctx->swDirCells[slot] = clCells + cells * nDirs; ctx->swDirPairs[slot] = clPairs + pairs * nDirs; ctx->swDirWaveSteps[slot] = clSteps + winsts * nDirs;
     }
     HIPCHK(hipMemcpyAsync(ctx->s3pass.p, ctx->hS3pass.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, S));
-    // FSGPU_SW_EXCLUSIVE=1 (A/B measurement, DESIGN 4.4): the pass takes its turn in the database's chain of scan batches (DbStore::lastScanDone) --
+    // FSGPU_SW_EXCLUSIVE=1 (A/B measurement, DESIGN 4.3b): the pass takes its turn in the database's chain of scan batches (DbStore::lastScanDone) --
     // it starts when the scan batch enqueued before it is done and the next scan batch starts behind it -- instead of co-running with them from a
     // high-priority stream.  Uploads and the image build above stay outside the chain.
     static const bool swExclusive = [] { const char *e = getenv("FSGPU_SW_EXCLUSIVE"); return e && atoi(e) != 0; }();

@@ -167,10 +167,15 @@ extern "C" int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const 
     if ((rc = runPass(todo, kBtMaxBlock)) != FSGPU_OK) return rc;
     // (the backtraces of the first pass sit in the pinned buffer; the second pass copies the whole device buffer again: its own slices are added, the others unchanged)
     // The second pass is a 3-5 ms kernel whatever it is given (the latency of its longest alignment, restarted from the smallest block): a handful of
-    // alignments are back from the host's aligner sooner (36 us each on a core) -- it runs for 64 alignments per usable core or more (FSGPU_BT_PASS2 = 1 / 0:
+    // alignments are back from the host's aligner sooner (36 us each on a core) -- it runs for 64 alignments per core of this GPU's share or more (FSGPU_BT_PASS2 = 1 / 0:
     // always / never); what it does not take stays at status 0 and the caller's host path answers.
     const int pass2Env = [] { const char *e = getenv("FSGPU_BT_PASS2"); return e && *e ? atoi(e) : -1; }();          // per call: the tests switch it
-    const bool pass2 = pass2Env >= 0 ? pass2Env != 0 : todo.size() >= (size_t) 64 * (size_t) std::max(1, fshost_usable_cores());
+    const int coresPerGpu = [] {
+        const char *e = getenv("FSGPU_CORES_PER_GPU");
+        if (e && *e && atoi(e) > 0) return atoi(e);
+        return std::max(1, fshost_usable_cores() / std::max(1, fsgpu_live_devices()));
+    }();
+    const bool pass2 = pass2Env >= 0 ? pass2Env != 0 : todo.size() >= (size_t) 64 * (size_t) coresPerGpu;
     if (pass2 && (rc = runPass(todo, kBtMaxBlock2)) != FSGPU_OK) return rc;
     *btBase = (const char *) ctx->hBtOut.p;
     return FSGPU_OK;

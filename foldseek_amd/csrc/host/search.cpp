@@ -562,9 +562,16 @@ void precomputeBacktraces(const fshost_search *s, const std::vector<AlignQuery> 
     // shared 3.95 s with 294 k hits on the device -- k_block_backtrace keeps every SIMD issuing for the 10-20 ms of a chunk, and the k-mer batches'
     // chains of short kernels and the SW passes of the other feeders queue behind it (their waits doubled).  One rank's 2 cores of an 8-rank node
     // (bench.py --emulate-rank-share 8): host only 19.1 k queries/s, shared 30.1 k, device only 48.3 k -- two cores have no time to give.
-    // Hence the default by the cores this process may use: <= 4 -> the device aligner (1), more -> the host aligner (0); 2 = shared on request.
+    // Hence the default by the cores per GPU: <= 4 -> the device aligner (1), more -> the host aligner (0); 2 = shared on request.
     const int envMode = envDev && *envDev ? atoi(envDev) : -1;
-    const int mode = envMode == 0 || envMode == 1 || envMode == 2 ? envMode : (usableCores() <= 4 ? 1 : 0);          // 0 host, 1 device, 2 shared
+    // cores per GPU: what this process may use divided by the devices it drives; a rank of a multi-process job is told its share (bench.py sets
+    // FSGPU_CORES_PER_GPU = usable cores / local ranks: the cgroup quota and the affinity mask are the whole job's)
+    const int coresPerGpu = [] {
+        const char *e = getenv("FSGPU_CORES_PER_GPU");
+        if (e && *e && atoi(e) > 0) return atoi(e);
+        return std::max(1, usableCores() / std::max(1, fsgpu_live_devices()));
+    }();
+    const int mode = envMode == 0 || envMode == 1 || envMode == 2 ? envMode : (coresPerGpu <= 4 ? 1 : 0);          // 0 host, 1 device, 2 shared
     const fshost_params &par = s->par;
     const bool deviceCan = s->dataAA != nullptr && !tasks.empty() && par.gapOpen > par.gapExtend && par.gapExtend >= 1 && par.gapOpen <= 127;
     // hits from which a batch is shared (FSGPU_BT_SHARE_MIN; the tests lower it), smallest / largest device chunk

@@ -266,6 +266,9 @@ int fsgpu_block_backtrace(fsgpu_ctx *ctx, const int8_t *tblAA, const int8_t *tbl
  * and three waves per SIMD for the 10-20 ms of a call).  1 leaves two thirds of a CU's LDS and most issue slots to the kernels of other contexts: what a
  * caller that shares a batch between its host threads and the device asks for (fshost_search_align_batch with FSGPU_DEVICE_BACKTRACE=2). */
 int fsgpu_block_backtrace_footprint(fsgpu_ctx *ctx, int workgroupsPerCU);
+/* Number of devices that hold at least one live context of this process (a module run with --gpus 8 : 8).  The host side divides the cores the process may
+ * use by it when it decides who computes the backtraces (FSGPU_CORES_PER_GPU overrides the quotient: one rank of a multi-process job sets it to its share). */
+int fsgpu_live_devices(void);
 
 /* ---- prefilter: k-mer matching with double-diagonal hits + ungapped diagonal scoring ------------------------- */
 /* Index parameters == the subset of Prefiltering's members that shape IndexTable / SequenceLookup.  Sequence-

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The batch SW next to the other feeders' scans under different device-sharing schemes (DESIGN 4.4): tools/corun_variants.sh "ENV=V ..." ...
+# The batch SW next to the other feeders' scans under different device-sharing schemes (DESIGN 4.3b): tools/corun_variants.sh "ENV=V ..." ...
 # Each variant: main leg (configs[2], 20 steps of 64 queries) + the --alignment-type 2 leg (12 steps), nothing else.
 for v in "$@"; do echo "== $v"; env $v python bench.py --no-cpu-baseline --no-kmer --allvsall-steps 0 --fullrange-steps 0 --single-targets 0 2>/dev/null | python -c "
 import json,sys
