@@ -2001,7 +2001,9 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     if (slot == 0 || !ctx->evValid[1]) HIPCHK(hipEventRecord(ctx->ev[2], S));
     HIPCHK(hipEventRecord(ctx->swDirEv[2 * slot], S));
     // every launch group gets a stream: their long-target tails overlap instead of queueing up
-    const size_t nStreams = std::min<size_t>(groups.size(), 6);
+    // ... and, in the one-submission form, the two directions of a group: the forward and the reversed-query launch of all-vs-all's batches are one round of
+    // waves each (0.69 ms apiece for 1024 queries x 8 pairs, the wavefront of the longest target) and ran one behind the other on the group's stream
+    const size_t nStreams = std::min<size_t>(groups.size() * (size_t) nDirs, 6);
     if (nStreams > 1) {
         if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
         for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) { if (!ctx->swCuMask.empty()) HIPCHK(hipExtStreamCreateWithCUMask(&ctx->swAux[k], (uint32_t) ctx->swCuMask.size(), ctx->swCuMask.data())); else if (ctx->swHi) HIPCHK(hipStreamCreateWithPriority(&ctx->swAux[k], hipStreamNonBlocking, ctx->swHiPrio)); else HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking)); }
@@ -2012,7 +2014,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
         const size_t gi = gx % groups.size();
         const int d = (int) (gx / groups.size());
         const Group &g = groups[gi];
-        const size_t k = gi % nStreams;
+        const size_t k = gx % nStreams;
         hipStream_t gs = k == 0 ? S : ctx->swAux[k];
         Sw3Args sa;
         sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;

@@ -6,11 +6,12 @@ import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foldseek_amd import api, synth
 NQ = int(sys.argv[1]) if len(sys.argv) > 1 else 32          # queries per batch
+NP = int(sys.argv[2]) if len(sys.argv) > 2 else 1000        # pairs per query (8: the all-vs-all shape)
 q3, qa = synth.make_queries(max(64, NQ), seed=5000, lo=250, hi=450)
 db = synth.make_db(100000, synth.make_queries(8, seed=1000, lo=250, hi=450))
 ctx = api.Context(0); ctx.load_db(db)
 rng = np.random.default_rng(1)
-hits = [rng.choice(db.n, 1000, replace=False).astype(np.uint32) for _ in range(max(64, NQ))]
+hits = [rng.choice(db.n, NP, replace=False).astype(np.uint32) for _ in range(max(64, NQ))]
 for at in (0, 2):
     par = api.default_params(); par.alignmentType = at
     s = api.Search(ctx, par)
