@@ -1019,8 +1019,14 @@ def main():
     for i in range(n_warm, min(nq, n_warm + 8)):
         step1(0, i)
         solo_g.append(ctxs[0].kernel_ms(0)); solo_s.append(ctxs[0].kernel_ms(1))
-    step(0, batches[len(batches) // 2])                       # one whole batch alone on the device: the SW passes' solo figure
-    solo_swp = ctxs[0].sw_last_passes()
+    # one whole batch alone on the device, three times: the SW passes' solo figure is their fastest repetition (a single one moved by +-10 % from run to run)
+    solo_swp = None
+    _sw_ms = lambda p: sum(float(p[d][0]) for d in (0, 1) if p[d][0] >= 0)
+    for _ in range(3):
+        step(0, batches[len(batches) // 2])
+        p_ = ctxs[0].sw_last_passes()
+        if solo_swp is None or _sw_ms(p_) < _sw_ms(solo_swp):
+            solo_swp = p_
     tot = fdist.gather_objects((counts[0], counts[1], n_mine, host))
     ctx = ctx0
 
@@ -1127,8 +1133,12 @@ def main():
             pick = np.linspace(0, len(batches) - 1, nb2 + nthreads).astype(np.int64)          # spread over the length-sorted batches
             sel2 = [batches[i] for i in pick]
             dt2, rec2, step2 = search_region(api, ctxs, searches2, q3, qa, sel2[:nthreads], sel2[nthreads:], world, dev, fdist, False, nq)
-            step2(0, sel2[nthreads + (len(sel2) - nthreads) // 2])
-            solo2 = ctxs[0].sw_last_passes()
+            solo2 = None
+            for _ in range(3):
+                step2(0, sel2[nthreads + (len(sel2) - nthreads) // 2])
+                p_ = ctxs[0].sw_last_passes()
+                if solo2 is None or _sw_ms(p_) < _sw_ms(solo2):
+                    solo2 = p_
             n2 = sum(len(b) for b in sel2[nthreads:])
             tot2 = fdist.gather_objects((rec2["counts"][0], rec2["counts"][1], n2))
             if rank == 0:
