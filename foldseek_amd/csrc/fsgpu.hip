@@ -105,7 +105,7 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->swLong) (void) hipStreamSynchronize(ctx->swLong);
     if (ctx->swHi) (void) hipStreamSynchronize(ctx->swHi);          // the k_sw3 path runs here and on swAux: nothing may be in flight when its buffers go
-    for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamSynchronize(ctx->swAux[i]);
+    for (int i = 0; i < fsgpu_ctx::kSwAux; i++) if (ctx->swAux[i]) (void) hipStreamSynchronize(ctx->swAux[i]);
     if (ctx->swChainEv) {
         if (ctx->db) { std::lock_guard<std::mutex> g(ctx->db->scanMutex); if (ctx->db->lastScanDone == ctx->swChainEv) ctx->db->lastScanDone = nullptr; }
         (void) hipEventDestroy(ctx->swChainEv);
@@ -136,8 +136,8 @@ void fsgpu_destroy(fsgpu_ctx *ctx) {
     hipHostFree(ctx->hMqPssm.p); hipHostFree(ctx->hMqRec.p); hipHostFree(ctx->hMqMeta.p); hipHostFree(ctx->hMqOutId.p); hipHostFree(ctx->hMqOutScore.p); hipHostFree(ctx->hMqIdent.p);
     for (int i = 0; i < 4; i++) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 4; i++) if (ctx->swDirEv[i]) hipEventDestroy(ctx->swDirEv[i]);
-    for (int i = 0; i < 6; i++) if (ctx->swAux[i]) (void) hipStreamDestroy(ctx->swAux[i]);
-    for (int i = 0; i < 7; i++) if (ctx->swAuxEv[i]) (void) hipEventDestroy(ctx->swAuxEv[i]);
+    for (int i = 0; i < fsgpu_ctx::kSwAux; i++) if (ctx->swAux[i]) (void) hipStreamDestroy(ctx->swAux[i]);
+    for (int i = 0; i <= fsgpu_ctx::kSwAux; i++) if (ctx->swAuxEv[i]) (void) hipEventDestroy(ctx->swAuxEv[i]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1601,15 +1601,15 @@ int fsgpu_sw_multi_dir(fsgpu_ctx *ctx, const fsgpu_sw_query *q, int nq, int gapO
         HIPCHK(hipMemcpyAsync(ctx->img.p, ctx->hImg.p, descOff + nBlocks * sizeof(SwBlockDesc), hipMemcpyHostToDevice, ctx->stream));
         // every register-class group gets its own stream: their long-target tails overlap instead of queueing up
         if (groups.size() > 1) {
-            if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
+            if (!ctx->swAuxEv[fsgpu_ctx::kSwAux]) for (int i = 0; i <= fsgpu_ctx::kSwAux; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
             for (size_t gi = 1; gi < groups.size(); gi++)
                 if (!ctx->swAux[gi]) HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[gi], hipStreamNonBlocking));
-            HIPCHK(hipEventRecord(ctx->swAuxEv[6], ctx->stream));          // inputs (ids, images, descriptors) are on their way
+            HIPCHK(hipEventRecord(ctx->swAuxEv[fsgpu_ctx::kSwAux], ctx->stream));          // inputs (ids, images, descriptors) are on their way
         }
         size_t gi = 0;
         for (const Group &g : groups) {
             hipStream_t gs = gi == 0 ? ctx->stream : ctx->swAux[gi];
-            if (gi > 0) HIPCHK(hipStreamWaitEvent(gs, ctx->swAuxEv[6], 0));
+            if (gi > 0) HIPCHK(hipStreamWaitEvent(gs, ctx->swAuxEv[fsgpu_ctx::kSwAux], 0));
             SwArgs sa;
             sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;
             sa.targetIds = (const uint32_t *) ctx->tids.p; sa.nPairs = (int) total;
@@ -1707,7 +1707,7 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // fsgpu_destroy) would refill / free memory that is still being read
     struct Drain {
         fsgpu_ctx *c; hipStream_t s; bool ok = false;
-        ~Drain() { if (ok) return; (void) hipStreamSynchronize(s); for (int i = 0; i < 6; i++) if (c->swAux[i]) (void) hipStreamSynchronize(c->swAux[i]); (void) hipGetLastError(); }
+        ~Drain() { if (ok) return; (void) hipStreamSynchronize(s); for (int i = 0; i < fsgpu_ctx::kSwAux; i++) if (c->swAux[i]) (void) hipStreamSynchronize(c->swAux[i]); (void) hipGetLastError(); }
     } drain{ctx, S};
     std::vector<size_t> base(nq + 1, 0), sbase(nq + 1, 0);
     for (int i = 0; i < nq; i++) {
@@ -2003,18 +2003,19 @@ static int sw3MultiImpl(fsgpu_ctx *ctx, const int8_t *mat3Di, const int8_t *matA
     // every launch group gets a stream: their long-target tails overlap instead of queueing up
     // ... and, in the one-submission form, the two directions of a group: the forward and the reversed-query launch of all-vs-all's batches are one round of
     // waves each (0.69 ms apiece for 1024 queries x 8 pairs, the wavefront of the longest target) and ran one behind the other on the group's stream
-    const size_t nStreams = std::min<size_t>(groups.size() * (size_t) nDirs, 6);
+    static const bool dirStreams = [] { const char *e = getenv("FSGPU_SW3_DIRSTREAMS"); return !(e && atoi(e) == 0); }();          // 0: as until round 5 (A/B)
+    const size_t nStreams = std::min<size_t>(groups.size() * (size_t) (dirStreams ? nDirs : 1), dirStreams ? (size_t) fsgpu_ctx::kSwAux : 6);
     if (nStreams > 1) {
-        if (!ctx->swAuxEv[6]) for (int i = 0; i < 7; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
+        if (!ctx->swAuxEv[fsgpu_ctx::kSwAux]) for (int i = 0; i <= fsgpu_ctx::kSwAux; i++) HIPCHK(hipEventCreateWithFlags(&ctx->swAuxEv[i], hipEventDisableTiming));
         for (size_t k = 1; k < nStreams; k++) if (!ctx->swAux[k]) { if (!ctx->swCuMask.empty()) HIPCHK(hipExtStreamCreateWithCUMask(&ctx->swAux[k], (uint32_t) ctx->swCuMask.size(), ctx->swCuMask.data())); else if (ctx->swHi) HIPCHK(hipStreamCreateWithPriority(&ctx->swAux[k], hipStreamNonBlocking, ctx->swHiPrio)); else HIPCHK(hipStreamCreateWithFlags(&ctx->swAux[k], hipStreamNonBlocking)); }
-        HIPCHK(hipEventRecord(ctx->swAuxEv[6], S));
-        for (size_t k = 1; k < nStreams; k++) HIPCHK(hipStreamWaitEvent(ctx->swAux[k], ctx->swAuxEv[6], 0));
+        HIPCHK(hipEventRecord(ctx->swAuxEv[fsgpu_ctx::kSwAux], S));
+        for (size_t k = 1; k < nStreams; k++) HIPCHK(hipStreamWaitEvent(ctx->swAux[k], ctx->swAuxEv[fsgpu_ctx::kSwAux], 0));
     }
     for (size_t gx = 0; gx < groups.size() * (size_t) nDirs; gx++) {
         const size_t gi = gx % groups.size();
         const int d = (int) (gx / groups.size());
         const Group &g = groups[gi];
-        const size_t k = gx % nStreams;
+        const size_t k = (dirStreams ? gx : gi) % nStreams;
         hipStream_t gs = k == 0 ? S : ctx->swAux[k];
         Sw3Args sa;
         sa.aa = ctx->db->alnAA; sa.ss = ctx->db->aln3di; sa.offsets = ctx->db->dOffsets; sa.lengths = ctx->db->dLengths;

@@ -109,8 +109,9 @@ struct fsgpu_ctx {
     hipStream_t swHi = nullptr;                 // highest-priority stream of the batch SW (fsgpu_sw_multi_dir_c); null: ctx->stream
     int swHiPrio = 0;
     std::vector<uint32_t> swCuMask;             // FSGPU_SW_CUS: the CU mask of the batch SW's streams (empty: priorities)
-    hipStream_t swAux[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // side streams: register-class groups of a multi-query launch overlap their tails
-    hipEvent_t swAuxEv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kSwAux = 12;           // side streams: register-class groups (and, in the one-submission form, directions) of a multi-query launch overlap their tails
+    hipStream_t swAux[kSwAux] = {};
+    hipEvent_t swAuxEv[kSwAux + 1] = {};        // [kSwAux]: the fork event
     DevBuf img, tids, res0, res1, border0, border1, keys;
     // per-pass accounting of the last fsgpu_sw_multi_dir calls (fsgpu_sw_last_passes): k_sw2 launches only (single-tile queries),
     // events on the context stream around the launches of one direction (the side streams of the register classes join it)
