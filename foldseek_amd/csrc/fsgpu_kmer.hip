@@ -657,9 +657,19 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         RPCHK(hipEventRecord(S.ev[10], st));
         ctx->kmerKPerPos = (double) nLists / (double) std::max<uint64_t>(nPos, 1);
         if (waveForm >= 0 ? waveForm != 0 : ctx->kmerKPerPos < 2048)
-            hipLaunchKernelGGL(k_kmer_lists_w, dim3((unsigned) ((nPos + 3) / 4)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
-                               (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
-                               (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+        {
+            // few similar k-mers per position: the small LDS form (more waves per SIMD); FSGPU_KMER_WAVE_SMALL = 0 / 1 forces a form (A/B)
+            static const int smallEnv = [] { const char *e = getenv("FSGPU_KMER_WAVE_SMALL"); return e && *e ? atoi(e) : -1; }();
+            const bool small = smallEnv >= 0 ? smallEnv != 0 : ctx->kmerKPerPos < 128;
+            if (small)
+                hipLaunchKernelGGL((k_kmer_lists_w<128, 64>), dim3((unsigned) ((nPos + 3) / 4)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                                   (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
+                                   (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+            else
+                hipLaunchKernelGGL((k_kmer_lists_w<kWaveRowCap, kWaveRuns>), dim3((unsigned) ((nPos + 3) / 4)), dim3(256), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
+                                   (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,
+                                   (const uint64_t *) S.Kbase.p, ix.offsets, ix.bitmap, (uint32_t *) S.listStart.p, (uint32_t *) S.listSize.p, (uint32_t *) S.listPos.p);
+        }
         else
             hipLaunchKernelGGL(k_kmer_lists, dim3((unsigned) (nPos + nLists / kListSlice + 1)), dim3(kKmerBlock), 0, st, (const KmerQ *) S.qs.p, (const uint16_t *) S.posQuery.p,
                                (const uint8_t *) S.seqs.p, (const int16_t *) S.thrs.p, (uint32_t) nPos, ix.pat, ix.s3, ix.i3, (const uint32_t *) S.K.p,

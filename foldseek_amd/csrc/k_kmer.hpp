@@ -377,10 +377,11 @@ __global__ __launch_bounds__(kKmerBlock) void k_kmer_lists(const KmerQ *qs, cons
 constexpr int kWaveRowCap = 512;
 constexpr int kWaveRuns = 256;
 
-// leading entries of the descending row S (kRow3 entries) that are >= cut -> dst[0..n); false when there are more than kWaveRowCap
+// leading entries of the descending row S (kRow3 entries) that are >= cut -> dst[0..n); false when there are more than CAP
+template <int CAP = kWaveRowCap>
 __device__ inline bool kmerStagePrefix(const int16_t *S, const uint16_t *I, int cut, int16_t *dst, uint16_t *idst, int lane, int &n) {
     n = 0;
-    for (int base = 0; base < kWaveRowCap; base += 64) {
+    for (int base = 0; base < CAP; base += 64) {
         const int16_t v = S[base + lane];
         dst[base + lane] = v;
         if (I) idst[base + lane] = I[base + lane];
@@ -388,14 +389,17 @@ __device__ inline bool kmerStagePrefix(const int16_t *S, const uint16_t *I, int 
         n += cnt;
         if (cnt < 64) return true;
     }
-    return (int) S[kWaveRowCap] < cut;
+    return (int) S[CAP] < cut;
 }
 
-struct KmerWaveLds {
-    int16_t s1[kWaveRowCap], s2[kWaveRowCap];
-    uint16_t i1[kWaveRowCap], i2[kWaveRowCap];
-    uint32_t runOx[kWaveRuns + 1];
-    uint16_t runXs[kWaveRuns], runC[kWaveRuns];
+// CAP / RUNS = 512 / 256: 6.1 KB per wave, six workgroups per CU; 128 / 64 (round 6, batches with fewer than 128 similar k-mers per position: all-vs-all at -s 4.5 has
+// 30): 1.5 KB per wave -- the waves per SIMD are then bounded by the hardware's eight, and the kernel is a chain of dependent probes that only more waves hide
+template <int CAP, int RUNS>
+struct KmerWaveLdsT {
+    int16_t s1[CAP], s2[CAP];
+    uint16_t i1[CAP], i2[CAP];
+    uint32_t runOx[RUNS + 1];
+    uint16_t runXs[RUNS], runC[RUNS];
 };
 
 __global__ __launch_bounds__(256) void k_kmer_count_w(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
@@ -428,10 +432,13 @@ __global__ __launch_bounds__(256) void k_kmer_count_w(const KmerQ *qs, const uin
     if (lane == 0) K[p] = (uint32_t) (mine < (unsigned long long) (kMaxKmerResult - 1) ? mine : (kMaxKmerResult - 1));
 }
 
+template <int CAP, int RUNS>
 __global__ __launch_bounds__(256) void k_kmer_lists_w(const KmerQ *qs, const uint16_t *posQuery, const uint8_t *seqs, const int16_t *thrs,
                                                       uint32_t nPos, KmerPattern pat, const int16_t *s3, const uint16_t *i3,
                                                       const uint32_t *Kcount, const uint64_t *Kbase, const uint32_t *offsets, const uint32_t *bitmap,
                                                       uint32_t *listStart, uint32_t *listSize, uint32_t *listPos) {
+    using KmerWaveLds = KmerWaveLdsT<CAP, RUNS>;
+    constexpr int kWaveRuns = RUNS;
     __shared__ KmerWaveLds lds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t p = blockIdx.x * 4 + wave;
@@ -446,8 +453,8 @@ __global__ __launch_bounds__(256) void k_kmer_lists_w(const KmerQ *qs, const uin
     int n1 = kRow3, n2 = kRow3;
     {
         int m1, m2;
-        const bool f1 = kmerStagePrefix(S1, I1, info.vmax - info.nV + 1, W.s1, W.i1, lane, m1);
-        const bool f2 = kmerStagePrefix(S2, I2, (int) (int16_t) (info.thr - info.vmax), W.s2, W.i2, lane, m2);
+        const bool f1 = kmerStagePrefix<CAP>(S1, I1, info.vmax - info.nV + 1, W.s1, W.i1, lane, m1);
+        const bool f2 = kmerStagePrefix<CAP>(S2, I2, (int) (int16_t) (info.thr - info.vmax), W.s2, W.i2, lane, m2);
         if (f1) { S1 = W.s1; I1 = W.i1; n1 = m1; }
         if (f2) { S2 = W.s2; I2 = W.i2; n2 = m2; }
     }
