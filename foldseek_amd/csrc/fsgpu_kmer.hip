@@ -3,6 +3,7 @@
 // k_kmer.hpp).  No CPU fallback: everything below fails with FSGPU_E_* when there is no device.
 #include <cstring>
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -683,9 +684,24 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
     hipLaunchKernelGGL(k_kmer_chunks, dim3(gridFor(nq, 64)), dim3(64), 0, st, (const KmerQ *) S.qs.p, nq, (const uint64_t *) S.Kbase.p, (const uint64_t *) S.listP.p, (const uint32_t *) S.listPos.p, maxDbMatches, (KmerChunks *) S.chunks.p);
     RPCHK(hipGetLastError());
     RPCHK(hipMemcpyAsync(&misc[1], (uint64_t *) S.listP.p + nLists, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    RPCHK(hipMemcpyAsync(S.hChunks.p, S.chunks.p, (size_t) nq * sizeof(KmerChunks), hipMemcpyDeviceToHost, st));
+    // the chunk tables: 2 KB per query, of which a query uses nChunks + 1 entries -- a batch of 1024 all-vs-all queries (one or two chunks each) sent 2.1 MB
+    // over PCIe; large batches copy the header + the first nine entries of every query and fetch the rest only when a query has more than eight chunks
+    constexpr size_t kChunkHead = offsetof(KmerChunks, start) + 9 * sizeof(uint64_t);
+    const bool compactChunks = nq > 64;
+    if (compactChunks) RPCHK(hipMemcpy2DAsync(S.hChunks.p, sizeof(KmerChunks), S.chunks.p, sizeof(KmerChunks), kChunkHead, (size_t) nq, hipMemcpyDeviceToHost, st));
+    else RPCHK(hipMemcpyAsync(S.hChunks.p, S.chunks.p, (size_t) nq * sizeof(KmerChunks), hipMemcpyDeviceToHost, st));
     RPCHK(hipMemcpyAsync(S.hQs.p, S.qs.p, (size_t) nq * sizeof(KmerQ), hipMemcpyDeviceToHost, st));
     CHK(syncStream(ctx));
+    if (compactChunks) {
+        uint32_t maxC = 1;
+        for (int q = 0; q < nq; q++) maxC = std::max<uint32_t>(maxC, ((const KmerChunks *) S.hChunks.p)[q].nChunks);
+        if (maxC > 8) {
+            const size_t upTo = offsetof(KmerChunks, start) + ((size_t) std::min<uint32_t>(maxC, kMaxChunks) + 1) * sizeof(uint64_t);
+            RPCHK(hipMemcpy2DAsync((char *) S.hChunks.p + kChunkHead, sizeof(KmerChunks), (const char *) S.chunks.p + kChunkHead, sizeof(KmerChunks), upTo - kChunkHead, (size_t) nq,
+                                   hipMemcpyDeviceToHost, st));
+            CHK(syncStream(ctx));
+        }
+    }
     nHits = misc[1];
     mark("lists+sync");
     RPCHK(hipEventRecord(S.ev[2], st));
@@ -893,8 +909,15 @@ static int kmerBatch(fsgpu_ctx *ctx, const fsgpu_kmer_search_params &sp, const f
         for (int e = 6; e <= 7; e++) RPCHK(hipEventRecord(S.ev[e], st));
         RPCHK(hipMemsetAsync(S.thr.p, 0, (size_t) nq * sizeof(uint32_t), st));
     }
-    RPCHK(hipMemcpyAsync(S.hEc.p, S.ec.p, (size_t) nq * kMaxChunks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    RPCHK(hipMemcpyAsync(S.hRounds.p, S.rounds.p, (size_t) nq * kMaxChunks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    {
+        // per (query, chunk) counters: the host reads entries [0, nChunks) of a query only -- the columns the batch uses come back, not the 2 x 1 KB per query
+        // (a batch of 1024 all-vs-all queries with one or two chunks each sent 2 MB over PCIe for 8 KB)
+        uint32_t maxC = 1;
+        for (int q = 0; q < nq; q++) maxC = std::max<uint32_t>(maxC, hck[q].nChunks);
+        const size_t pitch = (size_t) kMaxChunks * sizeof(uint32_t), width = (size_t) std::min<uint32_t>(maxC, kMaxChunks) * sizeof(uint32_t);
+        RPCHK(hipMemcpy2DAsync(S.hEc.p, pitch, S.ec.p, pitch, width, (size_t) nq, hipMemcpyDeviceToHost, st));
+        RPCHK(hipMemcpy2DAsync(S.hRounds.p, pitch, S.rounds.p, pitch, width, (size_t) nq, hipMemcpyDeviceToHost, st));
+    }
     RPCHK(hipMemcpyAsync(S.hResSize.p, S.resSize.p, (size_t) nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     RPCHK(hipMemcpyAsync(S.hThr.p, S.thr.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RPCHK(hipMemcpyAsync(S.hOutCount.p, S.outCount.p, (size_t) nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
